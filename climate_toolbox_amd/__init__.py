@@ -1,0 +1,11 @@
+"""MI355X-native weighted grid->region aggregation engine: a drop-in for the aggregation path of
+ClimateImpactLab/climate_toolbox (``climate_toolbox.aggregations``).  See DESIGN.md."""
+
+__version__ = "0.1.0"
+
+from .aggregations import (  # noqa: F401
+    weighted_aggregate_grid_to_regions,
+    prepare_spatial_weights_data,
+    _reindex_spatial_data_to_regions,
+    _aggregate_reindexed_data_to_regions,
+)

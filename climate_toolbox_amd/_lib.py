@@ -1,0 +1,91 @@
+"""ctypes binding of libwagg.so (include/wagg.h).  There is NO fallback: if the HIP library is
+missing or a call fails, this raises -- the product path never computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
+
+LAYOUT_TG, LAYOUT_GT = 0, 1
+OUT_TR, OUT_RT = 0, 1
+
+# every symbol include/wagg.h declares (tests check that the .so exports all of them)
+EXPORTS = (
+    "wagg_version", "wagg_device_count", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
+    "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den",
+    "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
+    "wagg_gather_f32", "wagg_gather_f64",
+    "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments",
+    "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32",
+    "wagg_synth_field_f32", "wagg_synth_field_f64",
+)
+
+
+class WaggError(RuntimeError):
+    pass
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("nseg_in", C.c_int64), ("nnz", C.c_int64), ("n_groups", C.c_int64),
+                ("n_chunks", C.c_int64), ("n_ucells", C.c_int64), ("n_giant", C.c_int64),
+                ("n_empty", C.c_int64), ("G", C.c_int64), ("R", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libwagg.so once.  torch is imported first so that one HIP runtime serves both
+    (torch bundles libamdhip64.so.7; the loader then reuses it for libwagg.so)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WaggError(
+            "HIP engine not built: %s is missing. Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` or `make -C climate_toolbox_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  (runtime ordering, see docstring)
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, f64p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
+    L.wagg_version.restype = C.c_int
+    L.wagg_device_count.restype = C.c_int
+    L.wagg_last_error.restype = C.c_char_p
+    L.wagg_profile_enable.argtypes = [C.c_int]
+    L.wagg_profile_read.argtypes = [f32p, C.c_int, C.POINTER(C.c_int)]
+    L.wagg_plan_create.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.c_int64,
+                                   C.c_int, C.POINTER(vp)]
+    L.wagg_plan_destroy.argtypes = [vp]
+    L.wagg_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.wagg_plan_get_den.argtypes = [vp, f64p]
+    for name in ("wagg_apply_f32", "wagg_apply_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp]
+    for name in ("wagg_apply_host_f32", "wagg_apply_host_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int]
+    for name in ("wagg_gather_f32", "wagg_gather_f64"):
+        getattr(L, name).argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, vp, C.c_int64,
+                                     C.c_int, vp]
+    L.wagg_dense_create_synth.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.POINTER(vp)]
+    L.wagg_dense_create_host.argtypes = [f32p, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.wagg_dense_create_from_segments.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32,
+                                                  C.POINTER(vp)]
+    L.wagg_dense_destroy.argtypes = [vp]
+    L.wagg_dense_get_den.argtypes = [vp, f64p]
+    L.wagg_dense_apply_f32.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
+    L.wagg_synth_field_f32.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_float,
+                                       C.c_float, vp]
+    L.wagg_synth_field_f64.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_double,
+                                       C.c_double, vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("wagg_last_error",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().wagg_last_error().decode("utf-8", "replace")
+        raise WaggError("%s failed (%d): %s" % (what, rc, msg))

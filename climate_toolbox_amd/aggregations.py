@@ -1,0 +1,442 @@
+"""Drop-in for ``climate_toolbox.aggregations.aggregations`` -- same names, arguments and error
+behaviour; the arithmetic runs on MI355X through libwagg.so (include/wagg.h).
+
+Reference (read as text): /root/reference/climate_toolbox/aggregations/aggregations.py
+  _reindex_spatial_data_to_regions       :8-32     -> here: label lookup on host, NO data copy
+  _aggregate_reindexed_data_to_regions   :35-84    -> here: backup fill + label factorisation on
+                                                      host (fp64), grouped sums + division on GPU
+  weighted_aggregate_grid_to_regions     :87-124
+  prepare_spatial_weights_data           :127-152
+
+What stays on the host (before the C-ABI), exactly as SURVEY.md section 8b lays out: exact float
+label matching (S1), the per-row backup fill (S4), sorted-unique label factorisation (S3).  What
+the GPU does: the gather of :27 fused into the weighted group sums of :78-79 and the division.
+There is no CPU compute path: without the HIP library or a GPU these functions raise.
+"""
+from __future__ import annotations
+
+import functools
+import hashlib
+from collections import OrderedDict
+
+import numpy as np
+import pandas as pd
+
+from . import minixr
+from .engine import SparsePlan, gather as _device_gather, require_gpu
+
+try:  # optional: return real xarray objects when the caller hands us xarray objects
+    import xarray as _xr
+except Exception:  # pragma: no cover - xarray is absent from this image
+    _xr = None
+
+__all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data",
+           "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
+
+_PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
+_PLAN_CACHE_MAX = 8
+
+
+# ----------------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------------
+def _is_xarray(obj):
+    return _xr is not None and isinstance(obj, (_xr.Dataset, _xr.DataArray))
+
+
+def _exact_index(coord_values, wanted, name):
+    """Exact-equality label lookup, KeyError when a label is absent (``Dataset.sel`` without
+    ``method=``, aggregations.py:27; S1)."""
+    idx = pd.Index(np.asarray(coord_values))
+    pos = idx.get_indexer(np.asarray(wanted))
+    if (pos < 0).any():
+        bad = np.asarray(wanted)[pos < 0][:5]
+        raise KeyError("not all values found in index %r: %r" % (name, bad.tolist()))
+    return pos.astype(np.int64)
+
+
+def _is_null_label(v):
+    if v is None:
+        return True
+    try:
+        return bool(v != v)
+    except Exception:
+        return False
+
+
+def _factorize_labels(labels):
+    """Sorted unique labels and per-row codes, -1 for null labels (xarray groupby, :78; S3)."""
+    labels = np.asarray(labels)
+    if labels.dtype.kind in "fc":
+        null = np.isnan(labels)
+    elif labels.dtype == object:
+        null = np.array([_is_null_label(v) for v in labels.tolist()], dtype=bool)
+    else:
+        null = np.zeros(labels.shape, dtype=bool)
+    good = labels[~null]
+    if good.dtype == object:
+        uniq_list = sorted(set(good.tolist()))
+        lut = {v: i for i, v in enumerate(uniq_list)}
+        codes_good = np.fromiter((lut[v] for v in good.tolist()), dtype=np.int64, count=len(good))
+        uniq = np.array(uniq_list, dtype=object)
+    else:
+        uniq, codes_good = np.unique(good, return_inverse=True)
+    codes = np.full(labels.shape[0], -1, dtype=np.int32)
+    codes[~null] = codes_good
+    return uniq, codes
+
+
+def _spatial_layout(dims):
+    """Where lat/lon sit among the dims -> how the array flattens to (T x G) or (G x T)."""
+    dims = tuple(dims)
+    if "lat" not in dims or "lon" not in dims:
+        raise KeyError("dataset must have dimensions named 'lat' and 'lon' (aggregations.py:27), "
+                       "got %r" % (dims,))
+    ia, io = dims.index("lat"), dims.index("lon")
+    first, second = (ia, io) if ia < io else (io, ia)
+    others = [i for i in range(len(dims)) if i not in (ia, io)]
+    return ia, io, first, second, others
+
+
+def _result_dims(dims, group_dim):
+    """S10: the group dim takes the slot of the first indexed dim; the second one disappears."""
+    _, _, first, second, _ = _spatial_layout(dims)
+    return tuple(group_dim if i == first else d for i, d in enumerate(dims) if i != second)
+
+
+class _ReindexedArray:
+    """Lazy stand-in for one gathered data variable of aggregations.py:27."""
+
+    def __init__(self, owner, name):
+        self._owner, self.name = owner, name
+
+    @property
+    def dims(self):
+        return _result_dims(self._owner._src_dims[self.name], "reshape_index")
+
+    @property
+    def shape(self):
+        src_dims = self._owner._src_dims[self.name]
+        src_shape = dict(zip(src_dims, self._owner._src_values[self.name].shape))
+        return tuple(self._owner._nseg if d == "reshape_index" else src_shape[d] for d in self.dims)
+
+    @property
+    def dtype(self):
+        return self._owner._src_values[self.name].dtype
+
+    @property
+    def values(self):
+        return self._owner._materialise(self.name)
+
+    def isnull(self):
+        return minixr.DataArray(self.values, self.dims).isnull()
+
+    def __array__(self, dtype=None, copy=None):
+        v = self.values
+        return v.astype(dtype) if dtype is not None else v
+
+
+class ReindexedDataset(minixr.Dataset):
+    """What ``_reindex_spatial_data_to_regions`` returns here: the source arrays plus the cell
+    index of every segment row.  Nothing is copied until ``.values`` of a variable is asked for
+    (then a device gather kernel runs); ``_aggregate_reindexed_data_to_regions`` never
+    materialises it -- the gather is fused into the aggregation kernel."""
+
+    def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray):
+        super().__init__()
+        self._src_values, self._src_dims = src_values, src_dims
+        self._ilat, self._ilon = ilat, ilon
+        self._nseg = len(ilat)
+        self._was_xarray = was_xarray
+        for k, v in coords.items():
+            if k not in ("lat", "lon"):
+                self.coords[k] = v
+        self.coords["lat"] = minixr.DataArray(np.asarray(seg_lat), ("reshape_index",))
+        self.coords["lon"] = minixr.DataArray(np.asarray(seg_lon), ("reshape_index",))
+        for name in src_values:
+            self.data_vars[name] = _ReindexedArray(self, name)
+
+    @property
+    def dims(self):
+        out = {}
+        for name in self._src_values:
+            arr = self.data_vars[name]
+            if isinstance(arr, _ReindexedArray):
+                out.update(zip(arr.dims, arr.shape))
+        for c in self.coords.values():
+            for d, n in zip(c.dims, c.shape):
+                out.setdefault(d, n)
+        return out
+
+    def _cell_index(self, name):
+        dims = self._src_dims[name]
+        shape = dict(zip(dims, self._src_values[name].shape))
+        ia, io, *_ = _spatial_layout(dims)
+        if ia < io:
+            return (self._ilat * shape["lon"] + self._ilon).astype(np.int32), shape["lat"] * shape["lon"]
+        return (self._ilon * shape["lat"] + self._ilat).astype(np.int32), shape["lat"] * shape["lon"]
+
+    def _materialise(self, name):
+        torch = require_gpu()
+        X2, layout, others_shape, unflatten = _flatten_for_device(self._src_values[name], self._src_dims[name])
+        cell, _ = self._cell_index(name)
+        Xd = torch.from_numpy(X2).cuda()
+        ci = torch.from_numpy(np.ascontiguousarray(cell)).cuda()
+        out = _device_gather(Xd, ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
+        return unflatten(out.cpu().numpy(), self._nseg)
+
+
+def _flatten_for_device(values, dims):
+    """(values, dims) -> (2-D C-contiguous array, layout, others_shape, unflatten(result2d, R))."""
+    values = np.asarray(values)
+    if values.dtype not in (np.float32, np.float64):
+        values = values.astype(np.float64)
+    ia, io, first, second, others = _spatial_layout(dims)
+    shape = values.shape
+    G = shape[ia] * shape[io]
+    adjacent = second == first + 1
+    if adjacent and all(i < first for i in others):          # (..., lat, lon): gridcell axis contiguous
+        T = int(np.prod([shape[i] for i in others])) if others else 1
+        X2 = np.ascontiguousarray(values).reshape(T, G)
+        layout = "TG"
+    elif adjacent and all(i > second for i in others):       # (lat, lon, ...): the test fixture
+        T = int(np.prod([shape[i] for i in others])) if others else 1
+        X2 = np.ascontiguousarray(values).reshape(G, T)
+        layout = "GT"
+    else:                                                    # anything else: one host transpose
+        order = others + [first, second]
+        X2 = np.ascontiguousarray(np.transpose(values, order)).reshape(-1, G)
+        layout = "TG"
+    others_shape = tuple(shape[i] for i in others)
+    n_before = sum(1 for i in others if i < first)
+
+    def unflatten(res2d, R):
+        if layout == "TG":
+            arr = res2d.reshape(others_shape + (R,))
+        else:
+            arr = np.moveaxis(res2d.reshape((R,) + others_shape), 0, -1)
+        return np.moveaxis(arr, -1, n_before)
+
+    return X2, layout, others_shape, unflatten
+
+
+def _plan_for(cell_idx, codes, w_eff, G, R, row_len):
+    h = hashlib.blake2b(digest_size=16)
+    for a in (cell_idx, codes, w_eff):
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(repr((int(G), int(R), int(row_len))).encode())
+    key = h.hexdigest()
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
+        _PLAN_CACHE[key] = plan
+        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+            _PLAN_CACHE.popitem(last=False)[1].close()
+    else:
+        _PLAN_CACHE.move_to_end(key)
+    return plan
+
+
+def _extract(ds):
+    """Pull (values, dims) of every data variable and the 1-D coords out of an xarray or minixr
+    Dataset."""
+    if _is_xarray(ds):
+        src_values = {k: v.values for k, v in ds.data_vars.items()}
+        src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
+        coords = {k: minixr.DataArray(v.values, tuple(v.dims)) for k, v in ds.coords.items()}
+        return src_values, src_dims, coords, True
+    src_values = {k: v.values for k, v in ds.data_vars.items()}
+    src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
+    return src_values, src_dims, dict(ds.coords), False
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's functions
+# ----------------------------------------------------------------------------------------------
+def _reindex_spatial_data_to_regions(ds, df):
+    """
+    Reindexes spatial and segment weight data to regions
+    Enables region index-based math operations
+
+    Same contract as aggregations.py:8-32: every segment row ``i`` of ``df`` picks the grid cell
+    with ``lat == df.lat[i]`` and ``lon == df.lon[i]`` (exact match, KeyError otherwise); the new
+    dimension ``reshape_index`` replaces the first of the two indexed dims.  Returns a lazy
+    :class:`ReindexedDataset` (no gathered copy is made).
+    """
+    src_values, src_dims, coords, was_xr = _extract(ds)
+    if "lat" not in coords or "lon" not in coords:
+        raise KeyError("dataset must have 'lat' and 'lon' coordinates (aggregations.py:27)")
+    lat = np.asarray(coords["lat"].values)
+    lon = np.asarray(coords["lon"].values)
+    ilat = _exact_index(lat, df["lat"].values, "lat")
+    ilon = _exact_index(lon, df["lon"].values, "lon")
+    # xarray's vectorised sel indexes EVERY data variable (S9); variables without lat/lon dims
+    # are carried through untouched
+    keep_vals, keep_dims = {}, {}
+    passthrough = {}
+    for k, dims in src_dims.items():
+        if "lat" in dims and "lon" in dims:
+            keep_vals[k], keep_dims[k] = src_values[k], dims
+        else:
+            passthrough[k] = minixr.DataArray(src_values[k], dims)
+    out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, df["lat"].values, df["lon"].values,
+                           was_xr)
+    for k, v in passthrough.items():
+        out.data_vars[k] = v
+    return out
+
+
+def _aggregate_reindexed_data_to_regions(
+    ds, variable, aggwt, agglev, weights, backup_aggwt="areawt"
+):
+    """
+    Performs weighted avg for climate variable by region
+
+    Parameters
+    ----------
+
+    ds: ReindexedDataset (from ``_reindex_spatial_data_to_regions``) or any Dataset that already
+        carries a ``reshape_index`` dimension
+
+    variable: str
+        name of the data variable
+
+    aggwt: str
+        variable to weight by (i.e popwt, areawt, cropwt)
+
+    agglev: str
+        indicates which regional id scheme to select in the dataframe
+
+    weights: pd.DataFrame
+        pandas DataFrame of weights
+
+    backup_aggwt: str, optional
+        aggregation weight to use in regions with no aggwt data (default
+        'areawt')
+
+    Follows aggregations.py:64-82.  ``w_eff = w if w > 0 else backup`` per ROW (:73, S4), regions
+    are the sorted unique labels (:78, S3), ``out = sum(x*w_eff) / sum(w_eff)`` with NaN products
+    counted as 0 (S6) and IEEE division (S7).  Like the reference it also attaches ``agglev``
+    and ``aggwt`` to ``ds`` (:64-71).
+    """
+    w = np.asarray(weights[aggwt].values, dtype=np.float64)
+    backup = np.asarray(weights[backup_aggwt].values, dtype=np.float64)
+    w_eff = np.where(w > 0, w, backup)                                   # :73
+    labels = np.asarray(weights[agglev].values)
+    uniq, codes = _factorize_labels(labels)                              # :78 group keys
+
+    if isinstance(ds, ReindexedDataset) and variable in ds._src_values:
+        values, dims = ds._src_values[variable], ds._src_dims[variable]
+        cell_idx, G = ds._cell_index(variable)
+        if len(cell_idx) != len(w_eff):
+            raise ValueError("weights has %d rows but the dataset was reindexed with %d"
+                             % (len(w_eff), len(cell_idx)))
+        shape = dict(zip(dims, np.asarray(values).shape))
+        ia, io, *_ = _spatial_layout(dims)
+        row_len = shape["lon"] if ia < io else shape["lat"]
+        was_xr = ds._was_xarray
+        carried = {k: v for k, v in ds.coords.items()}
+        # mirror the mutation of :64-71
+        ds.coords[agglev] = minixr.DataArray(labels, ("reshape_index",))
+        ds.data_vars[aggwt] = minixr.DataArray(w_eff, ("reshape_index",), name=aggwt)
+    else:
+        # an already materialised dataset: its reshape_index axis is the "grid"
+        arr = ds[variable]
+        dims = tuple(arr.dims)
+        if "reshape_index" not in dims:
+            raise KeyError("dataset has no 'reshape_index' dimension; call "
+                           "_reindex_spatial_data_to_regions first")
+        values = np.asarray(arr.values)
+        k = dims.index("reshape_index")
+        # present it as (lat=reshape_index, lon=1) so that the same flattening code applies
+        dims = dims[:k] + ("lat", "lon") + dims[k + 1:]
+        values = values.reshape(values.shape[:k] + (values.shape[k], 1) + values.shape[k + 1:])
+        G = values.shape[k]
+        cell_idx = np.arange(G, dtype=np.int32)
+        if G != len(w_eff):
+            raise ValueError("weights has %d rows but reshape_index has %d" % (len(w_eff), G))
+        row_len = 0
+        was_xr = _is_xarray(ds)
+        carried = ({k2: minixr.DataArray(v.values, tuple(v.dims)) for k2, v in ds.coords.items()}
+                   if was_xr else dict(ds.coords))
+
+    torch = require_gpu()
+    X2, layout, _, unflatten = _flatten_for_device(values, dims)
+    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len)
+    Xd = torch.from_numpy(X2).cuda()
+    out_d = plan.apply(Xd, layout=layout, out_layout="TR" if layout == "TG" else "RT")
+    res = unflatten(out_d.cpu().numpy(), len(uniq))
+    rdims = _result_dims(dims, agglev)
+
+    coords = {}
+    for d in rdims:
+        if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+            coords[d] = np.asarray(carried[d].values)
+    coords[agglev] = uniq
+    if was_xr:
+        return _xr.Dataset({variable: (rdims, res)}, coords=coords)
+    return minixr.Dataset({variable: (rdims, res)}, coords={k: ((k,), v) for k, v in coords.items()})
+
+
+def weighted_aggregate_grid_to_regions(ds, variable, aggwt, agglev, weights=None):
+    """
+    Computes the weighted reshape of gridded data
+
+    Parameters
+    ----------
+    ds : xr.Dataset (or minixr.Dataset)
+        Dataset to be aggregated. Must have 'lat' and 'lon' in the
+        coordinates.
+
+    variable : str
+        name of the variable to be aggregated
+
+    aggwt : str
+        Weighting variable (e.g. 'popwt', 'areawt'). This must be a column name
+        in the weights file.
+
+    agglev : str
+        Target regional aggregation level (e.g. 'ISO', 'hierid'). This must be
+        a column name in the weights file.
+
+    weights : pd.DataFrame (or str path to the weights CSV), optional
+        Regional aggregation weights.  As in the reference (aggregations.py:118-119 vs :128)
+        the ``None`` default cannot work -- there is no bundled weights file -- and raises
+        TypeError.
+
+    Returns
+    -------
+    ds: Dataset
+        weighted and averaged dataset based on agglev
+    """
+    if weights is None:
+        weights = prepare_spatial_weights_data()          # TypeError, like the reference
+    elif isinstance(weights, str):
+        weights = prepare_spatial_weights_data(weights)
+
+    ds = _reindex_spatial_data_to_regions(ds, weights)
+    ds = _aggregate_reindexed_data_to_regions(ds, variable, aggwt, agglev, weights)
+
+    return ds
+
+
+@functools.lru_cache(maxsize=None)   # the reference memoises on the path (toolz.memoize, :127)
+def prepare_spatial_weights_data(weights_file):
+    """
+    Rescales the pix_cent_x colum values
+
+    Parameters
+    ----------
+    weights_file: str
+        location of file used for weighting
+
+    Mirrors aggregations.py:141-150: read the CSV, relabel pixel centres at 180.125 to -179.875
+    (:144), name the index ``reshape_index`` (:148), rename ``pix_cent_x/y`` to ``lon/lat``
+    (:150).  The reference's ``drop_duplicates()`` result is discarded (:147), so duplicates are
+    kept here too (they add, S5).
+    """
+    df = pd.read_csv(weights_file)
+    df.loc[df["pix_cent_x"] == 180.125, "pix_cent_x"] = -179.875
+    df.index.names = ["reshape_index"]
+    df.rename(columns={"pix_cent_x": "lon", "pix_cent_y": "lat"}, inplace=True)
+    return df

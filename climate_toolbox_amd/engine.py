@@ -1,0 +1,215 @@
+"""Device-side objects over the C-ABI (include/wagg.h).  torch supplies device memory and streams
+only; every number is produced by the HIP kernels in climate_toolbox_amd/csrc/."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LAYOUT_GT, LAYOUT_TG, OUT_RT, OUT_TR, WaggError
+
+_LAYOUTS = {"TG": LAYOUT_TG, "GT": LAYOUT_GT}
+_OUTS = {"TR": OUT_TR, "RT": OUT_RT}
+
+
+def require_gpu():
+    L = _lib.load()
+    if L.wagg_device_count() < 1:
+        raise WaggError("no HIP device visible: the aggregation engine has no CPU fallback")
+    import torch
+    if not torch.cuda.is_available():
+        raise WaggError("torch sees no GPU (needed for device buffers and streams)")
+    return torch
+
+
+def _stream_handle(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _np_ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _check_X(X, layout):
+    import torch
+    if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dim() == 2):
+        raise TypeError("X must be a 2-D CUDA torch tensor")
+    if X.dtype not in (torch.float32, torch.float64):
+        raise TypeError("X must be float32 or float64, got %s" % X.dtype)
+    if X.stride(1) != 1:
+        raise ValueError("X rows must be contiguous (stride(1) == 1)")
+    if layout not in _LAYOUTS:
+        raise ValueError("layout must be 'TG' or 'GT'")
+    return X
+
+
+class SparsePlan:
+    """Coded segment table -> device plan (wagg_plan_create).  Immutable after construction."""
+
+    def __init__(self, cell_idx, region_code, w_eff, G, R, row_len=0):
+        require_gpu()
+        L = _lib.load()
+        ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
+        rc = np.ascontiguousarray(region_code, dtype=np.int32)
+        we = np.ascontiguousarray(w_eff, dtype=np.float64)
+        if not (ci.shape == rc.shape == we.shape and ci.ndim == 1):
+            raise ValueError("cell_idx, region_code, w_eff must be 1-D and of equal length")
+        self._h = C.c_void_p()
+        self.G, self.R = int(G), int(R)
+        _lib.check(L.wagg_plan_create(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32),
+                                      _np_ptr(we, C.c_double), len(ci), self.G, self.R,
+                                      int(row_len), 0, C.byref(self._h)), "wagg_plan_create")
+        info = _lib.PlanInfo()
+        _lib.check(L.wagg_plan_get_info(self._h, C.byref(info)), "wagg_plan_get_info")
+        self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_ if k != "reserved"}
+        den = np.empty(self.R, dtype=np.float64)
+        _lib.check(L.wagg_plan_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_plan_get_den")
+        self.den = den
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().wagg_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def apply(self, X, layout="TG", out=None, out_layout="TR", stream=None):
+        """out[t, r] on the device; asynchronous on torch's current stream (or `stream`)."""
+        import torch
+        X = _check_X(X, layout)
+        T = X.shape[0] if layout == "TG" else X.shape[1]
+        n_g = X.shape[1] if layout == "TG" else X.shape[0]
+        if n_g != self.G:
+            raise ValueError("X has %d grid cells, plan expects %d" % (n_g, self.G))
+        shape = (T, self.R) if out_layout == "TR" else (self.R, T)
+        if out is None:
+            out = torch.empty(shape, dtype=X.dtype, device=X.device)
+        elif tuple(out.shape) != shape or out.dtype != X.dtype or out.stride(1) != 1:
+            raise ValueError("out must be a %s %s tensor with contiguous rows" % (shape, X.dtype))
+        L = _lib.load()
+        fn = L.wagg_apply_f32 if X.dtype == torch.float32 else L.wagg_apply_f64
+        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, X.stride(0), _LAYOUTS[layout],
+                      C.c_void_p(out.data_ptr()), out.stride(0) if out.numel() else max(1, shape[1]),
+                      _OUTS[out_layout], _stream_handle(stream)), "wagg_apply")
+        return out
+
+    def apply_host(self, X, layout="TG", out_layout="TR"):
+        """Blocking host-buffer form (wagg_apply_host_*): numpy in, numpy out."""
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64) or X.ndim != 2:
+            raise TypeError("X must be a 2-D float32/float64 array")
+        T = X.shape[0] if layout == "TG" else X.shape[1]
+        shape = (T, self.R) if out_layout == "TR" else (self.R, T)
+        out = np.empty(shape, dtype=X.dtype)
+        L = _lib.load()
+        fn = L.wagg_apply_host_f32 if X.dtype == np.float32 else L.wagg_apply_host_f64
+        _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], _LAYOUTS[layout],
+                      C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout]), "wagg_apply_host")
+        return out
+
+
+class DensePlan:
+    """(gridcell x region) fp32 weight matrix resident in HBM + MFMA contraction."""
+
+    def __init__(self, handle, G, R):
+        self._h, self.G, self.R = handle, int(G), int(R)
+        den = np.empty(self.R, dtype=np.float64)
+        _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
+        self.den = den
+
+    @classmethod
+    def synth(cls, G, R, seed):
+        require_gpu()
+        h = C.c_void_p()
+        _lib.check(_lib.load().wagg_dense_create_synth(int(G), int(R), int(seed), C.byref(h)),
+                   "wagg_dense_create_synth")
+        return cls(h, G, R)
+
+    @classmethod
+    def from_host(cls, W):
+        require_gpu()
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        h = C.c_void_p()
+        _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1],
+                                                      C.byref(h)), "wagg_dense_create_host")
+        return cls(h, W.shape[0], W.shape[1])
+
+    @classmethod
+    def from_segments(cls, cell_idx, region_code, w_eff, G, R):
+        require_gpu()
+        ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
+        rc = np.ascontiguousarray(region_code, dtype=np.int32)
+        we = np.ascontiguousarray(w_eff, dtype=np.float64)
+        h = C.c_void_p()
+        _lib.check(_lib.load().wagg_dense_create_from_segments(
+            _np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
+            int(R), C.byref(h)), "wagg_dense_create_from_segments")
+        return cls(h, G, R)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().wagg_dense_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def apply(self, X, out=None, ksplit=0, stream=None):
+        import torch
+        X = _check_X(X, "TG")
+        if X.dtype != torch.float32:
+            raise TypeError("dense path is fp32")
+        if X.shape[1] != self.G:
+            raise ValueError("X has %d grid cells, plan expects %d" % (X.shape[1], self.G))
+        T = X.shape[0]
+        if out is None:
+            out = torch.empty((T, self.R), dtype=torch.float32, device=X.device)
+        _lib.check(_lib.load().wagg_dense_apply_f32(
+            self._h, C.c_void_p(X.data_ptr()), T, X.stride(0), C.c_void_p(out.data_ptr()),
+            out.stride(0), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_f32")
+        return out
+
+
+def gather(X, cell_idx_dev, layout="TG", out_layout="TR", stream=None):
+    """Materialised pointwise gather (aggregations.py:27) on the device."""
+    import torch
+    X = _check_X(X, layout)
+    if not (cell_idx_dev.is_cuda and cell_idx_dev.dtype == torch.int32 and cell_idx_dev.is_contiguous()):
+        raise TypeError("cell_idx_dev must be a contiguous int32 CUDA tensor")
+    T = X.shape[0] if layout == "TG" else X.shape[1]
+    n = cell_idx_dev.numel()
+    shape = (T, n) if out_layout == "TR" else (n, T)
+    out = torch.empty(shape, dtype=X.dtype, device=X.device)
+    L = _lib.load()
+    fn = L.wagg_gather_f32 if X.dtype == torch.float32 else L.wagg_gather_f64
+    _lib.check(fn(C.c_void_p(X.data_ptr()), T, X.stride(0), _LAYOUTS[layout],
+                  C.c_void_p(cell_idx_dev.data_ptr()), n, C.c_void_p(out.data_ptr()), max(1, shape[1]),
+                  _OUTS[out_layout], _stream_handle(stream)), "wagg_gather")
+    return out
+
+
+def synth_field(T, G, seed, base, amp, dtype="float32", device="cuda"):
+    """X[t, g] = base + amp * (hash_u01(t*G + g, seed) - 0.5), generated on the device."""
+    torch = require_gpu()
+    dt = torch.float32 if dtype in ("float32", torch.float32) else torch.float64
+    X = torch.empty((T, G), dtype=dt, device=device)
+    L = _lib.load()
+    fn = L.wagg_synth_field_f32 if dt == torch.float32 else L.wagg_synth_field_f64
+    _lib.check(fn(C.c_void_p(X.data_ptr()), T, G, G, int(seed), base, amp, _stream_handle(None)),
+               "wagg_synth_field")
+    return X
+
+
+def profile_enable(on=True):
+    """Record HIP event pairs around the dominant kernel of every following apply."""
+    _lib.check(_lib.load().wagg_profile_enable(1 if on else 0), "wagg_profile_enable")
+
+
+def profile_read():
+    """Durations (ms) of the dominant kernels recorded since profile_enable(); blocks."""
+    buf = (C.c_float * 256)()
+    n = C.c_int(0)
+    _lib.check(_lib.load().wagg_profile_read(buf, 256, C.byref(n)), "wagg_profile_read")
+    return [float(buf[i]) for i in range(n.value)]

@@ -1,0 +1,140 @@
+/* wagg.h -- C-ABI of the MI355X (gfx950) weighted grid->region aggregation engine (libwagg.so).
+ *
+ * This is the drop-in boundary for ONE path of ClimateImpactLab/climate_toolbox:
+ *
+ *   climate_toolbox/aggregations/aggregations.py
+ *     :8-32    _reindex_spatial_data_to_regions      (pointwise gather, live branch :24-27)
+ *     :35-84   _aggregate_reindexed_data_to_regions  (backup fill :73, grouped sums :78-79, divide)
+ *     :87-124  weighted_aggregate_grid_to_regions    (:121-122 = the two above)
+ *
+ * The reference has no FFI; these entry points are what a ctypes binding placed at
+ * aggregations.py:121-122 would call (INTEGRATION.md shows that binding).  Everything the
+ * reference does with float LABELS (exact lat/lon match :27, backup fill :73, sorted unique
+ * region labels :78) is resolved on the host, in fp64, BEFORE this boundary; what crosses it is
+ * the coded segment table (cell_idx, region_code, w_eff) and plain device/host pointers.
+ *
+ * Conventions: every function returns 0 (WAGG_OK) or a negative wagg_status; nothing throws,
+ * nothing calls exit(); wagg_last_error() gives the thread-local message of the last failure.
+ * Plans are immutable after creation: concurrent wagg_apply_* on distinct streams is allowed,
+ * create/destroy must not race with apply.  "_dev" pointers are HIP device pointers on the
+ * current device; stream is a hipStream_t passed as void* (NULL = the null stream).
+ * wagg_apply_* on device pointers is asynchronous on `stream`; the *_host_* forms block.
+ */
+#ifndef WAGG_H
+#define WAGG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum wagg_status {
+    WAGG_OK = 0,
+    WAGG_EINVAL = -1,  /* bad argument (shape, index out of range, null pointer) */
+    WAGG_EHIP = -2,    /* a HIP runtime call failed; see wagg_last_error() */
+    WAGG_ENOMEM = -3,  /* host or device allocation failed */
+    WAGG_ENODEV = -4,  /* no gfx950 device visible */
+    WAGG_EUNSUPPORTED = -5
+} wagg_status;
+
+/* memory layout of the flattened data matrix X and of the result */
+#define WAGG_LAYOUT_TG 0 /* X[t*ldx + g]  -- (time, lat, lon) files: gridcell axis contiguous   */
+#define WAGG_LAYOUT_GT 1 /* X[g*ldx + t]  -- (lat, lon, time) test fixture: time axis contiguous */
+#define WAGG_OUT_TR 0    /* out[t*ldo + r]  (S10: (time, region)) */
+#define WAGG_OUT_RT 1    /* out[r*ldo + t]  (S10 for the fixture layout: (region, time)) */
+
+typedef struct wagg_plan wagg_plan;   /* sparse: coded segment table, region-grouped gather form */
+typedef struct wagg_dense wagg_dense; /* dense (gridcell x region) fp32 weight matrix in HBM      */
+
+typedef struct wagg_plan_info {
+    int64_t nseg_in;     /* rows handed to wagg_plan_create                                      */
+    int64_t nnz;         /* coalesced (cell, region) pairs kept (null label / NaN weight dropped) */
+    int64_t n_groups;    /* region groups (one workgroup walks one group per time block)        */
+    int64_t n_chunks;    /* LDS gather chunks (<= 256 unique cells each)                         */
+    int64_t n_ucells;    /* sum over chunks of unique cells gathered per timestep                */
+    int64_t n_giant;     /* regions with more unique cells than one chunk                       */
+    int64_t n_empty;     /* regions with no kept segment (result 0/den)                          */
+    int64_t G;
+    int32_t R;
+    int32_t reserved;
+} wagg_plan_info;
+
+/* ---- process / device ------------------------------------------------------------------- */
+int wagg_version(void);                 /* 10000*major + 100*minor + patch */
+int wagg_device_count(void);            /* number of visible HIP devices (0 if none), never <0  */
+const char *wagg_last_error(void);      /* thread-local, never NULL                              */
+
+/* ---- in-library kernel timing (HIP events on the stream the kernel is launched on) ----------- */
+/* While enabled, every apply records an event pair around its DOMINANT kernel (sparse: the
+ * gather kernel; dense: the MFMA kernel) into a ring of WAGG_PROFILE_SLOTS pairs, without any
+ * synchronisation.  wagg_profile_read blocks until the recorded kernels have finished and
+ * returns their durations in milliseconds, oldest first.                                       */
+#define WAGG_PROFILE_SLOTS 256
+int wagg_profile_enable(int on);        /* also resets the ring */
+int wagg_profile_read(float *ms_out, int max_out, int *n_out);
+
+/* ---- sparse plan: replaces aggregations.py:24-27 + :64-71 (gather index, labels, weights) --- */
+/* cell_idx[i]    flat grid cell of segment row i  = ilat*nlon + ilon            (0 <= . < G)
+ * region_code[i] rank of the row's label among the sorted unique labels, -1 = null label (S3)
+ * w_eff[i]       fp64 weight after the per-row backup fill of :73; NaN rows leave both sums
+ * row_len        cells per grid row (nlon); only a locality hint for grouping, 0 = unknown
+ * Host pointers; copied.  Duplicate (cell, region) rows add (S5).                              */
+int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
+                     int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
+                     wagg_plan **out);
+int wagg_plan_destroy(wagg_plan *plan);
+int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info);
+int wagg_plan_get_den(const wagg_plan *plan, double *den_host /* R values */); /* :79 */
+
+/* ---- apply: replaces aggregations.py:78-80 (and the gather of :27, fused) ------------------ */
+/* out[t, r] = sum_i X[t, cell_i] * w_i / den[r]; NaN products count as 0 (skipna, S6); den == 0
+ * gives IEEE NaN/inf (S7).  f32 accumulates in fp32 (declared deviation from S8, 1e-4 rel),
+ * f64 in fp64 (1e-6 rel).  T may be any size >= 0.                                             */
+int wagg_apply_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
+                   float *out_dev, int64_t ldo, int out_layout, void *stream);
+int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
+                   double *out_dev, int64_t ldo, int out_layout, void *stream);
+/* blocking convenience forms on host buffers (hipMalloc + H2D + apply + D2H inside) */
+int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
+                        int layout, float *out_host, int64_t ldo, int out_layout);
+int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
+                        int layout, double *out_host, int64_t ldo, int out_layout);
+
+/* ---- materialised gather: what _reindex_spatial_data_to_regions returns (:27) -------------- */
+/* out[t, i] = X[t, cell_idx[i]] in out_layout (WAGG_OUT_TR: out[t*ldo+i], RT: out[i*ldo+t]).   */
+int wagg_gather_f32(const float *X_dev, int64_t T, int64_t ldx, int layout,
+                    const int32_t *cell_idx_dev, int64_t nseg, float *out_dev, int64_t ldo,
+                    int out_layout, void *stream);
+int wagg_gather_f64(const double *X_dev, int64_t T, int64_t ldx, int layout,
+                    const int32_t *cell_idx_dev, int64_t nseg, double *out_dev, int64_t ldo,
+                    int out_layout, void *stream);
+
+/* ---- dense weights: W[g, r] as an fp32 matrix resident in HBM, MFMA contraction ------------- */
+/* synth: W[g,r] = hash_u01(g*R + r, seed) in [0,1), generated on device (never on host); this is
+ * the c2-dense benchmark operand (1,036,800 x 24,378 = 101 GB).                                */
+int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out);
+/* from a host row-major (G, R) fp32 matrix (small cases / tests) */
+int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
+/* from a sparse plan's coded table, densified on device (weights that are not very sparse)    */
+int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
+                                    const double *w_eff, int64_t nseg, int64_t G, int32_t R,
+                                    wagg_dense **out);
+int wagg_dense_destroy(wagg_dense *d);
+int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
+/* out[t, r] = sum_g nan0(X[t,g]) * W[g,r] / den[r], fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * ksplit = 0 picks the k-slice count; otherwise a multiple of 8.                               */
+int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
+                         float *out_dev, int64_t ldo, int ksplit, void *stream);
+
+/* ---- synthetic data generators (device side, shared with the CPU oracle bit for bit) ------- */
+/* X[t*ldx + g] = base + amp * (hash_u01(t*G + g, seed) - 0.5)                                   */
+int wagg_synth_field_f32(float *X_dev, int64_t T, int64_t G, int64_t ldx, uint32_t seed,
+                         float base, float amp, void *stream);
+int wagg_synth_field_f64(double *X_dev, int64_t T, int64_t G, int64_t ldx, uint32_t seed,
+                         double base, double amp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAGG_H */

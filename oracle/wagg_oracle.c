@@ -1,0 +1,118 @@
+/* CPU oracle (plain C) for the weighted grid->region aggregation path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (climate_toolbox_amd/, include/wagg.h) never links or calls it.
+ *
+ * It restates, on the coded segment table that crosses the C-ABI, the arithmetic of
+ *   /root/reference/climate_toolbox/aggregations/aggregations.py
+ *     :24-27  gather of the grid cells listed in the segment table
+ *     :78     (ds[variable] * ds[aggwt]).groupby(agglev).sum(dim="reshape_index")   (fp64, skipna)
+ *     :79     ds[aggwt].groupby(agglev).sum(dim="reshape_index")
+ *     :77-80  numerator / denominator (IEEE division, no guard)
+ * Label resolution (:27 exact match), backup fill (:73) and label factorisation happen on the
+ * host before this point, exactly as for the HIP engine (see oracle/ref_numpy.py for those).
+ * Parity status: see the header of oracle/ref_numpy.py ("pinned by restatement agreement").
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define WAGG_LAYOUT_TG 0 /* X[t*ldx + g] */
+#define WAGG_LAYOUT_GT 1 /* X[g*ldx + t] */
+
+int wagg_oracle_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* Faithful, single-threaded like the reference: per timestep gather -> multiply -> group-sum.
+ * out is (T, R) row-major double.  Returns 0, or -1 on a bad index. */
+#define DEFINE_SEGMENTS(NAME, TYPE)                                                              \
+    int NAME(const TYPE *X, int64_t T, int64_t ldx, int layout, const int32_t *cell_idx,          \
+             const int32_t *region_code, const double *w_eff, int64_t nseg, int64_t G, int32_t R, \
+             double *out) {                                                                       \
+        double *den = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));                  \
+        if (!den) return -2;                                                                      \
+        for (int64_t i = 0; i < nseg; ++i) {                                                      \
+            int32_t r = region_code[i];                                                           \
+            if (r < 0) continue;                       /* null label: row dropped (S3) */         \
+            if (r >= R || cell_idx[i] < 0 || cell_idx[i] >= G) { free(den); return -1; }          \
+            if (!isnan(w_eff[i])) den[r] += w_eff[i];  /* :79, skipna */                          \
+        }                                                                                         \
+        for (int64_t t = 0; t < T; ++t) {                                                         \
+            double *row = out + t * (int64_t)R;                                                   \
+            for (int32_t r = 0; r < R; ++r) row[r] = 0.0;                                         \
+            for (int64_t i = 0; i < nseg; ++i) {                                                  \
+                int32_t r = region_code[i];                                                       \
+                if (r < 0) continue;                                                              \
+                int64_t g = cell_idx[i];                                                          \
+                double x = (double)(layout == WAGG_LAYOUT_TG ? X[t * ldx + g] : X[g * ldx + t]);  \
+                double p = x * w_eff[i];               /* :78 fp64 product (S8) */                \
+                if (!isnan(p)) row[r] += p;            /* skipna (S6) */                          \
+            }                                                                                     \
+            for (int32_t r = 0; r < R; ++r) row[r] = row[r] / den[r]; /* :77-80 (S7) */           \
+        }                                                                                         \
+        free(den);                                                                                \
+        return 0;                                                                                 \
+    }
+
+DEFINE_SEGMENTS(wagg_oracle_segments_f32, float)
+DEFINE_SEGMENTS(wagg_oracle_segments_f64, double)
+
+/* counter hash shared with the device generator (climate_toolbox_amd/csrc/wagg_synth.hip) */
+static inline uint32_t hash32(uint64_t idx, uint32_t seed) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t x = lo ^ (hi * 0x85EBCA6Bu) ^ (seed * 0x9E3779B9u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+float wagg_oracle_hash_u01(uint64_t idx, uint32_t seed) {
+    return (float)(hash32(idx, seed) >> 8) * (1.0f / 16777216.0f);
+}
+
+/* Dense form (X . W) / (1^T W) with W[g,r] = hash_u01(g*R_total + r0 + r, seed) generated on the
+ * fly for the column window [r0, r0+Rw) and the row window [g0, g0+Gw) -- the CPU comparator of
+ * the c2-dense workload on a bounded sample.  fp32 inputs, fp64 accumulation, threads = OpenMP.
+ * X is (T, ldx) with the Gw cells of the window at columns g0.. ; out is (T, Rw) double. */
+int wagg_oracle_dense_synth_f32(const float *X, int64_t T, int64_t ldx, int64_t g0, int64_t Gw,
+                                int64_t R_total, int64_t r0, int64_t Rw, uint32_t seed,
+                                double *out) {
+    double *den = (double *)calloc((size_t)Rw, sizeof(double));
+    if (!den) return -2;
+    memset(out, 0, sizeof(double) * (size_t)T * (size_t)Rw);
+    enum { GB = 64 };
+    float *wblk = (float *)malloc(sizeof(float) * GB * (size_t)Rw);
+    if (!wblk) { free(den); return -2; }
+    for (int64_t gb = 0; gb < Gw; gb += GB) {
+        int64_t gn = Gw - gb < GB ? Gw - gb : GB;
+#pragma omp parallel for schedule(static)
+        for (int64_t gi = 0; gi < gn; ++gi)
+            for (int64_t r = 0; r < Rw; ++r)
+                wblk[gi * Rw + r] =
+                    wagg_oracle_hash_u01((uint64_t)(g0 + gb + gi) * (uint64_t)R_total + (uint64_t)(r0 + r), seed);
+        for (int64_t gi = 0; gi < gn; ++gi)
+            for (int64_t r = 0; r < Rw; ++r) den[r] += (double)wblk[gi * Rw + r];
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < T; ++t) {
+            double *row = out + t * Rw;
+            for (int64_t gi = 0; gi < gn; ++gi) {
+                float xf = X[t * ldx + g0 + gb + gi];
+                double x = isnan(xf) ? 0.0 : (double)xf;   /* S6 */
+                const float *wr = wblk + gi * Rw;
+                for (int64_t r = 0; r < Rw; ++r) row[r] += x * (double)wr[r];
+            }
+        }
+    }
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t r = 0; r < Rw; ++r) out[t * Rw + r] /= den[r];
+    free(wblk);
+    free(den);
+    return 0;
+}

@@ -1,0 +1,270 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every comparison goes through the C-ABI
+(libwagg.so); the oracle is only the checker.  Tolerances: fp64 1e-6 relative, fp32 1e-4
+relative (BASELINE.json north_star), written next to each assertion."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL64, RTOL32 = 1e-6, 1e-4
+
+
+def _rel_ok(got, ref, rtol, scale=None):
+    """|got - ref| <= rtol * max(|ref|, scale) per region-timestep; NaN/inf must match exactly."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape
+    fin = np.isfinite(ref)
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)])
+    s = np.abs(ref[fin]) if scale is None else np.maximum(np.abs(ref[fin]), scale)
+    err = np.abs(got[fin] - ref[fin])
+    bad = err > rtol * s + 1e-300
+    assert not bad.any(), "max rel err %.3e at %d of %d" % ((err / np.maximum(s, 1e-300)).max(), bad.sum(), bad.size)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def _mk_ds(fx):
+    from climate_toolbox_amd import minixr
+    return minixr.Dataset({"temperature": (["lat", "lon", "time"], fx["temp"])},
+                          coords={"lon": fx["lon"], "lat": fx["lat"], "time": np.arange(10)})
+
+
+def _mk_weights(fx):
+    df = pd.DataFrame({"lat": fx["seg_lat"], "lon": fx["seg_lon"], "areawt": fx["areawt"],
+                       "popwt": fx["popwt"], "hierid": fx["hierid"], "ISO": fx["ISO"]})
+    df.index.names = ["reshape_index"]
+    return df
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own tests, replayed through the drop-in (tests/test_climate_toolbox.py:109-135)
+# ---------------------------------------------------------------------------------------------
+def test_reference_test_reindex_spatial_weights(ref_fixture, torch_cuda):
+    from climate_toolbox_amd import _reindex_spatial_data_to_regions
+    fx, _ = ref_fixture
+    clim_data, weights = _mk_ds(fx), _mk_weights(fx)
+    assert not clim_data.temperature.isnull().any()
+    ds = _reindex_spatial_data_to_regions(clim_data, weights)
+    assert ds.temperature.shape == (len(ds["lon"]), len(ds["time"]))
+    assert "reshape_index" in ds.dims
+    # the materialised gather equals numpy pointwise indexing (bit exact: it is a copy)
+    ilat = np.searchsorted(fx["lat"], fx["seg_lat"])
+    ilon = np.searchsorted(fx["lon"], fx["seg_lon"])
+    np.testing.assert_array_equal(ds.temperature.values, fx["temp"][ilat, ilon, :])
+
+
+def test_reference_test_weighting(ref_fixture, torch_cuda):
+    from climate_toolbox_amd import _aggregate_reindexed_data_to_regions, _reindex_spatial_data_to_regions
+    fx, gold = ref_fixture
+    clim_data, weights = _mk_ds(fx), _mk_weights(fx)
+    assert np.isnan(weights["popwt"].values).any()
+    ds = _reindex_spatial_data_to_regions(clim_data, weights)
+    assert not ds.temperature.isnull().any()
+    for wname in ("popwt", "areawt"):
+        wtd = _aggregate_reindexed_data_to_regions(ds, "temperature", wname, "ISO", weights)
+        assert not wtd.temperature.isnull().any()
+        assert wtd.temperature.dims == ("ISO", "time")                       # S10
+        np.testing.assert_array_equal(wtd["ISO"].values, gold["labels_ISO"])  # S3
+        _rel_ok(wtd.temperature.values, gold["expect_%s_ISO" % wname], RTOL64)  # fp64 data -> 1e-6
+
+
+@pytest.mark.parametrize("wname", ["popwt", "areawt"])
+@pytest.mark.parametrize("lname", ["ISO", "hierid"])
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, RTOL64), (np.float32, RTOL32)])
+def test_weighted_aggregate_grid_to_regions_fixture(ref_fixture, torch_cuda, wname, lname, dtype, rtol):
+    from climate_toolbox_amd import minixr, weighted_aggregate_grid_to_regions
+    fx, gold = ref_fixture
+    ds = minixr.Dataset({"temperature": (["lat", "lon", "time"], fx["temp"].astype(dtype))},
+                        coords={"lon": fx["lon"], "lat": fx["lat"], "time": np.arange(10)})
+    out = weighted_aggregate_grid_to_regions(ds, "temperature", wname, lname, _mk_weights(fx))
+    assert out.temperature.dims == (lname, "time")
+    _rel_ok(out.temperature.values, gold["expect_%s_%s" % (wname, lname)], rtol)
+    # (time, lat, lon) files: same numbers, (time, region) order
+    ds2 = minixr.Dataset({"temperature": (["time", "lat", "lon"],
+                                          np.ascontiguousarray(np.moveaxis(fx["temp"], -1, 0)).astype(dtype))},
+                         coords={"lon": fx["lon"], "lat": fx["lat"], "time": np.arange(10)})
+    out2 = weighted_aggregate_grid_to_regions(ds2, "temperature", wname, lname, _mk_weights(fx))
+    assert out2.temperature.dims == ("time", lname)
+    _rel_ok(out2.temperature.values.T, gold["expect_%s_%s" % (wname, lname)], rtol)
+
+
+def test_known_answers_through_dropin(golden_dir, torch_cuda):
+    from climate_toolbox_amd import minixr, weighted_aggregate_grid_to_regions
+    k = np.load(os.path.join(golden_dir, "kat_small.npz"), allow_pickle=False)
+    lab = np.array([None if n else str(s) for s, n in zip(k["lab"], k["lab_null"])], dtype=object)
+    df = pd.DataFrame({"lat": k["seg_lat"], "lon": k["seg_lon"], "areawt": k["areawt"],
+                       "popwt": k["popwt"], "lab": lab})
+    ds = minixr.Dataset({"v": (("time", "lat", "lon"), k["X"])}, coords={"lat": k["lat"], "lon": k["lon"]})
+    for wname in ("areawt", "popwt"):
+        out = weighted_aggregate_grid_to_regions(ds, "v", wname, "lab", df)
+        assert list(out["lab"].values) == list(k["labels"])
+        _rel_ok(out.v.values, k["expect_%s" % wname], 1e-14)       # tiny sums: exact to rounding
+    bad = df.copy()
+    bad.loc[0, "lon"] = 105.0
+    with pytest.raises(KeyError):                                   # S1
+        weighted_aggregate_grid_to_regions(ds, "v", "areawt", "lab", bad)
+
+
+# ---------------------------------------------------------------------------------------------
+# coded-table cases straight on the C-ABI objects
+# ---------------------------------------------------------------------------------------------
+def _random_case(rng, T, G, R, nseg, giant=0, row_len=0):
+    cell = rng.integers(0, G, nseg)
+    code = rng.integers(0, R, nseg)
+    if giant:                      # a few regions covering thousands of cells (multi-chunk path)
+        for r in range(giant):
+            n = int(rng.integers(300, 3000))
+            start = int(rng.integers(0, G - n))
+            cell = np.concatenate([cell, np.arange(start, start + n)])
+            code = np.concatenate([code, np.full(n, r)])
+    w = rng.uniform(0.05, 3.0, len(cell))
+    X = 250.0 + 50.0 * rng.standard_normal((T, G))
+    return X, cell.astype(np.int32), code.astype(np.int32), w
+
+
+@pytest.mark.parametrize("T,G,R,nseg,giant", [(1, 50, 3, 40, 0), (10, 1000, 37, 3000, 0),
+                                              (64, 5000, 200, 20000, 2), (65, 5000, 200, 20000, 1),
+                                              (130, 20000, 50, 5000, 3), (33, 300, 1, 299, 0)])
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, RTOL64), (np.float32, RTOL32)])
+def test_sparse_random_cases(torch_cuda, T, G, R, nseg, giant, dtype, rtol):
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import c_oracle, ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(T * 1000 + G + nseg + giant)
+    X, cell, code, w = _random_case(rng, T, G, R, nseg, giant)
+    X = X.astype(dtype)
+    X[rng.integers(0, T), rng.integers(0, G)] = np.nan            # S6
+    ref = O.agg_coded(X, cell, code, w, R)
+    np.testing.assert_allclose(c_oracle.segments(X, cell, code, w, R), ref, rtol=1e-11)   # oracle vs oracle
+    plan = SparsePlan(cell, code, w, G, R, row_len=100)
+    assert plan.info["n_giant"] >= giant - 0 if giant else True
+    np.testing.assert_allclose(plan.den, np.bincount(code, weights=w, minlength=R), rtol=1e-13)
+    Xd = torch.from_numpy(X).cuda()
+    got = plan.apply(Xd).cpu().numpy()
+    _rel_ok(got, ref, rtol, scale=1.0)
+    got_rt = plan.apply(Xd, out_layout="RT").cpu().numpy()
+    np.testing.assert_array_equal(got_rt.T, got)                  # same kernel arithmetic, bitwise
+    Xgt = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    got_gt = plan.apply(Xgt, layout="GT").cpu().numpy()
+    np.testing.assert_array_equal(got_gt, got)
+    again = plan.apply(Xd).cpu().numpy()
+    np.testing.assert_array_equal(again, got)                     # no atomics: reproducible
+    host = plan.apply_host(X)                                     # blocking host-buffer ABI form
+    np.testing.assert_array_equal(host, got)
+
+
+def test_sparse_edge_semantics(torch_cuda):
+    """S3-S7 on the device: null labels, NaN/zero/negative weights after the backup fill, NaN and
+    inf data, zero denominators, regions without any kept row, duplicate rows."""
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    G, R = 12, 7
+    X = np.arange(3 * G, dtype=np.float64).reshape(3, G) + 1.0
+    X[1, 2] = np.nan
+    X[2, 5] = np.inf
+    cell = np.array([0, 1, 2, 2, 3, 4, 5, 5, 6, 7, 8, 9, 9], dtype=np.int32)
+    code = np.array([0, 0, 1, 1, -1, 2, 3, 3, 4, 4, 5, 6, 6], dtype=np.int32)
+    w = np.array([1.0, 2.0, 0.5, 0.5, 9.0, np.nan, 0.0, 2.0, 1.0, -1.0, -2.0, 0.0, 0.0])
+    ref = O.agg_coded(X, cell, code, w, R)
+    for dtype, rtol in ((np.float64, 1e-14), (np.float32, 1e-6)):
+        plan = SparsePlan(cell, code, w, G, R)
+        got = plan.apply(torch.from_numpy(X.astype(dtype)).cuda()).cpu().numpy()
+        _rel_ok(got, ref, rtol)
+    assert np.isnan(ref[:, 2]).all()          # only a NaN-weight row: 0/0 (region without kept row)
+    assert ref[1, 1] == 0.0                   # all-NaN data region -> 0/den = 0   (S6)
+    assert np.isposinf(ref[2, 3])             # inf*0 is a NaN product -> skipped; inf*2/2 = inf
+    assert np.isneginf(ref[:, 4]).all()       # 1 + (-1) = 0 denominator, negative numerator (S7)
+    assert (ref[:, 5] > 0).all()              # negative weight alone: (-2x)/(-2) = x
+    assert np.isnan(ref[:, 6]).all()          # zero weights: 0/0
+
+
+def test_empty_and_degenerate(torch_cuda):
+    from climate_toolbox_amd.engine import SparsePlan
+    torch = torch_cuda
+    plan = SparsePlan(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), 10, 3)
+    out = plan.apply(torch.ones((4, 10), dtype=torch.float32, device="cuda")).cpu().numpy()
+    assert out.shape == (4, 3) and np.isnan(out).all()             # every region empty: 0/0
+    out0 = plan.apply(torch.ones((0, 10), dtype=torch.float64, device="cuda"))
+    assert tuple(out0.shape) == (0, 3)
+    with pytest.raises(Exception):
+        SparsePlan(np.array([11], np.int32), np.array([0], np.int32), np.ones(1), 10, 3)   # cell out of range
+    with pytest.raises(Exception):
+        SparsePlan(np.array([1], np.int32), np.array([3], np.int32), np.ones(1), 10, 3)    # code out of range
+
+
+def test_c1_full(torch_cuda):
+    """BASELINE.json configs[0]: 1-year daily, 2-degree grid, 100 regions, fp64, area- and pop-weighted."""
+    from climate_toolbox_amd import minixr, weighted_aggregate_grid_to_regions, synth
+    from oracle import ref_numpy as O
+    lat, lon, tas, df = synth.c1_workload(T=365)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"lat": lat, "lon": lon})
+    for wname in ("areawt", "popwt"):
+        ref, dims, labs = O.agg_scatter(tas, ("time", "lat", "lon"), lat, lon, df["lat"].values,
+                                        df["lon"].values, df[wname].values, df["areawt"].values,
+                                        df["hierid"].values, group_dim="hierid")
+        out = weighted_aggregate_grid_to_regions(ds, "tas", wname, "hierid", df)
+        assert out.tas.dims == dims and list(out["hierid"].values) == list(labs)
+        _rel_ok(out.tas.values, ref, RTOL64)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense path
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,G,R", [(5, 64, 7), (365, 1000, 130), (368, 4099, 257), (400, 777, 129)])
+def test_dense_small_vs_oracle(torch_cuda, T, G, R):
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(T + G + R)
+    W = rng.uniform(0, 1, (G, R)).astype(np.float32)
+    X = (250 + 50 * rng.standard_normal((T, G))).astype(np.float32)
+    X[rng.integers(0, T), rng.integers(0, G)] = np.nan
+    ref = O.agg_dense(X, W)
+    plan = DensePlan.from_host(W)
+    np.testing.assert_allclose(plan.den, W.astype(np.float64).sum(0), rtol=1e-12)
+    for ks in (0, 8, 16):
+        got = plan.apply(torch.from_numpy(X).cuda(), ksplit=ks).cpu().numpy()
+        _rel_ok(got, ref, RTOL32)
+    # A = I check with an asymmetric B: catches a transposed C/D fragment map
+    if T <= G:
+        Xi = np.zeros((T, G), dtype=np.float32)
+        Xi[np.arange(T), np.arange(T)] = 1.0
+        goti = plan.apply(torch.from_numpy(Xi).cuda()).cpu().numpy()
+        _rel_ok(goti, W[:T].astype(np.float64) / W.astype(np.float64).sum(0)[None, :], 1e-6)
+
+
+def test_dense_synth_matches_oracle_hash(torch_cuda):
+    from climate_toolbox_amd.engine import DensePlan, synth_field
+    from oracle import c_oracle, ref_numpy as O
+    torch = torch_cuda
+    G, R, seed = 3000, 300, 2
+    plan = DensePlan.synth(G, R, seed)
+    W = O.dense_weights_oracle(G, R, seed)
+    np.testing.assert_allclose(plan.den, W.astype(np.float64).sum(0), rtol=1e-12)
+    X = synth_field(40, G, 7, 280.0, 60.0)
+    Xh = X.cpu().numpy()
+    idx = (np.arange(40)[:, None] * G + np.arange(G)[None, :]).astype(np.uint64)
+    np.testing.assert_array_equal(Xh, (np.float32(280.0) + np.float32(60.0) * (O.hash_u01(idx, 7) - np.float32(0.5))))
+    got = plan.apply(X).cpu().numpy()
+    _rel_ok(got, c_oracle.dense_synth(Xh, 0, G, R, 0, R, seed), RTOL32)
+
+
+def test_dense_from_segments_equals_sparse(torch_cuda):
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    X, cell, code, w = _random_case(rng, 40, 2000, 60, 8000)
+    Xd = torch.from_numpy(X.astype(np.float32)).cuda()
+    a = SparsePlan(cell, code, w, 2000, 60).apply(Xd).cpu().numpy()
+    b = DensePlan.from_segments(cell, code, w, 2000, 60).apply(Xd).cpu().numpy()
+    _rel_ok(b, a, 2e-4, scale=1.0)

@@ -1,0 +1,130 @@
+"""Host-side logic of the drop-in (label lookup, backup fill inputs, factorisation, layout
+bookkeeping, weights CSV preparation) -- everything that runs before the C-ABI.  CPU only."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from climate_toolbox_amd import aggregations as A, minixr
+from climate_toolbox_amd._lib import WaggError
+
+
+def test_exact_index_is_exact_and_raises_keyerror():
+    lat = np.arange(-89.875, 90, 2)
+    np.testing.assert_array_equal(A._exact_index(lat, [lat[3], lat[0]], "lat"), [3, 0])
+    with pytest.raises(KeyError):
+        A._exact_index(lat, [lat[3] + 1e-9], "lat")          # S1: no tolerance, no nearest
+    with pytest.raises(KeyError):
+        A._exact_index(lat, [np.nan], "lat")
+
+
+def test_factorize_labels_sorted_unique_and_nulls():
+    u, c = A._factorize_labels(np.array([3, 1, 3, 2]))
+    assert list(u) == [1, 2, 3] and list(c) == [2, 0, 2, 1]
+    u, c = A._factorize_labels(np.array(["b", None, "a", "b", np.nan], dtype=object))
+    assert list(u) == ["a", "b"] and list(c) == [1, -1, 0, 1, -1]   # S3
+    u, c = A._factorize_labels(np.array([2.0, np.nan, 1.0]))
+    assert list(u) == [1.0, 2.0] and list(c) == [1, -1, 0]
+    u, c = A._factorize_labels(np.array(["USA.10", "USA.2", "CAN.1"], dtype=object))
+    assert list(u) == ["CAN.1", "USA.10", "USA.2"]                    # plain string sort
+
+
+@pytest.mark.parametrize("dims,exp", [
+    (("time", "lat", "lon"), ("time", "g")), (("lat", "lon", "time"), ("g", "time")),
+    (("lon", "lat", "time"), ("g", "time")), (("ens", "time", "lat", "lon"), ("ens", "time", "g")),
+    (("lat", "time", "lon"), ("g", "time")), (("time", "lat", "lon", "ens"), ("time", "g", "ens"))])
+def test_result_dims_S10(dims, exp):
+    assert A._result_dims(dims, "g") == exp
+
+
+def test_result_dims_needs_lat_lon_names():
+    with pytest.raises(KeyError):                                   # S2: names are literal
+        A._result_dims(("time", "latitude", "longitude"), "g")
+
+
+@pytest.mark.parametrize("dims", [("time", "lat", "lon"), ("lat", "lon", "time"), ("lon", "lat", "time"),
+                                  ("ens", "time", "lat", "lon"), ("lat", "time", "lon"),
+                                  ("time", "lat", "lon", "ens"), ("lat", "lon")])
+def test_flatten_unflatten_roundtrip(dims):
+    """The (T x G)/(G x T) flattening must address cell (ilat, ilon) where _cell_index says."""
+    sizes = {"time": 3, "lat": 4, "lon": 5, "ens": 2}
+    shape = tuple(sizes[d] for d in dims)
+    vals = np.random.default_rng(0).random(shape)
+    X2, layout, _, unflatten = A._flatten_for_device(vals, dims)
+    ia, io = dims.index("lat"), dims.index("lon")
+    ilat, ilon = np.array([1, 3, 0]), np.array([4, 0, 2])
+    cell = ilat * sizes["lon"] + ilon if ia < io else ilon * sizes["lat"] + ilat
+    picked = X2[:, cell] if layout == "TG" else X2[cell, :].T           # (T, 3)
+    idx = [slice(None)] * len(dims)
+    idx[ia], idx[io] = ilat, ilon
+    expect = vals[tuple(idx)]                                           # numpy pointwise gather
+    # numpy puts the broadcast axis first when the advanced indices are separated; normalise
+    first = min(ia, io)
+    adjacent = abs(ia - io) == 1
+    expect = np.moveaxis(expect, first if adjacent else 0, -1).reshape(-1, 3)
+    np.testing.assert_array_equal(picked, expect)
+    res = picked if layout == "TG" else picked.T
+    back = unflatten(np.ascontiguousarray(res), 3)
+    rd = A._result_dims(dims, "g")
+    assert back.shape == tuple(3 if d == "g" else sizes[d] for d in rd)
+    np.testing.assert_array_equal(np.moveaxis(back, rd.index("g"), -1).reshape(-1, 3), expect)
+
+
+def test_prepare_spatial_weights_data(tmp_path):
+    p = tmp_path / "w.csv"
+    pd.DataFrame({"pix_cent_x": [180.125, 10.125, 180.125], "pix_cent_y": [1.0, 2.0, 1.0],
+                  "areawt": [1.0, 2.0, 1.0], "hierid": ["a", "b", "a"]}).to_csv(p, index=False)
+    df = A.prepare_spatial_weights_data(str(p))
+    assert list(df["lon"]) == [-179.875, 10.125, -179.875]            # aggregations.py:144
+    assert "lat" in df.columns and "pix_cent_x" not in df.columns     # :150
+    assert df.index.names == ["reshape_index"]                        # :148
+    assert len(df) == 3                                               # :147 drop_duplicates is a no-op
+    assert A.prepare_spatial_weights_data(str(p)) is df               # memoised (:127)
+
+
+def test_weights_none_raises_typeerror_like_reference():
+    ds = minixr.Dataset({"t": (("time", "lat", "lon"), np.zeros((1, 2, 2)))},
+                        coords={"lat": [0.0, 1.0], "lon": [0.0, 1.0]})
+    with pytest.raises(TypeError):                                    # aggregations.py:118-119 vs :128
+        A.weighted_aggregate_grid_to_regions(ds, "t", "areawt", "ISO")
+
+
+def test_reindex_is_lazy_and_shapes_match_reference_test(ref_fixture):
+    fx, _ = ref_fixture
+    ds = minixr.Dataset({"temperature": (["lat", "lon", "time"], fx["temp"])},
+                        coords={"lon": fx["lon"], "lat": fx["lat"], "time": np.arange(10)})
+    df = pd.DataFrame({"lat": fx["seg_lat"], "lon": fx["seg_lon"]})
+    out = A._reindex_spatial_data_to_regions(ds, df)
+    # tests/test_climate_toolbox.py:115-116
+    assert out.temperature.shape == (len(out["lon"]), len(out["time"])) == (100, 10)
+    assert "reshape_index" in out.dims
+    assert out.temperature.dims == ("reshape_index", "time")
+    bad = df.copy()
+    bad.loc[0, "lat"] = 0.123
+    with pytest.raises(KeyError):
+        A._reindex_spatial_data_to_regions(ds, bad)
+
+
+def test_no_cpu_fallback_without_gpu(ref_fixture):
+    """On a machine without a GPU the product path must raise, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    fx, _ = ref_fixture
+    ds = minixr.Dataset({"temperature": (["lat", "lon", "time"], fx["temp"])},
+                        coords={"lon": fx["lon"], "lat": fx["lat"], "time": np.arange(10)})
+    df = pd.DataFrame({"lat": fx["seg_lat"], "lon": fx["seg_lon"], "areawt": fx["areawt"],
+                       "popwt": fx["popwt"], "ISO": fx["ISO"]})
+    with pytest.raises(WaggError):
+        A.weighted_aggregate_grid_to_regions(ds, "temperature", "popwt", "ISO", df)
+
+
+def test_synth_workloads_are_wellformed():
+    from climate_toolbox_amd import synth
+    lat, lon, tas, df = synth.c1_workload(T=3)
+    assert tas.shape == (3, 90, 180) and df["hierid"].nunique() == 100
+    cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, "popwt", "hierid")
+    assert len(uniq) == 100 and (w_eff > 0).all() and cell.max() < 90 * 180
+    lat2, lon2, df2 = synth.realistic_segments(nlat=90, nlon=180, R=300, seed=3)
+    assert df2["hierid"].nunique() == 300
+    per_cell = df2.groupby(["lat", "lon"]).size()
+    assert per_cell.max() <= 3 and per_cell.min() >= 1

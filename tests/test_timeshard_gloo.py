@@ -1,0 +1,73 @@
+"""world_size-2 (and 3, ragged) gloo tests of the time-shard + gather path on CPU.  The per-rank
+compute is played by the ORACLE here (tests may use it as a stand-in checker; the product's
+compute needs a GPU) -- what is under test is the shard map and the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from climate_toolbox_amd.timeshard import shard_bounds
+
+
+def test_shard_bounds():
+    assert shard_bounds(10950, 8) == [(0, 1369), (1369, 2738), (2738, 4107), (4107, 5476), (5476, 6845),
+                                      (6845, 8214), (8214, 9582), (9582, 10950)]          # c4: 1369/1368 rows
+    b = shard_bounds(18250, 8)
+    assert [e - s for s, e in b] == [2282, 2282, 2281, 2281, 2281, 2281, 2281, 2281]      # c5
+    assert shard_bounds(3, 5) == [(0, 1), (1, 2), (2, 3), (3, 3), (3, 3)]
+    assert shard_bounds(0, 2) == [(0, 0), (0, 0)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from climate_toolbox_amd.timeshard import aggregate_time_sharded, shard_bounds as sb
+        from oracle import ref_numpy as O
+        rng = np.random.default_rng(0)
+        G, R, n = 200, 9, 500
+        X = rng.standard_normal((T, G))
+        cell, code, w = rng.integers(0, G, n), rng.integers(0, R, n), rng.uniform(0.1, 1, n)
+        bounds = sb(T, world)
+        s, e = bounds[rank]
+        rows = [b - a for a, b in bounds]
+
+        def apply_fn(xl):
+            return torch.from_numpy(O.agg_coded(xl.numpy(), cell, code, w, R))
+
+        got = aggregate_time_sharded(apply_fn, torch.from_numpy(X[s:e]), rows=rows, dst=0)
+        if rank == 0:
+            ref = O.agg_coded(X, cell, code, w, R)
+            q.put(("ok", bool(np.array_equal(got.numpy(), ref)), tuple(got.shape)))
+        else:
+            assert got is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 10), (2, 7), (3, 8), (2, 1)])
+def test_time_shard_gather_gloo(world, T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    tag, equal, shape = q.get(timeout=5)
+    assert tag == "ok" and equal and shape == (T, 9)
