@@ -20,6 +20,8 @@
 //     den[r] (deterministic, no atomics).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 
 #include "wagg_common.h"
 
@@ -28,29 +30,38 @@ namespace wagg {
 constexpr int D_MT = 23;            // 16-row MFMA tiles per workgroup
 constexpr int D_BM = D_MT * 16;     // 368 rows
 constexpr int D_BN = 128;           // 8 waves x 16 columns
-constexpr int D_LDA = 368;          // 368 % 32 == 16
-constexpr int D_LDB = 144;          // 144 % 32 == 16
+constexpr int D_BK = 32;            // k depth of one LDS tile = 8 MFMA k-steps
+constexpr int D_KS = D_BK / 4;
+constexpr int D_LDA = 370;          // words per k-row of the X image (370 % 32 == 2, see below)
+constexpr int D_LDB = 132;          // words per k-row of the W image (16-byte aligned rows)
 constexpr int D_THREADS = 512;
+constexpr int D_STAGE = D_BK * D_LDA + D_BK * D_LDB;          // floats per LDS buffer (64,256 B)
+constexpr int D_XQ = D_BM * (D_BK / 4);                       // 16-byte pieces of the X tile (2944)
+constexpr int D_XLOADS = (D_XQ + D_THREADS - 1) / D_THREADS;  // 6 per thread
+constexpr int D_WLOADS = D_BK * D_BN / 4 / D_THREADS;         // 2 per thread
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float nan0(float v) { return v == v ? v : 0.0f; }
 
-template <int BK> struct DenseCfg {
-    static constexpr int STAGE = BK * D_LDA + BK * D_LDB;                         // floats per LDS buffer
-    static constexpr int XQ = D_BM * (BK / 4);                                    // float4 pieces of the X tile
-    static constexpr int XLOADS = (XQ + D_THREADS - 1) / D_THREADS;               // per thread
-    static constexpr int WLOADS = BK * D_BN / 4 / D_THREADS;                      // per thread
-    static_assert(BK % 16 == 0 && WLOADS >= 1, "BK must be a multiple of 16");
-};
-
-template <int BK, bool ALIGNED>
+// LDS images (both k-major):  xs[k][row] with row stride 370 words, ws[k][col] with 132.
+//  * X is fetched as whole 128-byte lines: 8 consecutive lanes take the 8 16-byte pieces of one
+//    row's 32 k-values (8 rows per wave instruction).  Piece q of row r is stored as 4
+//    ds_write_b32 to xs[4q+c][r]: bank = (8q + 2c + r) mod 32 -> each bank is hit by exactly two
+//    lanes of a 32-lane half (2-way is free for ds_write_b32).
+//  * MFMA k-step s (0..7) takes k = 8*kq + s for lane group kq = lane>>4 (any 4 distinct k per
+//    step work as long as A and B agree).  The two lane groups of a 32-lane half then read rows
+//    8 apart: 8*370 mod 32 = 16 -> lanes 0-15 and 16-31 sit on disjoint banks, no conflict.
+//
+// DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the global
+// loads of the k-loop, bit1 = skip the LDS restage, bit2 = skip the per-tile barrier.  Results are
+// wrong with any bit set; only the timing is of interest.
+template <bool ALIGNED, int DBG = 0>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const float *__restrict__ X, int64_t Ttot, int64_t ldx, const float *__restrict__ W,
     int64_t ldw, int64_t G, int n_nt, int n_mb, int S, int64_t k_per_slice,
     float *__restrict__ slabs) {
-    using C = DenseCfg<BK>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][STAGE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D_STAGE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,129 +74,180 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const int mb = j % n_mb;
     const int ks = (blockIdx.x & 7) + 8 * (j / n_mb);
     const int64_t k_begin = (int64_t)ks * k_per_slice;
+    // G here is the part of the gridcell axis that is a whole number of LDS tiles; the ragged
+    // remainder (< 32 cells) is contracted by dense_ktail_kernel into one extra slab
     const int64_t k_end = (k_begin + k_per_slice < G) ? k_begin + k_per_slice : G;
     const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
-    const int nfull = (int)(klen / BK);
-    const int ntiles = (int)((klen + BK - 1) / BK);
+    const int ntiles = (int)(klen / D_BK);
     const int64_t n0 = (int64_t)nt * D_BN;
     const int64_t m0 = (int64_t)mb * D_BM;
 
-    // staging coordinates.  Rows past T are clamped to the last row: their accumulators hold
-    // garbage that the reduce kernel never reads, and the loads need no row predicate.
-    const float *xp[C::XLOADS];
-    int xoff[C::XLOADS];      // LDS word offset of element c=0 of the piece, -1 = this lane idles
-    int xk[C::XLOADS];        // k offset of the piece inside the tile
+    // staging coordinates: wave-uniform 64-bit bases + 32-bit per-lane byte offsets (saddr form),
+    // LDS offsets that differ between a thread's pieces only by immediates.  Rows past T are
+    // clamped to the last row: their accumulators hold garbage that the reduce kernel never
+    // reads, and the loads need no row predicate.
+    const int xrow0 = tid >> 3, xq = tid & 7;          // piece i of this thread: row xrow0 + 64 i
+    unsigned xvoff[D_XLOADS];
 #pragma unroll
-    for (int i = 0; i < C::XLOADS; ++i) {
-        const int idx = tid + D_THREADS * i;
-        const int cidx = idx < C::XQ ? idx : C::XQ - 1;
-        const int row = cidx % D_BM, q = cidx / D_BM;
-        int64_t grow = m0 + row;
+    for (int i = 0; i < D_XLOADS; ++i) {
+        int64_t grow = m0 + xrow0 + 64 * i;
         grow = grow < Ttot ? grow : Ttot - 1;
-        xp[i] = X + grow * ldx + k_begin + q * 4;
-        xoff[i] = idx < C::XQ ? (q * 4) * D_LDA + row : -1;
-        xk[i] = q * 4;
+        xvoff[i] = (unsigned)(((grow - m0) * ldx + xq * 4) * 4);
     }
-    const float *wp[C::WLOADS];
-    int woff[C::WLOADS];
-#pragma unroll
-    for (int i = 0; i < C::WLOADS; ++i) {
-        const int idx = tid + D_THREADS * i;
-        const int row = idx >> 5, c4 = idx & 31;
-        wp[i] = W + (k_begin + row) * ldw + n0 + c4 * 4;
-        woff[i] = row * D_LDB + c4 * 4;
-    }
+    const bool x_last_ok = tid + D_THREADS * (D_XLOADS - 1) < D_XQ;    // piece 5 exists for tid < 384
+    const int xoff0 = (xq * 4) * D_LDA + xrow0;        // + 64 i (+ c * LDA)
+    const int wrow0 = tid >> 5, wc4 = tid & 31;        // piece i: k-row wrow0 + 16 i
+    const unsigned wvoff = (unsigned)((wrow0 * ldw + wc4 * 4) * 4);
+    const int woff0 = D_BK * D_LDA + wrow0 * D_LDB + wc4 * 4;          // + 16 i * LDB
+    const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx + k_begin);      // uniform
+    const char *wbase = reinterpret_cast<const char *>(W + k_begin * ldw + n0);      // uniform
 
     f32x4 acc[D_MT];
 #pragma unroll
     for (int m = 0; m < D_MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xr[C::XLOADS], wr[C::WLOADS];
-    // full tile: no k predicate anywhere -> straight-line loads that stay in flight under the MFMAs
-    auto load_full = [&](int tile) {
-#pragma unroll
-        for (int i = 0; i < C::XLOADS; ++i) {
-            const float *p = xp[i] + (int64_t)tile * BK;
-            if (ALIGNED) xr[i] = *reinterpret_cast<const f32x4 *>(p);
-            else xr[i] = f32x4{p[0], p[1], p[2], p[3]};
-        }
-#pragma unroll
-        for (int i = 0; i < C::WLOADS; ++i)
-            wr[i] = *reinterpret_cast<const f32x4 *>(wp[i] + (int64_t)tile * BK * ldw);
-    };
-    // the (at most one) ragged last tile of a slice
-    auto load_tail = [&](int tile) {
-        const int64_t krem = klen - (int64_t)tile * BK;      // 1 .. BK-1 valid k
-#pragma unroll
-        for (int i = 0; i < C::XLOADS; ++i) {
-            const float *p = xp[i] + (int64_t)tile * BK;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) xr[i][c] = (xk[i] + c < krem) ? p[c] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < C::WLOADS; ++i) {
-            const int row = (tid + D_THREADS * i) >> 5;
-            wr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < krem) wr[i] = *reinterpret_cast<const f32x4 *>(wp[i] + (int64_t)tile * BK * ldw);
-        }
-    };
-    auto load_tile = [&](int tile) { if (tile < nfull) load_full(tile); else load_tail(tile); };
-    auto store_tile = [&](int buf) {
-        float *xs = lds + buf * C::STAGE;
-        float *ws = xs + BK * D_LDA;
-#pragma unroll
-        for (int i = 0; i < C::XLOADS; ++i) {
-            if (xoff[i] >= 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) xs[xoff[i] + c * D_LDA] = nan0(xr[i][c]);   // S6
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < C::WLOADS; ++i) *reinterpret_cast<f32x4 *>(ws + woff[i]) = wr[i];
-    };
+    // staging registers are NAMED scalars (not arrays): arrays indexed inside the unrolled MFMA
+    // stream end up in scratch memory with hipcc (ROCm 7.2)
+    f32x4 xr0, xr1, xr2, xr3, xr4, xr5, wr0, wr1;
+    static_assert(D_XLOADS == 6 && D_WLOADS == 2, "staging registers are named for 6 + 2 pieces");
+#define WAGG_XPTR(i, tile) (xbase + (int64_t)(tile) * (D_BK * 4) + xvoff[i])
+#define WAGG_WPTR(i, tile) (wbase + ((int64_t)(tile) * D_BK + 16 * (i)) * ldw * 4 + wvoff)
+#define WAGG_LOAD_X(i, tile)                                                                     \
+    do {                                                                                         \
+        if (ALIGNED) xr##i = *reinterpret_cast<const f32x4 *>(WAGG_XPTR(i, tile));               \
+        else { const float *f_ = reinterpret_cast<const float *>(WAGG_XPTR(i, tile));            \
+               xr##i = f32x4{f_[0], f_[1], f_[2], f_[3]}; }                                      \
+    } while (0)
+#define WAGG_LOAD_W(i, tile) wr##i = *reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile))
+#define WAGG_STORE_X(i, buf)                                                                     \
+    do {                                                                                         \
+        float *xs_ = lds + (buf) * D_STAGE + xoff0 + 64 * (i);                                   \
+        if ((i) + 1 < D_XLOADS || x_last_ok) {                                                   \
+            xs_[0] = nan0(xr##i[0]); xs_[D_LDA] = nan0(xr##i[1]);          /* S6 */              \
+            xs_[2 * D_LDA] = nan0(xr##i[2]); xs_[3 * D_LDA] = nan0(xr##i[3]);                    \
+        }                                                                                        \
+    } while (0)
+#define WAGG_STORE_W(i, buf)                                                                     \
+    *reinterpret_cast<f32x4 *>(lds + (buf) * D_STAGE + woff0 + 16 * (i) * D_LDB) = wr##i
+#define WAGG_LOAD_ALL(tile)                                                                      \
+    do { WAGG_LOAD_X(0, tile); WAGG_LOAD_X(1, tile); WAGG_LOAD_X(2, tile); WAGG_LOAD_X(3, tile); \
+         WAGG_LOAD_X(4, tile); WAGG_LOAD_X(5, tile); WAGG_LOAD_W(0, tile); WAGG_LOAD_W(1, tile); } while (0)
+#define WAGG_STORE_ALL(buf)                                                                      \
+    do { WAGG_STORE_X(0, buf); WAGG_STORE_X(1, buf); WAGG_STORE_X(2, buf); WAGG_STORE_X(3, buf); \
+         WAGG_STORE_X(4, buf); WAGG_STORE_X(5, buf); WAGG_STORE_W(0, buf); WAGG_STORE_W(1, buf); } while (0)
 
+    xr0 = xr1 = xr2 = xr3 = xr4 = xr5 = wr0 = wr1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ntiles > 0) {
-        load_tile(0);
-        store_tile(0);
+        WAGG_LOAD_ALL(0);
+        WAGG_STORE_ALL(0);
+        if (ntiles > 1) WAGG_LOAD_ALL(1);
     }
     __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int cur = tile & 1;
-        if (tile + 1 < ntiles) load_tile(tile + 1);       // global loads fly under the MFMAs
-        const float *xs = lds + cur * C::STAGE;
-        const float *ws = xs + BK * D_LDA;
-        // fragment double buffer: the ds_reads of k-step s+1 are issued before the 23 MFMAs of
-        // k-step s, so LDS latency never sits between two MFMAs
-        float af[2][D_MT], bf[2];
-        auto load_frag = [&](int kk, float (&a)[D_MT], float &b) {
-            b = ws[(kk + kq) * D_LDB + wave * 16 + lr];
-            const float *xa = xs + (kk + kq) * D_LDA + lr;
+
+    const int a_lane = (8 * kq) * D_LDA + lr;                    // + s*LDA + m*16 (immediates)
+    const int b_lane = D_BK * D_LDA + (8 * kq) * D_LDB + wave * 16 + lr;
+
+    // One LDS tile = 8 MFMA k-steps = 184 MFMAs per wave.  A fragments run D_AHEAD MFMAs ahead of
+    // their use (a rolling window of ~8 VGPRs instead of a 46-register double buffer); the
+    // fragment reads and (PF) the next tile's global loads are spread between the MFMAs -- one
+    // small group after every second MFMA, pinned with sched_barriers (hipcc otherwise sinks each
+    // ds_read next to its MFMA and waits lgkmcnt(0) between every pair, and a burst of reads per
+    // k-step leaves the matrix pipe idle when both waves of a SIMD burst together).
+    constexpr int D_AHEAD = 6;
+    constexpr int NMF = D_KS * D_MT;
+    // MODE 2: inside tile t's MFMA stream, store the staged registers (tile t+1) into the other
+    //         LDS buffer and refill each register with its piece of tile t+2 right after;
+    // MODE 1: store only (t+2 does not exist);  MODE 0: neither (last tile).
+    // Loads therefore run a whole tile (~5 us) ahead of their LDS store, and the LDS stores
+    // (ds_write_b32 runs at 64 B/clk/CU: ~950 cycles per tile) hide under the MFMAs.
+    auto tile_body = [&](auto mode_tag, int tile) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const float *xs = lds + (tile & 1) * D_STAGE;
+        const int nbuf = (tile & 1) ^ 1;
+        float a[8], b[2];                                  // rolling windows, static indices
+        b[0] = xs[b_lane];
 #pragma unroll
-            for (int m = 0; m < D_MT; ++m) a[m] = xa[m * 16];
-        };
-        load_frag(0, af[0], bf[0]);
+        for (int jj = 0; jj < D_AHEAD; ++jj) a[jj] = xs[a_lane + (jj / D_MT) * D_LDA + (jj % D_MT) * 16];
 #pragma unroll
-        for (int s4 = 0; s4 < BK / 4; ++s4) {
-            // hipcc otherwise sinks every ds_read next to its MFMA and waits lgkmcnt(0) between
-            // each pair; the sched_barriers keep the next step's reads ahead of this step's MFMAs
-            if (s4 + 1 < BK / 4) load_frag((s4 + 1) * 4, af[(s4 + 1) & 1], bf[(s4 + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int s4 = 0; s4 < D_KS; ++s4) {
 #pragma unroll
-            for (int m = 0; m < D_MT; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4 & 1][m], bf[s4 & 1], acc[m], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int m = 0; m < D_MT; ++m) {
+            const int j = s4 * D_MT + m;
+            if ((j & 1) == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + D_AHEAD < NMF)
+                    a[(j + D_AHEAD) & 7] = xs[a_lane + ((j + D_AHEAD) / D_MT) * D_LDA + ((j + D_AHEAD) % D_MT) * 16];
+                if (j + D_AHEAD + 1 < NMF)
+                    a[(j + D_AHEAD + 1) & 7] =
+                        xs[a_lane + ((j + D_AHEAD + 1) / D_MT) * D_LDA + ((j + D_AHEAD + 1) % D_MT) * 16];
+                if ((m == 0 || m == 1) && s4 + 1 < D_KS) b[(s4 + 1) & 1] = xs[b_lane + (s4 + 1) * D_LDB];
+                if (MODE >= 1 && (m == 4 || m == 5) && !(DBG & 2)) {      // one piece per k-step: store ...
+                    if (s4 == 0) WAGG_STORE_X(0, nbuf);
+                    if (s4 == 1) WAGG_STORE_X(1, nbuf);
+                    if (s4 == 2) WAGG_STORE_X(2, nbuf);
+                    if (s4 == 3) WAGG_STORE_X(3, nbuf);
+                    if (s4 == 4) WAGG_STORE_X(4, nbuf);
+                    if (s4 == 5) WAGG_STORE_X(5, nbuf);
+                    if (s4 == 6) WAGG_STORE_W(0, nbuf);
+                    if (s4 == 7) WAGG_STORE_W(1, nbuf);
+                }
+                if (MODE == 2 && (m == 10 || m == 11) && !(DBG & 1)) {    // ... then refill its register
+                    if (s4 == 0 && !(DBG & 8)) WAGG_LOAD_X(0, tile + 2);
+                    if (s4 == 1 && !(DBG & 8)) WAGG_LOAD_X(1, tile + 2);
+                    if (s4 == 2 && !(DBG & 8)) WAGG_LOAD_X(2, tile + 2);
+                    if (s4 == 3 && !(DBG & 8)) WAGG_LOAD_X(3, tile + 2);
+                    if (s4 == 4 && !(DBG & 8)) WAGG_LOAD_X(4, tile + 2);
+                    if (s4 == 5 && !(DBG & 8)) WAGG_LOAD_X(5, tile + 2);
+                    if (s4 == 6) WAGG_LOAD_W(0, tile + 2);
+                    if (s4 == 7) WAGG_LOAD_W(1, tile + 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j & 7], b[s4 & 1], acc[m], 0, 0, 0);
+          }
         }
-        if (tile + 1 < ntiles) store_tile(cur ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // single hot body in the loop; the two drain tiles are peeled (merging differently shaped
+    // bodies at a loop join makes hipcc copy and spill the accumulators)
+    int tile = 0;
+    for (; tile + 2 < ntiles; ++tile) {
+        tile_body(std::integral_constant<int, 2>{}, tile);
+        if (!(DBG & 4)) __syncthreads();
     }
+    if (tile + 1 < ntiles) {
+        tile_body(std::integral_constant<int, 1>{}, tile);
+        __syncthreads();
+        ++tile;
+    }
+    if (tile < ntiles) tile_body(std::integral_constant<int, 0>{}, tile);
 
     // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * D_BM) * D_BN;
+    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * (S + 1) + ks) * D_BM) * D_BN;
 #pragma unroll
     for (int m = 0; m < D_MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             slab[(m * 16 + kq * 4 + r) * D_BN + wave * 16 + lr] = acc[m][r];
+}
+
+// ragged remainder of the gridcell axis (k in [Gfull, G), fewer than 32 cells): plain FMA into the
+// extra slab S of every (row block, column tile); zero when there is no remainder
+__global__ void dense_ktail_kernel(const float *__restrict__ X, int64_t Ttot, int64_t ldx,
+                                   const float *__restrict__ W, int64_t ldw, int64_t Gfull, int64_t G,
+                                   int n_nt, int S, float *__restrict__ slabs) {
+    const int c = threadIdx.x & (D_BN - 1);
+    const int nt = blockIdx.x;
+    const int64_t t = (int64_t)blockIdx.y * 2 + (threadIdx.x >> 7);     // 256 threads = 2 rows x 128 cols
+    const int mb = (int)(t / D_BM), tl = (int)(t % D_BM);
+    if (t >= (int64_t)gridDim.y * 2) return;
+    float s = 0.f;
+    if (t < Ttot) {
+        for (int64_t k = Gfull; k < G; ++k)
+            s = fmaf(nan0(X[t * ldx + k]), W[k * ldw + (int64_t)nt * D_BN + c], s);
+    }
+    slabs[((((int64_t)mb * n_nt + nt) * (S + 1) + S) * D_BM + tl) * D_BN + c] = s;
 }
 
 // out[t, r] = sum_s slab[mb][nt][s][t_local][c] / den[r]        (aggregations.py:77-80 fused)
@@ -197,9 +259,9 @@ __global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, i
     if (r >= R) return;
     const int mb = (int)(t / D_BM), tl = (int)(t % D_BM);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * D_BM + tl) * D_BN + c;
+    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * (S + 1)) * D_BM + tl) * D_BN + c;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += p[(int64_t)k * D_BM * D_BN];
+    for (int k = 0; k < S + 1; ++k) s += p[(int64_t)k * D_BM * D_BN];     // slab S = ragged k tail
     out[t * ldo + r] = s / den[r];
 }
 
@@ -292,7 +354,7 @@ static int pick_ksplit(int64_t items, int64_t G) {
     int best = 8;
     double best_eff = 0.0;
     for (int S = 8; S <= 64; S += 8) {
-        if (S > 8 && G / S < 64 * 16) break;           // keep >= 64 k-steps per slice
+        if (S > 8 && G / S < 32 * D_BK) break;         // keep >= 32 LDS tiles per slice
         const double w = (double)items * S / 256.0;
         const double eff = w / std::ceil(w);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
@@ -404,21 +466,38 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     const int n_nt = (int)(d->ldw / D_BN);
     const int n_mb = (int)((T + D_BM - 1) / D_BM);
     const int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, d->G);
-    constexpr int BK = 16;
-    const int64_t k_per_slice = ((d->G + S - 1) / S + BK - 1) / BK * BK;
+    constexpr int BK = D_BK;
+    const int64_t Gfull = d->G / BK * BK;
+    const int64_t k_per_slice = ((Gfull + S - 1) / S + BK - 1) / BK * BK;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
     WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && T <= 65535, "grid too large");
-    const size_t need = (size_t)nblk * D_BM * D_BN;
+    if ((int64_t)D_BM * ldx * 4 >= ((int64_t)1 << 32)) {
+        set_error("dense path: 368 rows x ldx x 4 bytes must stay below 4 GiB (ldx = %lld)", (long long)ldx);
+        return WAGG_EUNSUPPORTED;
+    }
+    const size_t need = (size_t)n_nt * n_mb * (S + 1) * D_BM * D_BN;
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
     const bool aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
-    const size_t shmem = sizeof(float) * 2 * DenseCfg<BK>::STAGE;
+    const size_t shmem = sizeof(float) * 2 * D_STAGE;
     hipStream_t st = (hipStream_t)stream;
-    auto kern = aligned ? dense_mfma_kernel<BK, true> : dense_mfma_kernel<BK, false>;
+    auto kern = aligned ? dense_mfma_kernel<true> : dense_mfma_kernel<false>;
+    if (const char *dbg = getenv("WAGG_DENSE_DBG")) {
+        switch (atoi(dbg)) {
+            case 1: kern = dense_mfma_kernel<true, 1>; break;
+            case 2: kern = dense_mfma_kernel<true, 2>; break;
+            case 3: kern = dense_mfma_kernel<true, 3>; break;
+            case 7: kern = dense_mfma_kernel<true, 7>; break;
+            case 8: kern = dense_mfma_kernel<true, 8>; break;
+            default: break;
+        }
+    }
     WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     profile_mark(st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, X_dev, T, ldx, d->W.p, d->ldw,
-                       d->G, n_nt, n_mb, S, k_per_slice, d->slabs.p);
+                       Gfull, n_nt, n_mb, S, k_per_slice, d->slabs.p);
     profile_mark(st, false);
+    hipLaunchKernelGGL(dense_ktail_kernel, dim3((unsigned)n_nt, (unsigned)(n_mb * D_BM / 2)), dim3(256), 0, st,
+                       X_dev, T, ldx, d->W.p, d->ldw, Gfull, d->G, n_nt, S, d->slabs.p);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,
                        d->slabs.p, n_nt, S, T, d->R, d->den32.p, out_dev, ldo);

@@ -67,13 +67,21 @@ static int gather(const T *X, int64_t Ttot, int64_t ldx, int layout, const int32
     return WAGG_OK;
 }
 
+// separately rounded multiply and add (no FMA contraction) so that the field equals the
+// oracle's numpy expression bit for bit
+template <typename T> __device__ __forceinline__ T mul_add_rn(T b, T a, T h) {
+#pragma clang fp contract(off)
+    const T p = a * h;
+    return b + p;
+}
+
 template <typename T>
 __global__ void synth_field_kernel(T *__restrict__ X, int64_t Ttot, int64_t G, int64_t ldx,
                                    uint32_t seed, T base, T amp) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Ttot * G; i += stride) {
         const int64_t t = i / G, g = i % G;
-        X[t * ldx + g] = base + amp * ((T)hash_u01((uint64_t)i, seed) - (T)0.5);
+        X[t * ldx + g] = mul_add_rn(base, amp, (T)hash_u01((uint64_t)i, seed) - (T)0.5);
     }
 }
 

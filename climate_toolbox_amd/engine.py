@@ -29,6 +29,11 @@ def _stream_handle(stream):
     return C.c_void_p(s.cuda_stream)
 
 
+def _ld(t):
+    """Leading dimension of a 2-D row-contiguous tensor (size-1 axes carry arbitrary strides)."""
+    return int(t.stride(0)) if t.shape[0] > 1 and t.shape[1] > 1 else max(1, int(t.shape[1]))
+
+
 def _np_ptr(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
 
@@ -39,7 +44,7 @@ def _check_X(X, layout):
         raise TypeError("X must be a 2-D CUDA torch tensor")
     if X.dtype not in (torch.float32, torch.float64):
         raise TypeError("X must be float32 or float64, got %s" % X.dtype)
-    if X.stride(1) != 1:
+    if X.shape[1] > 1 and X.stride(1) != 1:
         raise ValueError("X rows must be contiguous (stride(1) == 1)")
     if layout not in _LAYOUTS:
         raise ValueError("layout must be 'TG' or 'GT'")
@@ -87,13 +92,13 @@ class SparsePlan:
         shape = (T, self.R) if out_layout == "TR" else (self.R, T)
         if out is None:
             out = torch.empty(shape, dtype=X.dtype, device=X.device)
-        elif tuple(out.shape) != shape or out.dtype != X.dtype or out.stride(1) != 1:
+        elif tuple(out.shape) != shape or out.dtype != X.dtype or (shape[1] > 1 and out.stride(1) != 1):
             raise ValueError("out must be a %s %s tensor with contiguous rows" % (shape, X.dtype))
         L = _lib.load()
         fn = L.wagg_apply_f32 if X.dtype == torch.float32 else L.wagg_apply_f64
-        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, X.stride(0), _LAYOUTS[layout],
-                      C.c_void_p(out.data_ptr()), out.stride(0) if out.numel() else max(1, shape[1]),
-                      _OUTS[out_layout], _stream_handle(stream)), "wagg_apply")
+        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout],
+                      C.c_void_p(out.data_ptr()), _ld(out), _OUTS[out_layout], _stream_handle(stream)),
+                   "wagg_apply")
         return out
 
     def apply_host(self, X, layout="TG", out_layout="TR"):
@@ -167,8 +172,8 @@ class DensePlan:
         if out is None:
             out = torch.empty((T, self.R), dtype=torch.float32, device=X.device)
         _lib.check(_lib.load().wagg_dense_apply_f32(
-            self._h, C.c_void_p(X.data_ptr()), T, X.stride(0), C.c_void_p(out.data_ptr()),
-            out.stride(0), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_f32")
+            self._h, C.c_void_p(X.data_ptr()), T, _ld(X), C.c_void_p(out.data_ptr()),
+            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_f32")
         return out
 
 
@@ -184,7 +189,7 @@ def gather(X, cell_idx_dev, layout="TG", out_layout="TR", stream=None):
     out = torch.empty(shape, dtype=X.dtype, device=X.device)
     L = _lib.load()
     fn = L.wagg_gather_f32 if X.dtype == torch.float32 else L.wagg_gather_f64
-    _lib.check(fn(C.c_void_p(X.data_ptr()), T, X.stride(0), _LAYOUTS[layout],
+    _lib.check(fn(C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout],
                   C.c_void_p(cell_idx_dev.data_ptr()), n, C.c_void_p(out.data_ptr()), max(1, shape[1]),
                   _OUTS[out_layout], _stream_handle(stream)), "wagg_gather")
     return out
