@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--R", type=int, default=24378)
     ap.add_argument("--ksplit", type=int, default=0)
+    ap.add_argument("--land-frac", type=float, default=0.30, help="experiment knob for c2-real")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -137,7 +138,7 @@ def main():
     result = {}
 
     def run_sparse(dtype):
-        lat, lon, df = synth.realistic_segments(nlat=a.nlat, nlon=a.nlon, R=R, seed=2)
+        lat, lon, df = synth.realistic_segments(nlat=a.nlat, nlon=a.nlon, R=R, seed=2, land_frac=a.land_frac)
         wname = "areawt" if dtype == "float32" else "popwt"
         cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, "hierid")
         plan = engine.SparsePlan(cell, codes, w_eff, G, len(uniq), row_len=a.nlon)
