@@ -268,3 +268,75 @@ def test_dense_from_segments_equals_sparse(torch_cuda):
     a = SparsePlan(cell, code, w, 2000, 60).apply(Xd).cpu().numpy()
     b = DensePlan.from_segments(cell, code, w, 2000, 60).apply(Xd).cpu().numpy()
     _rel_ok(b, a, 2e-4, scale=1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes (configs[1], [2]): direct comparison where the oracle finishes in
+# seconds, size-independent properties where it cannot (dense 1,036,800 x 24,378)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2_real():
+    from climate_toolbox_amd import synth
+    lat, lon, df = synth.realistic_segments()           # 720 x 1440, R = 24,378, ~4e5 segments
+    return lat, lon, df
+
+
+@pytest.mark.parametrize("wname,dtype,rtol", [("areawt", np.float32, RTOL32), ("popwt", np.float64, RTOL64),
+                                              ("popwt", np.float32, RTOL32)])
+def test_c2_c3_full_size_vs_oracle(torch_cuda, c2_real, wname, dtype, rtol):
+    """configs[1] (area-weighted fp32) and configs[2] (pop-weighted fp64 tolerance check, plus the
+    fp32 run at 1e-4): every region-timestep against the fp64 oracle."""
+    from climate_toolbox_amd import engine, synth
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = c2_real
+    T, G = 365, len(lat) * len(lon)
+    cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, "hierid")
+    assert len(uniq) == 24378
+    if wname == "popwt":
+        assert (~(df["popwt"].values > 0)).mean() > 0.15       # S4 really exercised (NaN / 0 rows)
+    X = engine.synth_field(T, G, seed=11, base=280.0, amp=60.0, dtype="float64" if dtype == np.float64 else "float32")
+    Xh = X.cpu().numpy()
+    plan = engine.SparsePlan(cell, codes, w_eff, G, len(uniq), row_len=len(lon))
+    got = plan.apply(X).cpu().numpy()
+    ref = O.agg_coded(Xh, cell, codes, w_eff, len(uniq))
+    _rel_ok(got, ref, rtol)
+    # size-independent properties at full size
+    const = plan.apply(torch.full((3, G), 7.25, dtype=X.dtype, device="cuda")).cpu().numpy()
+    np.testing.assert_allclose(const, 7.25, rtol=1e-6 if dtype == np.float32 else 1e-12)   # constant field
+    got2 = plan.apply(X * 2.0).cpu().numpy()
+    np.testing.assert_array_equal(got2, got * dtype(2.0))                                  # exact linearity in 2x
+    perm = np.random.default_rng(0).permutation(len(cell))
+    plan_p = engine.SparsePlan(cell[perm], codes[perm], w_eff[perm], G, len(uniq), row_len=len(lon))
+    np.testing.assert_allclose(plan_p.apply(X).cpu().numpy(), got, rtol=1e-5 if dtype == np.float32 else 1e-12)
+
+
+def test_c2_dense_full_size_properties(torch_cuda):
+    """configs[1] in its dense north-star form (101 GB W generated on the device).  The fp64 oracle
+    cannot do 1.8e13 MACs, so: a column window against the C oracle on all 1,036,800 cells, the
+    denominators against the hash, constant-field and scaling properties over all 24,378 regions."""
+    from climate_toolbox_amd import engine
+    from oracle import c_oracle, ref_numpy as O
+    torch = torch_cuda
+    G, R, seed = 720 * 1440, 24378, 2
+    try:
+        plan = engine.DensePlan.synth(G, R, seed)
+    except Exception as e:                      # a box without 110 GB free HBM cannot hold the operand
+        pytest.skip("dense W does not fit: %s" % e)
+    T = 24
+    X = engine.synth_field(T, G, seed=5, base=280.0, amp=60.0)
+    got = plan.apply(X).cpu().numpy()
+    Xh = X.cpu().numpy()
+    for r0 in (0, 12000, R - 16):
+        ref = c_oracle.dense_synth(Xh, 0, G, R, r0, 16, seed)
+        _rel_ok(got[:, r0:r0 + 16], ref, RTOL32)
+    idx = (np.arange(G, dtype=np.uint64) * np.uint64(R) + np.uint64(777))
+    np.testing.assert_allclose(plan.den[777], O.hash_u01(idx, seed).astype(np.float64).sum(), rtol=1e-12)
+    const = plan.apply(torch.full((2, G), 3.5, dtype=torch.float32, device="cuda")).cpu().numpy()
+    np.testing.assert_allclose(const, 3.5, rtol=2e-5)                   # constant field -> constant
+    np.testing.assert_array_equal(plan.apply(X * 2.0).cpu().numpy(), got * np.float32(2.0))
+    # all rows of a 365-row block agree with the same rows computed in a short block
+    X365 = engine.synth_field(365, G, seed=5, base=280.0, amp=60.0)
+    got365 = plan.apply(X365).cpu().numpy()
+    np.testing.assert_array_equal(got365[:T], got)
+    plan.close()
