@@ -31,7 +31,11 @@ constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of 
 constexpr int UROW = UC + 4; // LDS row stride in elements (t-major image, 16-byte aligned rows)
 constexpr int RG_MAX = 255;  // regions per group (bounded by cells anyway)
 constexpr int SEG_MAX = 768; // segments per chunk staged in LDS
-constexpr int NWAVE = 4;
+constexpr int SEG_LAST = 0x8000;   // flag bit in a segment's local cell index: last segment of its entry
+constexpr int SEG_UMASK = 0x7fff;
+constexpr int NWAVE = 4;      // waves of the chunk-walking kernel (256 threads)
+constexpr int SWAVE = 8;      // waves of the persistent stream kernel (512 threads)
+constexpr int STHREADS = SWAVE * 64;
 
 struct SparsePlanDev {
     DevBuf<int32_t> grp_chunk_begin, grp_giant;   // [n_groups+1], [n_groups]
@@ -44,6 +48,10 @@ struct SparsePlanDev {
     DevBuf<float> den32;
     DevBuf<double> den64;
     DevBuf<int32_t> empty_regions;
+    DevBuf<int32_t> chunk_desc;
+    DevBuf<float> ent_den32;
+    DevBuf<double> ent_den64;
+    int g0_normal = 0, c0_normal = 0;
 };
 
 }  // namespace wagg
@@ -60,22 +68,26 @@ namespace wagg {
 template <typename T> struct PlanView {
     const int32_t *grp_chunk_begin, *grp_giant, *chunk_u_begin, *chunk_e_begin, *ucell;
     const int32_t *ent_region, *ent_seg_begin, *seg_u;
-    const T *seg_w, *den;
+    const T *seg_w, *den, *ent_den;   // ent_den[e] = den[ent_region[e]]
+    const int32_t *chunk_desc;   // [n_chunks][8]: u0, nq, e0, ne, sb, ns, 0, 0
     int n_groups;
+    int g0_normal;               // groups [0, g0_normal) are giant, the rest own exactly one chunk
+    int c0_normal;               // first chunk of the first normal group
 };
 
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
-// LDS carve-up (bytes):  xs [TB][UROW] T | red [NWAVE][TB] T | seg_w [SEG_MAX] T |
-//                        ent_r [RG_MAX] i32 | seg_u [SEG_MAX] u16 | ent_s [RG_MAX+1] u16
-// f32/TB=64: 74.8 KB, f64/TB=32: 79.9 KB  ->  two workgroups per CU (160 KB).
+// LDS carve-up (bytes):  xs [TB][UROW] T | red [NWAVE][TB] T | seg_w [SEG_MAX] T | ent_den [RG_MAX+1] T |
+//                        ent_r [RG_MAX+1] i32 | seg_u [SEG_MAX] u16 | ent_s [RG_MAX+1] u16
+// f32/TB=64: 75.8 KB, f64/TB=32: 78.9 KB  ->  two workgroups per CU (160 KB).
 template <typename T, int TB> struct SparseLds {
     static constexpr size_t xs = 0;
     static constexpr size_t red = xs + sizeof(T) * TB * UROW;
     static constexpr size_t seg_w = red + sizeof(T) * NWAVE * TB;
-    static constexpr size_t ent_r = seg_w + sizeof(T) * SEG_MAX;
-    static constexpr size_t seg_u = ent_r + sizeof(int32_t) * RG_MAX;
+    static constexpr size_t ent_den = seg_w + sizeof(T) * SEG_MAX;
+    static constexpr size_t ent_r = ent_den + sizeof(T) * (RG_MAX + 1);
+    static constexpr size_t seg_u = ent_r + sizeof(int32_t) * (RG_MAX + 1);
     static constexpr size_t ent_s = seg_u + sizeof(uint16_t) * SEG_MAX;
     static constexpr size_t total = (ent_s + sizeof(uint16_t) * (RG_MAX + 1) + 15) / 16 * 16;
     static_assert(total <= 80 * 1024, "two workgroups must fit one CU's LDS");
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
             if (lane < TB && !(DBG & 4)) {
 #pragma unroll 8
                 for (int s = s0; s < s1; ++s) {
-                    const int u = sm_u[s];
+                    const int u = sm_u[s] & SEG_UMASK;
                     const T w = sm_w[s];
                     const T p = xs[lane * UROW + u] * w;        // aggregations.py:78 product
                     acc += (p == p) ? p : T(0);                 // skipna: NaN product counts 0 (S6)
@@ -221,6 +233,279 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
             if constexpr (OUT_LAYOUT == WAGG_OUT_TR) out[(t0 + lane) * ldo + r] = q;
             else out[(int64_t)r * ldo + t0 + lane] = q;
         }
+    }
+}
+
+// Persistent, software-pipelined form of the gather kernel for the single-chunk ("normal") groups,
+// TG layout.  NW workgroups (two per CU) each walk items it = w, w+NW, ...; item = (chunk, time
+// block).  While item i is reduced out of LDS, the 64 KB of item i+1 are already in flight into
+// registers (issued right after item i's registers were parked in LDS), the quad list of item
+// i+2 and the descriptor of item i+3 are being fetched -- the dependent metadata chain and the
+// LDS/compute phase no longer sit between two bursts of HBM requests.
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains
+// vmcnt, which would stall on the NEXT item's global loads that are deliberately in flight
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct StreamDesc { int u0, nq, e0, ne, sb, ns; unsigned long long split; };
+
+// STAMP (diagnostic build only, WAGG_SPARSE_STAMP env): per-phase s_memtime sums of wave 0 go to a
+// debug buffer that nothing else reads.
+template <typename T, int TB, bool VEC, bool STAMP = false>
+__global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> pv, const T *__restrict__ X,
+                                                              int64_t Ttot, int64_t ldx, int64_t G,
+                                                              T *__restrict__ out, int64_t ldo,
+                                                              int n_norm, long long n_items,
+                                                              unsigned long long *__restrict__ stamps,
+                                                              int knob) {
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (i >= 0) ph[i] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+    using L = SparseLds<T, TB>;
+    constexpr int TPW = TB / SWAVE;
+    constexpr int NM = (SEG_MAX + STHREADS - 1) / STHREADS;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *xs = reinterpret_cast<T *>(smem_raw + L::xs);
+    T *sm_w = reinterpret_cast<T *>(smem_raw + L::seg_w);
+    T *sm_ed = reinterpret_cast<T *>(smem_raw + L::ent_den);
+    int32_t *sm_er = reinterpret_cast<int32_t *>(smem_raw + L::ent_r);
+    uint16_t *sm_u = reinterpret_cast<uint16_t *>(smem_raw + L::seg_u);
+    uint16_t *sm_es = reinterpret_cast<uint16_t *>(smem_raw + L::ent_s);
+    int *sm_flag = reinterpret_cast<int *>(smem_raw + L::red);    // the giant-group scratch is free here
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw0 = wave * TPW;
+    if (tid == 0) *sm_flag = 0;
+    lds_only_barrier();
+    // XCD-contiguous ids (speed only): at every step the NW resident workgroups cover a contiguous
+    // run of items, and each XCD a contiguous part of it
+    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
+    const long long NW = NWu;
+    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
+    if (w0 >= n_items) return;
+    // item -> (chunk g, time block tb) without divisions in the loop: items advance by NW, i.e. by
+    // (dg, dtb) with a carry; everything is 32-bit (n_items < 2^31 is checked on the host)
+    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
+    const int nst = (int)((n_items - 1 - w0) / NW) + 1;          // stages of this workgroup
+    struct Item { int g, tb; };
+    auto advance = [&](Item a) {
+        Item b{a.g + dg, a.tb + dtb};
+        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
+        return b;
+    };
+    const Item i0{(int)(w0 % n_norm), (int)(w0 / n_norm)};
+
+    // Every load below is UNCONDITIONAL (indices clamped into the chunk): no exec-skip branches, so
+    // hipcc's s_waitcnt pass sees one straight path and emits counted vmcnt(N) instead of vmcnt(0).
+    auto load_desc = [&](Item a, StreamDesc &d) {
+        const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
+        const int4v x = *reinterpret_cast<const int4v *>(p);
+        const int4v y = *reinterpret_cast<const int4v *>(p + 4);
+        d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1];
+        d.split = (unsigned long long)(unsigned)y[2] | ((unsigned long long)(unsigned)y[3] << 32);
+    };
+    auto load_cell = [&](const StreamDesc &d) {
+        return pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
+    };
+    vec4 v[TPW];
+    auto issue_x = [&](int cell0, int tb) {
+        const int64_t t0 = (int64_t)tb * TB;
+        const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
+        // rows of this wave: tw0 .. tw0+TPW-1, clamped into the (possibly ragged) block
+        const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
+        int cnt = nt - tw0;
+        cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
+        const T *p = X + (t0 + rbase) * ldx + cell0;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (VEC) v[i] = *reinterpret_cast<const vec4 *>(p);
+            else {
+                const int64_t lim = G - 1 - cell0;
+                v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
+            }
+            if (i + 1 < cnt) p += ldx;                                 // wave-uniform step
+        }
+    };
+    int mu[NM]; T mw[NM]; int er, es; T ed;
+    auto issue_meta = [&](const StreamDesc &d) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            int k = tid + STHREADS * i;
+            k = k < d.ns ? k : d.ns - 1;
+            mu[i] = pv.seg_u[d.sb + k];
+            mw[i] = pv.seg_w[d.sb + k];
+        }
+        er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+        ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+        es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];     // absolute; rebased when parked
+    };
+
+    // pipeline registers: C = current item, A = next, B = next-next, (D = the one after)
+    Item iC = i0, iA = nst > 1 ? advance(iC) : iC, iB = nst > 2 ? advance(iA) : iA;
+    StreamDesc dC, dA, dB;
+    load_desc(iC, dC);
+    load_desc(iA, dA);
+    load_desc(iB, dB);
+    int cellA = load_cell(dA);
+    issue_meta(dC);
+    issue_x(load_cell(dC), iC.tb);
+
+    // results of the previous item: up to KQ regions per wave are kept in registers and stored at
+    // the START of the next stage's traffic block (older than that block's loads, so no later
+    // wait ever depends on a store acknowledgement; vmcnt retires in order and counts stores)
+    constexpr int KQ = 8;
+    T q_prev[KQ];
+    int r_prev[KQ];
+    int ec_prev = 0;
+    int64_t t0_prev = 0;
+    bool live_prev = false;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) { q_prev[k] = T(0); r_prev[k] = 0; }
+    auto flush_prev = [&]() {
+#pragma unroll
+        for (int k = 0; k < KQ; ++k)
+            if (k < ec_prev && live_prev) out[(int64_t)r_prev[k] * ldo + t0_prev + lane] = q_prev[k];
+    };
+
+    auto stage = [&](auto pf_tag) {
+        constexpr bool PF = decltype(pf_tag)::value;
+        const int64_t t0 = (int64_t)iC.tb * TB;
+        const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
+        const bool lane_live = lane < nt && lane < TB;
+        stamp(-1);
+        if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }   // ph0: wait for the rows
+        // ---- park the current item (registers -> LDS); note whether the whole chunk is finite ----
+        bool odd = false;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = v[i];
+            const vec4 z = v[i] - v[i];                         // 0 for finite values, NaN for NaN / inf
+            odd |= !(z[0] == T(0) && z[1] == T(0) && z[2] == T(0) && z[3] == T(0));
+        }
+        if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) *sm_flag = 1;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int k = tid + STHREADS * i;
+            if (k < dC.ns) { sm_u[k] = (uint16_t)mu[i]; sm_w[k] = mw[i]; }
+        }
+        if (tid < dC.ne) { sm_er[tid] = er; sm_ed[tid] = ed; }
+        if (tid <= dC.ne) sm_es[tid] = (uint16_t)(es - dC.sb);
+        const int ne = dC.ne;
+        stamp(1);                                                                   // ph1: park
+        // ---- one block of global traffic per stage, in this order (vmcnt retires in order):
+        // previous item's results, next items' metadata, next item's rows ----
+        if (!(STAMP && (knob & 4))) flush_prev();
+        stamp(6);
+        StreamDesc dD = dB;
+        Item iD = iB;
+        int cellB = cellA;
+        if (PF) {
+            iD = advance(iB);
+            if (iD.tb * (long long)n_norm + iD.g >= n_items) iD = iB;     // past the end: any valid item
+            load_desc(iD, dD);
+            cellB = load_cell(dB);
+            stamp(7);
+            issue_meta(dA);
+            stamp(8);
+            if (!(STAMP && (knob & 2))) issue_x(cellA, iA.tb);
+        }
+        stamp(2);                                                                   // ph2: issue
+        lds_only_barrier();
+        const bool all_finite = __builtin_amdgcn_readfirstlane(*sm_flag) == 0;
+        stamp(3);                                                                   // ph3: barrier 1
+        // ---- weighted group sums of the current item out of LDS.  Each wave walks ONE flat run of
+        // segments (a contiguous range of region entries with ~1/4 of the chunk's segments): lane j
+        // of a 64-segment block holds segment j's (u, w) in registers (one LDS read per lane), the
+        // loop broadcasts them with v_readlane so the 8 x-reads of a group are independent, and a
+        // flag bit in u closes a region (wave-uniform branch): divide, keep the quotient in a
+        // register slot for the deferred store, reset the sum.  Padding lanes hold w = 0, u = 0
+        // and add exactly 0, so groups of 8 need no remainder loop. ----
+        const unsigned long long split = dC.split;   // captured before any rotation
+        const int ea = wave == 0 ? 0 : (int)((split >> (8 * (wave - 1))) & 0xff);
+        const int eb = wave == SWAVE - 1 ? ne : (int)((split >> (8 * wave)) & 0xff);
+        int ec = 0;                                            // regions closed by this wave
+        if (ea < eb) {
+            const int sa = __builtin_amdgcn_readfirstlane((int)sm_es[ea]);
+            const int se = __builtin_amdgcn_readfirstlane((int)sm_es[eb]);
+            T acc = T(0);
+            for (int base = sa; base < se; base += 64) {
+                const int n = se - base < 64 ? se - base : 64;
+                const int ul = lane < n ? (int)sm_u[base + lane] : 0;
+                const T wl = lane < n ? sm_w[base + lane] : T(0);
+                for (int j0 = 0; j0 < n; j0 += 8) {
+                    T xv[8], wv[8];
+                    int uf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {               // 8 independent LDS reads in flight
+                        uf[j] = __builtin_amdgcn_readlane(ul, j0 + j);
+                        if constexpr (sizeof(T) == 4) {
+                            wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
+                        } else {
+                            const long long wb = __builtin_bit_cast(long long, wl);
+                            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(wb & 0xffffffffll), j0 + j);
+                            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), j0 + j);
+                            wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+                        }
+                        xv[j] = xs[lane * UROW + (uf[j] & SEG_UMASK)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (all_finite) {                       // finite data: no skipna test needed;
+#pragma clang fp contract(off)                                  // same roundings as the general path
+                            const T p = xv[j] * wv[j];
+                            acc += p;
+                        } else {
+                            const T p = xv[j] * wv[j];          // aggregations.py:78 product
+                            acc += (p == p) ? p : T(0);         // skipna (S6)
+                        }
+                        if (uf[j] & SEG_LAST) {                 // wave-uniform: region complete
+                            const T qv = acc / sm_ed[ea + ec];  // aggregations.py:77-80
+                            const int r = __builtin_amdgcn_readfirstlane(sm_er[ea + ec]);
+                            if (ec < KQ) {
+#pragma unroll
+                                for (int k = 0; k < KQ; ++k) {
+                                    q_prev[k] = (ec == k) ? qv : q_prev[k];
+                                    r_prev[k] = (ec == k) ? r : r_prev[k];
+                                }
+                            } else if (lane_live) {             // more than KQ regions per wave (rare)
+                                out[(int64_t)r * ldo + t0 + lane] = qv;
+                            }
+                            acc = T(0);
+                            ++ec;
+                        }
+                    }
+                }
+            }
+        }
+        ec_prev = ec < KQ ? ec : KQ; t0_prev = t0; live_prev = lane_live;
+        stamp(4);                                                                   // ph4: compute
+        lds_only_barrier();                                     // every wave has read the flag
+        if (tid == 0) *sm_flag = 0;
+        if (PF) { dC = dA; dA = dB; dB = dD; cellA = cellB; iC = iA; iA = iB; iB = iD; }
+        lds_only_barrier();
+        stamp(5);                                                                   // ph5: rotate + barrier 2
+    };
+    for (int st = 0; st + 1 < nst; ++st) stage(std::true_type{});
+    stage(std::false_type{});
+    flush_prev();
+    if (STAMP && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) stamps[blockIdx.x * 10 + i] = ph[i];
     }
 }
 
@@ -270,8 +555,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
     pv.ucell = d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
     pv.seg_u = d.seg_u.p;
-    if constexpr (sizeof(T) == 4) { pv.seg_w = d.seg_w32.p; pv.den = d.den32.p; }
-    else { pv.seg_w = d.seg_w64.p; pv.den = d.den64.p; }
+    if constexpr (sizeof(T) == 4) { pv.seg_w = d.seg_w32.p; pv.den = d.den32.p; pv.ent_den = d.ent_den32.p; }
+    else { pv.seg_w = d.seg_w64.p; pv.den = d.den64.p; pv.ent_den = d.ent_den64.p; }
     pv.n_groups = (int)plan->info.n_groups;
     if (Ttot == 0) return WAGG_OK;
     const int64_t n_tb = (Ttot + TB - 1) / TB;
@@ -288,8 +573,48 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         kout = ws;
         kldo = ldws;
     }
-    if (plan->info.n_groups > 0) {
-        const int64_t nblk = plan->info.n_groups * n_tb;
+    pv.chunk_desc = d.chunk_desc.p; pv.g0_normal = d.g0_normal; pv.c0_normal = d.c0_normal;
+    // aligned fast path: 16-byte aligned rows
+    const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0);
+    const bool stream_path = layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM");
+    const int n_norm = (int)plan->info.n_groups - d.g0_normal;
+    if (stream_path && n_norm > 0) {
+        // persistent pipelined kernel over the single-chunk groups; two workgroups per CU
+        int dev = 0, ncu = 256;
+        WAGG_HIP(hipGetDevice(&dev));
+        WAGG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const long long n_items = (long long)n_norm * n_tb;
+        const long long nw = n_items < 2LL * ncu ? n_items : 2LL * ncu;
+        const size_t shmem = SparseLds<T, TB>::total;
+        auto kern = vec ? sparse_stream_kernel<T, TB, true> : sparse_stream_kernel<T, TB, false>;
+        unsigned long long *stamps = nullptr;
+        const bool do_stamp = getenv("WAGG_SPARSE_STAMP") != nullptr;
+        if (do_stamp) {
+            kern = sparse_stream_kernel<T, TB, true, true>;
+            WAGG_HIP(hipMalloc((void **)&stamps, sizeof(unsigned long long) * 10 * (size_t)nw));
+        }
+        WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        profile_mark(stream, true);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(STHREADS), shmem, stream, pv, X, Ttot, ldx, plan->info.G,
+                           kout, kldo, n_norm, n_items, stamps, do_stamp ? atoi(getenv("WAGG_SPARSE_STAMP")) : 0);
+        profile_mark(stream, false);
+        WAGG_HIP(hipGetLastError());
+        if (do_stamp) {           // diagnostic: print mean cycles per stage and phase
+            std::vector<unsigned long long> h(10 * (size_t)nw);
+            WAGG_HIP(hipStreamSynchronize(stream));
+            WAGG_HIP(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            (void)hipFree(stamps);
+            double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < h.size(); ++i) sum[i % 10] += (double)h[i];
+            const double stages = (double)n_items;
+            fprintf(stderr, "[wagg stamp] items=%lld nw=%lld cycles/stage: wait_rows=%.0f park=%.0f [flush=%.0f desc+cell=%.0f meta=%.0f rows=%.0f] bar1=%.0f compute=%.0f (first entry %.0f) rot+bar2=%.0f\n",
+                    n_items, nw, sum[0] / stages, sum[1] / stages, sum[6] / stages, sum[7] / stages, sum[8] / stages, sum[2] / stages,
+                    sum[3] / stages, (sum[4] + sum[9]) / stages, sum[9] / stages, sum[5] / stages);
+        }
+        pv.n_groups = d.g0_normal;          // what is left for the chunk-walking kernel: giant groups
+    }
+    if (pv.n_groups > 0) {
+        const int64_t nblk = (int64_t)pv.n_groups * n_tb;
         WAGG_REQUIRE(nblk < (int64_t)0x7fffffff, "grid too large: %lld", (long long)nblk);
         const size_t shmem = SparseLds<T, TB>::total;
         dim3 grid((unsigned)nblk), block(UC);
@@ -308,15 +633,11 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             }                                                                                    \
             WAGG_HIP(hipFuncSetAttribute((const void *)kern,                                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-            profile_mark(stream, true);                                                          \
+            if (!(stream_path && n_norm > 0)) profile_mark(stream, true);                        \
             hipLaunchKernelGGL(kern, grid, block, shmem, stream, pv, X, Ttot, ldx, plan->info.G, \
                                kout, kldo);                                                      \
-            profile_mark(stream, false);                                                         \
+            if (!(stream_path && n_norm > 0)) profile_mark(stream, false);                       \
         } while (0)
-        // aligned fast path: 16-byte aligned rows (fp32: ldx % 4 == 0; fp64 quads are 32 bytes but
-        // are fetched as two 16-byte halves, so the same condition on bytes applies)
-        const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0) &&
-                         (sizeof(T) == 4 || true);
         if (layout == WAGG_LAYOUT_TG) { if (vec) WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, true); else WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, false); }
         else WAGG_LAUNCH(WAGG_LAYOUT_GT, WAGG_OUT_RT, false);
 #undef WAGG_LAUNCH
@@ -554,6 +875,36 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             grp_chunk_begin.push_back((int32_t)(chunk_u_begin.size() - 1));
         }
 
+        // bit 15 of a segment's local cell index marks the LAST segment of its region entry
+        // (local indices are < 256); entries without segments cannot exist (every entry has >= 1)
+        for (size_t e = 0; e + 1 < ent_seg_begin.size(); ++e)
+            if (ent_seg_begin[e + 1] > ent_seg_begin[e]) seg_u[(size_t)ent_seg_begin[e + 1] - 1] |= SEG_LAST;
+        // per-chunk descriptors for the persistent kernel; giant groups come first.  dd[6] packs the
+        // entry split points of the four waves (contiguous entry ranges with ~equal segment counts)
+        std::vector<int32_t> chunk_desc((size_t)(chunk_u_begin.size() - 1) * 8, 0);
+        for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c) {
+            int32_t *dd = &chunk_desc[c * 8];
+            dd[0] = chunk_u_begin[c]; dd[1] = chunk_u_begin[c + 1] - chunk_u_begin[c];
+            dd[2] = chunk_e_begin[c]; dd[3] = chunk_e_begin[c + 1] - chunk_e_begin[c];
+            dd[4] = ent_seg_begin[(size_t)chunk_e_begin[c]];
+            dd[5] = ent_seg_begin[(size_t)chunk_e_begin[c + 1]] - dd[4];
+            int32_t split[SWAVE + 1];
+            for (int i = 0; i <= SWAVE; ++i) split[i] = i == SWAVE ? dd[3] : 0;
+            int w = 1;
+            for (int32_t e = 0; e < dd[3] && w < SWAVE; ++e) {
+                const int64_t done = ent_seg_begin[(size_t)(dd[2] + e + 1)] - dd[4];
+                while (w < SWAVE && done * SWAVE >= (int64_t)dd[5] * w) split[w++] = e + 1;
+            }
+            while (w < SWAVE) split[w++] = dd[3];
+            uint64_t packed = 0;
+            for (int i = 1; i < SWAVE; ++i) packed |= (uint64_t)(split[i] & 0xff) << (8 * (i - 1));
+            dd[6] = (int32_t)(uint32_t)(packed & 0xffffffffu);
+            dd[7] = (int32_t)(uint32_t)(packed >> 32);
+        }
+        int g0_normal = 0;
+        while (g0_normal < (int)groups.size() && groups[(size_t)g0_normal].giant) ++g0_normal;
+        const int c0_normal = grp_chunk_begin[(size_t)g0_normal];
+
         wagg_plan *plan = new wagg_plan();
         plan->den_host = den;
         plan->info.nseg_in = nseg; plan->info.nnz = nnz;
@@ -574,7 +925,17 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         up(d.chunk_u_begin, chunk_u_begin); up(d.chunk_e_begin, chunk_e_begin);
         up(d.ucell, ucell); up(d.ent_region, ent_region); up(d.ent_seg_begin, ent_seg_begin);
         up(d.seg_u, seg_u); up(d.seg_w32, seg_w32); up(d.seg_w64, seg_w);
-        up(d.den32, den32); up(d.den64, den); up(d.empty_regions, empty);
+        up(d.den32, den32); up(d.den64, den); up(d.empty_regions, empty); up(d.chunk_desc, chunk_desc);
+        {
+            std::vector<double> ed64(ent_region.size() + 1, 1.0);   // +1: the clamped ent_seg_begin twin
+            std::vector<float> ed32(ent_region.size() + 1, 1.0f);
+            for (size_t e = 0; e < ent_region.size(); ++e) {
+                ed64[e] = den[(size_t)ent_region[e]];
+                ed32[e] = den32[(size_t)ent_region[e]];
+            }
+            up(d.ent_den64, ed64); up(d.ent_den32, ed32);
+        }
+        d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));
             delete plan;
