@@ -61,6 +61,7 @@ def sparse_algorithmic_bytes(T, G, R, nnz, b):
 
 
 def timed_steps(torch, dist, step, steps, warmup, world):
+    world = world if not (dist.is_available() and dist.is_initialized()) else max(world, 2)   # forced-dist rehearsal
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -125,8 +126,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # WAGG_BENCH_FORCE_DIST=1 exercises the RCCL init + gather code path with a single rank (rehearsal
+    # on a one-GPU box); the timed step then includes the (trivial) gather exactly like N > 1 runs
+    force_dist = os.environ.get("WAGG_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from climate_toolbox_amd import engine, synth
@@ -148,7 +156,7 @@ def main():
 
         def step():
             plan.apply(Xs, out=out)
-            if world > 1:
+            if use_dist:
                 gathered[0] = gather_time_shards(out, dst=0)
 
         engine.profile_enable(True)       # event records only, no synchronisation
@@ -182,7 +190,7 @@ def main():
 
         def step():
             dense.apply(X, out=out, ksplit=a.ksplit)
-            if world > 1:
+            if use_dist:
                 gathered[0] = gather_time_shards(out, dst=0)
 
         engine.profile_enable(True)       # event records only (no sync): negligible next to 0.1 s
@@ -233,7 +241,7 @@ def main():
         if secondary:
             line["secondary"] = secondary
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

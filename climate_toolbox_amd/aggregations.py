@@ -23,7 +23,7 @@ import numpy as np
 import pandas as pd
 
 from . import minixr
-from .engine import SparsePlan, gather as _device_gather, require_gpu
+from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
 
 try:  # optional: return real xarray objects when the caller hands us xarray objects
     import xarray as _xr
@@ -220,15 +220,35 @@ def _flatten_for_device(values, dims):
     return X2, layout, others_shape, unflatten
 
 
-def _plan_for(cell_idx, codes, w_eff, G, R, row_len):
+DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins
+
+
+def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes):
+    """Device-form choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
+    per timestep; when regions are scattered all over the grid (e.g. <=1 % non-zeros at random
+    columns: every region is a multi-chunk "giant") that is many times the grid itself and the
+    dense (gridcell x region) MFMA contraction, whose cost does not depend on the structure, is
+    faster -- provided it is an fp32 (time, gridcell) problem and W fits comfortably in HBM."""
+    if not is_f32 or layout != "TG":
+        return False
+    w_bytes = 4 * int(G) * ((int(R) + 127) // 128 * 128)
+    return n_ucells > DENSE_SWITCH * G and w_bytes < 0.6 * free_bytes
+
+
+def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
     h = hashlib.blake2b(digest_size=16)
     for a in (cell_idx, codes, w_eff):
         h.update(np.ascontiguousarray(a).tobytes())
-    h.update(repr((int(G), int(R), int(row_len))).encode())
+    h.update(repr((int(G), int(R), int(row_len), bool(is_f32), layout)).encode())
     key = h.hexdigest()
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
+        import torch
+        free_bytes = torch.cuda.mem_get_info()[0]
+        if _prefer_dense(plan.info["n_ucells"], G, R, is_f32, layout, free_bytes):
+            plan.close()
+            plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
         _PLAN_CACHE[key] = plan
         while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
             _PLAN_CACHE.popitem(last=False)[1].close()
@@ -362,9 +382,12 @@ def _aggregate_reindexed_data_to_regions(
 
     torch = require_gpu()
     X2, layout, _, unflatten = _flatten_for_device(values, dims)
-    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len)
+    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=X2.dtype == np.float32, layout=layout)
     Xd = torch.from_numpy(X2).cuda()
-    out_d = plan.apply(Xd, layout=layout, out_layout="TR" if layout == "TG" else "RT")
+    if isinstance(plan, DensePlan):
+        out_d = plan.apply(Xd)
+    else:
+        out_d = plan.apply(Xd, layout=layout, out_layout="TR" if layout == "TG" else "RT")
     res = unflatten(out_d.cpu().numpy(), len(uniq))
     rdims = _result_dims(dims, agglev)
 

@@ -118,7 +118,11 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         else { const float *f_ = reinterpret_cast<const float *>(WAGG_XPTR(i, tile));            \
                xr##i = f32x4{f_[0], f_[1], f_[2], f_[3]}; }                                      \
     } while (0)
-#define WAGG_LOAD_W(i, tile) wr##i = *reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile))
+#define WAGG_LOAD_W(i, tile)                                                                     \
+    do {                                                                                         \
+        if (DBG & 32) wr##i = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile))); \
+        else wr##i = *reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile));                        \
+    } while (0)
 #define WAGG_STORE_X(i, buf)                                                                     \
     do {                                                                                         \
         float *xs_ = lds + (buf) * D_STAGE + xoff0 + 64 * (i);                                   \
@@ -200,6 +204,8 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
                     if (s4 == 5 && !(DBG & 8)) WAGG_LOAD_X(5, tile + 2);
                     if (s4 == 6) WAGG_LOAD_W(0, tile + 2);
                     if (s4 == 7) WAGG_LOAD_W(1, tile + 2);
+                }
+                if ((DBG & 64) && MODE == 2 && (m == 16 || m == 17)) {    // experiment: stagger waves 4-7
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -488,6 +494,7 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
             case 3: kern = dense_mfma_kernel<true, 3>; break;
             case 7: kern = dense_mfma_kernel<true, 7>; break;
             case 8: kern = dense_mfma_kernel<true, 8>; break;
+            case 32: kern = dense_mfma_kernel<true, 32>; break;
             default: break;
         }
     }

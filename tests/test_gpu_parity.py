@@ -340,3 +340,73 @@ def test_c2_dense_full_size_properties(torch_cuda):
     got365 = plan.apply(X365).cpu().numpy()
     np.testing.assert_array_equal(got365[:T], got)
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] shape at test scale: ensemble x time rows, CSR-like weights with a
+# fixed fraction of non-zeros, both structures SURVEY 8d names (uniform-random columns = every
+# region is a "giant" multi-chunk group; block-local = each 64-cell run touches few regions)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("structure", ["uniform", "block_local"])
+@pytest.mark.parametrize("dtype,rtol", [(np.float32, RTOL32), (np.float64, RTOL64)])
+def test_c5_like_sparse_structures(torch_cuda, structure, dtype, rtol):
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    members, days, G, R = 5, 37, 64 * 96, 300                # rows = ensemble x time = 185
+    T = members * days
+    nnz = int(0.01 * G * R)
+    if structure == "uniform":
+        flat = rng.choice(G * R, size=nnz, replace=False)
+        cell, code = (flat // R).astype(np.int32), (flat % R).astype(np.int32)
+    else:
+        runs = rng.integers(0, G // 64, nnz)
+        cell = (runs * 64 + rng.integers(0, 64, nnz)).astype(np.int32)
+        code = ((runs * 3 + rng.integers(0, 3, nnz)) % R).astype(np.int32)     # <= 3 regions per run
+    w = rng.uniform(0.1, 1.0, nnz)
+    X = (280 + 15 * rng.standard_normal((T, G))).astype(dtype)
+    ref = O.agg_coded(X, cell, code, w, R)
+    plan = SparsePlan(cell, code, w, G, R, row_len=96)
+    if structure == "uniform":
+        assert plan.info["n_giant"] > 0                       # multi-chunk path exercised
+    got = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    _rel_ok(got, ref, rtol, scale=1.0)
+    # ensemble x time is just more rows: aggregating members separately gives the same numbers
+    one = plan.apply(torch.from_numpy(np.ascontiguousarray(X[days:2 * days])).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(one, got[days:2 * days])
+    if dtype == np.float32:                                   # the dense-tile form of the same weights
+        dense = DensePlan.from_segments(cell, code, w, G, R)
+        _rel_ok(dense.apply(torch.from_numpy(X).cuda()).cpu().numpy(), ref, RTOL32, scale=1.0)
+
+
+def test_dropin_switches_to_dense_form_for_scattered_weights(torch_cuda):
+    """Through the reference-named API: weights whose regions are scattered over the whole grid
+    are contracted by the dense MFMA kernel, compact ones by the gather kernel -- same numbers."""
+    from climate_toolbox_amd import aggregations as A, minixr
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(3)
+    nlat, nlon, R, T = 48, 96, 40, 30
+    lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0
+    n = int(0.3 * nlat * nlon * R)                              # dense-ish random table
+    flat = rng.choice(nlat * nlon * R, size=n, replace=False)
+    cell, lab = flat // R, flat % R
+    df = pd.DataFrame({"lat": lat[cell // nlon], "lon": lon[cell % nlon], "areawt": rng.uniform(0.1, 1, n),
+                       "hierid": lab})
+    tas = (280 + 10 * rng.standard_normal((T, nlat, nlon))).astype(np.float32)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"lat": lat, "lon": lon})
+    A._PLAN_CACHE.clear()
+    out = A.weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    assert any(isinstance(p, DensePlan) for p in A._PLAN_CACHE.values())
+    ref, dims, labs = O.agg_scatter(tas, ("time", "lat", "lon"), lat, lon, df["lat"].values, df["lon"].values,
+                                    df["areawt"].values, df["areawt"].values, df["hierid"].values, group_dim="hierid")
+    assert out.tas.dims == dims and list(out["hierid"].values) == list(labs)
+    _rel_ok(out.tas.values, ref, RTOL32)
+    out64 = A.weighted_aggregate_grid_to_regions(
+        minixr.Dataset({"tas": (("time", "lat", "lon"), tas.astype(np.float64))}, coords={"lat": lat, "lon": lon}),
+        "tas", "areawt", "hierid", df)
+    assert any(isinstance(p, SparsePlan) for p in A._PLAN_CACHE.values())
+    _rel_ok(out64.tas.values, O.agg_scatter(tas.astype(np.float64), ("time", "lat", "lon"), lat, lon, df["lat"].values,
+                                            df["lon"].values, df["areawt"].values, df["areawt"].values,
+                                            df["hierid"].values)[0], RTOL64)

@@ -128,3 +128,13 @@ def test_synth_workloads_are_wellformed():
     assert df2["hierid"].nunique() == 300
     per_cell = df2.groupby(["lat", "lon"]).size()
     assert per_cell.max() <= 3 and per_cell.min() >= 1
+
+
+def test_dense_form_choice():
+    """Structure-driven choice between the gather form and the dense MFMA form (host logic only)."""
+    G, R, GB = 1036800, 24378, 1 << 30
+    assert not A._prefer_dense(1.4 * G, G, R, True, "TG", 250 * GB)        # c2-real: compact regions
+    assert A._prefer_dense(240 * G, G, R, True, "TG", 250 * GB)            # c5 uniform-random columns
+    assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB)       # fp64 stays on the gather form
+    assert not A._prefer_dense(240 * G, G, R, True, "GT", 250 * GB)        # fixture layout stays too
+    assert not A._prefer_dense(240 * G, G, R, True, "TG", 100 * GB)        # 101 GB of W must fit
