@@ -29,8 +29,8 @@ namespace wagg {
 constexpr int UC = 256;      // cell slots per LDS chunk == workgroup size
 constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of a wave)
 constexpr int UROW = UC + 4; // LDS row stride in elements (t-major image, 16-byte aligned rows)
-constexpr int RG_MAX = 255;  // regions per group (bounded by cells anyway)
-constexpr int SEG_MAX = 768; // segments per chunk staged in LDS
+constexpr int RG_MAX = 127;  // regions per group
+constexpr int SEG_MAX = 512; // segments per chunk staged in LDS
 constexpr int SEG_LAST = 0x8000;   // flag bit in a segment's local cell index: last segment of its entry
 constexpr int SEG_UMASK = 0x7fff;
 constexpr int NWAVE = 4;      // waves of the chunk-walking kernel (256 threads)
@@ -509,6 +509,329 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Loader/consumer form (fp32, TG layout, single-chunk groups): ONE 768-thread workgroup per CU.
+//   * 8 LOADER waves stream the next item's 64 rows x 64 quads into registers and park them in the
+//     other half of a double-buffered LDS image (NaN -> 0 on the way, S6; a flag notes +-inf);
+//     they block at VMEM issue for as long as the transfer takes -- which is why they do nothing
+//     else (microbenchmarks: a wave that issues its own loads cannot overlap them with work).
+//   * 4 CONSUMER waves reduce the current item with the matrix cores: the chunk's segment list is
+//     scattered into a dense LDS tile Aw[16 regions][256 cells] (zero elsewhere) and
+//     out[e][t] = sum_u Aw[e][u] * img[t][u] runs as 64 v_mfma_f32_16x16x4_f32 per wave (wave c
+//     owns timesteps 16c..16c+15); more than 16 regions take further passes.  ~3k cycles per
+//     pass against ~6k cycles of load time per item: the kernel is HBM-bound.
+//   * one workgroup barrier per item swaps the image halves; the consumer waves synchronise among
+//     themselves through a monotonic LDS counter (bounded spin).
+// Chunks whose data contain +-inf fall back to the exact per-segment VALU reduction.
+// ---------------------------------------------------------------------------------------------
+constexpr int LC_LW = 8, LC_CW = 4, LC_THREADS = (LC_LW + LC_CW) * 64;
+constexpr int LC_TB = 64;
+constexpr int LC_AROW = UC + 4;                 // Aw row stride (elements)
+constexpr int LC_ENT = RG_MAX + 1;              // entries per chunk
+constexpr int LC_SEGS = SEG_MAX;                // segments per chunk the metadata block can hold
+struct LcLds {
+    static constexpr size_t img = 0;                                            // [2][64][UROW] f32
+    static constexpr size_t aw = img + 2 * sizeof(float) * LC_TB * UROW;        // [16][LC_AROW] f32
+    static constexpr size_t seg_w = aw + sizeof(float) * 16 * LC_AROW;          // [2][LC_SEGS] f32
+    static constexpr size_t seg_u = seg_w + 2 * sizeof(float) * LC_SEGS;        // [2][LC_SEGS] i32 (packed)
+    static constexpr size_t ent_r = seg_u + 2 * sizeof(int32_t) * LC_SEGS;      // [2][LC_ENT] i32
+    static constexpr size_t ent_d = ent_r + 2 * sizeof(int32_t) * LC_ENT;       // [2][LC_ENT] f32
+    static constexpr size_t ent_s = ent_d + 2 * sizeof(float) * LC_ENT;         // [2][LC_ENT + 2] u16
+    static constexpr size_t hdr = ent_s + 2 * sizeof(uint16_t) * (LC_ENT + 2);  // [2][8] i32
+    static constexpr size_t cnt = hdr + 2 * 8 * sizeof(int32_t);                // consumer barrier counter
+    static constexpr size_t total = (cnt + 16 + 15) / 16 * 16;
+    static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
+                                                                  int64_t Ttot, int64_t ldx, int64_t G,
+                                                                  float *__restrict__ out, int64_t ldo,
+                                                                  int n_norm, long long n_items,
+                                                                  int *__restrict__ timeout_word,
+                                                                  unsigned long long *__restrict__ stamps) {
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *img = reinterpret_cast<float *>(smem_raw + LcLds::img);
+    float *aw = reinterpret_cast<float *>(smem_raw + LcLds::aw);
+    float *sm_w = reinterpret_cast<float *>(smem_raw + LcLds::seg_w);
+    int32_t *sm_u = reinterpret_cast<int32_t *>(smem_raw + LcLds::seg_u);
+    int32_t *sm_er = reinterpret_cast<int32_t *>(smem_raw + LcLds::ent_r);
+    float *sm_ed = reinterpret_cast<float *>(smem_raw + LcLds::ent_d);
+    uint16_t *sm_es = reinterpret_cast<uint16_t *>(smem_raw + LcLds::ent_s);
+    int32_t *hdr = reinterpret_cast<int32_t *>(smem_raw + LcLds::hdr);
+    int *ccnt = reinterpret_cast<int *>(smem_raw + LcLds::cnt);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave < LC_LW;
+    const bool out_vec = (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // XCD-contiguous ids (speed only)
+    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
+    const long long NW = NWu;
+    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
+    if (w0 >= n_items) return;
+    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
+    const int nst = (int)((n_items - 1 - w0) / NW) + 1;
+    struct Item { int g, tb; };
+    auto advance = [&](Item a) {
+        Item b{a.g + dg, a.tb + dtb};
+        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
+        return b;
+    };
+    if (tid == 0) { *ccnt = 0; hdr[2] = 0; hdr[8 + 2] = 0; }
+    lds_only_barrier();
+    // diagnostic phase stamps (only when a stamp buffer is passed; nothing else reads it)
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            if (i >= 0) ph[i] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+
+    if (loader) {
+        // =============================== loader waves ===============================
+        constexpr int TPW = LC_TB / LC_LW;                       // 8 rows per wave
+        const int tw0 = wave * TPW;
+        auto load_desc = [&](Item a, StreamDesc &d) {
+            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
+            const int4v x = *reinterpret_cast<const int4v *>(p);
+            const int4v y = *reinterpret_cast<const int4v *>(p + 4);
+            d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
+        };
+        auto load_cell = [&](const StreamDesc &d) { return pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)]; };
+        struct Regs { vec4 v[TPW]; int mu; float mw; int er, es; float ed; };
+        static_assert(LC_SEGS <= LC_LW * 64, "one metadata element per loader thread");
+        auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
+            // small metadata loads first, the rows last (vmcnt retires in order)
+            {
+                const int k = tid < d.ns ? tid : d.ns - 1;
+                R.mu = pv.seg_u[d.sb + k];
+                R.mw = pv.seg_w[d.sb + k];
+            }
+            R.er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+            R.ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+            R.es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];
+            const int64_t t0 = (int64_t)tb * LC_TB;
+            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
+            const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
+            int cnt = nt - tw0;
+            cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
+            const float *p = X + (t0 + rbase) * ldx + cell0;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (VEC) R.v[i] = *reinterpret_cast<const vec4 *>(p);
+                else {
+                    const int64_t lim = G - 1 - cell0;
+                    R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
+                }
+                if (i + 1 < cnt) p += ldx;
+            }
+        };
+        auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
+            float *im = img + buf * LC_TB * UROW;
+            // one v_cmp_class per element finds NaN / +-inf; the select runs only if the wave saw any
+            bool odd = false;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN|qNaN|-inf|+inf
+            if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
+                bool inf_seen = false;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = R.v[i][c];
+                        inf_seen |= __builtin_amdgcn_classf(x, 0x204);           // -inf | +inf: exact path
+                        R.v[i][c] = (x == x) ? x : 0.0f;                           // NaN data counts 0 (S6)
+                    }
+                if (__builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull)) hdr[buf * 8 + 2] = 1;
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = R.v[i];
+            if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
+            if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
+            if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
+            if (tid == 0) { hdr[buf * 8 + 0] = d.ne; hdr[buf * 8 + 1] = d.ns; hdr[buf * 8 + 3] = tb; }
+        };
+        // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
+        Item itq[3];
+        StreamDesc dq[3];
+        int cellq[2];
+        itq[0] = Item{(int)(w0 % n_norm), (int)(w0 / n_norm)};
+        itq[1] = nst > 1 ? advance(itq[0]) : itq[0];
+        itq[2] = nst > 2 ? advance(itq[1]) : itq[1];
+        load_desc(itq[0], dq[0]); load_desc(itq[1], dq[1]); load_desc(itq[2], dq[2]);
+        cellq[0] = load_cell(dq[0]);
+        cellq[1] = load_cell(dq[1]);
+        Regs RA, RB;
+        // item 0 -> RA -> buffer 0; item 1 (if any) already in flight in RB while item 0 is parked
+        issue(RA, dq[0], cellq[0], itq[0].tb);
+        StreamDesc dPark = dq[0];
+        int tbPark = itq[0].tb;
+        // look-ahead queue: itq/dq/cellq[0] = next item to issue.  vmcnt retires in order, so the
+        // queue's own loads (descriptor of the item after next-next, quad list of next-next) are
+        // issued BEFORE a stage's row loads and consumed after them with a counted wait.
+        struct Ahead { Item nx; StreamDesc dn; int cn; };
+        auto ahead_load = [&](Ahead &a) {
+            a.nx = advance(itq[2]);
+            if (a.nx.tb * (long long)n_norm + a.nx.g >= n_items) a.nx = itq[2];
+            load_desc(a.nx, a.dn);
+            a.cn = load_cell(dq[2]);
+        };
+        auto ahead_commit = [&](const Ahead &a) {
+            itq[0] = itq[1]; itq[1] = itq[2]; itq[2] = a.nx;
+            dq[0] = dq[1]; dq[1] = dq[2]; dq[2] = a.dn;
+            cellq[0] = cellq[1]; cellq[1] = a.cn;
+        };
+        { Ahead a; ahead_load(a); ahead_commit(a); }              // queue now describes items 1, 2, 3
+        // two register sets alternate: while one item is parked, the next one's loads are in flight
+        auto lstage = [&](Regs &Rcur, Regs &Rnext, int st, int pbuf) {
+            // Rcur holds item st (in flight since the previous call); item st+1 goes to Rnext
+            const StreamDesc dn = dq[0];
+            const int tbn = itq[0].tb;
+            const bool more = st + 1 < nst;
+            Ahead a;
+            stamp(-1);
+            if (more) { ahead_load(a); issue(Rnext, dn, cellq[0], tbn); }
+            stamp(0);                                             // loader ph0: issue (blocked at VMEM)
+            park(Rcur, dPark, tbPark, pbuf);
+            stamp(2);                                             // ph2: wait for item st + park
+            if (more) { dPark = dn; tbPark = tbn; ahead_commit(a); }
+            stamp(1);                                             // ph1: queue rotation (must not wait for rows)
+            lds_only_barrier();                                   // item st is in buffer pbuf
+            stamp(3);                                             // ph3: waiting for the consumers
+        };
+        // item st is parked during call st (into buffer st & 1); consumers reduce item st after it.
+        // The buffer is free: its previous tenant (item st-2) was reduced before barrier st-1.
+        for (int st = 0; st < nst; st += 2) {
+            lstage(RA, RB, st, 0);
+            if (st + 1 < nst) lstage(RB, RA, st + 1, 1);
+        }
+        lds_only_barrier();                                       // consumers finish the last item
+        if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
+    } else {
+        // =============================== consumer waves ===============================
+        const int cw = wave - LC_LW;                              // 0..3: owns timesteps 16cw .. 16cw+15
+        const int ctid = tid - LC_LW * 64;                        // 0..255
+        const int lr = lane & 15, kq = lane >> 4;
+        int epoch = 0;
+        bool dead = false;
+        auto cbarrier = [&]() {                                   // the 4 consumer waves only (bounded spin)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            epoch += LC_CW;
+            if (lane == 0) {
+                __hip_atomic_fetch_add(ccnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int spins = 0;
+                while (__hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) { if (timeout_word) *timeout_word = 1; dead = true; break; }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        // the dense weight tile starts all-zero and is returned to all-zero after every pass
+        for (int i = ctid * 4; i < 16 * LC_AROW; i += 256 * 4)
+            *reinterpret_cast<vec4 *>(&aw[i]) = vec4{0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nst; ++st) {
+            stamp(-1);
+            lds_only_barrier();                                   // item st has been parked
+            stamp(3);                                             // consumer ph3: waiting for the loaders
+            const int buf = st & 1;
+            const float *im = img + buf * LC_TB * UROW;
+            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 0]);
+            const int ns = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 1]);
+            const bool exact = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 2]) != 0;
+            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 8 + 3]) * LC_TB;
+            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
+            cbarrier();                                           // every consumer wave has read the header
+            if (ctid == 0) hdr[buf * 8 + 2] = 0;                  // re-arm the +-inf flag for this buffer's next use
+            if (!exact) {
+                for (int e0 = 0; e0 < ne; e0 += 16) {
+                    // ---- dense weight tile of regions e0..e0+15: scatter the segments ----
+                    for (int k = ctid; k < ns; k += 256) {
+                        const int pu = sm_u[buf * LC_SEGS + k];
+                        const int e = (pu >> 16) & 0xff;
+                        if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = sm_w[buf * LC_SEGS + k];
+                    }
+                    cbarrier();
+                    stamp(0);                                     // consumer ph0: build the weight tile
+                    // ---- out[t][e] = sum_u img[t][u] * Aw[e][u].  A = img (i = timestep), B = Aw^T
+                    // (j = region); lane group kq = lane >> 4 walks cells 64 kq .. 64 kq + 63, so one
+                    // ds_read_b128 per operand feeds four MFMA k-steps (any 4 distinct cells per step
+                    // work as long as A and B agree); conflict-free with the 260-element row stride.
+                    // With timesteps on the rows a lane ends up with FOUR CONSECUTIVE timesteps of one
+                    // region: one 16-byte store per lane instead of four scattered dwords (consumer
+                    // stores queue behind the loaders' row loads, so their count matters) ----
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const float *ap = im + (16 * cw + lr) * UROW + 64 * kq;
+                    const float *bp = aw + lr * LC_AROW + 64 * kq;
+                    f32x4 af[2], bf[2];
+                    af[0] = *reinterpret_cast<const f32x4 *>(ap);
+                    bf[0] = *reinterpret_cast<const f32x4 *>(bp);
+#pragma unroll
+                    for (int g4 = 0; g4 < 16; ++g4) {
+                        if (g4 + 1 < 16) {
+                            af[(g4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + 4 * (g4 + 1));
+                            bf[(g4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(bp + 4 * (g4 + 1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // C/D map: column (region) = lane & 15, row (timestep) = 4 * (lane >> 4) + reg
+                    const int e = e0 + lr;
+                    const int tl = 16 * cw + 4 * kq;
+                    if (e < ne && tl < nt) {
+                        const float den = sm_ed[buf * LC_ENT + e];
+                        float *op = out + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+                        const f32x4 qv = {acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den};   // :77-80
+                        if (out_vec && tl + 3 < nt) {
+                            *reinterpret_cast<f32x4 *>(op) = qv;
+                        } else {
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                        }
+                    }
+                    stamp(1);                                     // ph1: MFMAs + stores
+                    cbarrier();                                   // every wave is done reading the tile
+                    for (int k = ctid; k < ns; k += 256) {        // return the tile to all-zero
+                        const int pu = sm_u[buf * LC_SEGS + k];
+                        const int e = (pu >> 16) & 0xff;
+                        if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = 0.f;
+                    }
+                    if (e0 + 16 < ne) cbarrier();                 // next pass scatters into a clean tile
+                    stamp(2);                                     // ph2: un-scatter + consumer barrier
+                }
+            } else {
+                // ---- exact path (+-inf in the data): per-segment products with the skipna test ----
+                for (int e = cw; e < ne; e += LC_CW) {
+                    const int s0 = sm_es[buf * (LC_ENT + 2) + e], s1 = sm_es[buf * (LC_ENT + 2) + e + 1];
+                    float acc = 0.f;
+                    for (int q = s0; q < s1; ++q) {
+                        const float p = im[lane * UROW + (sm_u[buf * LC_SEGS + q] & 0xff)] * sm_w[buf * LC_SEGS + q];
+                        acc += (p == p) ? p : 0.f;
+                    }
+                    if (lane < nt) out[(int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] = acc / sm_ed[buf * LC_ENT + e];
+                }
+            }
+        }
+        lds_only_barrier();                                       // matches the loaders' final barrier
+        if (stamps && ctid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
+        (void)dead;
+    }
+}
+
 // (R x T) -> (T x R) through a padded 64x64 LDS tile: both sides coalesced.  The gather kernel
 // stores region-major (lane = timestep: 256 contiguous bytes per region) because a (T x R) store
 // from it would scatter single dwords over R-strided lines (7x write amplification measured).
@@ -578,7 +901,40 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0);
     const bool stream_path = layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM");
     const int n_norm = (int)plan->info.n_groups - d.g0_normal;
-    if (stream_path && n_norm > 0) {
+    bool lc_done = false;
+    if constexpr (sizeof(T) == 4) {
+        if (stream_path && n_norm > 0 && !getenv("WAGG_SPARSE_NO_LC")) {
+            // loader/consumer MFMA kernel over the single-chunk groups; one workgroup per CU
+            int dev = 0, ncu = 256;
+            WAGG_HIP(hipGetDevice(&dev));
+            WAGG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
+            const long long nw = n_items < ncu ? n_items : ncu;
+            auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
+            WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LcLds::total));
+            unsigned long long *lc_stamps = nullptr;
+            if (getenv("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
+            profile_mark(stream, true);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
+                               plan->info.G, kout, kldo, n_norm, n_items, (int *)nullptr, lc_stamps);
+            profile_mark(stream, false);
+            WAGG_HIP(hipGetLastError());
+            if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
+                std::vector<unsigned long long> h(8 * (size_t)nw);
+                WAGG_HIP(hipStreamSynchronize(stream));
+                WAGG_HIP(hipMemcpy(h.data(), lc_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+                (void)hipFree(lc_stamps);
+                double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
+                const double stg = (double)n_items;
+                fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
+                        n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
+            }
+            pv.n_groups = d.g0_normal;
+            lc_done = true;
+        }
+    }
+    if (stream_path && n_norm > 0 && !lc_done) {
         // persistent pipelined kernel over the single-chunk groups; two workgroups per CU
         int dev = 0, ncu = 256;
         WAGG_HIP(hipGetDevice(&dev));
@@ -879,6 +1235,11 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         // (local indices are < 256); entries without segments cannot exist (every entry has >= 1)
         for (size_t e = 0; e + 1 < ent_seg_begin.size(); ++e)
             if (ent_seg_begin[e + 1] > ent_seg_begin[e]) seg_u[(size_t)ent_seg_begin[e + 1] - 1] |= SEG_LAST;
+        // bits 16..23: index of the segment's entry inside its chunk (read by the MFMA kernel)
+        for (size_t c = 0; c + 1 < chunk_e_begin.size(); ++c)
+            for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1]; ++e)
+                for (int32_t q = ent_seg_begin[(size_t)e]; q < ent_seg_begin[(size_t)e + 1]; ++q)
+                    seg_u[(size_t)q] |= (e - chunk_e_begin[c]) << 16;
         // per-chunk descriptors for the persistent kernel; giant groups come first.  dd[6] packs the
         // entry split points of the four waves (contiguous entry ranges with ~equal segment counts)
         std::vector<int32_t> chunk_desc((size_t)(chunk_u_begin.size() - 1) * 8, 0);

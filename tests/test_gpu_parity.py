@@ -155,7 +155,10 @@ def test_sparse_random_cases(torch_cuda, T, G, R, nseg, giant, dtype, rtol):
     np.testing.assert_array_equal(got_rt.T, got)                  # same kernel arithmetic, bitwise
     Xgt = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
     got_gt = plan.apply(Xgt, layout="GT").cpu().numpy()
-    np.testing.assert_array_equal(got_gt, got)
+    if dtype == np.float64:
+        np.testing.assert_array_equal(got_gt, got)                # same per-segment fp64 arithmetic, bitwise
+    else:                                                         # fp32 (T,G) data goes through the MFMA tile
+        _rel_ok(got_gt, got, 2e-6, scale=1.0)                     # reduction: other summation order (S12)
     again = plan.apply(Xd).cpu().numpy()
     np.testing.assert_array_equal(again, got)                     # no atomics: reproducible
     host = plan.apply_host(X)                                     # blocking host-buffer ABI form
