@@ -176,7 +176,7 @@ def main():
             "plan": {k: int(v) for k, v in plan.info.items()},
             "roofline": {"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic(wl),
-                         "kernel": "sparse_gather_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "kernel": "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": abytes},
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -238,6 +238,7 @@ def main():
         }
         if "nnz" in main_res:
             line["config"]["nnz"] = main_res["nnz"]
+            line["config"]["plan"] = main_res["plan"]
         if secondary:
             line["secondary"] = secondary
         print(json.dumps(line))

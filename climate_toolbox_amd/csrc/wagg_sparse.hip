@@ -537,8 +537,8 @@ struct LcLds {
     static constexpr size_t ent_r = seg_u + 2 * sizeof(int32_t) * LC_SEGS;      // [2][LC_ENT] i32
     static constexpr size_t ent_d = ent_r + 2 * sizeof(int32_t) * LC_ENT;       // [2][LC_ENT] f32
     static constexpr size_t ent_s = ent_d + 2 * sizeof(float) * LC_ENT;         // [2][LC_ENT + 2] u16
-    static constexpr size_t hdr = ent_s + 2 * sizeof(uint16_t) * (LC_ENT + 2);  // [2][8] i32
-    static constexpr size_t cnt = hdr + 2 * 8 * sizeof(int32_t);                // consumer barrier counter
+    static constexpr size_t hdr = ent_s + 2 * sizeof(uint16_t) * (LC_ENT + 2);  // [2][16] i32: ne, ns, -, tb, ..., 8 per-loader-wave inf flags
+    static constexpr size_t cnt = hdr + 2 * 16 * sizeof(int32_t);               // consumer barrier counter
     static constexpr size_t total = (cnt + 16 + 15) / 16 * 16;
     static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
 };
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
         return b;
     };
-    if (tid == 0) { *ccnt = 0; hdr[2] = 0; hdr[8 + 2] = 0; }
+    if (tid == 0) *ccnt = 0;
     lds_only_barrier();
     // diagnostic phase stamps (only when a stamp buffer is passed; nothing else reads it)
     unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN|qNaN|-inf|+inf
+            bool inf_any = false;
             if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
                 bool inf_seen = false;
 #pragma unroll
@@ -652,14 +653,15 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                         inf_seen |= __builtin_amdgcn_classf(x, 0x204);           // -inf | +inf: exact path
                         R.v[i][c] = (x == x) ? x : 0.0f;                           // NaN data counts 0 (S6)
                     }
-                if (__builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull)) hdr[buf * 8 + 2] = 1;
+                inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
             }
+            if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;      // every wave, every item: no reset needed
 #pragma unroll
             for (int i = 0; i < TPW; ++i) *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = R.v[i];
             if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
             if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
             if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
-            if (tid == 0) { hdr[buf * 8 + 0] = d.ne; hdr[buf * 8 + 1] = d.ns; hdr[buf * 8 + 3] = tb; }
+            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; }
         };
         // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
         Item itq[3];
@@ -731,8 +733,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                 __hip_atomic_fetch_add(ccnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 int spins = 0;
                 while (__hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22)) { if (timeout_word) *timeout_word = 1; dead = true; break; }
+                    if (++spins > (1 << 24)) { if (timeout_word) *timeout_word = 1; dead = true; break; }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -746,13 +747,12 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             stamp(3);                                             // consumer ph3: waiting for the loaders
             const int buf = st & 1;
             const float *im = img + buf * LC_TB * UROW;
-            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 0]);
-            const int ns = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 1]);
-            const bool exact = __builtin_amdgcn_readfirstlane(hdr[buf * 8 + 2]) != 0;
-            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 8 + 3]) * LC_TB;
+            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
+            const int ns = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 1]);
+            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LC_TB;
             const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
-            cbarrier();                                           // every consumer wave has read the header
-            if (ctid == 0) hdr[buf * 8 + 2] = 0;                  // re-arm the +-inf flag for this buffer's next use
+            const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
+            const bool exact = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);
             if (!exact) {
                 for (int e0 = 0; e0 < ne; e0 += 16) {
                     // ---- dense weight tile of regions e0..e0+15: scatter the segments ----
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     // region: one 16-byte store per lane instead of four scattered dwords (consumer
                     // stores queue behind the loaders' row loads, so their count matters) ----
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
                     const float *ap = im + (16 * cw + lr) * UROW + 64 * kq;
                     const float *bp = aw + lr * LC_AROW + 64 * kq;
                     f32x4 af[2], bf[2];
@@ -785,10 +785,13 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc, 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) {               // two chains: 40-cycle dependent latency vs 32 issue
+                            if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc2, 0, 0, 0);
+                            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc, 0, 0, 0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    acc += acc2;
                     // C/D map: column (region) = lane & 15, row (timestep) = 4 * (lane >> 4) + reg
                     const int e = e0 + lr;
                     const int tl = 16 * cw + 4 * kq;
@@ -1081,6 +1084,10 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         std::vector<int64_t> rbeg((size_t)R + 1, 0);
         for (const Seg &s : segs) rbeg[(size_t)s.region + 1]++;
         for (int32_t r = 0; r < R; ++r) rbeg[(size_t)r + 1] += rbeg[(size_t)r];
+        // regions are ordered along latitude bands of `band_rows` grid rows (column-major inside a
+        // band): a chunk then covers ~band_rows rows x a run of columns
+        int band_rows = 8;
+        if (const char *b = getenv("WAGG_BAND_ROWS")) { const int v = atoi(b); if (v >= 1 && v <= 1024) band_rows = v; }
         std::vector<int32_t> order, empty;
         std::vector<double> key_col((size_t)R, 0.0);
         std::vector<int64_t> key_band((size_t)R, 0);
@@ -1092,7 +1099,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                 srow += (double)(segs[(size_t)i].cell / row_len);
                 scol += (double)(segs[(size_t)i].cell % row_len);
             }
-            key_band[(size_t)r] = (int64_t)(srow / (double)n) / 8;
+            key_band[(size_t)r] = (int64_t)(srow / (double)n) / band_rows;
             key_col[(size_t)r] = scol / (double)n;
             order.push_back(r);
         }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const float* __restrict__ X, lon
 
 // MODE 3: wave-specialised: LW loader waves fill image buffer (i+1)&1 (global -> regs -> LDS) while CW
 // consumer waves run busy(work) on buffer i&1; one workgroup barrier per tile.
-template <int LW, int CW>
+template <int LW, int CW, int EX = 0>
 __global__ __launch_bounds__((LW + CW) * 64) void k3(const float* __restrict__ X, long T, long G, long nchunk,
                                                      long ntile, int work, float* out) {
     constexpr int RPW = 64 / LW;
@@ -64,6 +64,9 @@ __global__ __launch_bounds__((LW + CW) * 64) void k3(const float* __restrict__ X
     auto load_tile = [&](long bb, int bf) {
         const long c = bb % nchunk, tb = bb / nchunk;
         f4 v[RPW];
+        float ex[EX > 0 ? EX : 1];
+#pragma unroll
+        for (int i = 0; i < EX; ++i) ex[i] = X[(c * 977 + i * 131 + threadIdx.x) & 0xfffff];   // small L2-resident loads first
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             long t = tb * 64 + wave * RPW + i;
@@ -72,6 +75,8 @@ __global__ __launch_bounds__((LW + CW) * 64) void k3(const float* __restrict__ X
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) *reinterpret_cast<f4*>(&lds[bf * 64 * 260 + (wave * RPW + i) * 260 + lane * 4]) = v[i];
+#pragma unroll
+        for (int i = 0; i < EX; ++i) lds[2 * 64 * 260 - 1 - ((threadIdx.x + i * 768) & 1023)] += ex[i] * 0.f;
     };
     if (wave < LW && b < ntile) load_tile(b, 0);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -127,6 +132,10 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
         printf("%-34s thr %4d grid %5d work %5d : %.3f ms  %.2f TB/s\n", name, threads, grid, work, ms, sizeof(float) * T * G / ms * 1e-9);
     };
+    run3("mode3 8L+4C, 0 extra loads", k3<8, 4, 0>, 768, 256, 0);
+    run3("mode3 8L+4C, 4 extra loads", k3<8, 4, 4>, 768, 256, 0);
+    run3("mode3 8L+4C, 8 extra loads", k3<8, 4, 8>, 768, 256, 0);
+    run3("mode3 8L+4C, 16 extra loads", k3<8, 4, 16>, 768, 256, 0);
     for (int w : {0, 300, 1000}) run3("mode3 4 loaders + 4 consumers", k3<4, 4>, 512, 256, w);
     for (int w : {0, 300, 1000}) run3("mode3 8 loaders + 4 consumers", k3<8, 4>, 768, 256, w);
     for (int w : {0, 300, 1000}) run3("mode3 8 loaders + 8 consumers", k3<8, 8>, 1024, 256, w);

@@ -43,14 +43,17 @@ def mean(kernel_sub, counter):
 
 tj = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
-for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel", True), ("c2-real", "sparse_gather_kernel<float", True)):
+for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel", True), ("c2-real", "sparse_lc_kernel", False)):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
     if fs is None or ws is None:
         continue
     traffic[wl] = {
         "hbm_bytes_per_launch": (2.0 if wide else 1.0) * fs * 1024 + ws * 1024,
         "fetch_size_kib_raw": fs, "write_size_kib_raw": ws,
-        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests of 16-B/lane streams at 64 B), WRITE_SIZE exact",
+        "correction": ("FETCH_SIZE x2 (gfx950 tallies the 128-B requests of a 16-B/lane contiguous stream at 64 B; raw value "
+                       "56 GB < the 101 GB of W that must be read), WRITE_SIZE exact") if wide else
+                      ("FETCH_SIZE x1: calibrated on this kernel with every grid cell referenced (land_frac=1.0): "
+                       "raw 1.567 GB vs 1.514 GB of X, TCC_EA0_RDREQ x 64 B = 1.567 GB; WRITE_SIZE exact"),
         "source": "profiles/%s_pmc.csv" % tag,
     }
 json.dump(traffic, open(tj, "w"), indent=1)
