@@ -549,7 +549,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                                                                   float *__restrict__ out, int64_t ldo,
                                                                   int n_norm, long long n_items,
                                                                   int *__restrict__ timeout_word,
-                                                                  unsigned long long *__restrict__ stamps) {
+                                                                  unsigned long long *__restrict__ stamps, int knob) {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -610,14 +610,14 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         static_assert(LC_SEGS <= LC_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
             // small metadata loads first, the rows last (vmcnt retires in order)
-            {
+            if (!(knob & 2)) {
                 const int k = tid < d.ns ? tid : d.ns - 1;
                 R.mu = pv.seg_u[d.sb + k];
                 R.mw = pv.seg_w[d.sb + k];
+                R.er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+                R.ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+                R.es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];
             }
-            R.er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
-            R.ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
-            R.es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];
             const int64_t t0 = (int64_t)tb * LC_TB;
             const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
             const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
@@ -638,10 +638,12 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             float *im = img + buf * LC_TB * UROW;
             // one v_cmp_class per element finds NaN / +-inf; the select runs only if the wave saw any
             bool odd = false;
+            if (!(knob & 4)) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN|qNaN|-inf|+inf
+            }
             bool inf_any = false;
             if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
                 bool inf_seen = false;
@@ -658,9 +660,11 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;      // every wave, every item: no reset needed
 #pragma unroll
             for (int i = 0; i < TPW; ++i) *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = R.v[i];
+            if (!(knob & 2)) {
             if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
             if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
             if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
+            }
             if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; }
         };
         // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
@@ -685,6 +689,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         auto ahead_load = [&](Ahead &a) {
             a.nx = advance(itq[2]);
             if (a.nx.tb * (long long)n_norm + a.nx.g >= n_items) a.nx = itq[2];
+            if (knob & 8) { a.dn = dq[2]; a.cn = cellq[1]; return; }   // diagnostic: no look-ahead loads
             load_desc(a.nx, a.dn);
             a.cn = load_cell(dq[2]);
         };
@@ -753,6 +758,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
             const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
             const bool exact = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);
+            if (knob & 1) continue;                               // diagnostic: consumers idle
             if (!exact) {
                 for (int e0 = 0; e0 < ne; e0 += 16) {
                     // ---- dense weight tile of regions e0..e0+15: scatter the segments ----
@@ -919,7 +925,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (getenv("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
             hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
-                               plan->info.G, kout, kldo, n_norm, n_items, (int *)nullptr, lc_stamps);
+                               plan->info.G, kout, kldo, n_norm, n_items, (int *)nullptr, lc_stamps,
+                               getenv("WAGG_LC_KNOB") ? atoi(getenv("WAGG_LC_KNOB")) : 0);
             profile_mark(stream, false);
             WAGG_HIP(hipGetLastError());
             if (lc_stamps) {          // diagnostic: mean cycles per stage and phase

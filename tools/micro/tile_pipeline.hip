@@ -52,7 +52,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const float* __restrict__ X, lon
 
 // MODE 3: wave-specialised: LW loader waves fill image buffer (i+1)&1 (global -> regs -> LDS) while CW
 // consumer waves run busy(work) on buffer i&1; one workgroup barrier per tile.
-template <int LW, int CW, int EX = 0>
+template <int LW, int CW, int EX = 0, int PAT = 0>
 __global__ __launch_bounds__((LW + CW) * 64) void k3(const float* __restrict__ X, long T, long G, long nchunk,
                                                      long ntile, int work, float* out) {
     constexpr int RPW = 64 / LW;
@@ -71,7 +71,19 @@ __global__ __launch_bounds__((LW + CW) * 64) void k3(const float* __restrict__ X
         for (int i = 0; i < RPW; ++i) {
             long t = tb * 64 + wave * RPW + i;
             t = t < T ? t : T - 1;
-            v[i] = *reinterpret_cast<const f4*>(X + t * G + c * 256 + lane * 4);
+            long cell = c * 256 + lane * 4;
+            if (PAT == 1) {                                   // 8 grid rows x 32 cells: 8 pieces of 128 B per instruction
+                const long pr = c / 45, pc = c % 45;          // 1440 / 32 = 45 patches per band, 90 bands of 8 rows
+                cell = (pr * 8 + (lane >> 3)) * 1440 + pc * 32 + (lane & 7) * 4;
+            }
+            if (PAT == 2) {                                   // same patches, runs shifted off the 128-B lines
+                const long pr = c / 45, pc = c % 45;
+                const long r = lane >> 3;
+                long col = pc * 32 + (lane & 7) * 4 + ((r * 12 + 4) & 28);
+                col = col < 1436 ? col : 1436;
+                cell = (pr * 8 + r) * 1440 + col;
+            }
+            v[i] = *reinterpret_cast<const f4*>(X + t * G + cell);
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) *reinterpret_cast<f4*>(&lds[bf * 64 * 260 + (wave * RPW + i) * 260 + lane * 4]) = v[i];
@@ -132,6 +144,8 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
         printf("%-34s thr %4d grid %5d work %5d : %.3f ms  %.2f TB/s\n", name, threads, grid, work, ms, sizeof(float) * T * G / ms * 1e-9);
     };
+    run3("mode3 8L+4C, 8x128B patches", k3<8, 4, 0, 1>, 768, 256, 0);
+    run3("mode3 8L+4C, misaligned runs", k3<8, 4, 0, 2>, 768, 256, 0);
     run3("mode3 8L+4C, 0 extra loads", k3<8, 4, 0>, 768, 256, 0);
     run3("mode3 8L+4C, 4 extra loads", k3<8, 4, 4>, 768, 256, 0);
     run3("mode3 8L+4C, 8 extra loads", k3<8, 4, 8>, 768, 256, 0);
