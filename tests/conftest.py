@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native pieces are build products (git-ignored): build them once if this checkout has none
+    lib = os.path.join(ROOT, "climate_toolbox_amd", "lib", "libwagg.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "libwagg_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

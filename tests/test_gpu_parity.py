@@ -413,3 +413,46 @@ def test_dropin_switches_to_dense_form_for_scattered_weights(torch_cuda):
     _rel_ok(out64.tas.values, O.agg_scatter(tas.astype(np.float64), ("time", "lat", "lon"), lat, lon, df["lat"].values,
                                             df["lon"].values, df["areawt"].values, df["areawt"].values,
                                             df["hierid"].values)[0], RTOL64)
+
+
+def test_c4_rank_shard_shapes(torch_cuda, c2_real):
+    """BASELINE.json configs[3]: 10,950 daily steps sharded over 8 GPUs = 1,369 / 1,368 rows per
+    rank.  One rank's shard at full grid size: sparse fp32 against the oracle on a row sample, and
+    shard-by-shard results equal to the unsharded call (rows are independent: the time shard + gather
+    of timeshard.py reassembles exactly these blocks)."""
+    from climate_toolbox_amd import engine, synth
+    from climate_toolbox_amd.timeshard import shard_bounds
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = c2_real
+    G = len(lat) * len(lon)
+    bounds = shard_bounds(10950, 8)
+    assert [e - s for s, e in bounds][:3] == [1369, 1369, 1369] and bounds[-1] == (9582, 10950)
+    T = bounds[0][1] - bounds[0][0]                         # 1369 rows: rank 0's shard
+    cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    plan = engine.SparsePlan(cell, codes, w_eff, G, len(uniq), row_len=len(lon))
+    X = engine.synth_field(T, G, seed=21, base=280.0, amp=60.0)
+    got = plan.apply(X)
+    rows = np.r_[0:3, 700:703, T - 3:T]
+    ref = O.agg_coded(X[rows].cpu().numpy(), cell, codes, w_eff, len(uniq))
+    _rel_ok(got[rows].cpu().numpy(), ref, RTOL32)
+    # two "ranks" splitting this block reproduce it bit for bit
+    a, b = shard_bounds(T, 2)
+    parts = torch.cat([plan.apply(X[a[0]:a[1]]), plan.apply(X[b[0]:b[1]])], dim=0)
+    assert torch.equal(parts, got)
+
+
+def test_dense_multi_row_block(torch_cuda):
+    """Dense form with more than one 368-row block (a c4 rank holds 1,369 rows = 4 blocks)."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    T, G, R = 1369, 1024, 200
+    W = rng.uniform(0, 1, (G, R)).astype(np.float32)
+    X = (280 + 20 * rng.standard_normal((T, G))).astype(np.float32)
+    plan = DensePlan.from_host(W)
+    got = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    _rel_ok(got, O.agg_dense(X, W), RTOL32)
+    part = plan.apply(torch.from_numpy(X[368:736].copy()).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(part, got[368:736])
