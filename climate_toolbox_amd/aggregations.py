@@ -383,6 +383,9 @@ def _aggregate_reindexed_data_to_regions(
     torch = require_gpu()
     X2, layout, _, unflatten = _flatten_for_device(values, dims)
     plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=X2.dtype == np.float32, layout=layout)
+    # host-resident data: one pageable H2D copy (measured 51.7 GB/s on the MI355X box: 29 ms for the
+    # 1.5 GB c2 field, ~100x the kernel; a pinned double-buffered variant was 13x SLOWER because the
+    # pageable -> pinned host memcpy runs at ~4 GB/s), the kernels, one D2H copy of the result
     Xd = torch.from_numpy(X2).cuda()
     if isinstance(plan, DensePlan):
         out_d = plan.apply(Xd)

@@ -75,8 +75,8 @@ class SparsePlan:
         self.den = den
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            _lib.load().wagg_plan_destroy(self._h)
+        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+            _lib._lib.wagg_plan_destroy(self._h)     # (module globals may be gone at interpreter exit)
             self._h = C.c_void_p()
 
     __del__ = close
@@ -155,8 +155,8 @@ class DensePlan:
         return cls(h, G, R)
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            _lib.load().wagg_dense_destroy(self._h)
+        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+            _lib._lib.wagg_dense_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close
