@@ -894,6 +894,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const int64_t n_tb = (Ttot + TB - 1) / TB;
     // (T x R) results: gather kernel writes region-major into a stream-ordered workspace, then
     // one transpose; (R x T) results go straight to the caller's buffer
+    struct AsyncBuf {       // stream-ordered workspace, returned to the pool on every exit path
+        void *p = nullptr;
+        hipStream_t s = nullptr;
+        ~AsyncBuf() { if (p) (void)hipFreeAsync(p, s); }
+    } wsbuf;
+    wsbuf.s = stream;
     T *ws = nullptr;
     int64_t ldws = 0;
     T *kout = out;
@@ -901,7 +907,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const bool via_ws = out_layout == WAGG_OUT_TR && plan->info.n_groups > 0;
     if (via_ws) {
         ldws = (Ttot + 63) / 64 * 64;
-        WAGG_HIP(hipMallocAsync((void **)&ws, sizeof(T) * (size_t)(ldws * plan->info.R), stream));
+        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R), stream));
+        ws = static_cast<T *>(wsbuf.p);
         kout = ws;
         kldo = ldws;
     }
@@ -1014,7 +1021,6 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws, ldws,
                            (int64_t)plan->info.R, Ttot, out, ldo);
         WAGG_HIP(hipGetLastError());
-        WAGG_HIP(hipFreeAsync(ws, stream));
     }
     if (plan->info.n_empty > 0) {
         const int64_t n = plan->info.n_empty * Ttot;

@@ -69,7 +69,8 @@ const char *wagg_last_error(void);      /* thread-local, never NULL             
 /* While enabled, every apply records an event pair around its DOMINANT kernel (sparse: the
  * gather kernel; dense: the MFMA kernel) into a ring of WAGG_PROFILE_SLOTS pairs, without any
  * synchronisation.  wagg_profile_read blocks until the recorded kernels have finished and
- * returns their durations in milliseconds, oldest first.                                       */
+ * returns their durations in milliseconds, oldest first.  Process-global and not thread-safe:
+ * enable/read from the thread that issues the applies.                                         */
 #define WAGG_PROFILE_SLOTS 256
 int wagg_profile_enable(int on);        /* also resets the ring */
 int wagg_profile_read(float *ms_out, int max_out, int *n_out);
