@@ -605,7 +605,15 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             const int4v y = *reinterpret_cast<const int4v *>(p + 4);
             d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
         };
-        auto load_cell = [&](const StreamDesc &d) { return pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)]; };
+        auto load_cell = [&](const StreamDesc &d) {
+            const int c = pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
+            if (knob & 16) {                    // diagnostic: aligned 8 x 128-B patch instead of the chunk's quads
+                const int rowlen = 1440, pc = (d.u0 >> 6) % 45, pr = ((d.u0 >> 6) / 45) % 90;
+                return (pr * 8 + (lane >> 3)) * rowlen + pc * 32 + (lane & 7) * 4;
+            }
+            if (knob & 32) return ((d.u0 >> 6) % 4050) * 256 + lane * 4;      // diagnostic: 1 KB contiguous
+            return c;
+        };
         struct Regs { vec4 v[TPW]; int mu; float mw; int er, es; float ed; };
         static_assert(LC_SEGS <= LC_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
@@ -1295,6 +1303,15 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         plan->info.n_giant = n_giant;
         plan->info.n_empty = (int64_t)empty.size();
         plan->info.G = G; plan->info.R = R;
+        for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c) {      // locality statistics of the gather
+            int32_t l128 = -1, s64 = -1;
+            std::vector<int32_t> qs(ucell.begin() + chunk_u_begin[c], ucell.begin() + chunk_u_begin[c + 1]);
+            std::sort(qs.begin(), qs.end());
+            for (int32_t q : qs) {
+                if ((q >> 5) != l128) { l128 = q >> 5; ++plan->info.n_lines128; }
+                if ((q >> 4) != s64) { s64 = q >> 4; ++plan->info.n_sectors64; }
+            }
+        }
         std::vector<float> seg_w32(seg_w.size()), den32(den.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
         for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];

@@ -58,6 +58,8 @@ typedef struct wagg_plan_info {
     int64_t G;
     int32_t R;
     int32_t reserved;
+    int64_t n_lines128;  /* sum over chunks of distinct 128-byte lines (32 fp32 cells) their quads touch */
+    int64_t n_sectors64; /* ... of distinct 64-byte sectors */
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */
