@@ -8,12 +8,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
 
+EKEY = -6
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
 
 # every symbol include/wagg.h declares (tests check that the .so exports all of them)
 EXPORTS = (
     "wagg_version", "wagg_device_count", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
+    "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
     "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
     "wagg_gather_f32", "wagg_gather_f64",
@@ -55,6 +57,12 @@ def load():
     L.wagg_last_error.restype = C.c_char_p
     L.wagg_profile_enable.argtypes = [C.c_int]
     L.wagg_profile_read.argtypes = [f32p, C.c_int, C.POINTER(C.c_int)]
+    u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+    L.wagg_resolve_cells.argtypes = [f64p, C.c_int64, f64p, C.c_int64, f64p, f64p, C.c_int64, C.c_int, i32p, i64p]
+    L.wagg_backup_fill.argtypes = [f64p, f64p, C.c_int64, f64p]
+    L.wagg_relabel.argtypes = [f64p, C.c_int64, C.c_double, C.c_double]
+    L.wagg_factorize_i64.argtypes = [i64p, u8p, C.c_int64, i32p, i64p, i64p]
+    L.wagg_factorize_bytes.argtypes = [C.c_char_p, C.c_int64, u8p, C.c_int64, i32p, i64p, i64p]
     L.wagg_plan_create.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.c_int64,
                                    C.c_int, C.POINTER(vp)]
     L.wagg_plan_destroy.argtypes = [vp]

@@ -44,15 +44,55 @@ def _is_xarray(obj):
     return _xr is not None and isinstance(obj, (_xr.Dataset, _xr.DataArray))
 
 
+def _native():
+    from . import _lib
+    return _lib, _lib.load()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _resolve_cells(lat, lon, seg_lat, seg_lon, lon_major=False):
+    """Exact-equality join of the segment labels to the grid labels in native code
+    (``wagg_resolve_cells``; ``Dataset.sel`` without ``method=``, aggregations.py:27; S1).
+    A missing label raises KeyError, like the reference."""
+    import ctypes as C
+    _lib, L = _native()
+    lat, lon, sa, so = _f64(lat), _f64(lon), _f64(seg_lat), _f64(seg_lon)
+    if sa.shape != so.shape or sa.ndim != 1:
+        raise ValueError("segment lat/lon columns must be 1-D and of equal length")
+    cell = np.empty(len(sa), dtype=np.int32)
+    bad = C.c_int64(-1)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = L.wagg_resolve_cells(p(lat, C.c_double), len(lat), p(lon, C.c_double), len(lon), p(sa, C.c_double),
+                              p(so, C.c_double), len(sa), 1 if lon_major else 0, p(cell, C.c_int32), C.byref(bad))
+    if rc == _lib.EKEY:
+        raise KeyError("not all values found in index: row %d (lat %r, lon %r)"
+                       % (bad.value, float(sa[bad.value]), float(so[bad.value])))
+    _lib.check(rc, "wagg_resolve_cells")
+    return cell
+
+
 def _exact_index(coord_values, wanted, name):
-    """Exact-equality label lookup, KeyError when a label is absent (``Dataset.sel`` without
-    ``method=``, aggregations.py:27; S1)."""
+    """1-D form of the exact label lookup (kept for callers that need the two axes separately)."""
     idx = pd.Index(np.asarray(coord_values))
     pos = idx.get_indexer(np.asarray(wanted))
     if (pos < 0).any():
         bad = np.asarray(wanted)[pos < 0][:5]
         raise KeyError("not all values found in index %r: %r" % (name, bad.tolist()))
     return pos.astype(np.int64)
+
+
+def _backup_fill(w, backup):
+    """aggregations.py:73 per-row fill (``wagg_backup_fill``): w if w > 0 else backup (S4)."""
+    import ctypes as C
+    _lib, L = _native()
+    w, backup = _f64(w), _f64(backup)
+    out = np.empty_like(w)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _lib.check(L.wagg_backup_fill(p(w), p(backup), len(w), p(out)), "wagg_backup_fill")
+    return out
 
 
 def _is_null_label(v):
@@ -65,11 +105,44 @@ def _is_null_label(v):
 
 
 def _factorize_labels(labels):
-    """Sorted unique labels and per-row codes, -1 for null labels (xarray groupby, :78; S3).
-
-    ``pandas.factorize(sort=True)`` is the hash-table form of exactly this (NaN / None -> -1,
-    uniques in sorted order) and is 4x faster than Python sets on 4e5 string labels."""
+    """Sorted unique labels and per-row codes, -1 for null labels (xarray groupby, :78; S3), in
+    native code for integer and string labels (``wagg_factorize_i64`` / ``_bytes``); other label
+    types go through ``pandas.factorize(sort=True)``, which has the same contract."""
+    import ctypes as C
     labels = np.asarray(labels)
+    n = len(labels)
+    kind = labels.dtype.kind
+    if kind in "iu" and labels.dtype.itemsize <= 8 and not (kind == "u" and labels.dtype.itemsize == 8):
+        _lib, L = _native()
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        codes = np.empty(n, dtype=np.int32)
+        uniq = np.empty(n, dtype=np.int64)
+        nu = C.c_int64(0)
+        _lib.check(L.wagg_factorize_i64(lab.ctypes.data_as(C.POINTER(C.c_int64)), None, n,
+                                        codes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        uniq.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)), "wagg_factorize_i64")
+        return uniq[:nu.value].astype(labels.dtype), codes
+    if kind in "OUS" and n:
+        null = pd.isna(labels) if kind == "O" else np.zeros(n, dtype=bool)
+        vals = labels[~null]
+        if kind != "O" or all(isinstance(v, str) for v in vals.tolist()):
+            _lib, L = _native()
+            filled = np.where(null, "", labels) if kind == "O" else labels
+            enc = np.char.encode(filled.astype(str), "utf-8") if kind != "S" else np.ascontiguousarray(filled)
+            enc = np.ascontiguousarray(enc)
+            width = enc.dtype.itemsize
+            if width == 0:
+                return np.array([], dtype=object), np.full(n, -1, dtype=np.int32)
+            codes = np.empty(n, dtype=np.int32)
+            rows = np.empty(n, dtype=np.int64)
+            nu = C.c_int64(0)
+            nm = np.ascontiguousarray(null, dtype=np.uint8)
+            _lib.check(L.wagg_factorize_bytes(enc.ctypes.data_as(C.c_char_p), width,
+                                              nm.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                              codes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              rows.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)),
+                       "wagg_factorize_bytes")
+            return labels[rows[:nu.value]], codes
     codes, uniq = pd.factorize(labels, sort=True)
     return np.asarray(uniq), np.asarray(codes, dtype=np.int32)
 
@@ -276,8 +349,8 @@ def _reindex_spatial_data_to_regions(ds, df):
         raise KeyError("dataset must have 'lat' and 'lon' coordinates (aggregations.py:27)")
     lat = np.asarray(coords["lat"].values)
     lon = np.asarray(coords["lon"].values)
-    ilat = _exact_index(lat, df["lat"].values, "lat")
-    ilon = _exact_index(lon, df["lon"].values, "lon")
+    cell = _resolve_cells(lat, lon, df["lat"].values, df["lon"].values)      # native, KeyError on a miss
+    ilat, ilon = (cell // len(lon)).astype(np.int64), (cell % len(lon)).astype(np.int64)
     # xarray's vectorised sel indexes EVERY data variable (S9); variables without lat/lon dims
     # are carried through untouched
     keep_vals, keep_dims = {}, {}
@@ -327,9 +400,7 @@ def _aggregate_reindexed_data_to_regions(
     counted as 0 (S6) and IEEE division (S7).  Like the reference it also attaches ``agglev``
     and ``aggwt`` to ``ds`` (:64-71).
     """
-    w = np.asarray(weights[aggwt].values, dtype=np.float64)
-    backup = np.asarray(weights[backup_aggwt].values, dtype=np.float64)
-    w_eff = np.where(w > 0, w, backup)                                   # :73
+    w_eff = _backup_fill(weights[aggwt].values, weights[backup_aggwt].values)   # :73 (native)
     labels = np.asarray(weights[agglev].values)
     uniq, codes = _factorize_labels(labels)                              # :78 group keys
 
@@ -450,7 +521,11 @@ def prepare_spatial_weights_data(weights_file):
     kept here too (they add, S5).
     """
     df = pd.read_csv(weights_file)
-    df.loc[df["pix_cent_x"] == 180.125, "pix_cent_x"] = -179.875
+    import ctypes as C
+    _lib, L = _native()
+    x = np.ascontiguousarray(df["pix_cent_x"].values, dtype=np.float64).copy()
+    _lib.check(L.wagg_relabel(x.ctypes.data_as(C.POINTER(C.c_double)), len(x), 180.125, -179.875), "wagg_relabel")
+    df["pix_cent_x"] = x                                              # aggregations.py:144
     df.index.names = ["reshape_index"]
     df.rename(columns={"pix_cent_x": "lon", "pix_cent_y": "lat"}, inplace=True)
     return df

@@ -116,11 +116,8 @@ def realistic_segments(nlat=720, nlon=1440, R=N_IMPACT_REGIONS, land_frac=0.30, 
 def code_segments(df, lat, lon, aggwt, agglev, backup="areawt"):
     """Host-side label resolution for callers that drive the C-ABI directly (bench, tests):
     exact label lookup (S1), backup fill (S4), sorted-unique factorisation (S3)."""
-    from .aggregations import _exact_index, _factorize_labels
-    ilat = _exact_index(lat, df["lat"].values, "lat")
-    ilon = _exact_index(lon, df["lon"].values, "lon")
-    cell = (ilat * len(lon) + ilon).astype(np.int32)
-    w = df[aggwt].values.astype(np.float64)
-    w_eff = np.where(w > 0, w, df[backup].values.astype(np.float64))
+    from .aggregations import _backup_fill, _factorize_labels, _resolve_cells
+    cell = _resolve_cells(lat, lon, df["lat"].values, df["lon"].values)
+    w_eff = _backup_fill(df[aggwt].values, df[backup].values)
     uniq, codes = _factorize_labels(df[agglev].values)
     return cell, codes, w_eff, uniq

@@ -35,7 +35,8 @@ typedef enum wagg_status {
     WAGG_EHIP = -2,    /* a HIP runtime call failed; see wagg_last_error() */
     WAGG_ENOMEM = -3,  /* host or device allocation failed */
     WAGG_ENODEV = -4,  /* no gfx950 device visible */
-    WAGG_EUNSUPPORTED = -5
+    WAGG_EUNSUPPORTED = -5,
+    WAGG_EKEY = -6     /* a segment label is absent from the grid (the reference's KeyError, S1) */
 } wagg_status;
 
 /* memory layout of the flattened data matrix X and of the result */
@@ -76,6 +77,23 @@ const char *wagg_last_error(void);      /* thread-local, never NULL             
 #define WAGG_PROFILE_SLOTS 256
 int wagg_profile_enable(int on);        /* also resets the ring */
 int wagg_profile_read(float *ms_out, int max_out, int *n_out);
+
+/* ---- label work ahead of the plan (host only) ------------------------------------- */
+/* Exact-equality join of the segment table's lat/lon labels to the grid's (Dataset.sel without
+ * method=, aggregations.py:27): cell_idx[i] = ilat*nlon + ilon (or ilon*nlat + ilat when lon_major).
+ * WAGG_EKEY with *bad_row = first row whose label is absent; grid labels must be unique.          */
+int wagg_resolve_cells(const double *lat, int64_t nlat, const double *lon, int64_t nlon,
+                       const double *seg_lat, const double *seg_lon, int64_t nseg, int lon_major,
+                       int32_t *cell_idx, int64_t *bad_row);
+/* w_eff[i] = w[i] > 0 ? w[i] : backup[i]   (aggregations.py:73: NaN, 0 and negative take the row's backup) */
+int wagg_backup_fill(const double *w, const double *backup, int64_t n, double *w_eff);
+/* values[i] == from -> to   (aggregations.py:144: pix_cent_x 180.125 -> -179.875) */
+int wagg_relabel(double *values, int64_t n, double from, double to);
+/* sorted unique labels and per-row codes (-1 for null rows), aggregations.py:78 group keys (S3) */
+int wagg_factorize_i64(const int64_t *labels, const uint8_t *isnull, int64_t n, int32_t *codes,
+                       int64_t *uniq, int64_t *n_uniq);
+int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, int64_t n,
+                         int32_t *codes, int64_t *uniq_rows, int64_t *n_uniq);
 
 /* ---- sparse plan: replaces aggregations.py:24-27 + :64-71 (gather index, labels, weights) --- */
 /* cell_idx[i]    flat grid cell of segment row i  = ilat*nlon + ilon            (0 <= . < G)

@@ -138,3 +138,45 @@ def test_dense_form_choice():
     assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB)       # fp64 stays on the gather form
     assert not A._prefer_dense(240 * G, G, R, True, "GT", 250 * GB)        # fixture layout stays too
     assert not A._prefer_dense(240 * G, G, R, True, "TG", 100 * GB)        # 101 GB of W must fit
+
+
+# ---------------------------------------------------------------------------------------------
+# the label work in native code, checked against pandas / the oracle (no GPU needed)
+# ---------------------------------------------------------------------------------------------
+def test_native_resolve_cells_matches_oracle_and_raises():
+    from oracle import ref_numpy as O
+    lat, lon = np.arange(-89.875, 90, 2), np.arange(0.125, 360.0, 2)
+    rng = np.random.default_rng(0)
+    sl, so = rng.choice(lat, 500), rng.choice(lon, 500)
+    cell = A._resolve_cells(lat, lon, sl, so)
+    ref = O._lookup_dict(lat, sl, "lat") * len(lon) + O._lookup_dict(lon, so, "lon")
+    np.testing.assert_array_equal(cell, ref)
+    np.testing.assert_array_equal(A._resolve_cells(lat, lon, sl, so, lon_major=True),
+                                  O._lookup_dict(lon, so, "lon") * len(lat) + O._lookup_dict(lat, sl, "lat"))
+    for bad in (sl[3] + 1e-9, np.nan, 1e9):
+        s2 = sl.copy(); s2[3] = bad
+        with pytest.raises(KeyError, match="row 3"):
+            A._resolve_cells(lat, lon, s2, so)                       # S1: exact, no nearest
+    np.testing.assert_array_equal(A._resolve_cells(np.array([-0.0, 1.0]), np.array([5.0]), [0.0], [5.0]), [0])
+    with pytest.raises(Exception, match="not unique"):
+        A._resolve_cells(np.array([1.0, 1.0]), np.array([5.0]), [1.0], [5.0])
+
+
+def test_native_backup_fill_and_relabel():
+    from oracle import ref_numpy as O
+    w = np.array([2.0, np.nan, 0.0, -1.0, 3.0, np.inf])
+    b = np.array([1.0, 3.0, 2.0, 1.0, 9.0, np.nan])
+    np.testing.assert_array_equal(A._backup_fill(w, b), O.effective_weights(w, b))
+    np.testing.assert_array_equal(A._backup_fill(w, b), [2.0, 3.0, 2.0, 1.0, 3.0, np.inf])
+
+
+@pytest.mark.parametrize("labels", [
+    np.array([3, 1, 3, 2, -7]), np.array([3, 1, 3], dtype=np.int32), np.array(["b", "a", "b", "USA.10", "USA.2"]),
+    np.array(["b", None, "a", "b", np.nan, "é", "z"], dtype=object), np.array([2.0, np.nan, 1.0]),
+    np.array([], dtype=np.int64), np.array([None, None], dtype=object)])
+def test_native_factorize_matches_pandas(labels):
+    uniq, codes = A._factorize_labels(labels)
+    c_ref, u_ref = pd.factorize(labels, sort=True)
+    assert list(uniq) == list(u_ref)
+    np.testing.assert_array_equal(codes, c_ref)
+    assert codes.dtype == np.int32
