@@ -292,7 +292,7 @@ def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes):
     faster -- provided it is an fp32 (time, gridcell) problem and W fits comfortably in HBM."""
     if not is_f32 or layout != "TG":
         return False
-    w_bytes = 4 * int(G) * ((int(R) + 127) // 128 * 128)
+    w_bytes = 4 * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
     return n_ucells > DENSE_SWITCH * G and w_bytes < 0.6 * free_bytes
 
 

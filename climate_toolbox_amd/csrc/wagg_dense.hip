@@ -4,20 +4,26 @@
 //
 // Shape: M = T (365) is skinny, K = G (1e6) is huge, N = R (24k).  fp32 MFMA runs at the vector
 // rate (256 flop/clk/CU), so the contraction is MFMA-issue-bound by ~7x over HBM; the design
-// therefore spends nothing on bandwidth tricks and everything on keeping the matrix pipe fed:
-//   * one workgroup (8 waves, 2 per SIMD) owns ALL 365 rows (padded to 23 x 16 = 368, 0.8 %
-//     waste) x 128 columns of the output, so every W element is read from HBM exactly once;
-//   * wave w owns columns [16w, 16w+16): 23 independent 16x16 accumulators (92 AGPR/VGPR), one B
-//     fragment per k-step feeds 23 back-to-back v_mfma_f32_16x16x4_f32 (no dependent-issue
-//     stalls: 40-cycle latency vs 23 x 32 cycles between reuses of an accumulator);
+// spends nothing on bandwidth tricks and everything on keeping the matrix pipe fed:
+//   * one workgroup (8 waves, 2 per SIMD, all 160 KB of LDS) owns ALL 365 rows (23 x 16 = 368,
+//     0.8 % padding) x 256 columns of the output, so every W element leaves HBM exactly once and
+//     the X panel is re-read only once per 256 columns; wave w owns columns [32w, 32w+32):
+//     46 independent 16x16 accumulators (184 registers);
+//   * both operands are kept in HBM in the exact byte order of their LDS tile image
+//     ("packed": W at plan time, X by dense_pack_x_kernel at the start of every apply, which also
+//     applies NaN -> 0 (S6) and zero-pads rows/cells), so a tile is filled by 1-KiB LDS-DMA pieces
+//     (global_load_lds_dwordx4: contiguous 1 KiB in HBM -> contiguous 1 KiB in LDS, no staging
+//     registers, no ds_write) -- 10 per wave per tile against 368 MFMAs;
+//   * tile image = [row][8 x 16-byte pieces] (32 k-values per row), piece p stored at position
+//     p ^ ((row >> 1) & 7): every ds_read_b128 fragment read is bank-conflict free (see the lane
+//     groups of ds_read_b128 on gfx950), and one b128 read feeds four MFMA k-steps;
 //   * K is split into S slices (multiple of 8): blocks with equal blockIdx % 8 (one XCD under
-//     round-robin placement -- speed only) walk the same k-slice over neighbouring column
-//     tiles, so the 23.5 KB X panel of each k-step is served by that XCD's L2;
-//   * global -> register -> LDS staging, double-buffered, ONE barrier per 16-deep k-step; both
-//     LDS images are k-major with row strides 368 and 144 words (= 16 mod 32) so that the
-//     ds_read_b32 fragment reads (lanes 0-15: k, lanes 16-31: k+1) are bank-conflict free;
-//   * fp32 partial slabs per (tile, k-slice), then one reduce kernel fuses the division by
-//     den[r] (deterministic, no atomics).
+//     round-robin placement -- speed only) walk the same k-slice over neighbouring column tiles,
+//     so the 46 KB X tile of each k-step is served by that XCD's L2;
+//   * two LDS buffers, ONE barrier per tile: the DMA of tile t+1 is issued piecewise inside tile
+//     t's MFMA stream and has ~10 us to land;
+//   * fp32 partial slabs per (tile, k-slice), then one reduce kernel fuses the division by den[r]
+//     (deterministic, no atomics).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -27,41 +33,45 @@
 
 namespace wagg {
 
-constexpr int D_MT = 23;            // 16-row MFMA tiles per workgroup
-constexpr int D_BM = D_MT * 16;     // 368 rows
-constexpr int D_BN = 128;           // 8 waves x 16 columns
-constexpr int D_BK = 32;            // k depth of one LDS tile = 8 MFMA k-steps
-constexpr int D_KS = D_BK / 4;
-constexpr int D_LDA = 370;          // words per k-row of the X image (370 % 32 == 2, see below)
-constexpr int D_LDB = 132;          // words per k-row of the W image (16-byte aligned rows)
+constexpr int D_MT = 23;                 // 16-row MFMA tiles per workgroup
+constexpr int D_BM = D_MT * 16;          // 368 rows
+constexpr int D_BN = 256;                // 8 waves x 32 columns
+constexpr int D_BK = 32;                 // k depth of one LDS tile = 8 MFMA k-steps
 constexpr int D_THREADS = 512;
-constexpr int D_STAGE = D_BK * D_LDA + D_BK * D_LDB;          // floats per LDS buffer (64,256 B)
-constexpr int D_XQ = D_BM * (D_BK / 4);                       // 16-byte pieces of the X tile (2944)
-constexpr int D_XLOADS = (D_XQ + D_THREADS - 1) / D_THREADS;  // 6 per thread
-constexpr int D_WLOADS = D_BK * D_BN / 4 / D_THREADS;         // 2 per thread
+constexpr int D_XT = D_BM * D_BK;        // floats per packed X tile (47,104 B)
+constexpr int D_WT = D_BN * D_BK;        // floats per packed W tile (32,768 B)
+constexpr int D_XPIECES = D_XT / 256;    // 46 one-KiB pieces
+constexpr int D_WPIECES = D_WT / 256;    // 32
+static_assert(D_XPIECES <= 48 && D_WPIECES == 32, "10 DMA pieces per wave");
+constexpr int D_BUF_BYTES = (D_XT + D_WT) * 4;   // 79,872 B per LDS buffer, two buffers
+static_assert(2 * D_BUF_BYTES <= 160 * 1024, "LDS budget");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
 
 __device__ __forceinline__ float nan0(float v) { return v == v ? v : 0.0f; }
 
-// LDS images (both k-major):  xs[k][row] with row stride 370 words, ws[k][col] with 132.
-//  * X is fetched as whole 128-byte lines: 8 consecutive lanes take the 8 16-byte pieces of one
-//    row's 32 k-values (8 rows per wave instruction).  Piece q of row r is stored as 4
-//    ds_write_b32 to xs[4q+c][r]: bank = (8q + 2c + r) mod 32 -> each bank is hit by exactly two
-//    lanes of a 32-lane half (2-way is free for ds_write_b32).
-//  * MFMA k-step s (0..7) takes k = 8*kq + s for lane group kq = lane>>4 (any 4 distinct k per
-//    step work as long as A and B agree).  The two lane groups of a 32-lane half then read rows
-//    8 apart: 8*370 mod 32 = 16 -> lanes 0-15 and 16-31 sit on disjoint banks, no conflict.
+// Position of (row, piece p) inside a packed tile, in 16-byte slots.  The same involution is
+// applied by the packers (source side) and by the fragment reads.
+__host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row * 8 + (p ^ ((row >> 1) & 7)); }
+
+// MFMA k mapping: lane group kq = lane >> 4, fragment read h (0/1) fetches piece p = kq + 4h, i.e.
+// k = 4 kq + 16 h + c (c = 0..3); MFMA k-step s = 4h + c then sums k in {c, 4+c, 8+c, 12+c} + 16h.
+// A and B use the same mapping, so any permutation of k inside the tile is fine.
 //
-// DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the global
-// loads of the k-loop, bit1 = skip the LDS restage, bit2 = skip the per-tile barrier.  Results are
-// wrong with any bit set; only the timing is of interest.
-template <bool ALIGNED, int DBG = 0>
+// Bank check for ds_read_b128 (banks = (byte/4) % 64, lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31} and their +32 mirrors): a group holds rows i in {0-3,12-15} of one kq and
+// rows {4-11} of the next; with f = i >> 1 the 16-byte positions (i & 1) * 8 + ((kq + 4h) ^ f)
+// are all distinct within each group.
+//
+// DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
+// of the k-loop, bit2 = skip the per-tile barrier.  Results are wrong with any bit set.
+template <int DBG = 0>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
-    const float *__restrict__ X, int64_t Ttot, int64_t ldx, const float *__restrict__ W,
-    int64_t ldw, int64_t G, int n_nt, int n_mb, int S, int64_t k_per_slice,
-    float *__restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][D_STAGE]
+    const float *__restrict__ Xp, const float *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
+    int kt_per_slice, float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][D_BUF_BYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,187 +83,152 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const int nt = j % n_nt; j /= n_nt;
     const int mb = j % n_mb;
     const int ks = (blockIdx.x & 7) + 8 * (j / n_mb);
-    const int64_t k_begin = (int64_t)ks * k_per_slice;
-    // G here is the part of the gridcell axis that is a whole number of LDS tiles; the ragged
-    // remainder (< 32 cells) is contracted by dense_ktail_kernel into one extra slab
-    const int64_t k_end = (k_begin + k_per_slice < G) ? k_begin + k_per_slice : G;
-    const int64_t klen = k_end > k_begin ? k_end - k_begin : 0;
-    const int ntiles = (int)(klen / D_BK);
-    const int64_t n0 = (int64_t)nt * D_BN;
-    const int64_t m0 = (int64_t)mb * D_BM;
+    const int kt0 = ks * kt_per_slice;
+    const int kt1 = kt0 + kt_per_slice < n_kt ? kt0 + kt_per_slice : n_kt;
+    const int ntiles = kt1 > kt0 ? kt1 - kt0 : 0;
 
-    // staging coordinates: wave-uniform 64-bit bases + 32-bit per-lane byte offsets (saddr form),
-    // LDS offsets that differ between a thread's pieces only by immediates.  Rows past T are
-    // clamped to the last row: their accumulators hold garbage that the reduce kernel never
-    // reads, and the loads need no row predicate.
-    const int xrow0 = tid >> 3, xq = tid & 7;          // piece i of this thread: row xrow0 + 64 i
-    unsigned xvoff[D_XLOADS];
+    // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
+    // moves X pieces wave + 8 i (i < 6; the two pieces that do not exist are clamped onto piece
+    // 45 -- an identical rewrite) and W pieces wave + 8 i (i < 4)
+    const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * (D_XT * 4) + lane * 16;
+    const char *wsrc = reinterpret_cast<const char *>(Wp) + ((int64_t)nt * n_kt + kt0) * (D_WT * 4) + lane * 16;
+    const int xq5 = wave + 40 < D_XPIECES ? wave + 40 : D_XPIECES - 1;
+#define WAGG_DMA_X(q, tile, buf)                                                                  \
+    __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * (D_XT * 4) + (q) * 1024),   \
+                                     (lptr_t)(lds + (buf) * D_BUF_BYTES + (q) * 1024), 16, 0, 0)
+#define WAGG_DMA_W(q, tile, buf)                                                                  \
+    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * (D_WT * 4) + (q) * 1024),   \
+                                     (lptr_t)(lds + (buf) * D_BUF_BYTES + D_XT * 4 + (q) * 1024), 16, 0, 0)
+#define WAGG_DMA_PIECE(i, tile, buf)                                                              \
+    do {                                                                                          \
+        if ((i) < 5) WAGG_DMA_X(wave + 8 * (i), tile, buf);                                       \
+        else if ((i) == 5) WAGG_DMA_X(xq5, tile, buf);                                            \
+        else WAGG_DMA_W(wave + 8 * ((i) - 6), tile, buf);                                         \
+    } while (0)
+
+    f32x4 acc[D_MT][2];
 #pragma unroll
-    for (int i = 0; i < D_XLOADS; ++i) {
-        int64_t grow = m0 + xrow0 + 64 * i;
-        grow = grow < Ttot ? grow : Ttot - 1;
-        xvoff[i] = (unsigned)(((grow - m0) * ldx + xq * 4) * 4);
-    }
-    const bool x_last_ok = tid + D_THREADS * (D_XLOADS - 1) < D_XQ;    // piece 5 exists for tid < 384
-    const int xoff0 = (xq * 4) * D_LDA + xrow0;        // + 64 i (+ c * LDA)
-    const int wrow0 = tid >> 5, wc4 = tid & 31;        // piece i: k-row wrow0 + 16 i
-    const unsigned wvoff = (unsigned)((wrow0 * ldw + wc4 * 4) * 4);
-    const int woff0 = D_BK * D_LDA + wrow0 * D_LDB + wc4 * 4;          // + 16 i * LDB
-    const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx + k_begin);      // uniform
-    const char *wbase = reinterpret_cast<const char *>(W + k_begin * ldw + n0);      // uniform
+    for (int m = 0; m < D_MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[D_MT];
-#pragma unroll
-    for (int m = 0; m < D_MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // staging registers are NAMED scalars (not arrays): arrays indexed inside the unrolled MFMA
-    // stream end up in scratch memory with hipcc (ROCm 7.2)
-    f32x4 xr0, xr1, xr2, xr3, xr4, xr5, wr0, wr1;
-    static_assert(D_XLOADS == 6 && D_WLOADS == 2, "staging registers are named for 6 + 2 pieces");
-#define WAGG_XPTR(i, tile) (xbase + (int64_t)(tile) * (D_BK * 4) + xvoff[i])
-#define WAGG_WPTR(i, tile) (wbase + ((int64_t)(tile) * D_BK + 16 * (i)) * ldw * 4 + wvoff)
-#define WAGG_LOAD_X(i, tile)                                                                     \
-    do {                                                                                         \
-        if (ALIGNED) xr##i = *reinterpret_cast<const f32x4 *>(WAGG_XPTR(i, tile));               \
-        else { const float *f_ = reinterpret_cast<const float *>(WAGG_XPTR(i, tile));            \
-               xr##i = f32x4{f_[0], f_[1], f_[2], f_[3]}; }                                      \
-    } while (0)
-#define WAGG_LOAD_W(i, tile)                                                                     \
-    do {                                                                                         \
-        if (DBG & 32) wr##i = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile))); \
-        else wr##i = *reinterpret_cast<const f32x4 *>(WAGG_WPTR(i, tile));                        \
-    } while (0)
-#define WAGG_STORE_X(i, buf)                                                                     \
-    do {                                                                                         \
-        float *xs_ = lds + (buf) * D_STAGE + xoff0 + 64 * (i);                                   \
-        if ((i) + 1 < D_XLOADS || x_last_ok) {                                                   \
-            xs_[0] = nan0(xr##i[0]); xs_[D_LDA] = nan0(xr##i[1]);          /* S6 */              \
-            xs_[2 * D_LDA] = nan0(xr##i[2]); xs_[3 * D_LDA] = nan0(xr##i[3]);                    \
-        }                                                                                        \
-    } while (0)
-#define WAGG_STORE_W(i, buf)                                                                     \
-    *reinterpret_cast<f32x4 *>(lds + (buf) * D_STAGE + woff0 + 16 * (i) * D_LDB) = wr##i
-#define WAGG_LOAD_ALL(tile)                                                                      \
-    do { WAGG_LOAD_X(0, tile); WAGG_LOAD_X(1, tile); WAGG_LOAD_X(2, tile); WAGG_LOAD_X(3, tile); \
-         WAGG_LOAD_X(4, tile); WAGG_LOAD_X(5, tile); WAGG_LOAD_W(0, tile); WAGG_LOAD_W(1, tile); } while (0)
-#define WAGG_STORE_ALL(buf)                                                                      \
-    do { WAGG_STORE_X(0, buf); WAGG_STORE_X(1, buf); WAGG_STORE_X(2, buf); WAGG_STORE_X(3, buf); \
-         WAGG_STORE_X(4, buf); WAGG_STORE_X(5, buf); WAGG_STORE_W(0, buf); WAGG_STORE_W(1, buf); } while (0)
-
-    xr0 = xr1 = xr2 = xr3 = xr4 = xr5 = wr0 = wr1 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ntiles > 0) {
-        WAGG_LOAD_ALL(0);
-        WAGG_STORE_ALL(0);
-        if (ntiles > 1) WAGG_LOAD_ALL(1);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) WAGG_DMA_PIECE(i, 0, 0);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
-    const int a_lane = (8 * kq) * D_LDA + lr;                    // + s*LDA + m*16 (immediates)
-    const int b_lane = D_BK * D_LDA + (8 * kq) * D_LDB + wave * 16 + lr;
+    // per-lane fragment offsets (bytes inside a tile image); + 2048 per 16-row block (immediate)
+    const int f = lr >> 1;
+    const int frag0 = (lr * 8 + (kq ^ f)) * 16;            // h = 0: piece kq
+    const int frag1 = (lr * 8 + ((kq ^ f) ^ 4)) * 16;      // h = 1: piece kq + 4
+    const int boff = D_XT * 4 + wave * (32 * 128);         // this wave's 32 columns of the W image
 
-    // One LDS tile = 8 MFMA k-steps = 184 MFMAs per wave.  A fragments run D_AHEAD MFMAs ahead of
-    // their use (a rolling window of ~8 VGPRs instead of a 46-register double buffer); the
-    // fragment reads and (PF) the next tile's global loads are spread between the MFMAs -- one
-    // small group after every second MFMA, pinned with sched_barriers (hipcc otherwise sinks each
-    // ds_read next to its MFMA and waits lgkmcnt(0) between every pair, and a burst of reads per
-    // k-step leaves the matrix pipe idle when both waves of a SIMD burst together).
-    constexpr int D_AHEAD = 6;
-    constexpr int NMF = D_KS * D_MT;
-    // MODE 2: inside tile t's MFMA stream, store the staged registers (tile t+1) into the other
-    //         LDS buffer and refill each register with its piece of tile t+2 right after;
-    // MODE 1: store only (t+2 does not exist);  MODE 0: neither (last tile).
-    // Loads therefore run a whole tile (~5 us) ahead of their LDS store, and the LDS stores
-    // (ds_write_b32 runs at 64 B/clk/CU: ~950 cycles per tile) hide under the MFMAs.
-    auto tile_body = [&](auto mode_tag, int tile) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        const float *xs = lds + (tile & 1) * D_STAGE;
+    // One 16-row block = 16 MFMAs: k-steps 0..7 x the wave's two 16-column blocks.  k-steps 0..3
+    // come from the first fragment read (h = 0), 4..7 from the second.
+#define WAGG_MFMA(RB, CB, A, B, c) \
+    acc[RB][CB] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c], B[c], acc[RB][CB], 0, 0, 0)
+#define WAGG_MFMA_REST7(RB, A, B0, B1)                                                            \
+    do {                                                                                          \
+        WAGG_MFMA(RB, 1, A, B1, 0);                                                               \
+        _Pragma("unroll") for (int c = 1; c < 4; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
+    } while (0)
+#define WAGG_MFMA8(RB, A, B0, B1)                                                                 \
+    do {                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
+    } while (0)
+#define WAGG_READ_A(D0, D1, RB)                                                                   \
+    do {                                                                                          \
+        D0 = *reinterpret_cast<const f32x4 *>(img + frag0 + (RB) * 2048);                         \
+        D1 = *reinterpret_cast<const f32x4 *>(img + frag1 + (RB) * 2048);                         \
+    } while (0)
+    // Row blocks 2P and 2P+1.  The fragment reads of the NEXT block are issued right behind the
+    // first MFMA of the current one: hipcc's s_waitcnt for the current fragments (always a full
+    // lgkmcnt(0) once an LDS-DMA is in the stream) then finds only reads that were issued 15
+    // MFMAs earlier.  DMA piece P of the next tile goes in the middle of block 2P (10 pieces
+    // over 11 pairs).
+#define WAGG_BLOCK(RB, A0, A1, N0, N1, NEXT_RB, DMA)                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WAGG_MFMA(RB, 0, A0, b00, 0);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((NEXT_RB) < D_MT) WAGG_READ_A(N0, N1, NEXT_RB);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((DMA) >= 0 && (DMA) < 10 && !(DBG & 1)) WAGG_DMA_PIECE(DMA, tnext, nbuf);             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        WAGG_MFMA8(RB, A1, b01, b11);                                                             \
+    } while (0)
+#define WAGG_PAIR(P)                                                                              \
+    do {                                                                                          \
+        WAGG_BLOCK(2 * (P), aA0, aA1, aB0, aB1, 2 * (P) + 1, P);                                  \
+        WAGG_BLOCK(2 * (P) + 1, aB0, aB1, aA0, aA1, 2 * (P) + 2, -1);                             \
+    } while (0)
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const char *img = lds + (tile & 1) * D_BUF_BYTES;
         const int nbuf = (tile & 1) ^ 1;
-        float a[8], b[2];                                  // rolling windows, static indices
-        b[0] = xs[b_lane];
-#pragma unroll
-        for (int jj = 0; jj < D_AHEAD; ++jj) a[jj] = xs[a_lane + (jj / D_MT) * D_LDA + (jj % D_MT) * 16];
-#pragma unroll
-        for (int s4 = 0; s4 < D_KS; ++s4) {
-#pragma unroll
-          for (int m = 0; m < D_MT; ++m) {
-            const int j = s4 * D_MT + m;
-            if ((j & 1) == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + D_AHEAD < NMF)
-                    a[(j + D_AHEAD) & 7] = xs[a_lane + ((j + D_AHEAD) / D_MT) * D_LDA + ((j + D_AHEAD) % D_MT) * 16];
-                if (j + D_AHEAD + 1 < NMF)
-                    a[(j + D_AHEAD + 1) & 7] =
-                        xs[a_lane + ((j + D_AHEAD + 1) / D_MT) * D_LDA + ((j + D_AHEAD + 1) % D_MT) * 16];
-                if ((m == 0 || m == 1) && s4 + 1 < D_KS) b[(s4 + 1) & 1] = xs[b_lane + (s4 + 1) * D_LDB];
-                if (MODE >= 1 && (m == 4 || m == 5) && !(DBG & 2)) {      // one piece per k-step: store ...
-                    if (s4 == 0) WAGG_STORE_X(0, nbuf);
-                    if (s4 == 1) WAGG_STORE_X(1, nbuf);
-                    if (s4 == 2) WAGG_STORE_X(2, nbuf);
-                    if (s4 == 3) WAGG_STORE_X(3, nbuf);
-                    if (s4 == 4) WAGG_STORE_X(4, nbuf);
-                    if (s4 == 5) WAGG_STORE_X(5, nbuf);
-                    if (s4 == 6) WAGG_STORE_W(0, nbuf);
-                    if (s4 == 7) WAGG_STORE_W(1, nbuf);
-                }
-                if (MODE == 2 && (m == 10 || m == 11) && !(DBG & 1)) {    // ... then refill its register
-                    if (s4 == 0 && !(DBG & 8)) WAGG_LOAD_X(0, tile + 2);
-                    if (s4 == 1 && !(DBG & 8)) WAGG_LOAD_X(1, tile + 2);
-                    if (s4 == 2 && !(DBG & 8)) WAGG_LOAD_X(2, tile + 2);
-                    if (s4 == 3 && !(DBG & 8)) WAGG_LOAD_X(3, tile + 2);
-                    if (s4 == 4 && !(DBG & 8)) WAGG_LOAD_X(4, tile + 2);
-                    if (s4 == 5 && !(DBG & 8)) WAGG_LOAD_X(5, tile + 2);
-                    if (s4 == 6) WAGG_LOAD_W(0, tile + 2);
-                    if (s4 == 7) WAGG_LOAD_W(1, tile + 2);
-                }
-                if ((DBG & 64) && MODE == 2 && (m == 16 || m == 17)) {    // experiment: stagger waves 4-7
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j & 7], b[s4 & 1], acc[m], 0, 0, 0);
-          }
-        }
+        const int tnext = tile + 1 < ntiles ? tile + 1 : tile;     // last tile: harmless re-load
+        f32x4 b00, b01, b10, b11, aA0, aA1, aB0, aB1;
+        b00 = *reinterpret_cast<const f32x4 *>(img + boff + frag0);
+        b01 = *reinterpret_cast<const f32x4 *>(img + boff + frag1);
+        b10 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag0);
+        b11 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag1);
+        WAGG_READ_A(aA0, aA1, 0);
+        WAGG_PAIR(0); WAGG_PAIR(1); WAGG_PAIR(2); WAGG_PAIR(3); WAGG_PAIR(4); WAGG_PAIR(5);
+        WAGG_PAIR(6); WAGG_PAIR(7); WAGG_PAIR(8); WAGG_PAIR(9); WAGG_PAIR(10);
+        WAGG_BLOCK(22, aA0, aA1, aB0, aB1, 23, -1);
         __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // single hot body in the loop; the two drain tiles are peeled (merging differently shaped
-    // bodies at a loop join makes hipcc copy and spill the accumulators)
-    int tile = 0;
-    for (; tile + 2 < ntiles; ++tile) {
-        tile_body(std::integral_constant<int, 2>{}, tile);
-        if (!(DBG & 4)) __syncthreads();
+        // this wave's DMA pieces of tile+1 have landed; every wave is done reading this buffer
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     }
-    if (tile + 1 < ntiles) {
-        tile_body(std::integral_constant<int, 1>{}, tile);
-        __syncthreads();
-        ++tile;
-    }
-    if (tile < ntiles) tile_body(std::integral_constant<int, 0>{}, tile);
 
     // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * (S + 1) + ks) * D_BM) * D_BN;
+    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * D_BM) * D_BN;
 #pragma unroll
     for (int m = 0; m < D_MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            slab[(m * 16 + kq * 4 + r) * D_BN + wave * 16 + lr] = acc[m][r];
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(m * 16 + kq * 4 + r) * D_BN + wave * 32 + cb * 16 + lr] = acc[m][cb][r];
 }
 
-// ragged remainder of the gridcell axis (k in [Gfull, G), fewer than 32 cells): plain FMA into the
-// extra slab S of every (row block, column tile); zero when there is no remainder
-__global__ void dense_ktail_kernel(const float *__restrict__ X, int64_t Ttot, int64_t ldx,
-                                   const float *__restrict__ W, int64_t ldw, int64_t Gfull, int64_t G,
-                                   int n_nt, int S, float *__restrict__ slabs) {
-    const int c = threadIdx.x & (D_BN - 1);
-    const int nt = blockIdx.x;
-    const int64_t t = (int64_t)blockIdx.y * 2 + (threadIdx.x >> 7);     // 256 threads = 2 rows x 128 cols
-    const int mb = (int)(t / D_BM), tl = (int)(t % D_BM);
-    if (t >= (int64_t)gridDim.y * 2) return;
-    float s = 0.f;
-    if (t < Ttot) {
-        for (int64_t k = Gfull; k < G; ++k)
-            s = fmaf(nan0(X[t * ldx + k]), W[k * ldw + (int64_t)nt * D_BN + c], s);
+// X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one f32x4 per slot), NaN -> 0 (S6),
+// zero for rows >= T and cells >= G.  One thread per slot; the 8 slots of a row read one 128-byte
+// line of X.
+__global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
+                                    int n_kt, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
+        const int slot = (int)(s % (D_XT / 4));
+        const int64_t tk = s / (D_XT / 4);
+        const int kt = (int)(tk % n_kt);
+        const int64_t mb = tk / n_kt;
+        const int row = slot >> 3, p = (slot & 7) ^ ((row >> 1) & 7);
+        const int64_t t = mb * D_BM + row, k0 = (int64_t)kt * D_BK + 4 * p;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < T) {
+            const float *src = X + t * ldx + k0;
+            if (aligned && k0 + 4 <= G) {
+                v = *reinterpret_cast<const f32x4 *>(src);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (k0 + c < G) v[c] = src[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = nan0(v[c]);
+        }
+        Xp[s] = v;
     }
-    slabs[((((int64_t)mb * n_nt + nt) * (S + 1) + S) * D_BM + tl) * D_BN + c] = s;
+}
+
+// float index of W[g][r] inside the packed matrix Wp[nt][kt][slot][4]
+__host__ __device__ __forceinline__ int64_t wp_index(int64_t g, int64_t r, int n_kt) {
+    const int64_t nt = r / D_BN, kt = g / D_BK;
+    const int cl = (int)(r % D_BN), kk = (int)(g % D_BK);
+    return ((nt * n_kt + kt) * (D_WT / 4) + tile_slot(cl, kk >> 2)) * 4 + (kk & 3);
 }
 
 // out[t, r] = sum_s slab[mb][nt][s][t_local][c] / den[r]        (aggregations.py:77-80 fused)
@@ -265,36 +240,45 @@ __global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, i
     if (r >= R) return;
     const int mb = (int)(t / D_BM), tl = (int)(t % D_BM);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * (S + 1)) * D_BM + tl) * D_BN + c;
+    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * D_BM + tl) * D_BN + c;
     float s = 0.f;
-    for (int k = 0; k < S + 1; ++k) s += p[(int64_t)k * D_BM * D_BN];     // slab S = ragged k tail
+    for (int k = 0; k < S; ++k) s += p[(int64_t)k * D_BM * D_BN];
     out[t * ldo + r] = s / den[r];
 }
 
-__global__ void dense_synth_w_kernel(float *__restrict__ W, int64_t G, int32_t R, int64_t ldw,
-                                     uint32_t seed) {
-    const int64_t n4 = ldw / 4;
+// synthetic W[g][r] = hash_u01(g R + r, seed) written straight into the packed order
+__global__ void dense_synth_w_kernel(f32x4 *__restrict__ Wp, int64_t G, int32_t R, int n_kt,
+                                     int64_t n_slots, uint32_t seed) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G * n4; i += stride) {
-        const int64_t g = i / n4, r = (i % n4) * 4;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
+        const int slot = (int)(s % (D_WT / 4));
+        const int64_t tk = s / (D_WT / 4);
+        const int64_t kt = tk % n_kt, nt = tk / n_kt;
+        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
+        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            v[c] = (r + c < R) ? hash_u01((uint64_t)g * (uint64_t)R + (uint64_t)(r + c), seed) : 0.f;
-        *reinterpret_cast<f32x4 *>(W + g * ldw + r) = v;
+            v[c] = (r < R && g0 + c < G) ? hash_u01((uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r, seed) : 0.f;
+        Wp[s] = v;
     }
 }
 
-// column sums in fp64 (plan time): block = 256 columns x a strip of rows
-__global__ void dense_colsum_kernel(const float *__restrict__ W, int64_t G, int32_t R, int64_t ldw,
-                                    int64_t rows_per_block, double *__restrict__ den) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const int64_t g0 = (int64_t)blockIdx.y * rows_per_block;
-    const int64_t g1 = g0 + rows_per_block < G ? g0 + rows_per_block : G;
-    double s = 0.0;
-    for (int64_t g = g0; g < g1; ++g) s += (double)W[g * ldw + r];
-    atomicAdd(&den[r], s);
+// column sums in fp64 (plan time): one block per (column tile, strip of k tiles); thread = slot
+__global__ void dense_colsum_kernel(const f32x4 *__restrict__ Wp, int32_t R, int n_kt, int kt_per_block,
+                                    double *__restrict__ den) {
+    const int nt = blockIdx.x;
+    const int ktb = blockIdx.y * kt_per_block;
+    const int kte = ktb + kt_per_block < n_kt ? ktb + kt_per_block : n_kt;
+    for (int slot = threadIdx.x; slot < D_WT / 4; slot += blockDim.x) {
+        double s = 0.0;
+        for (int kt = ktb; kt < kte; ++kt) {
+            const f32x4 v = Wp[((int64_t)nt * n_kt + kt) * (D_WT / 4) + slot];
+            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+        }
+        const int64_t r = (int64_t)nt * D_BN + (slot >> 3);
+        if (r < R) atomicAdd(&den[r], s);
+    }
 }
 
 __global__ void dense_den32_kernel(const double *__restrict__ den64, float *__restrict__ den32, int32_t R) {
@@ -302,22 +286,40 @@ __global__ void dense_den32_kernel(const double *__restrict__ den64, float *__re
     if (r < R) den32[r] = (float)den64[r];
 }
 
-__global__ void dense_scatter_kernel(float *__restrict__ W, int64_t ldw, const int32_t *__restrict__ cell,
+__global__ void dense_scatter_kernel(float *__restrict__ Wp, int n_kt, const int32_t *__restrict__ cell,
                                      const int32_t *__restrict__ region, const float *__restrict__ w,
                                      int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) W[(int64_t)cell[i] * ldw + region[i]] = w[i];
+    if (i < n) Wp[wp_index(cell[i], region[i], n_kt)] = w[i];
+}
+
+// plain row-major W (G x R) -> packed order (small matrices handed over by the host)
+__global__ void dense_pack_w_kernel(const float *__restrict__ W, int64_t G, int32_t R, int n_kt,
+                                    int64_t n_slots, f32x4 *__restrict__ Wp) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
+        const int slot = (int)(s % (D_WT / 4));
+        const int64_t tk = s / (D_WT / 4);
+        const int64_t kt = tk % n_kt, nt = tk / n_kt;
+        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
+        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (r < R && g0 + c < G) v[c] = W[(g0 + c) * R + r];
+        Wp[s] = v;
+    }
 }
 
 }  // namespace wagg
 
 struct wagg_dense {
-    int64_t G = 0, ldw = 0;
+    int64_t G = 0;
     int32_t R = 0;
-    wagg::DevBuf<float> W, den32, slabs;
+    int n_kt = 0, n_nt = 0;            // k tiles (32 cells) and column tiles (256 regions)
+    wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order
     wagg::DevBuf<double> den64;
     std::vector<double> den_host;
-    bool den_exact_host = false;
+    int64_t w_slots() const { return (int64_t)n_nt * n_kt * (wagg::D_WT / 4); }
 };
 
 namespace wagg {
@@ -326,15 +328,17 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out) {
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
+    WAGG_REQUIRE((G + D_BK - 1) / D_BK < (int64_t)0x7fffffff / 8, "G too large");
     wagg_dense *d = new (std::nothrow) wagg_dense();
     if (!d) { set_error("host allocation failed"); return WAGG_ENOMEM; }
     d->G = G; d->R = R;
-    d->ldw = ((int64_t)R + D_BN - 1) / D_BN * D_BN;
-    hipError_t e = d->W.alloc((size_t)(G * d->ldw));
+    d->n_kt = (int)((G + D_BK - 1) / D_BK);
+    d->n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    hipError_t e = d->W.alloc((size_t)d->w_slots() * 4);
     if (e == hipSuccess) e = d->den32.alloc((size_t)R);
     if (e == hipSuccess) e = d->den64.alloc((size_t)R);
     if (e != hipSuccess) {
-        set_error("dense W allocation of %.1f GB failed: %s", (double)G * d->ldw * 4e-9, hipGetErrorString(e));
+        set_error("dense W allocation of %.1f GB failed: %s", (double)d->w_slots() * 16e-9, hipGetErrorString(e));
         delete d;
         return e == hipErrorOutOfMemory ? WAGG_ENOMEM : WAGG_EHIP;
     }
@@ -344,10 +348,10 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out) {
 
 static int dense_finish_den(wagg_dense *d) {
     WAGG_HIP(hipMemset(d->den64.p, 0, sizeof(double) * (size_t)d->R));
-    const int64_t rows_per_block = 4096;
-    dim3 grid((unsigned)((d->R + 255) / 256), (unsigned)((d->G + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL(dense_colsum_kernel, grid, dim3(256), 0, nullptr, d->W.p, d->G, d->R, d->ldw,
-                       rows_per_block, d->den64.p);
+    const int kt_per_block = 128;
+    dim3 grid((unsigned)d->n_nt, (unsigned)((d->n_kt + kt_per_block - 1) / kt_per_block));
+    hipLaunchKernelGGL(dense_colsum_kernel, grid, dim3(512), 0, nullptr,
+                       reinterpret_cast<const f32x4 *>(d->W.p), d->R, d->n_kt, kt_per_block, d->den64.p);
     hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, nullptr,
                        d->den64.p, d->den32.p, d->R);
     WAGG_HIP(hipGetLastError());
@@ -356,11 +360,11 @@ static int dense_finish_den(wagg_dense *d) {
     return WAGG_OK;
 }
 
-static int pick_ksplit(int64_t items, int64_t G) {
+static int pick_ksplit(int64_t items, int n_kt) {
     int best = 8;
     double best_eff = 0.0;
     for (int S = 8; S <= 64; S += 8) {
-        if (S > 8 && G / S < 32 * D_BK) break;         // keep >= 32 LDS tiles per slice
+        if (S > 8 && n_kt / S < 32) break;             // keep >= 32 LDS tiles per slice
         const double w = (double)items * S / 256.0;
         const double eff = w / std::ceil(w);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = S; }
@@ -376,7 +380,8 @@ extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg
     int rc = dense_alloc(G, R, out);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    hipLaunchKernelGGL(dense_synth_w_kernel, dim3(256 * 32), dim3(256), 0, nullptr, d->W.p, G, R, d->ldw, seed);
+    hipLaunchKernelGGL(dense_synth_w_kernel, dim3(256 * 32), dim3(256), 0, nullptr,
+                       reinterpret_cast<f32x4 *>(d->W.p), G, R, d->n_kt, d->w_slots(), seed);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) rc = dense_finish_den(d); else { set_error("synth launch: %s", hipGetErrorString(e)); rc = WAGG_EHIP; }
     if (rc != WAGG_OK) { delete d; *out = nullptr; }
@@ -389,10 +394,15 @@ extern "C" int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R,
     int rc = dense_alloc(G, R, out);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * (size_t)(G * d->ldw));
-    if (e == hipSuccess)
-        e = hipMemcpy2D(d->W.p, sizeof(float) * (size_t)d->ldw, W_host, sizeof(float) * (size_t)R,
-                        sizeof(float) * (size_t)R, (size_t)G, hipMemcpyHostToDevice);
+    DevBuf<float> plain;
+    hipError_t e = plain.alloc((size_t)(G * R));
+    if (e == hipSuccess) e = hipMemcpy(plain.p, W_host, sizeof(float) * (size_t)(G * R), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dense_pack_w_kernel, dim3(256 * 8), dim3(256), 0, nullptr, plain.p, G, R, d->n_kt,
+                           d->w_slots(), reinterpret_cast<f32x4 *>(d->W.p));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { set_error("dense upload: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
     rc = dense_finish_den(d);
     if (rc != WAGG_OK) { delete d; *out = nullptr; }
@@ -428,13 +438,13 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
     DevBuf<int32_t> dc, dr; DevBuf<float> dw;
-    hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * (size_t)(G * d->ldw));
+    hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * 4 * (size_t)d->w_slots());
     if (e == hipSuccess) e = dc.upload(hc);
     if (e == hipSuccess) e = dr.upload(hr);
     if (e == hipSuccess) e = dw.upload(hw);
     if (e == hipSuccess && !hc.empty()) {
         hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                           d->W.p, d->ldw, dc.p, dr.p, dw.p, (int64_t)hc.size());
+                           d->W.p, d->n_kt, dc.p, dr.p, dw.p, (int64_t)hc.size());
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -469,42 +479,36 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     WAGG_REQUIRE(X_dev && out_dev, "X/out is NULL");
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
-    const int n_nt = (int)(d->ldw / D_BN);
+    const int n_nt = d->n_nt, n_kt = d->n_kt;
     const int n_mb = (int)((T + D_BM - 1) / D_BM);
-    const int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, d->G);
-    constexpr int BK = D_BK;
-    const int64_t Gfull = d->G / BK * BK;
-    const int64_t k_per_slice = ((Gfull + S - 1) / S + BK - 1) / BK * BK;
+    const int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
+    const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
     WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && T <= 65535, "grid too large");
-    if ((int64_t)D_BM * ldx * 4 >= ((int64_t)1 << 32)) {
-        set_error("dense path: 368 rows x ldx x 4 bytes must stay below 4 GiB (ldx = %lld)", (long long)ldx);
-        return WAGG_EUNSUPPORTED;
-    }
-    const size_t need = (size_t)n_nt * n_mb * (S + 1) * D_BM * D_BN;
+    const size_t need = (size_t)n_nt * n_mb * S * D_BM * D_BN;
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
-    const bool aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
-    const size_t shmem = sizeof(float) * 2 * D_STAGE;
+    const int64_t x_slots = (int64_t)n_mb * n_kt * (D_XT / 4);
+    if (d->xp.n < (size_t)x_slots * 4) WAGG_HIP(d->xp.alloc((size_t)x_slots * 4));
+    const int aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
+    const size_t shmem = 2 * (size_t)D_BUF_BYTES;
     hipStream_t st = (hipStream_t)stream;
-    auto kern = aligned ? dense_mfma_kernel<true> : dense_mfma_kernel<false>;
+    auto kern = dense_mfma_kernel<0>;
     if (const char *dbg = getenv("WAGG_DENSE_DBG")) {
         switch (atoi(dbg)) {
-            case 1: kern = dense_mfma_kernel<true, 1>; break;
-            case 2: kern = dense_mfma_kernel<true, 2>; break;
-            case 3: kern = dense_mfma_kernel<true, 3>; break;
-            case 7: kern = dense_mfma_kernel<true, 7>; break;
-            case 8: kern = dense_mfma_kernel<true, 8>; break;
-            case 32: kern = dense_mfma_kernel<true, 32>; break;
+            case 1: kern = dense_mfma_kernel<1>; break;
+            case 4: kern = dense_mfma_kernel<4>; break;
+            case 5: kern = dense_mfma_kernel<5>; break;
             default: break;
         }
     }
     WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(dense_pack_x_kernel, dim3(256 * 16), dim3(256), 0, st, X_dev, T, ldx, d->G, n_kt, x_slots,
+                       aligned, reinterpret_cast<f32x4 *>(d->xp.p));
+    WAGG_HIP(hipGetLastError());
     profile_mark(st, true);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, X_dev, T, ldx, d->W.p, d->ldw,
-                       Gfull, n_nt, n_mb, S, k_per_slice, d->slabs.p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, d->xp.p, d->W.p, n_kt, n_nt, n_mb,
+                       S, kt_per_slice, d->slabs.p);
     profile_mark(st, false);
-    hipLaunchKernelGGL(dense_ktail_kernel, dim3((unsigned)n_nt, (unsigned)(n_mb * D_BM / 2)), dim3(256), 0, st,
-                       X_dev, T, ldx, d->W.p, d->ldw, Gfull, d->G, n_nt, S, d->slabs.p);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,
                        d->slabs.p, n_nt, S, T, d->R, d->den32.p, out_dev, ldo);
