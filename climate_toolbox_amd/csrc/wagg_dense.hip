@@ -66,7 +66,8 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // are all distinct within each group.
 //
 // DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
-// of the k-loop, bit2 = skip the per-tile barrier.  Results are wrong with any bit set.
+// of the k-loop, bit2 = skip the per-tile barrier, bit3 = one DMA piece per row-block PAIR (instead
+// of one per block in the first 10 blocks).  Results are wrong with any bit set.
 template <int DBG = 0>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const float *__restrict__ Xp, const float *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
@@ -99,11 +100,17 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 #define WAGG_DMA_W(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * (D_WT * 4) + (q) * 1024),   \
                                      (lptr_t)(lds + (buf) * D_BUF_BYTES + D_XT * 4 + (q) * 1024), 16, 0, 0)
-#define WAGG_DMA_PIECE(i, tile, buf)                                                              \
+#define WAGG_DMA_PIECE_XW(i, tile, buf)                                                           \
     do {                                                                                          \
         if ((i) < 5) WAGG_DMA_X(wave + 8 * (i), tile, buf);                                       \
         else if ((i) == 5) WAGG_DMA_X(xq5, tile, buf);                                            \
         else WAGG_DMA_W(wave + 8 * ((i) - 6), tile, buf);                                         \
+    } while (0)
+    // W pieces (HBM, longest latency) first, then the X pieces (served by the XCD's L2)
+#define WAGG_DMA_PIECE(i, tile, buf)                                                              \
+    do {                                                                                          \
+        if (DBG & 16) WAGG_DMA_PIECE_XW(i, tile, buf);                                            \
+        else WAGG_DMA_PIECE_XW(((i) + 6) % 10, tile, buf);                                        \
     } while (0)
 
     f32x4 acc[D_MT][2];
@@ -155,14 +162,17 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if ((DMA) >= 0 && (DMA) < 10 && !(DBG & 1)) WAGG_DMA_PIECE(DMA, tnext, nbuf);             \
+        if ((DMA) >= 0 && (DMA) < 10 && !(DBG & 1)) {                                             \
+            if (DBG & 32) { if ((DMA) < 5) { WAGG_DMA_PIECE(2 * (DMA), tnext, nbuf); WAGG_DMA_PIECE(2 * (DMA) + 1, tnext, nbuf); } } \
+            else WAGG_DMA_PIECE(DMA, tnext, nbuf);                                                \
+        }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA8(RB, A1, b01, b11);                                                             \
     } while (0)
 #define WAGG_PAIR(P)                                                                              \
     do {                                                                                          \
-        WAGG_BLOCK(2 * (P), aA0, aA1, aB0, aB1, 2 * (P) + 1, P);                                  \
-        WAGG_BLOCK(2 * (P) + 1, aB0, aB1, aA0, aA1, 2 * (P) + 2, -1);                             \
+        WAGG_BLOCK(2 * (P), aA0, aA1, aB0, aB1, 2 * (P) + 1, (DBG & 8) ? (P) : 2 * (P));          \
+        WAGG_BLOCK(2 * (P) + 1, aB0, aB1, aA0, aA1, 2 * (P) + 2, (DBG & 8) ? -1 : 2 * (P) + 1);   \
     } while (0)
 
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -498,6 +508,9 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
             case 1: kern = dense_mfma_kernel<1>; break;
             case 4: kern = dense_mfma_kernel<4>; break;
             case 5: kern = dense_mfma_kernel<5>; break;
+            case 8: kern = dense_mfma_kernel<8>; break;
+            case 16: kern = dense_mfma_kernel<16>; break;
+            case 32: kern = dense_mfma_kernel<32>; break;
             default: break;
         }
     }
