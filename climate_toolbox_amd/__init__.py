@@ -9,3 +9,9 @@ from .aggregations import (  # noqa: F401
     _reindex_spatial_data_to_regions,
     _aggregate_reindexed_data_to_regions,
 )
+from .standardize import (  # noqa: F401  (coordinate standardisation folded into the plan)
+    standardize_climate_data,
+    convert_lons_split,
+    convert_lons_mono,
+    rename_coords_to_lon_and_lat,
+)

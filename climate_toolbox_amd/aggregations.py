@@ -203,10 +203,12 @@ class ReindexedDataset(minixr.Dataset):
     (then a device gather kernel runs); ``_aggregate_reindexed_data_to_regions`` never
     materialises it -- the gather is fused into the aggregation kernel."""
 
-    def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray):
+    def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray,
+                 lon_perms=None):
         super().__init__()
         self._src_values, self._src_dims = src_values, src_dims
         self._ilat, self._ilon = ilat, ilon
+        self._lon_perms = dict(lon_perms or {})     # variable -> file column of each sorted lon label
         self._nseg = len(ilat)
         self._was_xarray = was_xarray
         for k, v in coords.items():
@@ -233,9 +235,11 @@ class ReindexedDataset(minixr.Dataset):
         dims = self._src_dims[name]
         shape = dict(zip(dims, self._src_values[name].shape))
         ia, io, *_ = _spatial_layout(dims)
+        perm = self._lon_perms.get(name)
+        ilon = self._ilon if perm is None else np.asarray(perm)[self._ilon]
         if ia < io:
-            return (self._ilat * shape["lon"] + self._ilon).astype(np.int32), shape["lat"] * shape["lon"]
-        return (self._ilon * shape["lat"] + self._ilat).astype(np.int32), shape["lat"] * shape["lon"]
+            return (self._ilat * shape["lon"] + ilon).astype(np.int32), shape["lat"] * shape["lon"]
+        return (ilon * shape["lat"] + self._ilat).astype(np.int32), shape["lat"] * shape["lon"]
 
     def _materialise(self, name):
         torch = require_gpu()
@@ -326,9 +330,18 @@ def _extract(ds):
         src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
         coords = {k: minixr.DataArray(v.values, tuple(v.dims)) for k, v in ds.coords.items()}
         return src_values, src_dims, coords, True
-    src_values = {k: v.values for k, v in ds.data_vars.items()}
+    # a lazily lon-sorted variable (standardize.py) hands over its file-order buffer; the column
+    # permutation is folded into the cell index by _reindex_spatial_data_to_regions
+    src_values = {k: (v._values if getattr(v, "_lon_perm", None) is not None else v.values)
+                  for k, v in ds.data_vars.items()}
     src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
     return src_values, src_dims, dict(ds.coords), False
+
+
+def _lon_perms(ds):
+    if _is_xarray(ds):
+        return {}
+    return {k: v._lon_perm for k, v in ds.data_vars.items() if getattr(v, "_lon_perm", None) is not None}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -361,7 +374,7 @@ def _reindex_spatial_data_to_regions(ds, df):
         else:
             passthrough[k] = minixr.DataArray(src_values[k], dims)
     out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, df["lat"].values, df["lon"].values,
-                           was_xr)
+                           was_xr, lon_perms=_lon_perms(ds))
     for k, v in passthrough.items():
         out.data_vars[k] = v
     return out

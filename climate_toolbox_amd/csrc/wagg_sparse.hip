@@ -73,7 +73,24 @@ template <typename T> struct PlanView {
     int n_groups;
     int g0_normal;               // groups [0, g0_normal) are giant, the rest own exactly one chunk
     int c0_normal;               // first chunk of the first normal group
+    // element transform applied to the data when it is loaded (tas_poly,
+    // transformations.py:188: (tas - 273.15) ** power): xpow = 0 -> identity, else (x + xoff)^xpow
+    T xoff;
+    int xpow;
 };
+
+template <typename T> __device__ __forceinline__ T xform1(T x, T off, int pw) {
+    const T y = x + off;
+    T r = y;
+    for (int i = 1; i < pw; ++i) r *= y;
+    return r;
+}
+template <typename V, typename T> __device__ __forceinline__ V xform4(V v, T off, int pw) {
+    V r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = xform1<T>(v[c], off, pw);
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernel
@@ -167,6 +184,10 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                         v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
                     }
                 }
+                if (pv.xpow > 0) {
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) v[i] = xform4<vec4, T>(v[i], pv.xoff, pv.xpow);
+                }
                 if (!(DBG & 2)) {
 #pragma unroll
                     for (int i = 0; i < TPW; ++i)
@@ -182,7 +203,11 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
             for (int u = wave; u < 4 * nu; u += NWAVE) {
                 int64_t cell = (int64_t)pv.ucell[u0 + (u >> 2)] + (u & 3);
                 cell = cell < G ? cell : G - 1;
-                if (lane < TB) xs[lane * UROW + u] = lane_live ? X[cell * ldx + t0 + lane] : T(0);
+                if (lane < TB) {
+                    T xv = lane_live ? X[cell * ldx + t0 + lane] : T(0);
+                    if (pv.xpow > 0) xv = xform1<T>(xv, pv.xoff, pv.xpow);
+                    xs[lane * UROW + u] = xv;
+                }
             }
         }
 #pragma unroll
@@ -390,6 +415,10 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
         if (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(0); }   // ph0: wait for the rows
         // ---- park the current item (registers -> LDS); note whether the whole chunk is finite ----
         bool odd = false;
+        if (pv.xpow > 0) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) v[i] = xform4<vec4, T>(v[i], pv.xoff, pv.xpow);
+        }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = v[i];
@@ -646,6 +675,10 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             float *im = img + buf * LC_TB * UROW;
             // one v_cmp_class per element finds NaN / +-inf; the select runs only if the wave saw any
             bool odd = false;
+            if (pv.xpow > 0) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) R.v[i] = xform4<vec4, float>(R.v[i], pv.xoff, pv.xpow);
+            }
             if (!(knob & 4)) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
@@ -888,9 +921,10 @@ __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_emp
 
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
-                         T *out, int64_t ldo, int out_layout, hipStream_t stream) {
+                         T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0) {
     const auto &d = plan->d;
     PlanView<T> pv;
+    pv.xoff = xoff; pv.xpow = xpow;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
     pv.ucell = d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
@@ -1381,6 +1415,25 @@ extern "C" int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_
 }
 
 namespace wagg {
+// (x + offset)^p for p = 1..n_pow, each aggregated like wagg_apply.  Power p lands at
+// out + (p - 1) * out_pstride.
+template <typename T, int TB>
+static int apply_poly(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, double offset,
+                      int n_pow, T *out, int64_t ldo, int64_t out_pstride, int out_layout, hipStream_t st) {
+    int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
+    if (rc != WAGG_OK) return rc;
+    WAGG_REQUIRE(n_pow >= 1 && n_pow <= 16, "n_pow must be in [1, 16], got %d", n_pow);
+    const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : (int64_t)plan->info.R;
+    WAGG_REQUIRE(n_pow == 1 || out_pstride >= orows * ldo, "out_pstride %lld overlaps the previous power",
+                 (long long)out_pstride);
+    for (int p = 1; p <= n_pow; ++p) {
+        rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out + (int64_t)(p - 1) * out_pstride, ldo, out_layout,
+                                  st, (T)offset, p);
+        if (rc != WAGG_OK) return rc;
+    }
+    return WAGG_OK;
+}
+
 template <typename T, typename F>
 static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, T *out,
                       int64_t ldo, int out_layout, F fn) {
@@ -1408,4 +1461,17 @@ extern "C" int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, i
 extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                    int layout, double *out_host, int64_t ldo, int out_layout) {
     return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, wagg_apply_f64);
+}
+
+extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
+                                   double offset, int n_pow, float *out_dev, int64_t ldo, int64_t out_pstride,
+                                   int out_layout, void *stream) {
+    return wagg::apply_poly<float, 64>(plan, X_dev, T, ldx, layout, offset, n_pow, out_dev, ldo, out_pstride,
+                                       out_layout, (hipStream_t)stream);
+}
+extern "C" int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
+                                   double offset, int n_pow, double *out_dev, int64_t ldo, int64_t out_pstride,
+                                   int out_layout, void *stream) {
+    return wagg::apply_poly<double, 32>(plan, X_dev, T, ldx, layout, offset, n_pow, out_dev, ldo, out_pstride,
+                                        out_layout, (hipStream_t)stream);
 }

@@ -285,3 +285,24 @@ def agg_dense(X_TG, W_GR):
     W = np.asarray(W_GR, dtype=np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
         return (Xz @ W) / W.sum(axis=0)[None, :]
+
+
+# ---------------------------------------------------------------------------------------------
+# coordinate standardisation in front of the path
+# ---------------------------------------------------------------------------------------------
+def convert_lons_split(values, dims, lon):
+    """climate_toolbox/utils/utils.py:33-40: relabel ``(lon + 180) % 360 - 180``, then
+    ``ds.sel(lon=np.sort(new))`` -- returns (values re-ordered along 'lon', sorted labels)."""
+    new = (np.asarray(lon, dtype=np.float64) + 180) % 360 - 180
+    order = np.argsort(new, kind="stable")
+    return np.take(np.asarray(values), order, axis=tuple(dims).index("lon")), new[order]
+
+
+# ---------------------------------------------------------------------------------------------
+# grid-level transform in front of the path (SURVEY 8f-3)
+# ---------------------------------------------------------------------------------------------
+def tas_poly_values(values, power, offset=-273.15):
+    """climate_toolbox/transformations/transformations.py:188: ``(ds.tas - 273.15) ** power``,
+    evaluated in the data's own dtype (a Python float does not promote a float32 array)."""
+    values = np.asarray(values)
+    return (values + values.dtype.type(offset)) ** power

@@ -456,3 +456,64 @@ def test_dense_multi_row_block(torch_cuda):
     _rel_ok(got, O.agg_dense(X, W), RTOL32)
     part = plan.apply(torch.from_numpy(X[368:736].copy()).cuda()).cpu().numpy()
     np.testing.assert_array_equal(part, got[368:736])
+
+
+@pytest.mark.gpu
+def test_standardized_raw_0_360_file_matches_reference_order_of_operations(torch_cuda):
+    """a raw 0..360 'latitude/longitude' file goes through standardize_climate_data
+    (io/io.py:6-24) and the aggregation; the reference permutes the array first, here the
+    permutation lives in the plan's cell index -- same numbers."""
+    from climate_toolbox_amd import minixr, standardize_climate_data, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(5)
+    lat, lon = np.arange(-89.5, 90, 1.0), np.arange(0.5, 360, 1.0)
+    for dims, shape in ((("time", "latitude", "longitude"), (40, 180, 360)),
+                        (("latitude", "longitude", "time"), (180, 360, 7))):
+        tas = (280 + 10 * rng.standard_normal(shape)).astype(np.float32 if dims[0] == "time" else np.float64)
+        ds = minixr.Dataset({"tas": (dims, tas)}, coords={"latitude": lat, "longitude": lon})
+        std_dims = tuple({"latitude": "lat", "longitude": "lon"}.get(d, d) for d in dims)
+        ref_vals, ref_lon = O.convert_lons_split(tas, std_dims, lon)       # what the reference aggregates
+        n = 3000
+        df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(ref_lon, n),
+                           "areawt": rng.uniform(0.1, 1, n), "popwt": rng.uniform(0, 5, n),
+                           "hierid": rng.integers(0, 150, n)})
+        df.loc[rng.random(n) < 0.2, "popwt"] = np.nan
+        ref, rdims, labs = O.agg_scatter(ref_vals, std_dims, lat, ref_lon, df["lat"].values, df["lon"].values,
+                                         df["popwt"].values, df["areawt"].values, df["hierid"].values,
+                                         group_dim="hierid")
+        out = weighted_aggregate_grid_to_regions(standardize_climate_data(ds), "tas", "popwt", "hierid", df)
+        assert out.tas.dims == rdims and list(out["hierid"].values) == list(labs)
+        _rel_ok(out.tas.values, ref, RTOL32 if tas.dtype == np.float32 else RTOL64)
+
+
+@pytest.mark.parametrize("dtype,layout", [(np.float32, "TG"), (np.float64, "TG"), (np.float32, "GT"), (np.float64, "GT")])
+def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layout):
+    """(tas - 273.15) ** p for p = 1..4 fused into the aggregation's loads
+    (wagg_apply_poly_*) equals the reference order of operations: transform the grid
+    (transformations.py:188), then aggregate (aggregations.py:78-80)."""
+    from climate_toolbox_amd import synth
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    nlat, nlon, R, T = 96, 192, 300, 77
+    lat, lon, df = synth.realistic_segments(nlat, nlon, R=R, seed=4, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "popwt", "hierid")
+    # one region spread over the whole grid -> a multi-chunk ("giant") group rides along
+    rng = np.random.default_rng(8)
+    extra = rng.choice(nlat * nlon, 900, replace=False).astype(np.int32)
+    cell = np.concatenate([cell, extra]); code = np.concatenate([code, np.full(900, len(uniq), np.int32)])
+    w = np.concatenate([w, rng.uniform(0.1, 1, 900)])
+    Rn, G = len(uniq) + 1, nlat * nlon
+    X = (288.15 + 8 * rng.standard_normal((T, G))).astype(dtype)   # ~15 +- 8 degrees C
+    X[3, cell[:40]] = np.nan                                      # NaN data: skipped products (S6)
+    plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon)
+    assert plan.info["n_giant"] >= 1
+    Xd = torch.from_numpy(X if layout == "TG" else np.ascontiguousarray(X.T)).cuda()
+    got = plan.apply_poly(Xd, -273.15, 4, layout=layout).cpu().numpy()
+    assert got.shape == (4, T, Rn)
+    for p in range(1, 5):
+        ref = O.agg_coded(O.tas_poly_values(X, p), cell, code, w, Rn)
+        _rel_ok(got[p - 1], ref, RTOL32 if dtype == np.float32 else RTOL64, scale=1.0)
+    # power 1 with offset 0 is the plain aggregation
+    np.testing.assert_array_equal(plan.apply_poly(Xd, 0.0, 1, layout=layout)[0].cpu().numpy(),
+                                  plan.apply(Xd, layout=layout).cpu().numpy())

@@ -180,3 +180,67 @@ def test_native_factorize_matches_pandas(labels):
     assert list(uniq) == list(u_ref)
     np.testing.assert_array_equal(codes, c_ref)
     assert codes.dtype == np.int32
+
+
+# ---------------------------------------------------------------------------------------------
+# standardize_climate_data folded into the plan (no permutation copy)
+# ---------------------------------------------------------------------------------------------
+def _raw_0_360_dataset(T=3, step=2.0, seed=0, names=("latitude", "longitude")):
+    from climate_toolbox_amd import minixr
+    rng = np.random.default_rng(seed)
+    lat = np.arange(-89.0, 90, step)
+    lon = np.arange(0.0, 360.0, step)                    # file order: 0 .. 358
+    tas = rng.standard_normal((T, len(lat), len(lon)))
+    ds = minixr.Dataset({"tas": (("time", names[0], names[1]), tas)},
+                        coords={"time": np.arange(T), names[0]: lat, names[1]: lon})
+    return ds, tas, lat, lon
+
+
+def test_standardize_is_lazy_and_matches_reference_semantics():
+    from climate_toolbox_amd.standardize import standardize_climate_data, LonSortedArray
+    from oracle import ref_numpy as O
+    ds, tas, lat, lon = _raw_0_360_dataset()
+    out = standardize_climate_data(ds)
+    ref_vals, ref_lon = O.convert_lons_split(tas, ("time", "lat", "lon"), lon)
+    assert set(out.coords) == {"time", "lat", "lon"} and out.tas.dims == ("time", "lat", "lon")
+    np.testing.assert_array_equal(out.lon.values, ref_lon)
+    assert (np.diff(out.lon.values) > 0).all() and out.lon.values.min() == -180.0
+    assert isinstance(out.tas, LonSortedArray) and out.tas._values is ds.tas._values   # no copy
+    np.testing.assert_array_equal(out.tas.values, ref_vals)                             # on demand
+
+
+def test_standardize_permutation_is_folded_into_the_cell_index():
+    from climate_toolbox_amd.standardize import standardize_climate_data
+    ds, tas, lat, lon = _raw_0_360_dataset(names=("lat", "long"))
+    out = standardize_climate_data(ds)
+    rng = np.random.default_rng(1)
+    seg_lat, seg_lon = rng.choice(lat, 50), rng.choice(out.lon.values, 50)   # -180..180 labels
+    df = pd.DataFrame({"lat": seg_lat, "lon": seg_lon})
+    re = A._reindex_spatial_data_to_regions(out, df)
+    cell, G = re._cell_index("tas")
+    assert G == len(lat) * len(lon)
+    raw = ds.tas._values.reshape(3, -1)
+    # the value picked from the FILE-order buffer is the value at that (lat, lon) label
+    ilat = np.searchsorted(lat, seg_lat)
+    raw_col = np.array([np.flatnonzero(((lon + 180) % 360 - 180) == v)[0] for v in seg_lon])
+    np.testing.assert_array_equal(raw[:, cell], tas[:, ilat, raw_col])
+    with pytest.raises(KeyError):
+        A._reindex_spatial_data_to_regions(out, pd.DataFrame({"lat": [lat[0]], "lon": [200.0]}))
+
+
+def test_standardize_drops_z_and_rejects_duplicate_longitudes():
+    from climate_toolbox_amd import minixr
+    from climate_toolbox_amd.standardize import standardize_climate_data, convert_lons_mono
+    lat, lon = np.array([0.0, 1.0]), np.array([0.0, 90.0, 180.0, 270.0])
+    v = np.arange(8.0).reshape(1, 2, 4)
+    ds = minixr.Dataset({"tas": (("z", "lat", "lon"), v)}, coords={"z": np.array([5.0]), "lat": lat, "lon": lon})
+    out = standardize_climate_data(ds)
+    assert "z" not in out.coords and out.tas.dims == ("lat", "lon")
+    np.testing.assert_array_equal(out.lon.values, [-180.0, -90.0, 0.0, 90.0])
+    np.testing.assert_array_equal(out.tas.values, v[0][:, [2, 3, 0, 1]])
+    back = convert_lons_mono(out, lon_name="lon")                     # and back to 0..360
+    np.testing.assert_array_equal(back.lon.values, lon)
+    np.testing.assert_array_equal(back.tas.values, v[0])
+    bad = minixr.Dataset({"tas": (("lat", "lon"), v[0][:, :2])}, coords={"lat": lat, "lon": np.array([0.0, 360.0])})
+    with pytest.raises(ValueError):
+        standardize_climate_data(bad)
