@@ -15,3 +15,7 @@ from .standardize import (  # noqa: F401  (coordinate standardisati
     convert_lons_mono,
     rename_coords_to_lon_and_lat,
 )
+from .transformations import (  # noqa: F401  (tas_poly fused into the aggregation)
+    tas_poly,
+    tas_poly_aggregate,
+)

@@ -72,8 +72,8 @@ def load():
     for name in ("wagg_apply_f32", "wagg_apply_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_poly_f32", "wagg_apply_poly_f64"):
-        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, vp, C.c_int64,
-                                     C.c_int64, C.c_int, vp]
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, vp,
+                                     C.c_int64, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_host_f32", "wagg_apply_host_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int]
     for name in ("wagg_gather_f32", "wagg_gather_f64"):

@@ -204,11 +204,12 @@ class ReindexedDataset(minixr.Dataset):
     materialises it -- the gather is fused into the aggregation kernel."""
 
     def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray,
-                 lon_perms=None):
+                 lon_perms=None, xforms=None):
         super().__init__()
         self._src_values, self._src_dims = src_values, src_dims
         self._ilat, self._ilon = ilat, ilon
         self._lon_perms = dict(lon_perms or {})     # variable -> file column of each sorted lon label
+        self._xforms = dict(xforms or {})           # variable -> (offset, power), evaluated on the GPU
         self._nseg = len(ilat)
         self._was_xarray = was_xarray
         for k, v in coords.items():
@@ -248,6 +249,9 @@ class ReindexedDataset(minixr.Dataset):
         Xd = torch.from_numpy(X2).cuda()
         ci = torch.from_numpy(np.ascontiguousarray(cell)).cuda()
         out = _device_gather(Xd, ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
+        if name in self._xforms:
+            off, pw = self._xforms[name]
+            out = (out + off) ** pw
         return unflatten(out.cpu().numpy(), self._nseg)
 
 
@@ -332,7 +336,7 @@ def _extract(ds):
         return src_values, src_dims, coords, True
     # a lazily lon-sorted variable (standardize.py) hands over its file-order buffer; the column
     # permutation is folded into the cell index by _reindex_spatial_data_to_regions
-    src_values = {k: (v._values if getattr(v, "_lon_perm", None) is not None else v.values)
+    src_values = {k: (v._values if isinstance(v, minixr.LazyArray) else v.values)
                   for k, v in ds.data_vars.items()}
     src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
     return src_values, src_dims, dict(ds.coords), False
@@ -342,6 +346,13 @@ def _lon_perms(ds):
     if _is_xarray(ds):
         return {}
     return {k: v._lon_perm for k, v in ds.data_vars.items() if getattr(v, "_lon_perm", None) is not None}
+
+
+def _xforms(ds):
+    """variable -> (offset, power) of a lazily transformed variable (transformations.tas_poly)."""
+    if _is_xarray(ds):
+        return {}
+    return {k: v._xform for k, v in ds.data_vars.items() if getattr(v, "_xform", None) is not None}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -374,10 +385,97 @@ def _reindex_spatial_data_to_regions(ds, df):
         else:
             passthrough[k] = minixr.DataArray(src_values[k], dims)
     out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, df["lat"].values, df["lon"].values,
-                           was_xr, lon_perms=_lon_perms(ds))
+                           was_xr, lon_perms=_lon_perms(ds), xforms=_xforms(ds))
     for k, v in passthrough.items():
         out.data_vars[k] = v
     return out
+
+
+def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=None, offset=0.0):
+    """Shared body of the aggregation.  ``powers=None``: aggregate ``variable`` as it is (with its
+    own lazy transform, if it carries one).  ``powers=[p, ...]``: aggregate ``(x + offset) ** p``
+    for every p in ONE pass over the data.  Returns (list of result arrays, result
+    dims, coords, was_xarray)."""
+    w_eff = _backup_fill(weights[aggwt].values, weights[backup_aggwt].values)   # :73 (native)
+    labels = np.asarray(weights[agglev].values)
+    uniq, codes = _factorize_labels(labels)                              # :78 group keys
+
+    xform = None
+    if isinstance(ds, ReindexedDataset) and variable in ds._src_values:
+        values, dims = ds._src_values[variable], ds._src_dims[variable]
+        xform = ds._xforms.get(variable)
+        cell_idx, G = ds._cell_index(variable)
+        if len(cell_idx) != len(w_eff):
+            raise ValueError("weights has %d rows but the dataset was reindexed with %d"
+                             % (len(w_eff), len(cell_idx)))
+        shape = dict(zip(dims, np.asarray(values).shape))
+        ia, io, *_ = _spatial_layout(dims)
+        row_len = shape["lon"] if ia < io else shape["lat"]
+        was_xr = ds._was_xarray
+        carried = {k: v for k, v in ds.coords.items()}
+        # mirror the mutation of :64-71
+        ds.coords[agglev] = minixr.DataArray(labels, ("reshape_index",))
+        ds.data_vars[aggwt] = minixr.DataArray(w_eff, ("reshape_index",), name=aggwt)
+    else:
+        # an already materialised dataset: its reshape_index axis is the "grid"
+        arr = ds[variable]
+        dims = tuple(arr.dims)
+        if "reshape_index" not in dims:
+            raise KeyError("dataset has no 'reshape_index' dimension; call "
+                           "_reindex_spatial_data_to_regions first")
+        values = np.asarray(arr.values)
+        k = dims.index("reshape_index")
+        # present it as (lat=reshape_index, lon=1) so that the same flattening code applies
+        dims = dims[:k] + ("lat", "lon") + dims[k + 1:]
+        values = values.reshape(values.shape[:k] + (values.shape[k], 1) + values.shape[k + 1:])
+        G = values.shape[k]
+        cell_idx = np.arange(G, dtype=np.int32)
+        if G != len(w_eff):
+            raise ValueError("weights has %d rows but reshape_index has %d" % (len(w_eff), G))
+        row_len = 0
+        was_xr = _is_xarray(ds)
+        carried = ({k2: minixr.DataArray(v.values, tuple(v.dims)) for k2, v in ds.coords.items()}
+                   if was_xr else dict(ds.coords))
+
+    if powers is not None and xform is not None:
+        raise ValueError("variable %r already carries a lazy transform" % (variable,))
+    if powers is None and xform is not None:
+        offset, powers, single = xform[0], [xform[1]], True
+    else:
+        single = powers is None
+    torch = require_gpu()
+    X2, layout, _, unflatten = _flatten_for_device(values, dims)
+    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=X2.dtype == np.float32, layout=layout)
+    # host-resident data: one pageable H2D copy (measured 51.7 GB/s on the MI355X box: 29 ms for the
+    # 1.5 GB c2 field, ~100x the kernel; a pinned double-buffered variant was 13x SLOWER because the
+    # pageable -> pinned host memcpy runs at ~4 GB/s), the kernels, one D2H copy of the result
+    Xd = torch.from_numpy(X2).cuda()
+    out_layout = "TR" if layout == "TG" else "RT"
+    if powers is None:
+        outs = [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
+    elif isinstance(plan, DensePlan):
+        # scattered weights in the dense MFMA form: the transform is one elementwise device pass
+        outs = [plan.apply((Xd + offset) ** int(p)) for p in powers]
+    else:
+        lo, hi = int(min(powers)), int(max(powers))
+        stack = plan.apply_poly(Xd, offset, hi - lo + 1, layout=layout, out_layout=out_layout, pow_first=lo)
+        outs = [stack[int(p) - lo] for p in powers]
+    res = [unflatten(o.cpu().numpy(), len(uniq)) for o in outs]
+    rdims = _result_dims(dims, agglev)
+
+    coords = {}
+    for d in rdims:
+        if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+            coords[d] = np.asarray(carried[d].values)
+    coords[agglev] = uniq
+    return (res[0] if single else res), rdims, coords, was_xr
+
+
+def _as_dataset(data_vars, rdims, coords, was_xr):
+    if was_xr:
+        return _xr.Dataset({k: (rdims, v) for k, v in data_vars.items()}, coords=coords)
+    return minixr.Dataset({k: (rdims, v) for k, v in data_vars.items()},
+                          coords={k: ((k,), v) for k, v in coords.items()})
 
 
 def _aggregate_reindexed_data_to_regions(
@@ -413,67 +511,8 @@ def _aggregate_reindexed_data_to_regions(
     counted as 0 (S6) and IEEE division (S7).  Like the reference it also attaches ``agglev``
     and ``aggwt`` to ``ds`` (:64-71).
     """
-    w_eff = _backup_fill(weights[aggwt].values, weights[backup_aggwt].values)   # :73 (native)
-    labels = np.asarray(weights[agglev].values)
-    uniq, codes = _factorize_labels(labels)                              # :78 group keys
-
-    if isinstance(ds, ReindexedDataset) and variable in ds._src_values:
-        values, dims = ds._src_values[variable], ds._src_dims[variable]
-        cell_idx, G = ds._cell_index(variable)
-        if len(cell_idx) != len(w_eff):
-            raise ValueError("weights has %d rows but the dataset was reindexed with %d"
-                             % (len(w_eff), len(cell_idx)))
-        shape = dict(zip(dims, np.asarray(values).shape))
-        ia, io, *_ = _spatial_layout(dims)
-        row_len = shape["lon"] if ia < io else shape["lat"]
-        was_xr = ds._was_xarray
-        carried = {k: v for k, v in ds.coords.items()}
-        # mirror the mutation of :64-71
-        ds.coords[agglev] = minixr.DataArray(labels, ("reshape_index",))
-        ds.data_vars[aggwt] = minixr.DataArray(w_eff, ("reshape_index",), name=aggwt)
-    else:
-        # an already materialised dataset: its reshape_index axis is the "grid"
-        arr = ds[variable]
-        dims = tuple(arr.dims)
-        if "reshape_index" not in dims:
-            raise KeyError("dataset has no 'reshape_index' dimension; call "
-                           "_reindex_spatial_data_to_regions first")
-        values = np.asarray(arr.values)
-        k = dims.index("reshape_index")
-        # present it as (lat=reshape_index, lon=1) so that the same flattening code applies
-        dims = dims[:k] + ("lat", "lon") + dims[k + 1:]
-        values = values.reshape(values.shape[:k] + (values.shape[k], 1) + values.shape[k + 1:])
-        G = values.shape[k]
-        cell_idx = np.arange(G, dtype=np.int32)
-        if G != len(w_eff):
-            raise ValueError("weights has %d rows but reshape_index has %d" % (len(w_eff), G))
-        row_len = 0
-        was_xr = _is_xarray(ds)
-        carried = ({k2: minixr.DataArray(v.values, tuple(v.dims)) for k2, v in ds.coords.items()}
-                   if was_xr else dict(ds.coords))
-
-    torch = require_gpu()
-    X2, layout, _, unflatten = _flatten_for_device(values, dims)
-    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=X2.dtype == np.float32, layout=layout)
-    # host-resident data: one pageable H2D copy (measured 51.7 GB/s on the MI355X box: 29 ms for the
-    # 1.5 GB c2 field, ~100x the kernel; a pinned double-buffered variant was 13x SLOWER because the
-    # pageable -> pinned host memcpy runs at ~4 GB/s), the kernels, one D2H copy of the result
-    Xd = torch.from_numpy(X2).cuda()
-    if isinstance(plan, DensePlan):
-        out_d = plan.apply(Xd)
-    else:
-        out_d = plan.apply(Xd, layout=layout, out_layout="TR" if layout == "TG" else "RT")
-    res = unflatten(out_d.cpu().numpy(), len(uniq))
-    rdims = _result_dims(dims, agglev)
-
-    coords = {}
-    for d in rdims:
-        if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-            coords[d] = np.asarray(carried[d].values)
-    coords[agglev] = uniq
-    if was_xr:
-        return _xr.Dataset({variable: (rdims, res)}, coords=coords)
-    return minixr.Dataset({variable: (rdims, res)}, coords={k: ((k,), v) for k, v in coords.items()})
+    res, rdims, coords, was_xr = _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt)
+    return _as_dataset({variable: res}, rdims, coords, was_xr)
 
 
 def weighted_aggregate_grid_to_regions(ds, variable, aggwt, agglev, weights=None):

@@ -572,13 +572,18 @@ struct LcLds {
     static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
 };
 
-template <bool VEC>
+// NPOW > 1 (fused tas_poly): the loaders park y = x + pv.xoff; the consumers raise each
+// fragment to the powers 1..NPOW in registers and keep NPOW accumulator sets, so X is read from HBM
+// once for all powers; power p is stored at out + (p - 1) * out_pstride.  A chunk whose |y| could
+// overflow fp32 at the highest power (or holds +-inf) takes the exact path, like +-inf data does.
+template <bool VEC, int NPOW = 1>
 __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
                                                                   int64_t Ttot, int64_t ldx, int64_t G,
                                                                   float *__restrict__ out, int64_t ldo,
                                                                   int n_norm, long long n_items,
                                                                   int *__restrict__ timeout_word,
-                                                                  unsigned long long *__restrict__ stamps, int knob) {
+                                                                  unsigned long long *__restrict__ stamps, int knob,
+                                                                  int64_t out_pstride = 0, float ylim = 0.f) {
     typedef float vec4 __attribute__((ext_vector_type(4)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -675,7 +680,10 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             float *im = img + buf * LC_TB * UROW;
             // one v_cmp_class per element finds NaN / +-inf; the select runs only if the wave saw any
             bool odd = false;
-            if (pv.xpow > 0) {
+            if (NPOW > 1) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) R.v[i] = R.v[i] + pv.xoff;
+            } else if (pv.xpow > 0) {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) R.v[i] = xform4<vec4, float>(R.v[i], pv.xoff, pv.xpow);
             }
@@ -683,7 +691,10 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN|qNaN|-inf|+inf
+                for (int c = 0; c < 4; ++c) {
+                    if (NPOW > 1) odd |= !(__builtin_fabsf(R.v[i][c]) < ylim);      // NaN, +-inf, or too large to raise
+                    else odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);          // sNaN|qNaN|-inf|+inf
+                }
             }
             bool inf_any = false;
             if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
@@ -693,7 +704,8 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const float x = R.v[i][c];
-                        inf_seen |= __builtin_amdgcn_classf(x, 0x204);           // -inf | +inf: exact path
+                        if (NPOW > 1) inf_seen |= __builtin_fabsf(x) >= ylim;     // exact path
+                        else inf_seen |= __builtin_amdgcn_classf(x, 0x204);       // -inf | +inf: exact path
                         R.v[i][c] = (x == x) ? x : 0.0f;                           // NaN data counts 0 (S6)
                     }
                 inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
@@ -818,7 +830,9 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     // region: one 16-byte store per lane instead of four scattered dwords (consumer
                     // stores queue behind the loaders' row loads, so their count matters) ----
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 accp[NPOW][2];
+#pragma unroll
+                    for (int pp = 0; pp < NPOW; ++pp) accp[pp][0] = accp[pp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float *ap = im + (16 * cw + lr) * UROW + 64 * kq;
                     const float *bp = aw + lr * LC_AROW + 64 * kq;
                     f32x4 af[2], bf[2];
@@ -831,26 +845,32 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                             bf[(g4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(bp + 4 * (g4 + 1));
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                        f32x4 pw = af[g4 & 1];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {               // two chains: 40-cycle dependent latency vs 32 issue
-                            if (j & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc2, 0, 0, 0);
-                            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g4 & 1][j], bf[g4 & 1][j], acc, 0, 0, 0);
+                        for (int pp = 0; pp < NPOW; ++pp) {
+                            if (pp > 0) pw = pw * af[g4 & 1];          // y^(pp+1), transformations.py:188
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)                 // two chains: 40-cycle dependent latency vs 32 issue
+                                accp[pp][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[j], bf[g4 & 1][j], accp[pp][j & 1], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    acc += acc2;
                     // C/D map: column (region) = lane & 15, row (timestep) = 4 * (lane >> 4) + reg
                     const int e = e0 + lr;
                     const int tl = 16 * cw + 4 * kq;
                     if (e < ne && tl < nt) {
                         const float den = sm_ed[buf * LC_ENT + e];
-                        float *op = out + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
-                        const f32x4 qv = {acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den};   // :77-80
-                        if (out_vec && tl + 3 < nt) {
-                            *reinterpret_cast<f32x4 *>(op) = qv;
-                        } else {
 #pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                        for (int pp = 0; pp < NPOW; ++pp) {
+                            const f32x4 acc = accp[pp][0] + accp[pp][1];
+                            float *op = out + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+                            const f32x4 qv = {acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den};   // :77-80
+                            if (out_vec && tl + 3 < nt) {
+                                *reinterpret_cast<f32x4 *>(op) = qv;
+                            } else {
+#pragma unroll
+                                for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                            }
                         }
                     }
                     stamp(1);                                     // ph1: MFMAs + stores
@@ -867,12 +887,25 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                 // ---- exact path (+-inf in the data): per-segment products with the skipna test ----
                 for (int e = cw; e < ne; e += LC_CW) {
                     const int s0 = sm_es[buf * (LC_ENT + 2) + e], s1 = sm_es[buf * (LC_ENT + 2) + e + 1];
-                    float acc = 0.f;
+                    float accx[NPOW];
+#pragma unroll
+                    for (int pp = 0; pp < NPOW; ++pp) accx[pp] = 0.f;
                     for (int q = s0; q < s1; ++q) {
-                        const float p = im[lane * UROW + (sm_u[buf * LC_SEGS + q] & 0xff)] * sm_w[buf * LC_SEGS + q];
-                        acc += (p == p) ? p : 0.f;
+                        const float y = im[lane * UROW + (sm_u[buf * LC_SEGS + q] & 0xff)], w = sm_w[buf * LC_SEGS + q];
+                        float yp = y;
+#pragma unroll
+                        for (int pp = 0; pp < NPOW; ++pp) {
+                            if (pp > 0) yp *= y;
+                            const float p = yp * w;
+                            accx[pp] += (p == p) ? p : 0.f;
+                        }
                     }
-                    if (lane < nt) out[(int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] = acc / sm_ed[buf * LC_ENT + e];
+                    if (lane < nt) {
+#pragma unroll
+                        for (int pp = 0; pp < NPOW; ++pp)
+                            out[(int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] =
+                                accx[pp] / sm_ed[buf * LC_ENT + e];
+                    }
                 }
             }
         }
@@ -921,8 +954,24 @@ __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_emp
 
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
-                         T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0) {
+                         T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
+                         int nfuse = 1, int64_t pstride = 0) {
+    // nfuse > 1: powers 1..nfuse of (x + xoff) in one pass over X (fused tas_poly); power p goes to
+    // out + (p - 1) * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
+    // (G,T) data, giant groups) runs once per power with the transform applied on load.
     const auto &d = plan->d;
+    if (nfuse > 1) {
+        const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM") &&
+                           !getenv("WAGG_SPARSE_NO_LC") && (int)plan->info.n_groups - d.g0_normal > 0 && Ttot > 0;
+        if (!lc_ok || nfuse > 4) {
+            for (int p = 1; p <= nfuse; ++p) {
+                const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)(p - 1) * pstride, ldo,
+                                                    out_layout, stream, xoff, p);
+                if (rc != WAGG_OK) return rc;
+            }
+            return WAGG_OK;
+        }
+    }
     PlanView<T> pv;
     pv.xoff = xoff; pv.xpow = xpow;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
@@ -947,12 +996,14 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     T *kout = out;
     int64_t kldo = ldo;
     const bool via_ws = out_layout == WAGG_OUT_TR && plan->info.n_groups > 0;
+    int64_t kpstride = pstride;
     if (via_ws) {
         ldws = (Ttot + 63) / 64 * 64;
-        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R), stream));
+        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nfuse, stream));
         ws = static_cast<T *>(wsbuf.p);
         kout = ws;
         kldo = ldws;
+        kpstride = ldws * (int64_t)plan->info.R;
     }
     pv.chunk_desc = d.chunk_desc.p; pv.g0_normal = d.g0_normal; pv.c0_normal = d.c0_normal;
     // aligned fast path: 16-byte aligned rows
@@ -969,13 +1020,18 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
             const long long nw = n_items < ncu ? n_items : ncu;
             auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
+            if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
+            if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
+            if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
+            // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
+            const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)nfuse) : 0.f;
             WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LcLds::total));
             unsigned long long *lc_stamps = nullptr;
             if (getenv("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
             hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
                                plan->info.G, kout, kldo, n_norm, n_items, (int *)nullptr, lc_stamps,
-                               getenv("WAGG_LC_KNOB") ? atoi(getenv("WAGG_LC_KNOB")) : 0);
+                               getenv("WAGG_LC_KNOB") ? atoi(getenv("WAGG_LC_KNOB")) : 0, kpstride, ylim);
             profile_mark(stream, false);
             WAGG_HIP(hipGetLastError());
             if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
@@ -1028,6 +1084,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         }
         pv.n_groups = d.g0_normal;          // what is left for the chunk-walking kernel: giant groups
     }
+    for (int pz = 0; pz < nfuse; ++pz) {      // per power: giant groups, transpose, empty regions
+    if (nfuse > 1) pv.xpow = pz + 1;
     if (pv.n_groups > 0) {
         const int64_t nblk = (int64_t)pv.n_groups * n_tb;
         WAGG_REQUIRE(nblk < (int64_t)0x7fffffff, "grid too large: %lld", (long long)nblk);
@@ -1050,7 +1108,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
             if (!(stream_path && n_norm > 0)) profile_mark(stream, true);                        \
             hipLaunchKernelGGL(kern, grid, block, shmem, stream, pv, X, Ttot, ldx, plan->info.G, \
-                               kout, kldo);                                                      \
+                               kout + (int64_t)pz * kpstride, kldo);                             \
             if (!(stream_path && n_norm > 0)) profile_mark(stream, false);                       \
         } while (0)
         if (layout == WAGG_LAYOUT_TG) { if (vec) WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, true); else WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, false); }
@@ -1060,8 +1118,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     }
     if (via_ws) {
         dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
-        hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws, ldws,
-                           (int64_t)plan->info.R, Ttot, out, ldo);
+        hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws + (int64_t)pz * kpstride, ldws,
+                           (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
         WAGG_HIP(hipGetLastError());
     }
     if (plan->info.n_empty > 0) {
@@ -1069,9 +1127,10 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         const T *den;
         if constexpr (sizeof(T) == 4) den = d.den32.p; else den = d.den64.p;
         hipLaunchKernelGGL((fill_empty_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, d.empty_regions.p, (int)plan->info.n_empty, den, Ttot, out, ldo,
+                           stream, d.empty_regions.p, (int)plan->info.n_empty, den, Ttot, out + (int64_t)pz * pstride, ldo,
                            out_layout);
         WAGG_HIP(hipGetLastError());
+    }
     }
     return WAGG_OK;
 }
@@ -1419,19 +1478,24 @@ namespace wagg {
 // out + (p - 1) * out_pstride.
 template <typename T, int TB>
 static int apply_poly(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, double offset,
-                      int n_pow, T *out, int64_t ldo, int64_t out_pstride, int out_layout, hipStream_t st) {
+                      int pow_first, int n_pow, T *out, int64_t ldo, int64_t out_pstride, int out_layout,
+                      hipStream_t st) {
     int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
     if (rc != WAGG_OK) return rc;
-    WAGG_REQUIRE(n_pow >= 1 && n_pow <= 16, "n_pow must be in [1, 16], got %d", n_pow);
+    WAGG_REQUIRE(pow_first >= 1 && n_pow >= 1 && pow_first + n_pow - 1 <= 16,
+                 "powers must lie in [1, 16], got %d..%d", pow_first, pow_first + n_pow - 1);
     const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : (int64_t)plan->info.R;
     WAGG_REQUIRE(n_pow == 1 || out_pstride >= orows * ldo, "out_pstride %lld overlaps the previous power",
                  (long long)out_pstride);
-    for (int p = 1; p <= n_pow; ++p) {
-        rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out + (int64_t)(p - 1) * out_pstride, ldo, out_layout,
-                                  st, (T)offset, p);
-        if (rc != WAGG_OK) return rc;
+    int done = 0;
+    if (pow_first == 1 && n_pow > 1) {                        // one pass over X for powers 1..4
+        done = n_pow < 4 ? n_pow : 4;
+        rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out, ldo, out_layout, st, (T)offset, 1, done, out_pstride);
     }
-    return WAGG_OK;
+    for (int i = done; i < n_pow && rc == WAGG_OK; ++i)
+        rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out + (int64_t)i * out_pstride, ldo, out_layout, st,
+                                  (T)offset, pow_first + i);
+    return rc;
 }
 
 template <typename T, typename F>
@@ -1464,14 +1528,14 @@ extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, 
 }
 
 extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
-                                   double offset, int n_pow, float *out_dev, int64_t ldo, int64_t out_pstride,
-                                   int out_layout, void *stream) {
-    return wagg::apply_poly<float, 64>(plan, X_dev, T, ldx, layout, offset, n_pow, out_dev, ldo, out_pstride,
+                                   double offset, int pow_first, int n_pow, float *out_dev, int64_t ldo,
+                                   int64_t out_pstride, int out_layout, void *stream) {
+    return wagg::apply_poly<float, 64>(plan, X_dev, T, ldx, layout, offset, pow_first, n_pow, out_dev, ldo, out_pstride,
                                        out_layout, (hipStream_t)stream);
 }
 extern "C" int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
-                                   double offset, int n_pow, double *out_dev, int64_t ldo, int64_t out_pstride,
-                                   int out_layout, void *stream) {
-    return wagg::apply_poly<double, 32>(plan, X_dev, T, ldx, layout, offset, n_pow, out_dev, ldo, out_pstride,
+                                   double offset, int pow_first, int n_pow, double *out_dev, int64_t ldo,
+                                   int64_t out_pstride, int out_layout, void *stream) {
+    return wagg::apply_poly<double, 32>(plan, X_dev, T, ldx, layout, offset, pow_first, n_pow, out_dev, ldo, out_pstride,
                                         out_layout, (hipStream_t)stream);
 }

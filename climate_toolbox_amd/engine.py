@@ -101,9 +101,9 @@ class SparsePlan:
                    "wagg_apply")
         return out
 
-    def apply_poly(self, X, offset, n_pow, layout="TG", out=None, out_layout="TR", stream=None):
-        """out[p-1, t, r] = aggregate of (X + offset)**p for p = 1..n_pow (``wagg_apply_poly_*``: the
-        arithmetic of tas_poly, transformations.py:188, fused into the loads of the aggregation)."""
+    def apply_poly(self, X, offset, n_pow, layout="TG", out=None, out_layout="TR", stream=None, pow_first=1):
+        """out[i, t, r] = aggregate of (X + offset)**(pow_first + i), i < n_pow (``wagg_apply_poly_*``:
+        the arithmetic of tas_poly, transformations.py:188, fused into the loads of the aggregation)."""
         import torch
         X = _check_X(X, layout)
         T = X.shape[0] if layout == "TG" else X.shape[1]
@@ -117,8 +117,8 @@ class SparsePlan:
             raise ValueError("out must be a contiguous %s %s tensor" % (shape, X.dtype))
         L = _lib.load()
         fn = L.wagg_apply_poly_f32 if X.dtype == torch.float32 else L.wagg_apply_poly_f64
-        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout], float(offset), int(n_pow),
-                      C.c_void_p(out.data_ptr()), max(1, shape[2]), shape[1] * shape[2], _OUTS[out_layout],
+        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout], float(offset), int(pow_first),
+                      int(n_pow), C.c_void_p(out.data_ptr()), max(1, shape[2]), shape[1] * shape[2], _OUTS[out_layout],
                       _stream_handle(stream)), "wagg_apply_poly")
         return out
 

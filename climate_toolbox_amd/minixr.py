@@ -24,6 +24,7 @@ class DataArray:
             raise ValueError("dims %r do not match array of shape %r" % (self.dims, self._values.shape))
         self.coords = dict(coords or {})
         self.name = name
+        self.attrs = {}
 
     @property
     def values(self):
@@ -74,6 +75,33 @@ class DataArray:
 
     def __repr__(self):
         return "<minixr.DataArray %s %r %s>" % (self.name or "", dict(zip(self.dims, self.shape)), self.dtype)
+
+
+class LazyArray(DataArray):
+    """A data variable that keeps the buffer it was loaded with and carries, instead of a copy,
+    (a) a re-ordering of its ``lon`` axis (element j along ``lon`` is column ``lon_perm[j]`` of
+    the buffer; standardize.py) and/or (b) an element transform ``(x + offset) ** power``
+    (transformations.py).  The aggregation folds (a) into the plan's cell index and evaluates (b)
+    while the data is loaded on the GPU; ``.values`` materialises the array on demand."""
+
+    def __init__(self, raw, dims, lon_perm=None, xform=None, name=None, attrs=None):
+        super().__init__(raw, dims, name=name)
+        self._lon_perm = None if lon_perm is None else np.asarray(lon_perm, dtype=np.int64)
+        self._xform = None if xform is None else (float(xform[0]), int(xform[1]))
+        self.attrs = dict(attrs or {})
+
+    @property
+    def values(self):
+        raw = np.asarray(self._values)
+        if self._lon_perm is not None and "lon" in self.dims:
+            raw = np.take(raw, self._lon_perm, axis=self.dims.index("lon"))
+        if self._xform is not None:
+            from .engine import require_gpu
+            torch = require_gpu()                       # evaluated on the device, like the fused path
+            off, pw = self._xform
+            t = torch.from_numpy(np.ascontiguousarray(raw)).cuda()
+            raw = ((t + off) ** pw).cpu().numpy()
+        return raw
 
 
 class _Coords(dict):

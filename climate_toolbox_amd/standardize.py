@@ -25,21 +25,10 @@ __all__ = ["standardize_climate_data", "convert_lons_split", "convert_lons_mono"
            "rename_coords_to_lon_and_lat"]
 
 
-class LonSortedArray(minixr.DataArray):
+def LonSortedArray(raw, dims, perm, name=None, xform=None):
     """A data variable whose ``lon`` axis is logically re-ordered: element j along ``lon`` is
-    column ``perm[j]`` of the stored buffer."""
-
-    def __init__(self, raw, dims, perm, name=None):
-        super().__init__(raw, dims, name=name)
-        self._lon_perm = np.asarray(perm, dtype=np.int64)
-        self._lon_axis = self.dims.index("lon") if "lon" in self.dims else None
-
-    @property
-    def values(self):
-        raw = np.asarray(self._values)
-        if self._lon_axis is None:
-            return raw
-        return np.take(raw, self._lon_perm, axis=self._lon_axis)
+    column ``perm[j]`` of the stored buffer (a :class:`minixr.LazyArray`)."""
+    return minixr.LazyArray(raw, dims, lon_perm=perm, xform=xform, name=name)
 
 
 def _is_xarray(ds):
@@ -78,9 +67,9 @@ def rename_coords_to_lon_and_lat(ds):
             keep = [i for i, n in enumerate(raw.shape) if n != 1]
             raw = np.asarray(raw).reshape([raw.shape[i] for i in keep])
             dims = tuple(dims[i] for i in keep)
-        perm = getattr(arr, "_lon_perm", None)
-        if perm is not None and "lon" in dims:
-            return LonSortedArray(raw, dims, perm)
+        perm, xf = getattr(arr, "_lon_perm", None), getattr(arr, "_xform", None)
+        if (perm is not None and "lon" in dims) or xf is not None:
+            return minixr.LazyArray(raw, dims, lon_perm=perm, xform=xf)
         return minixr.DataArray(raw, dims)
 
     out = minixr.Dataset()
@@ -113,7 +102,7 @@ def _relabel_sorted(ds, lon_name, relabel):
             prev = getattr(v, "_lon_perm", None)
             p = perm if prev is None else np.asarray(prev)[perm]
             if lon_name == "lon":
-                arr = LonSortedArray(v._values, v.dims, p, name=k)
+                arr = LonSortedArray(v._values, v.dims, p, name=k, xform=getattr(v, "_xform", None))
             else:                                             # a differently named axis: permute eagerly
                 arr = minixr.DataArray(np.take(v.values, perm, axis=v.dims.index(lon_name)), v.dims, name=k)
         else:

@@ -125,16 +125,19 @@ int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, 
 /* ---- fused grid-level transform ---------------------------------------------- */
 /* Replaces  tas_poly  (climate_toolbox/transformations/transformations.py:160-208, the arithmetic
  * at :188  ``(ds.tas - 273.15) ** power``) followed by the aggregation above, for the powers
- * p = 1..n_pow in ONE call: out_p[t, r] = sum_i (X[t, cell_i] + offset)^p * w_eff[i] / den[r].
+ * p = pow_first .. pow_first + n_pow - 1 in ONE call:
+ *   out_p[t, r] = sum_i (X[t, cell_i] + offset)^p * w_eff[i] / den[r].
  * The transform is evaluated in the data type while X is loaded (NaN stays NaN and is skipped
- * like any NaN product, S6), so the transformed grids are never written to memory.  Power p is
- * stored at out_dev + (p - 1) * out_pstride (elements) with leading dimension ldo.  1 <= n_pow <= 16. */
+ * like any NaN product, S6), so the transformed grids are never written to memory; with
+ * pow_first = 1, fp32 (time, gridcell) data is read from HBM once for up to four powers.  The i-th
+ * power is stored at out_dev + i * out_pstride (elements) with leading dimension ldo.  Powers must
+ * lie in [1, 16]. */
 int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
-                        double offset, int n_pow, float *out_dev, int64_t ldo, int64_t out_pstride,
-                        int out_layout, void *stream);
+                        double offset, int pow_first, int n_pow, float *out_dev, int64_t ldo,
+                        int64_t out_pstride, int out_layout, void *stream);
 int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
-                        double offset, int n_pow, double *out_dev, int64_t ldo, int64_t out_pstride,
-                        int out_layout, void *stream);
+                        double offset, int pow_first, int n_pow, double *out_dev, int64_t ldo,
+                        int64_t out_pstride, int out_layout, void *stream);
 
 /* ---- materialised gather: what _reindex_spatial_data_to_regions returns (:27) -------------- */
 /* out[t, i] = X[t, cell_idx[i]] in out_layout (WAGG_OUT_TR: out[t*ldo+i], RT: out[i*ldo+t]).   */

@@ -506,6 +506,7 @@ def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layo
     Rn, G = len(uniq) + 1, nlat * nlon
     X = (288.15 + 8 * rng.standard_normal((T, G))).astype(dtype)   # ~15 +- 8 degrees C
     X[3, cell[:40]] = np.nan                                      # NaN data: skipped products (S6)
+    X[5, cell[100]], X[6, cell[101]], X[7, cell[102]] = 1e12, np.inf, -np.inf   # overflow at p=4 / exact path
     plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon)
     assert plan.info["n_giant"] >= 1
     Xd = torch.from_numpy(X if layout == "TG" else np.ascontiguousarray(X.T)).cuda()
@@ -517,3 +518,45 @@ def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layo
     # power 1 with offset 0 is the plain aggregation
     np.testing.assert_array_equal(plan.apply_poly(Xd, 0.0, 1, layout=layout)[0].cpu().numpy(),
                                   plan.apply(Xd, layout=layout).cpu().numpy())
+
+
+def test_tas_poly_dropin_then_aggregate_and_batched(torch_cuda):
+    """tas_poly(ds, p, name) -> weighted_aggregate_grid_to_regions(...) (the reference's two calls,
+    transformations.py:160 + aggregations.py:87) and the one-pass tas_poly_aggregate give the
+    oracle's transform-then-aggregate numbers; leap day removed, time relabelled to YYYYDDD."""
+    from climate_toolbox_amd import (minixr, standardize_climate_data, tas_poly, tas_poly_aggregate,
+                                     weighted_aggregate_grid_to_regions)
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(21)
+    time = np.arange("2000-01-01", "2001-01-01", dtype="datetime64[D]")           # 366 days
+    lat, lon = np.arange(-44.5, 45, 1.0), np.arange(0.5, 360, 1.0)                # raw 0..360 file
+    tas = (288.15 + 8 * rng.standard_normal((len(time), len(lat), len(lon)))).astype(np.float32)
+    tas[10, 5, 7] = np.nan
+    ds = minixr.Dataset({"tas": (("time", "latitude", "longitude"), tas)},
+                        coords={"time": time, "latitude": lat, "longitude": lon})
+    ds = standardize_climate_data(ds)                                               # lazy lon wrap (8f-2)
+    ref_grid, ref_lon = O.convert_lons_split(np.delete(tas, 59, axis=0), ("time", "lat", "lon"), lon)
+    n = 4000
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(ref_lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "popwt": rng.uniform(0, 3, n), "hierid": rng.integers(0, 120, n)})
+    refs = {}
+    for p in (1, 2, 3, 4, 5):
+        refs[p], rdims, labs = O.agg_scatter(O.tas_poly_values(ref_grid, p), ("time", "lat", "lon"), lat, ref_lon,
+                                             df["lat"].values, df["lon"].values, df["popwt"].values,
+                                             df["areawt"].values, df["hierid"].values, group_dim="hierid")
+    # the reference's two-call form, one power at a time
+    for p in (1, 3):
+        out = weighted_aggregate_grid_to_regions(tas_poly(ds, p, "tas-poly-%d" % p), "tas-poly-%d" % p,
+                                                 "popwt", "hierid", df)
+        v = out["tas-poly-%d" % p]
+        assert v.dims == ("time", "hierid") and v.shape == (365, len(labs))
+        np.testing.assert_array_equal(out.time.values, 2000000 + np.arange(1, 366))
+        _rel_ok(v.values, refs[p], RTOL32, scale=1.0)
+    # all five powers, one pass for 1..4 + one for 5
+    out = tas_poly_aggregate(ds, [1, 2, 3, 4, 5], "popwt", "hierid", df)
+    assert list(out.data_vars) == ["tas-poly-%d" % p for p in (1, 2, 3, 4, 5)]
+    for p in (1, 2, 3, 4, 5):
+        _rel_ok(out["tas-poly-%d" % p].values, refs[p], RTOL32, scale=1.0)
+    # lazy .values of the transformed grid itself (device-evaluated) equals the oracle's grid
+    np.testing.assert_allclose(tas_poly(ds, 2, "p2").p2.values, O.tas_poly_values(ref_grid, 2), rtol=1e-6,
+                               equal_nan=True)

@@ -197,7 +197,8 @@ def _raw_0_360_dataset(T=3, step=2.0, seed=0, names=("latitude", "longitude")):
 
 
 def test_standardize_is_lazy_and_matches_reference_semantics():
-    from climate_toolbox_amd.standardize import standardize_climate_data, LonSortedArray
+    from climate_toolbox_amd.standardize import standardize_climate_data
+    from climate_toolbox_amd.minixr import LazyArray
     from oracle import ref_numpy as O
     ds, tas, lat, lon = _raw_0_360_dataset()
     out = standardize_climate_data(ds)
@@ -205,7 +206,7 @@ def test_standardize_is_lazy_and_matches_reference_semantics():
     assert set(out.coords) == {"time", "lat", "lon"} and out.tas.dims == ("time", "lat", "lon")
     np.testing.assert_array_equal(out.lon.values, ref_lon)
     assert (np.diff(out.lon.values) > 0).all() and out.lon.values.min() == -180.0
-    assert isinstance(out.tas, LonSortedArray) and out.tas._values is ds.tas._values   # no copy
+    assert isinstance(out.tas, LazyArray) and out.tas._values is ds.tas._values   # no copy
     np.testing.assert_array_equal(out.tas.values, ref_vals)                             # on demand
 
 
@@ -244,3 +245,46 @@ def test_standardize_drops_z_and_rejects_duplicate_longitudes():
     bad = minixr.Dataset({"tas": (("lat", "lon"), v[0][:, :2])}, coords={"lat": lat, "lon": np.array([0.0, 360.0])})
     with pytest.raises(ValueError):
         standardize_climate_data(bad)
+
+
+# ---------------------------------------------------------------------------------------------
+# tas_poly as a lazy variable (host-side contract; the arithmetic is GPU-only)
+# ---------------------------------------------------------------------------------------------
+def _tas_ds(year=2001, T=365, nlat=6, nlon=8, dtype=np.float32, seed=0):
+    from climate_toolbox_amd import minixr
+    rng = np.random.default_rng(seed)
+    time = np.arange("%d-01-01" % year, "%d-01-01" % (year + 1), dtype="datetime64[D]")[:T]
+    lat, lon = np.linspace(-50, 50, nlat), np.linspace(-100, 100, nlon)
+    tas = (288.15 + 8 * rng.standard_normal((len(time), nlat, nlon))).astype(dtype)
+    return minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": time, "lat": lat, "lon": lon}), tas
+
+
+def test_tas_poly_is_lazy_and_relabels_time_like_the_reference():
+    from climate_toolbox_amd import tas_poly
+    from climate_toolbox_amd.transformations import ordinal
+    from climate_toolbox_amd.minixr import LazyArray
+    ds, tas = _tas_ds()
+    out = tas_poly(ds, 3, "tas-poly-3")
+    v = out["tas-poly-3"]
+    assert isinstance(v, LazyArray) and v._values is ds.tas._values and v._xform == (-273.15, 3)
+    assert v.dims == ("time", "lat", "lon") and list(out.data_vars) == ["tas-poly-3"]
+    np.testing.assert_array_equal(out.time.values, 2001000 + np.arange(1, 366))     # transformations.py:195
+    assert v.attrs["units"] == "C^3" and "3rd power" in v.attrs["description"]
+    assert tas_poly(ds, 1, "t").t.attrs["units"] == "C"
+    got = [ordinal(n) for n in (1, 2, 3, 4, 11, 12, 13, 21, 22, 101)]
+    assert got == ["1st", "2nd", "3rd", "4th", "11th", "12th", "13th", "21st", "22nd", "101st"]
+
+
+def test_tas_poly_removes_leap_day_and_rejects_long_years():
+    from climate_toolbox_amd import tas_poly
+    ds, tas = _tas_ds(year=2000, T=366)                                             # leap year
+    out = tas_poly(ds, 2, "p2")
+    assert out.p2.shape[0] == 365
+    np.testing.assert_array_equal(out.p2._values, np.delete(tas, 59, axis=0))       # 29 Feb = day 60
+    np.testing.assert_array_equal(out.time.values, 2000000 + np.arange(1, 366))
+    from climate_toolbox_amd import minixr
+    time = np.arange("2001-01-01", "2002-02-01", dtype="datetime64[D]")
+    long_ds = minixr.Dataset({"tas": (("time", "lat", "lon"), np.zeros((len(time), 1, 1), np.float32))},
+                             coords={"time": time, "lat": np.zeros(1), "lon": np.zeros(1)})
+    with pytest.raises(ValueError):
+        tas_poly(long_ds, 2, "p2")
