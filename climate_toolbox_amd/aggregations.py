@@ -123,12 +123,23 @@ def _factorize_labels(labels):
                                         uniq.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)), "wagg_factorize_i64")
         return uniq[:nu.value].astype(labels.dtype), codes
     if kind in "OUS" and n:
-        null = pd.isna(labels) if kind == "O" else np.zeros(n, dtype=bool)
-        vals = labels[~null]
-        if kind != "O" or all(isinstance(v, str) for v in vals.tolist()):
+        null = None
+        is_str = kind != "O"
+        if kind == "O":
+            what = pd.api.types.infer_dtype(labels, skipna=False)           # C loop, no Python objects made
+            if what != "string" and pd.api.types.infer_dtype(labels, skipna=True) == "string":
+                null, what = pd.isna(labels), "string"
+            is_str = what == "string"
+        if is_str:
             _lib, L = _native()
-            filled = np.where(null, "", labels) if kind == "O" else labels
-            enc = np.char.encode(filled.astype(str), "utf-8") if kind != "S" else np.ascontiguousarray(filled)
+            filled = labels if null is None else np.where(null, "", labels)
+            if kind == "S":
+                enc = filled
+            else:
+                try:
+                    enc = filled.astype("S")                                 # ASCII labels: one C pass
+                except UnicodeEncodeError:
+                    enc = np.char.encode(filled.astype(str), "utf-8")        # UTF-8 keeps code point order
             enc = np.ascontiguousarray(enc)
             width = enc.dtype.itemsize
             if width == 0:
@@ -136,9 +147,9 @@ def _factorize_labels(labels):
             codes = np.empty(n, dtype=np.int32)
             rows = np.empty(n, dtype=np.int64)
             nu = C.c_int64(0)
-            nm = np.ascontiguousarray(null, dtype=np.uint8)
+            nm = None if null is None else np.ascontiguousarray(null, dtype=np.uint8)
             _lib.check(L.wagg_factorize_bytes(enc.ctypes.data_as(C.c_char_p), width,
-                                              nm.ctypes.data_as(C.POINTER(C.c_uint8)), n,
+                                              None if nm is None else nm.ctypes.data_as(C.POINTER(C.c_uint8)), n,
                                               codes.ctypes.data_as(C.POINTER(C.c_int32)),
                                               rows.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)),
                        "wagg_factorize_bytes")

@@ -114,19 +114,40 @@ extern "C" int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_
     WAGG_REQUIRE(n == 0 || (buf && codes && uniq_rows), "NULL argument");
     WAGG_REQUIRE(width > 0 && n_uniq != nullptr, "bad width / NULL argument");
     try {
-        std::vector<int64_t> rows;
-        rows.reserve((size_t)n);
-        for (int64_t i = 0; i < n; ++i) if (!isnull || !isnull[i]) rows.push_back(i);
-        auto less = [&](int64_t a, int64_t b) { return std::memcmp(buf + a * width, buf + b * width, (size_t)width) < 0; };
-        auto same = [&](int64_t a, int64_t b) { return std::memcmp(buf + a * width, buf + b * width, (size_t)width) == 0; };
-        std::sort(rows.begin(), rows.end(), less);
-        int64_t nu = 0;
-        for (size_t i = 0; i < rows.size(); ++i) {
-            if (i == 0 || !same(rows[i - 1], rows[i])) uniq_rows[nu++] = rows[i];
-            codes[rows[i]] = (int32_t)(nu - 1);
+        // pass 1: distinct labels through an open-addressing table (FNV-1a over the fixed width);
+        // first[j] = first row that carries distinct label j, tmp code = j
+        size_t cap = 64;
+        while (cap < (size_t)n * 2) cap <<= 1;
+        std::vector<int32_t> slot(cap, -1);
+        std::vector<int64_t> first;
+        const size_t w = (size_t)width;
+        for (int64_t i = 0; i < n; ++i) {
+            if (isnull && isnull[i]) { codes[i] = -1; continue; }
+            const unsigned char *p = reinterpret_cast<const unsigned char *>(buf) + (size_t)i * w;
+            uint64_t h = 1469598103934665603ull;
+            for (size_t k = 0; k < w; ++k) { h ^= p[k]; h *= 1099511628211ull; }
+            size_t at = (size_t)(h ^ (h >> 29)) & (cap - 1);
+            for (;;) {
+                const int32_t j = slot[at];
+                if (j < 0) {
+                    WAGG_REQUIRE(first.size() < (size_t)0x7fffffff, "too many distinct labels");
+                    slot[at] = (int32_t)first.size();
+                    codes[i] = (int32_t)first.size();
+                    first.push_back(i);
+                    break;
+                }
+                if (std::memcmp(buf + (size_t)first[(size_t)j] * w, p, w) == 0) { codes[i] = j; break; }
+                at = (at + 1) & (cap - 1);
+            }
         }
-        if (isnull) for (int64_t i = 0; i < n; ++i) if (isnull[i]) codes[i] = -1;
-        *n_uniq = nu;
+        // pass 2: sort the distinct labels bytewise, renumber
+        std::vector<int32_t> order(first.size()), rank(first.size());
+        for (size_t j = 0; j < order.size(); ++j) order[j] = (int32_t)j;
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return std::memcmp(buf + (size_t)first[(size_t)a] * w, buf + (size_t)first[(size_t)b] * w, w) < 0; });
+        for (size_t r = 0; r < order.size(); ++r) { rank[(size_t)order[r]] = (int32_t)r; uniq_rows[r] = first[(size_t)order[r]]; }
+        for (int64_t i = 0; i < n; ++i) if (codes[i] >= 0) codes[i] = rank[(size_t)codes[i]];
+        *n_uniq = (int64_t)first.size();
     } catch (const std::bad_alloc &) {
         set_error("host allocation failed");
         return WAGG_ENOMEM;

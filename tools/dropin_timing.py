@@ -14,7 +14,13 @@ for i in range(3):
     t0 = time.perf_counter()
     out = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
     print("call %d: %.1f ms  -> %s" % (i, (time.perf_counter() - t0) * 1e3, out.tas.shape))
-# breakdown of the host-side steps of a cached call
-t0 = time.perf_counter(); il = A._exact_index(lat, df["lat"].values, "lat"); io = A._exact_index(lon, df["lon"].values, "lon"); t1 = time.perf_counter()
+# breakdown of the host-side steps of a cached call (native label work)
+import hashlib
+t0 = time.perf_counter(); cell = A._resolve_cells(lat, lon, df["lat"].values, df["lon"].values); t1 = time.perf_counter()
 u, c = A._factorize_labels(df["hierid"].values); t2 = time.perf_counter()
-print("label lookup %.1f ms, factorize %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+w = A._backup_fill(df["areawt"].values, df["areawt"].values); t3 = time.perf_counter()
+h = hashlib.blake2b(digest_size=16)
+for a in (cell, c, w): h.update(np.ascontiguousarray(a).tobytes())
+t4 = time.perf_counter()
+print("cell join %.1f ms, factorize (string labels) %.1f ms, backup fill %.1f ms, cache key %.1f ms"
+      % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
