@@ -68,10 +68,17 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
 // of the k-loop, bit2 = skip the per-tile barrier, bit3 = one DMA piece per row-block PAIR (instead
 // of one per block in the first 10 blocks).  Results are wrong with any bit set.
-template <int DBG = 0>
+//
+// TILED (tile-sparse W, e.g. c5 "block-local" weights): only the non-empty (32-cell x 256-region)
+// tiles of W are stored, compacted per column tile; tile_kt[i] is the k-tile (= X tile) of stored
+// tile i and tile_off[nt][ks] .. tile_off[nt][ks+1] the run of stored tiles that block (nt, ks)
+// contracts.  The k index of tile t+2 is fetched by a plain vector load at the start of tile t
+// (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
+template <int DBG = 0, bool TILED = false>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const float *__restrict__ Xp, const float *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
-    int kt_per_slice, float *__restrict__ slabs) {
+    int kt_per_slice, float *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
+    const int32_t *__restrict__ tile_off = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][D_BUF_BYTES]
 
     const int tid = threadIdx.x;
@@ -80,19 +87,31 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const int lr = lane & 15, kq = lane >> 4;
 
     // work item: blocks with equal (blockIdx % 8) share a k-slice (XCD L2 affinity, speed only)
-    int j = blockIdx.x >> 3;
+    int j = TILED ? (int)(blockIdx.x / (unsigned)S) : (int)(blockIdx.x >> 3);
     const int nt = j % n_nt; j /= n_nt;
     const int mb = j % n_mb;
-    const int ks = (blockIdx.x & 7) + 8 * (j / n_mb);
-    const int kt0 = ks * kt_per_slice;
+    const int ks = TILED ? (int)(blockIdx.x % (unsigned)S) : (int)(blockIdx.x & 7) + 8 * (j / n_mb);
+    int kt0 = ks * kt_per_slice;
     const int kt1 = kt0 + kt_per_slice < n_kt ? kt0 + kt_per_slice : n_kt;
-    const int ntiles = kt1 > kt0 ? kt1 - kt0 : 0;
+    int ntiles = kt1 > kt0 ? kt1 - kt0 : 0;
+    int64_t w_first = (int64_t)nt * n_kt + kt0;            // first W tile of this block
+    int kt_next = 0;                                         // TILED: X tile of the tile after the current one
+    int x_first = 0;
+    if (TILED) {
+        const int t_begin = tile_off[nt * (S + 1) + ks];
+        ntiles = tile_off[nt * (S + 1) + ks + 1] - t_begin;
+        w_first = t_begin;
+        kt0 = 0;
+        tile_kt += t_begin;                                  // (padded by two entries at the end)
+        x_first = tile_kt[0];
+        kt_next = tile_kt[ntiles > 1 ? 1 : 0];
+    }
 
     // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
     // moves X pieces wave + 8 i (i < 6; the two pieces that do not exist are clamped onto piece
     // 45 -- an identical rewrite) and W pieces wave + 8 i (i < 4)
     const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * (D_XT * 4) + lane * 16;
-    const char *wsrc = reinterpret_cast<const char *>(Wp) + ((int64_t)nt * n_kt + kt0) * (D_WT * 4) + lane * 16;
+    const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * (D_WT * 4) + lane * 16;
     const int xq5 = wave + 40 < D_XPIECES ? wave + 40 : D_XPIECES - 1;
 #define WAGG_DMA_X(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * (D_XT * 4) + (q) * 1024),   \
@@ -100,17 +119,17 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 #define WAGG_DMA_W(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * (D_WT * 4) + (q) * 1024),   \
                                      (lptr_t)(lds + (buf) * D_BUF_BYTES + D_XT * 4 + (q) * 1024), 16, 0, 0)
-#define WAGG_DMA_PIECE_XW(i, tile, buf)                                                           \
+#define WAGG_DMA_PIECE_XW(i, xt, wt, buf)                                                         \
     do {                                                                                          \
-        if ((i) < 5) WAGG_DMA_X(wave + 8 * (i), tile, buf);                                       \
-        else if ((i) == 5) WAGG_DMA_X(xq5, tile, buf);                                            \
-        else WAGG_DMA_W(wave + 8 * ((i) - 6), tile, buf);                                         \
+        if ((i) < 5) WAGG_DMA_X(wave + 8 * (i), xt, buf);                                         \
+        else if ((i) == 5) WAGG_DMA_X(xq5, xt, buf);                                              \
+        else WAGG_DMA_W(wave + 8 * ((i) - 6), wt, buf);                                           \
     } while (0)
     // W pieces (HBM, longest latency) first, then the X pieces (served by the XCD's L2)
-#define WAGG_DMA_PIECE(i, tile, buf)                                                              \
+#define WAGG_DMA_PIECE(i, xt, wt, buf)                                                            \
     do {                                                                                          \
-        if (DBG & 16) WAGG_DMA_PIECE_XW(i, tile, buf);                                            \
-        else WAGG_DMA_PIECE_XW(((i) + 6) % 10, tile, buf);                                        \
+        if (DBG & 16) WAGG_DMA_PIECE_XW(i, xt, wt, buf);                                          \
+        else WAGG_DMA_PIECE_XW(((i) + 6) % 10, xt, wt, buf);                                      \
     } while (0)
 
     f32x4 acc[D_MT][2];
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 
     if (ntiles > 0) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) WAGG_DMA_PIECE(i, 0, 0);
+        for (int i = 0; i < 10; ++i) WAGG_DMA_PIECE(i, x_first, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -163,8 +182,8 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         if ((DMA) >= 0 && (DMA) < 10 && !(DBG & 1)) {                                             \
-            if (DBG & 32) { if ((DMA) < 5) { WAGG_DMA_PIECE(2 * (DMA), tnext, nbuf); WAGG_DMA_PIECE(2 * (DMA) + 1, tnext, nbuf); } } \
-            else WAGG_DMA_PIECE(DMA, tnext, nbuf);                                                \
+            if (DBG & 32) { if ((DMA) < 5) { WAGG_DMA_PIECE(2 * (DMA), xnext, tnext, nbuf); WAGG_DMA_PIECE(2 * (DMA) + 1, xnext, tnext, nbuf); } } \
+            else WAGG_DMA_PIECE(DMA, xnext, tnext, nbuf);                                         \
         }                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA8(RB, A1, b01, b11);                                                             \
@@ -179,6 +198,13 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         const char *img = lds + (tile & 1) * D_BUF_BYTES;
         const int nbuf = (tile & 1) ^ 1;
         const int tnext = tile + 1 < ntiles ? tile + 1 : tile;     // last tile: harmless re-load
+        const int xnext = TILED ? kt_next : tnext;
+        int ktn_v = 0;
+        if (TILED) {                                               // k index of tile + 2 (clamped)
+            const int32_t *pa = tile_kt + (tile + 2 < ntiles ? tile + 2 : ntiles - 1);
+            const int zero = 0;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(ktn_v) : "v"(zero), "s"(pa) : "memory");
+        }
         f32x4 b00, b01, b10, b11, aA0, aA1, aB0, aB1;
         b00 = *reinterpret_cast<const f32x4 *>(img + boff + frag0);
         b01 = *reinterpret_cast<const f32x4 *>(img + boff + frag1);
@@ -190,7 +216,8 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         WAGG_BLOCK(22, aA0, aA1, aB0, aB1, 23, -1);
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMA pieces of tile+1 have landed; every wave is done reading this buffer
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (TILED) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(kt_next) : "v"(ktn_v) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     }
 
@@ -303,6 +330,47 @@ __global__ void dense_scatter_kernel(float *__restrict__ Wp, int n_kt, const int
     if (i < n) Wp[wp_index(cell[i], region[i], n_kt)] = w[i];
 }
 
+__global__ void dense_scatter_at_kernel(float *__restrict__ Wp, const int64_t *__restrict__ at,
+                                        const float *__restrict__ w, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) Wp[at[i]] = w[i];
+}
+
+// synthetic "block-local" weights: every run of 64 cells touches the 256 regions of
+// ONE column tile, nt = (97 run) mod n_nt; inside, W[g][r] = hash_u01(g R + r, seed) where a second
+// hash is below `fill`, else 0.  Stored tile i holds k tile kt_of[i] of column tile nt_of[i].
+__global__ void dense_synth_blocklocal_kernel(f32x4 *__restrict__ Wp, const int32_t *__restrict__ tile_kt,
+                                              const int32_t *__restrict__ tile_nt, int64_t n_tiles, int64_t G,
+                                              int32_t R, uint32_t seed, float fill) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n_slots = n_tiles * (D_WT / 4);
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
+        const int slot = (int)(s % (D_WT / 4));
+        const int64_t ti = s / (D_WT / 4);
+        const int64_t kt = tile_kt[ti], nt = tile_nt[ti];
+        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
+        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t id = (uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r;
+            v[c] = (r < R && g0 + c < G && hash_u01(id, seed ^ 0x9e3779b9u) < fill) ? hash_u01(id, seed) : 0.f;
+        }
+        Wp[s] = v;
+    }
+}
+
+// column sums of the tile-sparse form: one block per stored tile
+__global__ void dense_colsum_tiled_kernel(const f32x4 *__restrict__ Wp, const int32_t *__restrict__ tile_nt,
+                                          int32_t R, double *__restrict__ den) {
+    const int64_t ti = blockIdx.x;
+    for (int slot = threadIdx.x; slot < D_WT / 4; slot += blockDim.x) {
+        const f32x4 v = Wp[ti * (D_WT / 4) + slot];
+        const double s = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+        const int64_t r = (int64_t)tile_nt[ti] * D_BN + (slot >> 3);
+        if (r < R && s != 0.0) atomicAdd(&den[r], s);
+    }
+}
+
 // plain row-major W (G x R) -> packed order (small matrices handed over by the host)
 __global__ void dense_pack_w_kernel(const float *__restrict__ W, int64_t G, int32_t R, int n_kt,
                                     int64_t n_slots, f32x4 *__restrict__ Wp) {
@@ -329,12 +397,24 @@ struct wagg_dense {
     wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order
     wagg::DevBuf<double> den64;
     std::vector<double> den_host;
-    int64_t w_slots() const { return (int64_t)n_nt * n_kt * (wagg::D_WT / 4); }
+    // tile-sparse form: only the non-empty (32-cell x 256-region) tiles of W are stored, grouped by
+    // column tile; tile_kt[i] = k tile of stored tile i (+2 padding entries), tile_off[nt][0..TS] =
+    // the column tile's run split into TS slices of equal length
+    bool tiled = false;
+    int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
+    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: one table per slice count 1, 2, 4, 8
+    static constexpr int TS = 8;
+    static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
+        int64_t at = 0;
+        for (int t = 1; t < ts; t *= 2) at += (int64_t)n_nt * (t + 1);
+        return at;
+    }
+    int64_t w_slots() const { return n_tiles * (wagg::D_WT / 4); }
 };
 
 namespace wagg {
 
-static int dense_alloc(int64_t G, int32_t R, wagg_dense **out) {
+static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_tiles = -1) {
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
@@ -344,7 +424,9 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out) {
     d->G = G; d->R = R;
     d->n_kt = (int)((G + D_BK - 1) / D_BK);
     d->n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
-    hipError_t e = d->W.alloc((size_t)d->w_slots() * 4);
+    d->n_tiles = stored_tiles >= 0 ? stored_tiles : (int64_t)d->n_nt * d->n_kt;
+    d->tiled = stored_tiles >= 0;
+    hipError_t e = d->W.alloc((size_t)(d->w_slots() > 0 ? d->w_slots() : 1) * 4);
     if (e == hipSuccess) e = d->den32.alloc((size_t)R);
     if (e == hipSuccess) e = d->den64.alloc((size_t)R);
     if (e != hipSuccess) {
@@ -368,6 +450,31 @@ static int dense_finish_den(wagg_dense *d) {
     d->den_host.resize((size_t)d->R);
     WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
     return WAGG_OK;
+}
+
+// stored-tile lists of the tile-sparse form from the sorted keys nt * n_kt + kt
+static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &tiles, std::vector<int32_t> *nt_out = nullptr) {
+    constexpr int TS = wagg_dense::TS;
+    std::vector<int32_t> kt(tiles.size() + 2, 0), ntv(tiles.size() + 1, 0);
+    std::vector<int32_t> off((size_t)wagg_dense::off_table(2 * TS, d->n_nt), 0);
+    std::vector<int64_t> first((size_t)d->n_nt + 1, 0);
+    for (size_t i = 0; i < tiles.size(); ++i) {
+        kt[i] = (int32_t)(tiles[i] % d->n_kt);
+        ntv[i] = (int32_t)(tiles[i] / d->n_kt);
+        first[(size_t)ntv[i] + 1]++;
+    }
+    for (int nt = 0; nt < d->n_nt; ++nt) first[(size_t)nt + 1] += first[(size_t)nt];
+    for (int ts = 1; ts <= TS; ts *= 2) {
+        int32_t *tab = off.data() + wagg_dense::off_table(ts, d->n_nt);
+        for (int nt = 0; nt < d->n_nt; ++nt) {
+            const int64_t b = first[(size_t)nt], len = first[(size_t)nt + 1] - b;
+            for (int k = 0; k <= ts; ++k) tab[(size_t)nt * (ts + 1) + k] = (int32_t)(b + len * k / ts);
+        }
+    }
+    hipError_t e = d->tile_kt.upload(kt);
+    if (e == hipSuccess) e = d->tile_off.upload(off);
+    if (nt_out) *nt_out = ntv;
+    return e;
 }
 
 static int pick_ksplit(int64_t items, int n_kt) {
@@ -396,6 +503,55 @@ extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg
     if (e == hipSuccess) rc = dense_finish_den(d); else { set_error("synth launch: %s", hipGetErrorString(e)); rc = WAGG_EHIP; }
     if (rc != WAGG_OK) { delete d; *out = nullptr; }
     return rc;
+}
+
+extern "C" int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill,
+                                                  wagg_dense **out) {
+    using namespace wagg;
+    WAGG_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    WAGG_REQUIRE(G > 0 && R > 0 && fill > 0.0 && fill <= 1.0, "bad arguments");
+    const int n_kt = (int)((G + D_BK - 1) / D_BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    // run j (64 cells = k tiles 2j, 2j+1) touches column tile (97 j) mod n_nt
+    std::vector<int64_t> tiles;
+    tiles.reserve((size_t)n_kt);
+    for (int kt = 0; kt < n_kt; ++kt) tiles.push_back((int64_t)(((int64_t)97 * (kt / 2)) % n_nt) * n_kt + kt);
+    std::sort(tiles.begin(), tiles.end());
+    int rc = dense_alloc(G, R, out, (int64_t)tiles.size());
+    if (rc != WAGG_OK) return rc;
+    wagg_dense *d = *out;
+    std::vector<int32_t> ntv;
+    DevBuf<int32_t> dnt;
+    hipError_t e = dense_set_tiles(d, tiles, &ntv);
+    if (e == hipSuccess) e = dnt.upload(ntv);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dense_synth_blocklocal_kernel, dim3(256 * 16), dim3(256), 0, nullptr,
+                           reinterpret_cast<f32x4 *>(d->W.p), d->tile_kt.p, dnt.p, d->n_tiles, G, R, seed, (float)fill);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemset(d->den64.p, 0, sizeof(double) * (size_t)R);
+    if (e == hipSuccess && d->n_tiles > 0) {
+        hipLaunchKernelGGL(dense_colsum_tiled_kernel, dim3((unsigned)d->n_tiles), dim3(512), 0, nullptr,
+                           reinterpret_cast<const f32x4 *>(d->W.p), dnt.p, R, d->den64.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nullptr, d->den64.p,
+                           d->den32.p, R);
+        e = hipGetLastError();
+    }
+    d->den_host.resize((size_t)R);
+    if (e == hipSuccess) e = hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)R, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("block-local synth: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
+    return WAGG_OK;
+}
+
+extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
+    WAGG_REQUIRE(d && info, "NULL argument");
+    info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
+    info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
+    info->w_bytes = d->w_slots() * 16;
+    return WAGG_OK;
 }
 
 extern "C" int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out) {
@@ -444,18 +600,42 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
         hc.push_back(segs[i].cell); hr.push_back(segs[i].region); hw.push_back((float)s);
         i = j;
     }
-    int rc = dense_alloc(G, R, out);
+    // which (32-cell x 256-region) tiles of W hold anything?  Few -> tile-sparse form
+    const int n_kt = (int)((G + D_BK - 1) / D_BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    std::vector<int64_t> keys(hc.size());
+    for (size_t i = 0; i < hc.size(); ++i) keys[i] = (int64_t)(hr[i] / D_BN) * n_kt + hc[i] / D_BK;
+    std::vector<int64_t> tiles(keys);
+    std::sort(tiles.begin(), tiles.end());
+    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+    const bool tiled = (double)tiles.size() < 0.5 * (double)n_kt * (double)n_nt && !getenv("WAGG_DENSE_NO_TILED");
+    int rc = dense_alloc(G, R, out, tiled ? (int64_t)tiles.size() : -1);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    DevBuf<int32_t> dc, dr; DevBuf<float> dw;
+    DevBuf<int32_t> dc, dr; DevBuf<float> dw; DevBuf<int64_t> dat;
     hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * 4 * (size_t)d->w_slots());
-    if (e == hipSuccess) e = dc.upload(hc);
-    if (e == hipSuccess) e = dr.upload(hr);
     if (e == hipSuccess) e = dw.upload(hw);
-    if (e == hipSuccess && !hc.empty()) {
-        hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                           d->W.p, d->n_kt, dc.p, dr.p, dw.p, (int64_t)hc.size());
-        e = hipGetLastError();
+    if (tiled) {
+        std::vector<int64_t> at(hc.size());
+        for (size_t i = 0; i < hc.size(); ++i) {
+            const int64_t ti = std::lower_bound(tiles.begin(), tiles.end(), keys[i]) - tiles.begin();
+            const int cl = hr[i] % D_BN, kk = hc[i] % D_BK;
+            at[i] = (ti * (D_WT / 4) + tile_slot(cl, kk >> 2)) * 4 + (kk & 3);
+        }
+        if (e == hipSuccess) e = dat.upload(at);
+        if (e == hipSuccess) e = dense_set_tiles(d, tiles);
+        if (e == hipSuccess && !hc.empty()) {
+            hipLaunchKernelGGL(dense_scatter_at_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
+                               d->W.p, dat.p, dw.p, (int64_t)hc.size());
+            e = hipGetLastError();
+        }
+    } else {
+        if (e == hipSuccess) e = dc.upload(hc);
+        if (e == hipSuccess) e = dr.upload(hr);
+        if (e == hipSuccess && !hc.empty()) {
+            hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
+                               d->W.p, d->n_kt, dc.p, dr.p, dw.p, (int64_t)hc.size());
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { set_error("densify: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
@@ -491,7 +671,11 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
     const int n_nt = d->n_nt, n_kt = d->n_kt;
     const int n_mb = (int)((T + D_BM - 1) / D_BM);
-    const int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
+    int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
+    if (d->tiled) {               // fewest slices (1, 2, 4, 8) that still give >= 4 workgroups per CU
+        S = 1;
+        while (S < wagg_dense::TS && (int64_t)n_nt * n_mb * S < 1024) S *= 2;
+    }
     const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
     WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && T <= 65535, "grid too large");
@@ -502,8 +686,8 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     const int aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
     const size_t shmem = 2 * (size_t)D_BUF_BYTES;
     hipStream_t st = (hipStream_t)stream;
-    auto kern = dense_mfma_kernel<0>;
-    if (const char *dbg = getenv("WAGG_DENSE_DBG")) {
+    auto kern = d->tiled ? dense_mfma_kernel<0, true> : dense_mfma_kernel<0, false>;
+    if (const char *dbg = d->tiled ? nullptr : getenv("WAGG_DENSE_DBG")) {
         switch (atoi(dbg)) {
             case 1: kern = dense_mfma_kernel<1>; break;
             case 4: kern = dense_mfma_kernel<4>; break;
@@ -520,7 +704,8 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     WAGG_HIP(hipGetLastError());
     profile_mark(st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, d->xp.p, d->W.p, n_kt, n_nt, n_mb,
-                       S, kt_per_slice, d->slabs.p);
+                       S, kt_per_slice, d->slabs.p, d->tile_kt.p,
+                       d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr);
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,

@@ -145,6 +145,18 @@ class DensePlan:
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
         self.den = den
+        inf = _lib.DenseInfo()
+        _lib.check(_lib.load().wagg_dense_get_info(self._h, C.byref(inf)), "wagg_dense_get_info")
+        self.info = {k: int(getattr(inf, k)) for k, _ in _lib.DenseInfo._fields_}
+
+    @classmethod
+    def synth_blocklocal(cls, G, R, seed, fill=0.952):
+        """c5's block-local weights, generated on the device in tile-sparse form."""
+        require_gpu()
+        h = C.c_void_p()
+        _lib.check(_lib.load().wagg_dense_create_synth_blocklocal(int(G), int(R), int(seed), float(fill), C.byref(h)),
+                   "wagg_dense_create_synth_blocklocal")
+        return cls(h, G, R)
 
     @classmethod
     def synth(cls, G, R, seed):

@@ -154,10 +154,22 @@ int wagg_gather_f64(const double *X_dev, int64_t T, int64_t ldx, int layout,
 int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out);
 /* from a host row-major (G, R) fp32 matrix (small cases / tests) */
 int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
-/* from a sparse plan's coded table, densified on device (weights that are not very sparse)    */
+/* from a sparse plan's coded table, densified on device (weights that are not very sparse).
+ * W is kept as (32-cell x 256-region) tiles; when fewer than half of them hold a non-zero only
+ * those are stored and contracted ("tile-sparse": c5's block-local weights), else all of them.  */
 int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                     const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                     wagg_dense **out);
+/* synthetic block-local weights (SURVEY 8d, c5 "each 64-cell run touches <= 256 regions"): run j of
+ * 64 cells touches the 256 regions of column tile (97 j) mod ceil(R/256); inside, W[g,r] =
+ * hash_u01(g*R + r, seed) where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill, else 0.  Generated on
+ * the device in tile-sparse form (benchmark operand; the oracle regenerates it from the hashes).  */
+int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
+typedef struct wagg_dense_info {
+    int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles and their bytes in HBM */
+    int32_t R, n_kt, n_nt, tiled;  /* k tiles, column tiles, 1 = tile-sparse form */
+} wagg_dense_info;
+int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);
 int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
 /* out[t, r] = sum_g nan0(X[t,g]) * W[g,r] / den[r], fp32 MFMA (v_mfma_f32_16x16x4_f32).

@@ -306,3 +306,17 @@ def tas_poly_values(values, power, offset=-273.15):
     evaluated in the data's own dtype (a Python float does not promote a float32 array)."""
     values = np.asarray(values)
     return (values + values.dtype.type(offset)) ** power
+
+
+def blocklocal_weights_oracle(G, R, seed, fill=0.952, bn=256, bk=32):
+    """The c5 "block-local" synthetic weights of wagg_dense_create_synth_blocklocal (include/wagg.h)
+    as a dense (G, R) fp32 matrix: run j of 64 cells touches column tile (97 j) mod ceil(R/bn)."""
+    n_nt = (R + bn - 1) // bn
+    g = np.arange(G, dtype=np.uint64)[:, None]
+    r = np.arange(R, dtype=np.uint64)[None, :]
+    idx = g * np.uint64(R) + r
+    run = (np.arange(G) // bk) // 2
+    owner = (97 * run) % n_nt
+    inside = (np.arange(R)[None, :] // bn) == owner[:, None]
+    keep = hash_u01(idx, np.uint32(seed) ^ np.uint32(0x9e3779b9)) < np.float32(fill)
+    return np.where(inside & keep, hash_u01(idx, seed), np.float32(0)).astype(np.float32)

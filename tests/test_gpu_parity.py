@@ -560,3 +560,38 @@ def test_tas_poly_dropin_then_aggregate_and_batched(torch_cuda):
     # lazy .values of the transformed grid itself (device-evaluated) equals the oracle's grid
     np.testing.assert_allclose(tas_poly(ds, 2, "p2").p2.values, O.tas_poly_values(ref_grid, 2), rtol=1e-6,
                                equal_nan=True)
+
+
+def test_tile_sparse_dense_form_blocklocal(torch_cuda):
+    """c5 "block-local" weights (each 64-cell run touches the 256 regions of one column tile): only
+    the non-empty (32 x 256) tiles of W are stored and contracted by the MFMA kernel."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    G, R, T, seed = 64 * 75 + 40, 1000, 400, 5                    # ragged G and R, two row blocks
+    W = O.blocklocal_weights_oracle(G, R, seed)
+    plan = DensePlan.synth_blocklocal(G, R, seed)
+    n_kt, n_nt = (G + 31) // 32, (R + 255) // 256
+    assert plan.info["tiled"] == 1 and plan.info["n_tiles"] == n_kt and plan.info["n_tiles"] < n_kt * n_nt
+    np.testing.assert_allclose(plan.den, W.astype(np.float64).sum(0), rtol=1e-12)
+    rng = np.random.default_rng(2)
+    X = (280 + 20 * rng.standard_normal((T, G))).astype(np.float32)
+    X[7, 100] = np.nan
+    ref = O.agg_dense(X, W)
+    got = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    _rel_ok(got, ref, RTOL32)
+    # the same weights handed over as a segment table take the tile-sparse form automatically ...
+    gi, ri = np.nonzero(W)
+    seg = DensePlan.from_segments(gi.astype(np.int32), ri.astype(np.int32), W[gi, ri].astype(np.float64), G, R)
+    assert seg.info["tiled"] == 1 and seg.info["n_tiles"] == n_kt
+    _rel_ok(seg.apply(torch.from_numpy(X).cuda()).cpu().numpy(), ref, RTOL32)
+    # ... and agree with the fully dense layout of the same matrix
+    full = DensePlan.from_host(W)
+    assert full.info["tiled"] == 0 and full.info["n_tiles"] == n_kt * n_nt
+    _rel_ok(full.apply(torch.from_numpy(X).cuda()).cpu().numpy(), ref, RTOL32)
+    # empty column tiles / regions without any weight: 0/0
+    gi2, ri2 = gi[ri < 300], ri[ri < 300]
+    part = DensePlan.from_segments(gi2.astype(np.int32), ri2.astype(np.int32), W[gi2, ri2].astype(np.float64), G, R)
+    out = part.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    assert np.isnan(out[:, 300:]).all()
+    _rel_ok(out[:, :300], ref[:, :300], RTOL32)
