@@ -33,18 +33,18 @@
 
 namespace wagg {
 
-constexpr int D_MT = 23;                 // 16-row MFMA tiles per workgroup
+constexpr int D_MT = 23;                 // most 16-row MFMA tiles per workgroup (T = 365 -> 23)
 constexpr int D_BM = D_MT * 16;          // 368 rows
 constexpr int D_BN = 256;                // 8 waves x 32 columns
 constexpr int D_BK = 32;                 // k depth of one LDS tile = 8 MFMA k-steps
 constexpr int D_THREADS = 512;
-constexpr int D_XT = D_BM * D_BK;        // floats per packed X tile (47,104 B)
 constexpr int D_WT = D_BN * D_BK;        // floats per packed W tile (32,768 B)
-constexpr int D_XPIECES = D_XT / 256;    // 46 one-KiB pieces
-constexpr int D_WPIECES = D_WT / 256;    // 32
-static_assert(D_XPIECES <= 48 && D_WPIECES == 32, "10 DMA pieces per wave");
-constexpr int D_BUF_BYTES = (D_XT + D_WT) * 4;   // 79,872 B per LDS buffer, two buffers
-static_assert(2 * D_BUF_BYTES <= 160 * 1024, "LDS budget");
+constexpr int D_WPIECES = D_WT / 256;    // 32 one-KiB pieces: 4 per wave
+static_assert(D_WPIECES == 32, "4 W pieces per wave");
+// a workgroup owns MT x 16 rows (MT <= 23, chosen per T so that the row blocks are evenly filled)
+constexpr int d_xt(int mt) { return mt * 16 * D_BK; }            // floats per packed X tile (MT = 23: 47,104 B)
+constexpr int d_buf_bytes(int mt) { return (d_xt(mt) + D_WT) * 4; }   // per LDS buffer, two buffers (MT = 23: 79,872 B)
+static_assert(2 * d_buf_bytes(D_MT) <= 160 * 1024, "LDS budget");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -66,20 +66,26 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // are all distinct within each group.
 //
 // DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
-// of the k-loop, bit2 = skip the per-tile barrier, bit3 = one DMA piece per row-block PAIR (instead
-// of one per block in the first 10 blocks).  Results are wrong with any bit set.
+// of the k-loop, bit2 = skip the per-tile barrier, bit4 = X pieces before the W pieces.  Results are wrong
+// with bit0 or bit2 set.
 //
 // TILED (tile-sparse W, e.g. c5 "block-local" weights): only the non-empty (32-cell x 256-region)
 // tiles of W are stored, compacted per column tile; tile_kt[i] is the k-tile (= X tile) of stored
 // tile i and tile_off[nt][ks] .. tile_off[nt][ks+1] the run of stored tiles that block (nt, ks)
 // contracts.  The k index of tile t+2 is fetched by a plain vector load at the start of tile t
 // (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
-template <int DBG = 0, bool TILED = false>
+template <int DBG = 0, bool TILED = false, int MT = D_MT>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const float *__restrict__ Xp, const float *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
     int kt_per_slice, float *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
     const int32_t *__restrict__ tile_off = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][D_BUF_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][BUF_BYTES]
+    constexpr int XT4 = d_xt(MT) * 4;                // bytes of the packed X tile (MT x 16 rows x 128 B)
+    constexpr int BUF_BYTES = d_buf_bytes(MT);
+    constexpr int XPIECES = XT4 / 1024;              // 2 MT one-KiB pieces
+    constexpr int NXP = (XPIECES + 7) / 8;           // X pieces per wave (the last round may be partial)
+    constexpr int NP = 4 + NXP;                      // DMA pieces per wave and tile: 4 W + NXP X
+    constexpr int DPB = (NP + MT - 1) / MT;          // pieces issued per row block (1 when MT >= NP)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -108,38 +114,49 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     }
 
     // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
-    // moves X pieces wave + 8 i (i < 6; the two pieces that do not exist are clamped onto piece
-    // 45 -- an identical rewrite) and W pieces wave + 8 i (i < 4)
-    const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * (D_XT * 4) + lane * 16;
+    // moves W pieces wave + 8 i (i < 4) and X pieces wave + 8 i (i < NXP, those below XPIECES)
+    const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
     const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * (D_WT * 4) + lane * 16;
-    const int xq5 = wave + 40 < D_XPIECES ? wave + 40 : D_XPIECES - 1;
 #define WAGG_DMA_X(q, tile, buf)                                                                  \
-    __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * (D_XT * 4) + (q) * 1024),   \
-                                     (lptr_t)(lds + (buf) * D_BUF_BYTES + (q) * 1024), 16, 0, 0)
+    __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * XT4 + (q) * 1024),          \
+                                     (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0)
 #define WAGG_DMA_W(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * (D_WT * 4) + (q) * 1024),   \
-                                     (lptr_t)(lds + (buf) * D_BUF_BYTES + D_XT * 4 + (q) * 1024), 16, 0, 0)
-#define WAGG_DMA_PIECE_XW(i, xt, wt, buf)                                                         \
-    do {                                                                                          \
-        if ((i) < 5) WAGG_DMA_X(wave + 8 * (i), xt, buf);                                         \
-        else if ((i) == 5) WAGG_DMA_X(xq5, xt, buf);                                              \
-        else WAGG_DMA_W(wave + 8 * ((i) - 6), wt, buf);                                           \
-    } while (0)
-    // W pieces (HBM, longest latency) first, then the X pieces (served by the XCD's L2)
+                                     (lptr_t)(lds + (buf) * BUF_BYTES + XT4 + (q) * 1024), 16, 0, 0)
+    // piece i of this wave: W pieces (HBM, longest latency) first, then the X pieces (served by the
+    // XCD's L2); DBG bit4 = X first
 #define WAGG_DMA_PIECE(i, xt, wt, buf)                                                            \
     do {                                                                                          \
-        if (DBG & 16) WAGG_DMA_PIECE_XW(i, xt, wt, buf);                                          \
-        else WAGG_DMA_PIECE_XW(((i) + 6) % 10, xt, wt, buf);                                      \
+        constexpr int i_ = (DBG & 16) ? ((i) + 4) % NP : (i);                                     \
+        if constexpr (i_ < 4) WAGG_DMA_W(wave + 8 * i_, wt, buf);                                 \
+        else if constexpr (8 * (i_ - 4) + 7 < XPIECES) WAGG_DMA_X(wave + 8 * (i_ - 4), xt, buf);  \
+        else { if (wave + 8 * (i_ - 4) < XPIECES) WAGG_DMA_X(wave + 8 * (i_ - 4), xt, buf); }     \
     } while (0)
+#define WAGG_DMA_BLOCK(RB, xt, wt, buf)                                                           \
+    do {                                                                                          \
+        if constexpr (DPB * (RB) + 0 < NP && 0 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 0 < NP ? DPB * (RB) + 0 : 0, xt, wt, buf); \
+        if constexpr (DPB * (RB) + 1 < NP && 1 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 1 < NP ? DPB * (RB) + 1 : 0, xt, wt, buf); \
+        if constexpr (DPB * (RB) + 2 < NP && 2 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 2 < NP ? DPB * (RB) + 2 : 0, xt, wt, buf); \
+        if constexpr (DPB * (RB) + 3 < NP && 3 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 3 < NP ? DPB * (RB) + 3 : 0, xt, wt, buf); \
+        if constexpr (DPB * (RB) + 4 < NP && 4 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 4 < NP ? DPB * (RB) + 4 : 0, xt, wt, buf); \
+    } while (0)
+    static_assert(DPB <= 5, "at most five DMA pieces per row block (MT = 1: 4 W + 1 X)");
 
-    f32x4 acc[D_MT][2];
+    f32x4 acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < D_MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (ntiles > 0) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) WAGG_DMA_PIECE(i, x_first, 0, 0);
+        WAGG_DMA_PIECE(0, x_first, 0, 0); WAGG_DMA_PIECE(1, x_first, 0, 0);
+        WAGG_DMA_PIECE(2, x_first, 0, 0); WAGG_DMA_PIECE(3, x_first, 0, 0);
+        WAGG_DMA_PIECE(4, x_first, 0, 0);
+        if constexpr (NP > 5) WAGG_DMA_PIECE(NP > 5 ? 5 : 0, x_first, 0, 0);
+        if constexpr (NP > 6) WAGG_DMA_PIECE(NP > 6 ? 6 : 0, x_first, 0, 0);
+        if constexpr (NP > 7) WAGG_DMA_PIECE(NP > 7 ? 7 : 0, x_first, 0, 0);
+        if constexpr (NP > 8) WAGG_DMA_PIECE(NP > 8 ? 8 : 0, x_first, 0, 0);
+        if constexpr (NP > 9) WAGG_DMA_PIECE(NP > 9 ? 9 : 0, x_first, 0, 0);
     }
+    static_assert(NP <= 10, "prologue issues at most ten pieces");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const int f = lr >> 1;
     const int frag0 = (lr * 8 + (kq ^ f)) * 16;            // h = 0: piece kq
     const int frag1 = (lr * 8 + ((kq ^ f) ^ 4)) * 16;      // h = 1: piece kq + 4
-    const int boff = D_XT * 4 + wave * (32 * 128);         // this wave's 32 columns of the W image
+    const int boff = XT4 + wave * (32 * 128);              // this wave's 32 columns of the W image
 
     // One 16-row block = 16 MFMAs: k-steps 0..7 x the wave's two 16-column blocks.  k-steps 0..3
     // come from the first fragment read (h = 0), 4..7 from the second.
@@ -167,35 +184,36 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         D0 = *reinterpret_cast<const f32x4 *>(img + frag0 + (RB) * 2048);                         \
         D1 = *reinterpret_cast<const f32x4 *>(img + frag1 + (RB) * 2048);                         \
     } while (0)
-    // Row blocks 2P and 2P+1.  The fragment reads of the NEXT block are issued right behind the
-    // first MFMA of the current one: hipcc's s_waitcnt for the current fragments (always a full
-    // lgkmcnt(0) once an LDS-DMA is in the stream) then finds only reads that were issued 15
-    // MFMAs earlier.  DMA piece P of the next tile goes in the middle of block 2P (10 pieces
-    // over 11 pairs).
-#define WAGG_BLOCK(RB, A0, A1, N0, N1, NEXT_RB, DMA)                                              \
+    // Row block RB.  The fragment reads of the NEXT block are issued right behind the first MFMA
+    // of the current one: hipcc's s_waitcnt for the current fragments (always a full lgkmcnt(0)
+    // once an LDS-DMA is in the stream) then finds only reads that were issued 15 MFMAs earlier.
+    // The next tile's DMA pieces go in the middle of the first row blocks, one per block when
+    // MT >= NP (so the end-of-tile vmcnt(0) never waits).
+#define WAGG_BLOCK_(RB, A0, A1, N0, N1)                                                           \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA(RB, 0, A0, b00, 0);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if ((NEXT_RB) < D_MT) WAGG_READ_A(N0, N1, NEXT_RB);                                       \
+        if constexpr ((RB) + 1 < MT) WAGG_READ_A(N0, N1, (RB) + 1 < MT ? (RB) + 1 : 0);           \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if ((DMA) >= 0 && (DMA) < 10 && !(DBG & 1)) {                                             \
-            if (DBG & 32) { if ((DMA) < 5) { WAGG_DMA_PIECE(2 * (DMA), xnext, tnext, nbuf); WAGG_DMA_PIECE(2 * (DMA) + 1, xnext, tnext, nbuf); } } \
-            else WAGG_DMA_PIECE(DMA, xnext, tnext, nbuf);                                         \
-        }                                                                                         \
+        if constexpr (!(DBG & 1)) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf);                         \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA8(RB, A1, b01, b11);                                                             \
     } while (0)
-#define WAGG_PAIR(P)                                                                              \
+    // even blocks use register set A and prefetch into B, odd blocks the other way round
+#define WAGG_BLOCK(RB)                                                                            \
     do {                                                                                          \
-        WAGG_BLOCK(2 * (P), aA0, aA1, aB0, aB1, 2 * (P) + 1, (DBG & 8) ? (P) : 2 * (P));          \
-        WAGG_BLOCK(2 * (P) + 1, aB0, aB1, aA0, aA1, 2 * (P) + 2, (DBG & 8) ? -1 : 2 * (P) + 1);   \
+        if constexpr ((RB) < MT) {                                                                \
+            constexpr int rb_ = (RB) < MT ? (RB) : 0;                                             \
+            if constexpr ((RB) & 1) WAGG_BLOCK_(rb_, aB0, aB1, aA0, aA1);                         \
+            else WAGG_BLOCK_(rb_, aA0, aA1, aB0, aB1);                                            \
+        }                                                                                         \
     } while (0)
 
     for (int tile = 0; tile < ntiles; ++tile) {
-        const char *img = lds + (tile & 1) * D_BUF_BYTES;
+        const char *img = lds + (tile & 1) * BUF_BYTES;
         const int nbuf = (tile & 1) ^ 1;
         const int tnext = tile + 1 < ntiles ? tile + 1 : tile;     // last tile: harmless re-load
         const int xnext = TILED ? kt_next : tnext;
@@ -211,9 +229,11 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         b10 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag0);
         b11 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag1);
         WAGG_READ_A(aA0, aA1, 0);
-        WAGG_PAIR(0); WAGG_PAIR(1); WAGG_PAIR(2); WAGG_PAIR(3); WAGG_PAIR(4); WAGG_PAIR(5);
-        WAGG_PAIR(6); WAGG_PAIR(7); WAGG_PAIR(8); WAGG_PAIR(9); WAGG_PAIR(10);
-        WAGG_BLOCK(22, aA0, aA1, aB0, aB1, 23, -1);
+        WAGG_BLOCK(0); WAGG_BLOCK(1); WAGG_BLOCK(2); WAGG_BLOCK(3); WAGG_BLOCK(4); WAGG_BLOCK(5);
+        WAGG_BLOCK(6); WAGG_BLOCK(7); WAGG_BLOCK(8); WAGG_BLOCK(9); WAGG_BLOCK(10); WAGG_BLOCK(11);
+        WAGG_BLOCK(12); WAGG_BLOCK(13); WAGG_BLOCK(14); WAGG_BLOCK(15); WAGG_BLOCK(16); WAGG_BLOCK(17);
+        WAGG_BLOCK(18); WAGG_BLOCK(19); WAGG_BLOCK(20); WAGG_BLOCK(21); WAGG_BLOCK(22);
+        static_assert(MT <= 23, "row blocks are written out up to 22");
         __builtin_amdgcn_sched_barrier(0);
         // this wave's DMA pieces of tile+1 have landed; every wave is done reading this buffer
         if (TILED) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(kt_next) : "v"(ktn_v) : "memory");
@@ -222,9 +242,9 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     }
 
     // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * D_BM) * D_BN;
+    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * (MT * 16)) * D_BN;
 #pragma unroll
-    for (int m = 0; m < D_MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -232,19 +252,20 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
                 slab[(m * 16 + kq * 4 + r) * D_BN + wave * 32 + cb * 16 + lr] = acc[m][cb][r];
 }
 
-// X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one f32x4 per slot), NaN -> 0 (S6),
-// zero for rows >= T and cells >= G.  One thread per slot; the 8 slots of a row read one 128-byte
+// X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one f32x4 per slot; a row block has
+// bm = 16 MT rows), NaN -> 0 (S6), zero for rows >= T and cells >= G.  One thread per slot; the 8 slots of a row read one 128-byte
 // line of X.
 __global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
-                                    int n_kt, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp) {
+                                    int n_kt, int bm, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int tile_slots = bm * 8;                         // bm rows x 8 pieces of 16 bytes
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
-        const int slot = (int)(s % (D_XT / 4));
-        const int64_t tk = s / (D_XT / 4);
+        const int slot = (int)(s % tile_slots);
+        const int64_t tk = s / tile_slots;
         const int kt = (int)(tk % n_kt);
         const int64_t mb = tk / n_kt;
         const int row = slot >> 3, p = (slot & 7) ^ ((row >> 1) & 7);
-        const int64_t t = mb * D_BM + row, k0 = (int64_t)kt * D_BK + 4 * p;
+        const int64_t t = mb * bm + row, k0 = (int64_t)kt * D_BK + 4 * p;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
             const float *src = X + t * ldx + k0;
@@ -269,17 +290,17 @@ __host__ __device__ __forceinline__ int64_t wp_index(int64_t g, int64_t r, int n
 }
 
 // out[t, r] = sum_s slab[mb][nt][s][t_local][c] / den[r]        (aggregations.py:77-80 fused)
-__global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, int S, int64_t Ttot,
+__global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
                                     int32_t R, const float *__restrict__ den,
                                     float *__restrict__ out, int64_t ldo) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t t = blockIdx.y;
     if (r >= R) return;
-    const int mb = (int)(t / D_BM), tl = (int)(t % D_BM);
+    const int mb = (int)(t / bm), tl = (int)(t % bm);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * D_BM + tl) * D_BN + c;
+    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += p[(int64_t)k * D_BM * D_BN];
+    for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
     out[t * ldo + r] = s / den[r];
 }
 
@@ -670,7 +691,14 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
     const int n_nt = d->n_nt, n_kt = d->n_kt;
+    // row blocks: as few as possible (<= 368 rows each), evenly filled, 16 MT rows with MT from the
+    // instantiated set -- T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
     const int n_mb = (int)((T + D_BM - 1) / D_BM);
+    const int rows = (int)((T + n_mb - 1) / n_mb);
+    static const int mts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 21, 22, 23};
+    int MT = D_MT;
+    for (int m : mts) if (m * 16 >= rows) { MT = m; break; }
+    const int bm = MT * 16;
     int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
     if (d->tiled) {               // fewest slices (1, 2, 4, 8) that still give >= 4 workgroups per CU
         S = 1;
@@ -679,37 +707,45 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
     WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && T <= 65535, "grid too large");
-    const size_t need = (size_t)n_nt * n_mb * S * D_BM * D_BN;
+    const size_t need = (size_t)n_nt * n_mb * S * bm * D_BN;
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
-    const int64_t x_slots = (int64_t)n_mb * n_kt * (D_XT / 4);
+    const int64_t x_slots = (int64_t)n_mb * n_kt * bm * 8;
     if (d->xp.n < (size_t)x_slots * 4) WAGG_HIP(d->xp.alloc((size_t)x_slots * 4));
     const int aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
-    const size_t shmem = 2 * (size_t)D_BUF_BYTES;
+    const size_t shmem = 2 * (size_t)d_buf_bytes(MT);
     hipStream_t st = (hipStream_t)stream;
-    auto kern = d->tiled ? dense_mfma_kernel<0, true> : dense_mfma_kernel<0, false>;
-    if (const char *dbg = d->tiled ? nullptr : getenv("WAGG_DENSE_DBG")) {
+    typedef void (*kern_t)(const float *, const float *, int, int, int, int, int, float *, const int32_t *, const int32_t *);
+    kern_t kern = nullptr;
+#define WAGG_PICK(M) case M: kern = d->tiled ? (kern_t)dense_mfma_kernel<0, true, M> : (kern_t)dense_mfma_kernel<0, false, M>; break
+    switch (MT) {
+        WAGG_PICK(1); WAGG_PICK(2); WAGG_PICK(3); WAGG_PICK(4); WAGG_PICK(5); WAGG_PICK(6); WAGG_PICK(8);
+        WAGG_PICK(10); WAGG_PICK(12); WAGG_PICK(14); WAGG_PICK(16); WAGG_PICK(18); WAGG_PICK(20);
+        WAGG_PICK(21); WAGG_PICK(22); WAGG_PICK(23);
+        default: set_error("no kernel for MT=%d", MT); return WAGG_EINVAL;
+    }
+#undef WAGG_PICK
+    if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
         switch (atoi(dbg)) {
             case 1: kern = dense_mfma_kernel<1>; break;
             case 4: kern = dense_mfma_kernel<4>; break;
             case 5: kern = dense_mfma_kernel<5>; break;
-            case 8: kern = dense_mfma_kernel<8>; break;
             case 16: kern = dense_mfma_kernel<16>; break;
-            case 32: kern = dense_mfma_kernel<32>; break;
             default: break;
         }
     }
     WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(dense_pack_x_kernel, dim3(256 * 16), dim3(256), 0, st, X_dev, T, ldx, d->G, n_kt, x_slots,
+    hipLaunchKernelGGL(dense_pack_x_kernel, dim3(256 * 16), dim3(256), 0, st, X_dev, T, ldx, d->G, n_kt, bm, x_slots,
                        aligned, reinterpret_cast<f32x4 *>(d->xp.p));
     WAGG_HIP(hipGetLastError());
     profile_mark(st, true);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, d->xp.p, d->W.p, n_kt, n_nt, n_mb,
-                       S, kt_per_slice, d->slabs.p, d->tile_kt.p,
-                       d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, (const float *)d->xp.p,
+                       (const float *)d->W.p, n_kt, n_nt, n_mb, S, kt_per_slice, d->slabs.p,
+                       (const int32_t *)d->tile_kt.p,
+                       (const int32_t *)(d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr));
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,
-                       d->slabs.p, n_nt, S, T, d->R, d->den32.p, out_dev, ldo);
+                       d->slabs.p, n_nt, S, bm, T, d->R, d->den32.p, out_dev, ldo);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }

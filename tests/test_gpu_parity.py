@@ -223,7 +223,7 @@ def test_c1_full(torch_cuda):
 # ---------------------------------------------------------------------------------------------
 # dense path
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("T,G,R", [(5, 64, 7), (365, 1000, 130), (368, 4099, 257), (400, 777, 129), (3, 20, 600)])
+@pytest.mark.parametrize("T,G,R", [(5, 64, 7), (365, 1000, 130), (368, 4099, 257), (400, 777, 129), (3, 20, 600), (31, 500, 300), (100, 333, 20), (700, 256, 520), (17, 96, 257)])
 def test_dense_small_vs_oracle(torch_cuda, T, G, R):
     from climate_toolbox_amd.engine import DensePlan
     from oracle import ref_numpy as O
