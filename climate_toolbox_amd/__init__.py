@@ -18,4 +18,6 @@ from .standardize import (  # noqa: F401  (coordinate standardisati
 from .transformations import (  # noqa: F401  (tas_poly fused into the aggregation)
     tas_poly,
     tas_poly_aggregate,
+    snyder_edd,
+    snyder_gdd,
 )

@@ -18,7 +18,7 @@ EXPORTS = (
     "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
     "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
-    "wagg_apply_poly_f32", "wagg_apply_poly_f64",
+    "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
     "wagg_gather_f32", "wagg_gather_f64",
     "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_get_info",
     "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32",
@@ -78,6 +78,9 @@ def load():
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_poly_f32", "wagg_apply_poly_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, vp,
+                                     C.c_int64, C.c_int64, C.c_int, vp]
+    for name in ("wagg_apply_edd_f32", "wagg_apply_edd_f64"):
+        getattr(L, name).argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, f64p, C.c_int, vp,
                                      C.c_int64, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_host_f32", "wagg_apply_host_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int]

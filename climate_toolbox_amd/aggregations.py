@@ -215,12 +215,13 @@ class ReindexedDataset(minixr.Dataset):
     materialises it -- the gather is fused into the aggregation kernel."""
 
     def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray,
-                 lon_perms=None, xforms=None):
+                 lon_perms=None, xforms=None, edds=None):
         super().__init__()
         self._src_values, self._src_dims = src_values, src_dims
         self._ilat, self._ilon = ilat, ilon
         self._lon_perms = dict(lon_perms or {})     # variable -> file column of each sorted lon label
         self._xforms = dict(xforms or {})           # variable -> (offset, power), evaluated on the GPU
+        self._edds = dict(edds or {})               # variable -> (tasmax buffer, offset, [(coef, threshold)])
         self._nseg = len(ilat)
         self._was_xarray = was_xarray
         for k, v in coords.items():
@@ -263,6 +264,11 @@ class ReindexedDataset(minixr.Dataset):
         if name in self._xforms:
             off, pw = self._xforms[name]
             out = (out + off) ** pw
+        if name in self._edds:
+            hi, off, terms = self._edds[name]
+            H2 = _flatten_for_device(hi, self._src_dims[name])[0]
+            hig = _device_gather(torch.from_numpy(H2).cuda(), ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
+            out = sum(c * minixr.snyder_edd_device(torch, out + off, hig + off, e) for c, e in terms)
         return unflatten(out.cpu().numpy(), self._nseg)
 
 
@@ -359,6 +365,13 @@ def _lon_perms(ds):
     return {k: v._lon_perm for k, v in ds.data_vars.items() if getattr(v, "_lon_perm", None) is not None}
 
 
+def _edds(ds):
+    """variable -> (tasmax buffer, offset, [(coef, threshold)]) of a lazy degree-day variable."""
+    if _is_xarray(ds):
+        return {}
+    return {k: v._edd for k, v in ds.data_vars.items() if getattr(v, "_edd", None) is not None}
+
+
 def _xforms(ds):
     """variable -> (offset, power) of a lazily transformed variable (transformations.tas_poly)."""
     if _is_xarray(ds):
@@ -396,7 +409,7 @@ def _reindex_spatial_data_to_regions(ds, df):
         else:
             passthrough[k] = minixr.DataArray(src_values[k], dims)
     out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, df["lat"].values, df["lon"].values,
-                           was_xr, lon_perms=_lon_perms(ds), xforms=_xforms(ds))
+                           was_xr, lon_perms=_lon_perms(ds), xforms=_xforms(ds), edds=_edds(ds))
     for k, v in passthrough.items():
         out.data_vars[k] = v
     return out
@@ -411,10 +424,11 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     labels = np.asarray(weights[agglev].values)
     uniq, codes = _factorize_labels(labels)                              # :78 group keys
 
-    xform = None
+    xform = edd = None
     if isinstance(ds, ReindexedDataset) and variable in ds._src_values:
         values, dims = ds._src_values[variable], ds._src_dims[variable]
         xform = ds._xforms.get(variable)
+        edd = ds._edds.get(variable)
         cell_idx, G = ds._cell_index(variable)
         if len(cell_idx) != len(w_eff):
             raise ValueError("weights has %d rows but the dataset was reindexed with %d"
@@ -448,7 +462,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
         carried = ({k2: minixr.DataArray(v.values, tuple(v.dims)) for k2, v in ds.coords.items()}
                    if was_xr else dict(ds.coords))
 
-    if powers is not None and xform is not None:
+    if (powers is not None or edd is not None) and xform is not None:
         raise ValueError("variable %r already carries a lazy transform" % (variable,))
     if powers is None and xform is not None:
         offset, powers, single = xform[0], [xform[1]], True
@@ -462,7 +476,22 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     # pageable -> pinned host memcpy runs at ~4 GB/s), the kernels, one D2H copy of the result
     Xd = torch.from_numpy(X2).cuda()
     out_layout = "TR" if layout == "TG" else "RT"
-    if powers is None:
+    if edd is not None:
+        # Snyder degree days: sum of coef * EDD(threshold), both fields loaded once per threshold
+        H2 = _flatten_for_device(edd[0], dims)[0]
+        if H2.shape != X2.shape or H2.dtype != X2.dtype:
+            raise ValueError("tasmin and tasmax must have the same shape and dtype")
+        Hd = torch.from_numpy(H2).cuda()
+        coefs, thr = [c for c, _ in edd[2]], [e for _, e in edd[2]]
+        if isinstance(plan, DensePlan):
+            stack = [plan.apply(minixr.snyder_edd_device(torch, Xd + edd[1], Hd + edd[1], e)) for e in thr]
+        else:
+            stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
+        total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
+        for c, o in zip(coefs[1:], stack[1:]):
+            total = total + c * o
+        outs, single = [total], True
+    elif powers is None:
         outs = [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
     elif isinstance(plan, DensePlan):
         # scattered weights in the dense MFMA form: the transform is one elementwise device pass

@@ -77,7 +77,27 @@ template <typename T> struct PlanView {
     // transformations.py:188: (tas - 273.15) ** power): xpow = 0 -> identity, else (x + xoff)^xpow
     T xoff;
     int xpow;
+    // xpow == XF_EDD: Snyder exceedance degree days of (tasmin = X, tasmax = X2), both shifted by
+    // xoff, at threshold edd_thr (transformations.py:7-93); chunk-walking kernel only
+    const T *X2;
+    T edd_thr;
 };
+constexpr int XF_EDD = -1;
+
+// transformations.py:64-87, evaluated in the data type like the reference:
+//   tmin < e ? (tmax > e ? ((M - e)(pi/2 - theta) + w cos(theta)) / pi : 0) : M - e
+// (a NaN tasmin gives M - e = NaN, a NaN tasmax with tasmin < e gives 0 -- exactly what the two
+// nested xr.where calls select)
+template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T e) {
+    const T M = (tmax + tmin) / T(2), w = (tmax - tmin) / T(2);
+    if (!(tmin < e)) return M - e;
+    if (!(tmax > e)) return T(0);
+    const T pi = T(3.14159265358979323846);
+    T theta, c;
+    if constexpr (sizeof(T) == 4) { theta = asinf((e - M) / w); c = cosf(theta); }
+    else { theta = asin((e - M) / w); c = cos(theta); }
+    return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
+}
 
 template <typename T> __device__ __forceinline__ T xform1(T x, T off, int pw) {
     const T y = x + off;
@@ -187,6 +207,18 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                 if (pv.xpow > 0) {
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) v[i] = xform4<vec4, T>(v[i], pv.xoff, pv.xpow);
+                } else if (pv.xpow == XF_EDD) {
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const int tc = (tw0 + i < nt) ? tw0 + i : nt - 1;
+                        const T *p2 = pv.X2 + (t0 + tc) * ldx + cell0;
+                        const int64_t lim = G - 1 - cell0;
+                        vec4 hi;
+                        if (VEC) hi = *reinterpret_cast<const vec4 *>(p2);
+                        else hi = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[i][c] = snyder_edd1<T>(v[i][c] + pv.xoff, hi[c] + pv.xoff, pv.edd_thr);
+                    }
                 }
                 if (!(DBG & 2)) {
 #pragma unroll
@@ -206,6 +238,8 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                 if (lane < TB) {
                     T xv = lane_live ? X[cell * ldx + t0 + lane] : T(0);
                     if (pv.xpow > 0) xv = xform1<T>(xv, pv.xoff, pv.xpow);
+                    else if (pv.xpow == XF_EDD)
+                        xv = snyder_edd1<T>(xv + pv.xoff, (lane_live ? pv.X2[cell * ldx + t0 + lane] : T(0)) + pv.xoff, pv.edd_thr);
                     xs[lane * UROW + u] = xv;
                 }
             }
@@ -955,7 +989,7 @@ __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_emp
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
-                         int nfuse = 1, int64_t pstride = 0) {
+                         int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, T edd_thr = T(0)) {
     // nfuse > 1: powers 1..nfuse of (x + xoff) in one pass over X (fused tas_poly); power p goes to
     // out + (p - 1) * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
@@ -973,7 +1007,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         }
     }
     PlanView<T> pv;
-    pv.xoff = xoff; pv.xpow = xpow;
+    pv.xoff = xoff; pv.xpow = xpow; pv.X2 = X2; pv.edd_thr = edd_thr;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
     pv.ucell = d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
@@ -1008,7 +1042,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     pv.chunk_desc = d.chunk_desc.p; pv.g0_normal = d.g0_normal; pv.c0_normal = d.c0_normal;
     // aligned fast path: 16-byte aligned rows
     const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0);
-    const bool stream_path = layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM");
+    // two-field transforms (EDD) are implemented in the chunk-walking kernel only
+    const bool stream_path = layout == WAGG_LAYOUT_TG && xpow != XF_EDD && !getenv("WAGG_SPARSE_NO_STREAM");
     const int n_norm = (int)plan->info.n_groups - d.g0_normal;
     bool lc_done = false;
     if constexpr (sizeof(T) == 4) {
@@ -1538,4 +1573,38 @@ extern "C" int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, i
                                    int64_t out_pstride, int out_layout, void *stream) {
     return wagg::apply_poly<double, 32>(plan, X_dev, T, ldx, layout, offset, pow_first, n_pow, out_dev, ldo, out_pstride,
                                         out_layout, (hipStream_t)stream);
+}
+
+namespace wagg {
+// Snyder exceedance degree days (transformations.py:7-93) of (tasmin, tasmax) + offset at each of
+// n_thr thresholds, aggregated like wagg_apply; threshold i lands at out + i * out_pstride.
+template <typename T, int TB>
+static int apply_edd(const wagg_plan *plan, const T *tmin, const T *tmax, int64_t Tn, int64_t ldx, int layout,
+                     double offset, const double *thr, int n_thr, T *out, int64_t ldo, int64_t out_pstride,
+                     int out_layout, hipStream_t st) {
+    int rc = check_apply_args(plan, tmin, Tn, ldx, layout, out, ldo, out_layout);
+    if (rc != WAGG_OK) return rc;
+    WAGG_REQUIRE(Tn == 0 || tmax != nullptr, "tasmax is NULL");
+    WAGG_REQUIRE(n_thr >= 1 && thr != nullptr, "need at least one threshold");
+    const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : (int64_t)plan->info.R;
+    WAGG_REQUIRE(n_thr == 1 || out_pstride >= orows * ldo, "out_pstride %lld overlaps the previous threshold",
+                 (long long)out_pstride);
+    for (int i = 0; i < n_thr && rc == WAGG_OK; ++i)
+        rc = launch_sparse<T, TB>(plan, tmin, Tn, ldx, layout, out + (int64_t)i * out_pstride, ldo, out_layout, st,
+                                  (T)offset, XF_EDD, 1, 0, tmax, (T)thr[i]);
+    return rc;
+}
+}  // namespace wagg
+
+extern "C" int wagg_apply_edd_f32(const wagg_plan *plan, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+                                  int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
+                                  float *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream) {
+    return wagg::apply_edd<float, 64>(plan, tasmin_dev, tasmax_dev, T, ldx, layout, offset, thresholds, n_thr, out_dev,
+                                      ldo, out_pstride, out_layout, (hipStream_t)stream);
+}
+extern "C" int wagg_apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+                                  int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
+                                  double *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream) {
+    return wagg::apply_edd<double, 32>(plan, tasmin_dev, tasmax_dev, T, ldx, layout, offset, thresholds, n_thr, out_dev,
+                                       ldo, out_pstride, out_layout, (hipStream_t)stream);
 }

@@ -122,6 +122,31 @@ class SparsePlan:
                       _stream_handle(stream)), "wagg_apply_poly")
         return out
 
+    def apply_edd(self, tasmin, tasmax, thresholds, offset=0.0, layout="TG", out=None, out_layout="TR", stream=None):
+        """out[i, t, r] = aggregate of snyder_edd(tasmin + offset, tasmax + offset, thresholds[i])
+        (``wagg_apply_edd_*``; transformations.py:7-93 evaluated while the two fields are loaded)."""
+        import torch
+        tasmin, tasmax = _check_X(tasmin, layout), _check_X(tasmax, layout)
+        if tasmin.shape != tasmax.shape or tasmin.dtype != tasmax.dtype or _ld(tasmin) != _ld(tasmax):
+            raise ValueError("tasmin and tasmax must have the same shape, dtype and row stride")
+        T = tasmin.shape[0] if layout == "TG" else tasmin.shape[1]
+        n_g = tasmin.shape[1] if layout == "TG" else tasmin.shape[0]
+        if n_g != self.G:
+            raise ValueError("fields have %d grid cells, plan expects %d" % (n_g, self.G))
+        thr = np.ascontiguousarray(np.atleast_1d(thresholds), dtype=np.float64)
+        shape = (len(thr),) + ((T, self.R) if out_layout == "TR" else (self.R, T))
+        if out is None:
+            out = torch.empty(shape, dtype=tasmin.dtype, device=tasmin.device)
+        elif tuple(out.shape) != shape or out.dtype != tasmin.dtype or not out.is_contiguous():
+            raise ValueError("out must be a contiguous %s %s tensor" % (shape, tasmin.dtype))
+        L = _lib.load()
+        fn = L.wagg_apply_edd_f32 if tasmin.dtype == torch.float32 else L.wagg_apply_edd_f64
+        _lib.check(fn(self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin),
+                      _LAYOUTS[layout], float(offset), _np_ptr(thr, C.c_double), len(thr), C.c_void_p(out.data_ptr()),
+                      max(1, shape[2]), shape[1] * shape[2], _OUTS[out_layout], _stream_handle(stream)),
+                   "wagg_apply_edd")
+        return out
+
     def apply_host(self, X, layout="TG", out_layout="TR"):
         """Blocking host-buffer form (wagg_apply_host_*): numpy in, numpy out."""
         X = np.ascontiguousarray(X)

@@ -84,10 +84,13 @@ class LazyArray(DataArray):
     (transformations.py).  The aggregation folds (a) into the plan's cell index and evaluates (b)
     while the data is loaded on the GPU; ``.values`` materialises the array on demand."""
 
-    def __init__(self, raw, dims, lon_perm=None, xform=None, name=None, attrs=None):
+    def __init__(self, raw, dims, lon_perm=None, xform=None, name=None, attrs=None, edd=None):
         super().__init__(raw, dims, name=name)
         self._lon_perm = None if lon_perm is None else np.asarray(lon_perm, dtype=np.int64)
         self._xform = None if xform is None else (float(xform[0]), int(xform[1]))
+        # (c) Snyder degree days of (tasmin = this buffer, tasmax = edd[0]) shifted by edd[1]:
+        # sum of coef * EDD(threshold) over edd[2] = [(coef, threshold), ...]  (transformations.py)
+        self._edd = None if edd is None else (edd[0], float(edd[1]), [(float(c), float(e)) for c, e in edd[2]])
         self.attrs = dict(attrs or {})
 
     @property
@@ -101,7 +104,27 @@ class LazyArray(DataArray):
             off, pw = self._xform
             t = torch.from_numpy(np.ascontiguousarray(raw)).cuda()
             raw = ((t + off) ** pw).cpu().numpy()
+        if self._edd is not None:
+            from .engine import require_gpu
+            torch = require_gpu()
+            hi, off, terms = self._edd
+            hi = np.asarray(hi)
+            if self._lon_perm is not None and "lon" in self.dims:
+                hi = np.take(hi, self._lon_perm, axis=self.dims.index("lon"))
+            lo_t = torch.from_numpy(np.ascontiguousarray(raw)).cuda() + off
+            hi_t = torch.from_numpy(np.ascontiguousarray(hi)).cuda() + off
+            raw = sum(c * snyder_edd_device(torch, lo_t, hi_t, e) for c, e in terms).cpu().numpy()
         return raw
+
+
+def snyder_edd_device(torch, tmin, tmax, e):
+    """transformations.py:64-87 with torch ops on device tensors (materialised ``.values`` only; the
+    aggregation evaluates the same formula inside its load stage, csrc/wagg_sparse.hip)."""
+    mean, width = (tmax + tmin) / 2, (tmax - tmin) / 2
+    theta = torch.asin((e - mean) / width)
+    inner = torch.where(tmax > e, ((mean - e) * (np.pi / 2 - theta) + width * torch.cos(theta)) / np.pi,
+                        torch.zeros_like(mean))
+    return torch.where(tmin < e, inner, mean - e)
 
 
 class _Coords(dict):

@@ -3,6 +3,8 @@
 
 Reference (read as text): climate_toolbox/transformations/transformations.py
   tas_poly(ds, power, varname)   :160-208   (tas - 273.15) ** power, leap days removed, time -> YYYYDDD
+  snyder_edd(tasmin, tasmax, e)  :7-93      Snyder exceedance degree days (nested xr.where, :75-87)
+  snyder_gdd(tasmin, tasmax, lo, hi) :96-144   EDD(lo) - EDD(hi)
   ordinal(n)                     :211-214
   climate_toolbox/utils/utils.py:74-77   remove_leap_days
   climate_toolbox/utils/utils.py:10-20   convert_kelvin_to_celsius
@@ -20,7 +22,8 @@ import numpy as np
 from . import minixr
 from . import aggregations as _agg
 
-__all__ = ["tas_poly", "tas_poly_aggregate", "ordinal", "remove_leap_days", "convert_kelvin_to_celsius"]
+__all__ = ["tas_poly", "tas_poly_aggregate", "snyder_edd", "snyder_gdd", "ordinal", "remove_leap_days",
+           "convert_kelvin_to_celsius"]
 
 KELVIN = 273.15
 
@@ -142,3 +145,58 @@ def tas_poly_aggregate(ds, powers, aggwt, agglev, weights, varnames=None, backup
     res, rdims, coords, was_xr = _agg._aggregate_core(re, "tas", aggwt, agglev, weights, backup_aggwt,
                                                       powers=powers, offset=-KELVIN)
     return _agg._as_dataset(dict(zip(varnames, res)), rdims, coords, was_xr)
+
+
+def _units(arr):
+    return getattr(arr, "attrs", {}).get("units")
+
+
+def _degree_days(tasmin, tasmax, terms, units):
+    for a in (tasmin, tasmax):
+        if getattr(a, "_edd", None) is not None or (getattr(a, "_xform", None) is not None and a._xform[1] != 1):
+            raise ValueError("degree days need plain (or Kelvin-shifted) temperature fields")
+    off_lo = tasmin._xform[0] if getattr(tasmin, "_xform", None) is not None else 0.0
+    off_hi = tasmax._xform[0] if getattr(tasmax, "_xform", None) is not None else 0.0
+    if off_lo != off_hi:
+        raise ValueError("tasmin and tasmax carry different offsets")
+    lo, hi = tasmin._values, tasmax._values
+    if tuple(tasmin.dims) != tuple(tasmax.dims) or lo.shape != hi.shape or lo.dtype != hi.dtype:
+        raise ValueError("tasmin and tasmax must have the same dims, shape and dtype")
+    plo, phi = getattr(tasmin, "_lon_perm", None), getattr(tasmax, "_lon_perm", None)
+    if (plo is None) != (phi is None) or (plo is not None and not np.array_equal(plo, phi)):
+        raise ValueError("tasmin and tasmax must share their longitude order")
+    # check to make sure tasmax > tasmin everywhere (transformations.py:62), on the device
+    from .engine import require_gpu
+    torch = require_gpu()
+    bad = (torch.from_numpy(np.ascontiguousarray(hi)).cuda() < torch.from_numpy(np.ascontiguousarray(lo)).cuda()).any()
+    assert not bool(bad), "values encountered where tasmin > tasmax"
+    return minixr.LazyArray(lo, tasmin.dims, lon_perm=plo, edd=(hi, off_lo, terms), name=tasmin.name,
+                            attrs={"units": units})
+
+
+def snyder_edd(tasmin, tasmax, threshold):
+    r"""
+    Snyder exceedance degree days/cooling degree days
+
+    Same contract as transformations.py:7-93 (tasmin, tasmax: daily minimum / maximum temperature,
+    degrees C, as DataArrays of one Dataset; threshold in degrees C).  The result is a lazy
+    variable: assign it to a Dataset and hand that to ``weighted_aggregate_grid_to_regions`` -- the
+    degree days are evaluated on the GPU while both fields are loaded (``wagg_apply_edd_*``);
+    ``.values`` materialises the grid on demand.
+    """
+    # Check for unit agreement
+    assert _units(tasmin) == _units(tasmax)
+    return _degree_days(tasmin, tasmax, [(1.0, float(threshold))],
+                        "degreedays_{}{}".format(threshold, _units(tasmax)))
+
+
+def snyder_gdd(tasmin, tasmax, threshold_low, threshold_high):
+    r"""
+    Snyder growing degree days: EDD(threshold_low) - EDD(threshold_high)
+    (transformations.py:96-144).  Lazy like :func:`snyder_edd`; the aggregation of the difference is
+    the difference of the two aggregations.
+    """
+    # Check for unit agreement
+    assert _units(tasmin) == _units(tasmax)
+    return _degree_days(tasmin, tasmax, [(1.0, float(threshold_low)), (-1.0, float(threshold_high))],
+                        "degreedays_{}-{}{}".format(threshold_low, threshold_high, _units(tasmax)))

@@ -139,6 +139,19 @@ int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, i
                         double offset, int pow_first, int n_pow, double *out_dev, int64_t ldo,
                         int64_t out_pstride, int out_layout, void *stream);
 
+/* Replaces  snyder_edd  (transformations.py:7-93: Snyder exceedance degree days of the daily
+ * (tasmin, tasmax) pair at a threshold e, the nested xr.where of :75-87) followed by the
+ * aggregation, for n_thr thresholds in one call.  Both fields have the layout/ldx of X above and
+ * are shifted by `offset` first (-273.15 for Kelvin files; the thresholds are in the shifted
+ * unit).  Threshold i is stored at out_dev + i * out_pstride.  snyder_gdd (:96-144) is the
+ * difference of two of these outputs (the aggregation is linear).                               */
+int wagg_apply_edd_f32(const wagg_plan *plan, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+                       int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
+                       float *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream);
+int wagg_apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+                       int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
+                       double *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream);
+
 /* ---- materialised gather: what _reindex_spatial_data_to_regions returns (:27) -------------- */
 /* out[t, i] = X[t, cell_idx[i]] in out_layout (WAGG_OUT_TR: out[t*ldo+i], RT: out[i*ldo+t]).   */
 int wagg_gather_f32(const float *X_dev, int64_t T, int64_t ldx, int layout,

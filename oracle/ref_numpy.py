@@ -320,3 +320,22 @@ def blocklocal_weights_oracle(G, R, seed, fill=0.952, bn=256, bk=32):
     inside = (np.arange(R)[None, :] // bn) == owner[:, None]
     keep = hash_u01(idx, np.uint32(seed) ^ np.uint32(0x9e3779b9)) < np.float32(fill)
     return np.where(inside & keep, hash_u01(idx, seed), np.float32(0)).astype(np.float32)
+
+
+def snyder_edd_values(tasmin, tasmax, threshold):
+    """climate_toolbox/transformations/transformations.py:64-87 (Snyder exceedance degree days),
+    evaluated in the data's own dtype like xarray would (NumPy scalars of the array's type)."""
+    tasmin, tasmax = np.asarray(tasmin), np.asarray(tasmax)
+    ft = tasmin.dtype.type
+    e, pi = ft(threshold), ft(np.pi)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean = (tasmax + tasmin) / ft(2)                                   # :65
+        width = (tasmax - tasmin) / ft(2)                                  # :66
+        theta = np.arcsin((e - mean) / width)                              # :67
+        inner = np.where(tasmax > e, ((mean - e) * (pi / ft(2) - theta) + width * np.cos(theta)) / pi, ft(0))
+        return np.where(tasmin < e, inner, mean - e)                       # :73-87
+
+
+def snyder_gdd_values(tasmin, tasmax, threshold_low, threshold_high):
+    """transformations.py:138-140: difference of two EDDs."""
+    return snyder_edd_values(tasmin, tasmax, threshold_low) - snyder_edd_values(tasmin, tasmax, threshold_high)

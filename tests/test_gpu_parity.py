@@ -595,3 +595,82 @@ def test_tile_sparse_dense_form_blocklocal(torch_cuda):
     out = part.apply(torch.from_numpy(X).cuda()).cpu().numpy()
     assert np.isnan(out[:, 300:]).all()
     _rel_ok(out[:, :300], ref[:, :300], RTOL32)
+
+
+@pytest.mark.parametrize("dtype,layout", [(np.float32, "TG"), (np.float64, "TG"), (np.float32, "GT"), (np.float64, "GT")])
+def test_fused_snyder_edd_matches_transform_then_aggregate(torch_cuda, dtype, layout):
+    """Snyder exceedance degree days (transformations.py:7-93) of a (tasmin, tasmax)
+    pair evaluated while both fields are loaded (wagg_apply_edd_*) = transform the grids, then
+    aggregate; Kelvin inputs, thresholds in degrees C."""
+    from climate_toolbox_amd import synth
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    nlat, nlon, R, T = 96, 192, 300, 70
+    lat, lon, df = synth.realistic_segments(nlat, nlon, R=R, seed=6, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    rng = np.random.default_rng(9)
+    extra = rng.choice(nlat * nlon, 700, replace=False).astype(np.int32)        # one giant region
+    cell = np.concatenate([cell, extra]); code = np.concatenate([code, np.full(700, len(uniq), np.int32)])
+    w = np.concatenate([w, rng.uniform(0.1, 1, 700)])
+    Rn, G = len(uniq) + 1, nlat * nlon
+    tmean = 273.15 + 22 + 8 * rng.standard_normal((T, G))
+    half = rng.uniform(0, 8, (T, G))
+    tmin, tmax = (tmean - half).astype(dtype), (tmean + half).astype(dtype)
+    tmin[2, cell[:30]] = np.nan                      # NaN tasmin -> NaN EDD -> skipped product (S6)
+    tmax[3, cell[30:60]] = np.nan                    # NaN tasmax: 0 where tasmin < e, NaN elsewhere
+    tmax[4, cell[60:90]] = tmin[4, cell[60:90]]      # zero width
+    thr = [10.0, 25.0, 30.0]
+    plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon)
+    a, b = (tmin, tmax) if layout == "TG" else (np.ascontiguousarray(tmin.T), np.ascontiguousarray(tmax.T))
+    got = plan.apply_edd(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), thr, offset=-273.15,
+                         layout=layout).cpu().numpy()
+    assert got.shape == (3, T, Rn)
+    ft = np.dtype(dtype).type
+    cmin, cmax = tmin + ft(-273.15), tmax + ft(-273.15)
+    refs = [O.agg_coded(O.snyder_edd_values(cmin, cmax, e), cell, code, w, Rn) for e in thr]
+    for i in range(3):
+        _rel_ok(got[i], refs[i], RTOL32 if dtype == np.float32 else RTOL64, scale=0.05)
+    # growing degree days = difference of two aggregated EDDs (transformations.py:138-140; linear)
+    gdd_ref = O.agg_coded(O.snyder_gdd_values(cmin, cmax, 10.0, 30.0), cell, code, w, Rn)
+    _rel_ok(got[0] - got[2], gdd_ref, RTOL32 if dtype == np.float32 else RTOL64, scale=0.05)
+
+
+def test_snyder_degree_days_dropin(torch_cuda):
+    """snyder_edd / snyder_gdd (transformations.py:7-144) as lazy variables of a Dataset, aggregated
+    by the reference's own entry point; Kelvin fields via convert_kelvin_to_celsius."""
+    from climate_toolbox_amd import minixr, snyder_edd, snyder_gdd, weighted_aggregate_grid_to_regions
+    from climate_toolbox_amd.transformations import convert_kelvin_to_celsius
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(31)
+    lat, lon = np.arange(-29.5, 30, 1.0), np.arange(-59.5, 60, 1.0)
+    T = 45
+    mean = 273.15 + 24 + 7 * rng.standard_normal((T, len(lat), len(lon)))
+    half = rng.uniform(0, 9, mean.shape)
+    tmin, tmax = (mean - half).astype(np.float32), (mean + half).astype(np.float32)
+    tmin[5, 3, 4] = np.nan
+    ds = minixr.Dataset({"tasmin": (("time", "lat", "lon"), tmin), "tasmax": (("time", "lat", "lon"), tmax)},
+                        coords={"time": np.arange(T), "lat": lat, "lon": lon})
+    for name in ("tasmin", "tasmax"):
+        ds[name].attrs["units"] = "K"
+        ds = convert_kelvin_to_celsius(ds, name)                      # lazy offset (utils.py:10-20)
+    assert ds.tasmin.attrs["units"] == "C"
+    n = 2500
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "popwt": rng.uniform(0, 2, n), "ISO": rng.integers(0, 40, n)})
+    cmin, cmax = tmin + np.float32(-273.15), tmax + np.float32(-273.15)
+    ds["edd30"] = snyder_edd(ds.tasmin, ds.tasmax, 30)
+    ds["gdd"] = snyder_gdd(ds.tasmin, ds.tasmax, 10, 30)
+    assert ds["edd30"].attrs["units"] == "degreedays_30C" and ds["gdd"].attrs["units"] == "degreedays_10-30C"
+    for var, grid in (("edd30", O.snyder_edd_values(cmin, cmax, 30)), ("gdd", O.snyder_gdd_values(cmin, cmax, 10, 30))):
+        ref, rdims, labs = O.agg_scatter(grid, ("time", "lat", "lon"), lat, lon, df["lat"].values, df["lon"].values,
+                                         df["popwt"].values, df["areawt"].values, df["ISO"].values, group_dim="ISO")
+        out = weighted_aggregate_grid_to_regions(ds, var, "popwt", "ISO", df)
+        assert out[var].dims == rdims and list(out["ISO"].values) == list(labs)
+        _rel_ok(out[var].values, ref, RTOL32, scale=0.05)
+        np.testing.assert_allclose(ds[var].values, grid, rtol=2e-5, atol=2e-5, equal_nan=True)   # lazy .values
+    # tasmin > tasmax is refused like in the reference (transformations.py:62)
+    bad = minixr.Dataset({"tasmin": (("time", "lat", "lon"), tmax), "tasmax": (("time", "lat", "lon"), tmin)},
+                         coords={"time": np.arange(T), "lat": lat, "lon": lon})
+    with pytest.raises(AssertionError):
+        snyder_edd(bad.tasmin, bad.tasmax, 30)
