@@ -312,6 +312,12 @@ def test_c2_c3_full_size_vs_oracle(torch_cuda, c2_real, wname, dtype, rtol):
     perm = np.random.default_rng(0).permutation(len(cell))
     plan_p = engine.SparsePlan(cell[perm], codes[perm], w_eff[perm], G, len(uniq), row_len=len(lon))
     np.testing.assert_allclose(plan_p.apply(X).cpu().numpy(), got, rtol=1e-5 if dtype == np.float32 else 1e-12)
+    # fused tas_poly at full size (powers 1..3 in one pass): power 1 with offset 0 IS the plain
+    # aggregation, power 2 against the oracle on the squared field
+    poly = plan.apply_poly(X, 0.0, 3)
+    np.testing.assert_array_equal(poly[0].cpu().numpy(), got)
+    _rel_ok(poly[1].cpu().numpy(), O.agg_coded(Xh * Xh, cell, codes, w_eff, len(uniq)), rtol)
+    del poly
 
 
 def test_c2_dense_full_size_properties(torch_cuda):
