@@ -181,6 +181,19 @@ def main():
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_sparse(X.cpu().numpy(), cell, codes, w_eff, Rr, G, min(T, 64))
+        if dtype == "float32" and world == 1:
+            # fused tas_poly: (tas - 273.15)^p, p = 1..4, one pass over the field
+            pout = torch.empty((4, T, Rr), dtype=Xs.dtype, device="cuda")
+            for _ in range(2):
+                plan.apply_poly(Xs, -273.15, 4, out=pout)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                plan.apply_poly(Xs, -273.15, 4, out=pout)
+            torch.cuda.synchronize()
+            pdt = (time.perf_counter() - t0) / a.steps
+            res["fused_tas_poly_1to4"] = {"ms_per_step": pdt * 1e3, "value": 4 * T * G * Rr / pdt,
+                                          "unit": "gridcell-region-timesteps/s (4 powers)"}
         return res
 
     def run_dense():
