@@ -305,7 +305,8 @@ def tas_poly_values(values, power, offset=-273.15):
     """climate_toolbox/transformations/transformations.py:188: ``(ds.tas - 273.15) ** power``,
     evaluated in the data's own dtype (a Python float does not promote a float32 array)."""
     values = np.asarray(values)
-    return (values + values.dtype.type(offset)) ** power
+    with np.errstate(over="ignore", invalid="ignore"):
+        return (values + values.dtype.type(offset)) ** power
 
 
 def blocklocal_weights_oracle(G, R, seed, fill=0.952, bn=256, bk=32):
