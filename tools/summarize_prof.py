@@ -43,7 +43,7 @@ def mean(kernel_sub, counter):
 
 tj = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
-for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel", True), ("c2-real", "sparse_lc_kernel", False)):
+for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel", True), ("c2-real", "sparse_lc_kernel<true, 1>", False)):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
     if fs is None or ws is None:
         continue
