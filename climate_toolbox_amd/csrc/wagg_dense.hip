@@ -198,9 +198,11 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                        \
-        if constexpr (!(DBG & 1)) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf);                         \
+        if constexpr (!(DBG & 1)) { if ((DBG & 8) || early_dma) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf); } \
         __builtin_amdgcn_sched_barrier(0);                                                        \
         WAGG_MFMA8(RB, A1, b01, b11);                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if constexpr (!(DBG & 1) && !(DBG & 8)) { if (!early_dma) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf); } \
     } while (0)
     // even blocks use register set A and prefetch into B, odd blocks the other way round
 #define WAGG_BLOCK(RB)                                                                            \
@@ -212,6 +214,9 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         }                                                                                         \
     } while (0)
 
+    // waves w and w + 4 share a SIMD and run in step after every barrier: they issue their DMA
+    // pieces half a row block apart so that one of them always has MFMAs to issue (DBG bit3: off)
+    const bool early_dma = wave < 4;
     for (int tile = 0; tile < ntiles; ++tile) {
         const char *img = lds + (tile & 1) * BUF_BYTES;
         const int nbuf = (tile & 1) ^ 1;
@@ -729,6 +734,7 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
             case 1: kern = dense_mfma_kernel<1>; break;
             case 4: kern = dense_mfma_kernel<4>; break;
             case 5: kern = dense_mfma_kernel<5>; break;
+            case 8: kern = dense_mfma_kernel<8>; break;
             case 16: kern = dense_mfma_kernel<16>; break;
             default: break;
         }
