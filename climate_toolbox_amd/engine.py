@@ -30,8 +30,9 @@ def _stream_handle(stream):
 
 
 def _ld(t):
-    """Leading dimension of a 2-D row-contiguous tensor (size-1 axes carry arbitrary strides)."""
-    return int(t.stride(0)) if t.shape[0] > 1 and t.shape[1] > 1 else max(1, int(t.shape[1]))
+    """Leading dimension of a 2-D row-contiguous tensor: the row pitch; a single row carries an
+    arbitrary stride(0), so its own length stands in."""
+    return max(int(t.stride(0)), int(t.shape[1]), 1) if t.shape[0] > 1 else max(1, int(t.shape[1]))
 
 
 def _np_ptr(a, ct):

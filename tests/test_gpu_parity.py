@@ -2,6 +2,7 @@
 (libwagg.so); the oracle is only the checker.  Tolerances: fp64 1e-6 relative, fp32 1e-4
 relative (BASELINE.json north_star), written next to each assertion."""
 import os
+import sys
 
 import numpy as np
 import pandas as pd
@@ -680,3 +681,41 @@ def test_snyder_degree_days_dropin(torch_cuda):
                          coords={"time": np.arange(T), "lat": lat, "lon": lon})
     with pytest.raises(AssertionError):
         snyder_edd(bad.tasmin, bad.tasmax, 30)
+
+
+def test_randomised_differential_all_entry_points(torch_cuda):
+    """tools/fuzz_gpu.py, 80 seeded cases: random grids, tables (null labels, NaN / 0 weights,
+    giant regions), layouts, padded row strides, NaN / inf data -- plain, fused-power, degree-day
+    and dense / tile-sparse forms against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["fuzz_gpu.py"]
+    try:
+        spec.loader.exec_module(fz)
+    finally:
+        sys.argv = argv
+    rng = np.random.default_rng(2024)
+    failures = []
+    for i in range(80):
+        tag, fails = fz.one_case(i, rng)
+        if fails:
+            failures.append(tag + " | " + "; ".join(fails))
+    assert not failures, "\n".join(failures)
+
+
+def test_single_column_view_of_a_padded_buffer(torch_cuda):
+    """(G, 1) data with a row pitch > 1 (found by the fuzzer): the leading dimension is the pitch."""
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    G, R = 500, 20
+    cell, code = rng.integers(0, G, 900).astype(np.int32), rng.integers(0, R, 900).astype(np.int32)
+    w = rng.uniform(0.1, 1, 900)
+    X = rng.standard_normal((1, G))
+    buf = torch.zeros((G, 4), dtype=torch.float64, device="cuda")
+    buf[:, 0] = torch.from_numpy(X[0]).cuda()
+    got = SparsePlan(cell, code, w, G, R).apply(buf[:, :1], layout="GT").cpu().numpy()
+    _rel_ok(got, O.agg_coded(X, cell, code, w, R), RTOL64)

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Randomised differential run of every C-ABI compute entry point against the oracle (GPU box).
+usage: python tools/fuzz_gpu.py [n_cases] [seed]      -- prints one line per failing case, exit 1 on any"""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from climate_toolbox_amd.engine import SparsePlan, DensePlan
+from oracle import ref_numpy as O
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+
+
+def rel_bad(got, ref, rtol, scale):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if got.shape != ref.shape:
+        return "shape %r vs %r" % (got.shape, ref.shape)
+    if not np.array_equal(np.isnan(got), np.isnan(ref)):
+        return "NaN pattern differs at %d places" % (np.isnan(got) != np.isnan(ref)).sum()
+    fin = np.isfinite(ref)
+    inf = ~fin & ~np.isnan(ref)
+    if not np.array_equal(got[inf], ref[inf]):
+        return "inf values differ"
+    err = np.abs(got[fin] - ref[fin])
+    tol = rtol * np.maximum(np.abs(ref[fin]), scale)
+    if (err > tol).any():
+        return "max err/tol %.3g" % (err / tol).max()
+    return None
+
+
+def one_case(i, rng):
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    rtol = 1e-4 if dtype == np.float32 else 1e-6
+    T = int(rng.choice([1, 2, 3, 7, 16, 63, 64, 65, 100, 129, 200, 366]))
+    nlat, nlon = int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    G = nlat * nlon
+    R = int(rng.integers(1, 300))
+    nseg = int(rng.integers(0, 4 * G + 2))
+    cell = rng.integers(0, G, nseg).astype(np.int32)
+    code = rng.integers(-1 if rng.random() < 0.3 else 0, R, nseg).astype(np.int32)     # some null labels
+    if rng.random() < 0.4 and G > 700:                                                # a giant region
+        n = int(rng.integers(300, min(G, 3000)))
+        cell = np.concatenate([cell, rng.choice(G, n, replace=False).astype(np.int32)])
+        code = np.concatenate([code, np.zeros(n, np.int32)])
+    w = rng.uniform(0.05, 3.0, len(cell))
+    w[rng.random(len(cell)) < 0.05] = np.nan
+    w[rng.random(len(cell)) < 0.03] = 0.0
+    X = (288.0 + 9.0 * rng.standard_normal((T, G))).astype(dtype)
+    if rng.random() < 0.5:
+        X[rng.integers(0, T, 5), rng.integers(0, G, 5)] = np.nan
+    if rng.random() < 0.2:
+        X[rng.integers(0, T), rng.integers(0, G)] = np.inf
+    layout = "TG" if rng.random() < 0.7 else "GT"
+    out_layout = "TR" if rng.random() < 0.7 else "RT"
+    pad = int(rng.choice([0, 0, 1, 3, 4]))                                            # row stride > G / unaligned rows
+    tag = "case %d: %s T=%d grid=%dx%d R=%d nseg=%d %s->%s pad=%d" % (i, dtype.__name__, T, nlat, nlon, R, len(cell), layout, out_layout, pad)
+    plan = SparsePlan(cell, code, w, G, R, row_len=nlon)
+    ref = O.agg_coded(X, cell, code, w, R)
+    def dev(a):                                                                       # optionally padded rows
+        a = a if layout == "TG" else np.ascontiguousarray(a.T)
+        if pad:
+            buf = torch.zeros((a.shape[0], a.shape[1] + pad), dtype=torch.from_numpy(a).dtype, device="cuda")
+            buf[:, :a.shape[1]] = torch.from_numpy(a).cuda()
+            return buf[:, :a.shape[1]]
+        return torch.from_numpy(a).cuda()
+    Xd = dev(X)
+    fails = []
+    got = plan.apply(Xd, layout=layout, out_layout=out_layout).cpu().numpy()
+    got = got if out_layout == "TR" else got.T
+    b = rel_bad(got, ref, rtol, 1.0)
+    if b: fails.append("apply: " + b)
+    kind = rng.integers(0, 3)
+    if kind == 0:                                                                     # fused powers
+        K = int(rng.integers(1, 6))
+        gp = plan.apply_poly(Xd, -273.15, K, layout=layout, out_layout=out_layout).cpu().numpy()
+        for p in range(1, K + 1):
+            g = gp[p - 1] if out_layout == "TR" else gp[p - 1].T
+            b = rel_bad(g, O.agg_coded(O.tas_poly_values(X, p), cell, code, w, R), rtol, 1.0)
+            if b: fails.append("poly p=%d: %s" % (p, b))
+    elif kind == 1:                                                                   # degree days
+        half = rng.uniform(0, 8, X.shape).astype(dtype)
+        lo, hi = X - half, X + half
+        thr = [float(rng.uniform(5, 35)) for _ in range(int(rng.integers(1, 3)))]
+        ge = plan.apply_edd(dev(lo), dev(hi), thr, offset=-273.15, layout=layout, out_layout=out_layout).cpu().numpy()
+        ft = dtype
+        for k, e in enumerate(thr):
+            g = ge[k] if out_layout == "TR" else ge[k].T
+            b = rel_bad(g, O.agg_coded(O.snyder_edd_values(lo + ft(-273.15), hi + ft(-273.15), e), cell, code, w, R), rtol, 0.05)
+            if b: fails.append("edd e=%.2f: %s" % (e, b))
+    elif dtype == np.float32 and layout == "TG" and not np.isinf(X).any():            # dense / tile-sparse form
+        dp = DensePlan.from_segments(cell, code, w, G, R)
+        b = rel_bad(dp.apply(Xd.contiguous()).cpu().numpy(), ref, rtol, 1.0)
+        if b: fails.append("dense(%s): %s" % ("tiled" if dp.info["tiled"] else "full", b))
+        dp.close()
+    plan.close()
+    return tag, fails
+
+
+def main():
+    rng = np.random.default_rng(SEED)
+    bad = 0
+    for i in range(N):
+        try:
+            tag, fails = one_case(i, rng)
+        except Exception as e:                                                        # a crash is a failure too
+            tag, fails = "case %d" % i, ["exception: %s" % traceback.format_exc().splitlines()[-1]]
+        if fails:
+            bad += 1
+            print(tag, "|", "; ".join(fails), flush=True)
+        if i % 25 == 24:
+            print("... %d cases, %d failing" % (i + 1, bad), flush=True)
+    print("fuzz: %d cases, %d failing" % (N, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
