@@ -719,3 +719,33 @@ def test_single_column_view_of_a_padded_buffer(torch_cuda):
     buf[:, 0] = torch.from_numpy(X[0]).cuda()
     got = SparsePlan(cell, code, w, G, R).apply(buf[:, :1], layout="GT").cpu().numpy()
     _rel_ok(got, O.agg_coded(X, cell, code, w, R), RTOL64)
+
+
+@pytest.mark.parametrize("dims", [("time", "lat", "lon"), ("lat", "lon", "time"), ("lat", "time", "lon"),
+                                  ("member", "time", "lat", "lon"), ("lat", "lon", "member", "time"),
+                                  ("time", "lon", "lat"), ("lon", "member", "lat"), ("lat", "lon")])
+def test_dropin_any_dim_order_and_label_types(torch_cuda, dims):
+    """S2/S3/S10 through the drop-in: lat/lon anywhere among the dims (also lon before lat), extra
+    dims carried in place, string labels with nulls, against the oracle's xarray-semantics restatement."""
+    from climate_toolbox_amd import minixr, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(len(dims) * 7 + len(dims[0]))
+    sizes = {"time": 9, "member": 3, "lat": 12, "lon": 17}
+    lat, lon = np.linspace(-55, 55, sizes["lat"]), np.linspace(-160, 170, sizes["lon"])
+    vals = (280 + 10 * rng.standard_normal([sizes[d] for d in dims]))
+    vals.flat[rng.integers(0, vals.size, 3)] = np.nan
+    coords = {d: (lat if d == "lat" else lon if d == "lon" else np.arange(sizes[d])) for d in dims}
+    ds = minixr.Dataset({"tas": (dims, vals)}, coords=coords)
+    n = 400
+    labels = np.array(["R%02d" % k for k in rng.integers(0, 25, n)], dtype=object)
+    labels[rng.random(n) < 0.05] = None                                  # null labels are dropped (S3)
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "popwt": np.where(rng.random(n) < 0.2, np.nan, rng.uniform(0, 4, n)), "hierid": labels})
+    ref, rdims, labs = O.agg_scatter(vals, dims, lat, lon, df["lat"].values, df["lon"].values, df["popwt"].values,
+                                     df["areawt"].values, df["hierid"].values, group_dim="hierid")
+    out = weighted_aggregate_grid_to_regions(ds, "tas", "popwt", "hierid", df)
+    assert out.tas.dims == rdims and list(out["hierid"].values) == list(labs)
+    for d in rdims:
+        if d != "hierid":
+            np.testing.assert_array_equal(out[d].values, coords[d])
+    _rel_ok(out.tas.values, ref, RTOL64)
