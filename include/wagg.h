@@ -10,8 +10,12 @@
  * The reference has no FFI; these entry points are what a ctypes binding placed at
  * aggregations.py:121-122 would call (INTEGRATION.md shows that binding).  Everything the
  * reference does with float LABELS (exact lat/lon match :27, backup fill :73, sorted unique
- * region labels :78) is resolved on the host, in fp64, BEFORE this boundary; what crosses it is
- * the coded segment table (cell_idx, region_code, w_eff) and plain device/host pointers.
+ * region labels :78) is resolved on the host in fp64 -- by the caller or by the host-side entry
+ * points wagg_resolve_cells / wagg_backup_fill / wagg_factorize_* below; what reaches the
+ * device-side entry points is the coded segment table (cell_idx, region_code, w_eff) and plain
+ * device/host pointers.  The helpers either side of the path that have been folded in
+ * (tas_poly, snyder_edd: transformations.py) are evaluated while the data is loaded
+ * (wagg_apply_poly_*, wagg_apply_edd_*).
  *
  * Conventions: every function returns 0 (WAGG_OK) or a negative wagg_status; nothing throws,
  * nothing calls exit(); wagg_last_error() gives the thread-local message of the last failure.
