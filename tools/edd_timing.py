@@ -3,7 +3,7 @@
 grids on the device first and aggregating the result, on c2-real.  Run on the GPU box."""
 import json, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from climate_toolbox_amd import synth, minixr
 from climate_toolbox_amd.engine import SparsePlan, synth_field
 

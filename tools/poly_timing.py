@@ -3,7 +3,7 @@
 against K separate aggregations of pre-transformed grids, on c2-real.  Run on the GPU box."""
 import json, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from climate_toolbox_amd import synth
 from climate_toolbox_amd.engine import SparsePlan, synth_field
 
