@@ -80,7 +80,9 @@ template <typename T> struct PlanView {
     // xpow == XF_EDD: Snyder exceedance degree days of (tasmin = X, tasmax = X2), both shifted by
     // xoff, at threshold edd_thr (transformations.py:7-93); chunk-walking kernel only
     const T *X2;
-    T edd_thr;
+    T edd_thr[4];                // up to four thresholds per pass over the two fields
+    int n_thr;
+    int64_t thr_pstride;         // output of threshold k goes to out + k * thr_pstride
 };
 constexpr int XF_EDD = -1;
 
@@ -93,9 +95,12 @@ template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T
     if (!(tmin < e)) return M - e;
     if (!(tmax > e)) return T(0);
     const T pi = T(3.14159265358979323846);
+    // theta = arcsin(z) lies in [-pi/2, pi/2], where cos(theta) = sqrt((1 - z)(1 + z)) exactly
+    // (tmin < e < tmax puts z strictly inside (-1, 1)); this spares the general-argument cosine
+    const T z = (e - M) / w;
     T theta, c;
-    if constexpr (sizeof(T) == 4) { theta = asinf((e - M) / w); c = cosf(theta); }
-    else { theta = asin((e - M) / w); c = cos(theta); }
+    if constexpr (sizeof(T) == 4) { theta = asinf(z); c = sqrtf((T(1) - z) * (T(1) + z)); }
+    else { theta = asin(z); c = sqrt((T(1) - z) * (T(1) + z)); }
     return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
 }
 
@@ -133,7 +138,9 @@ template <typename T, int TB> struct SparseLds {
 // DBG: diagnostic knob (WAGG_SPARSE_DBG env, never set in production; results are wrong with
 // any bit set): bit0 = no gather loads, bit1 = no LDS image stores, bit2 = no segment loop.
 // VEC: rows of X are 16-byte aligned (base and ldx), so a quad is one aligned vector load.
-template <typename T, int TB, int LAYOUT, int OUT_LAYOUT, bool VEC, int DBG = 0>
+// NTHR > 1 (Snyder degree days, several thresholds): the two fields of a chunk are loaded ONCE and
+// the image / reduction phase runs once per threshold.
+template <typename T, int TB, int LAYOUT, int OUT_LAYOUT, bool VEC, int DBG = 0, int NTHR = 1>
 __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, const T *__restrict__ X,
                                                               int64_t Ttot, int64_t ldx, int64_t G,
                                                               T *__restrict__ out, int64_t ldo) {
@@ -164,7 +171,9 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
     const int c0 = pv.grp_chunk_begin[g], c1 = pv.grp_chunk_begin[g + 1];
     const bool lane_live = lane < nt && lane < TB;
 
-    T giant_acc = T(0);
+    T giant_acc[NTHR];
+#pragma unroll
+    for (int k = 0; k < NTHR; ++k) giant_acc[k] = T(0);
     for (int c = c0; c < c1; ++c) {
         const int u0 = pv.chunk_u_begin[c];
         const int nu = pv.chunk_u_begin[c + 1] - u0;
@@ -188,21 +197,20 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
         // 2.4 TB/s on MI355X however contiguous the cells are -- and one aligned vector LDS store.
         // Rows past a ragged last block are clamped to its last row (their lanes never store a
         // result), so every block keeps TPW independent loads per lane in flight.
+        vec4 v[TPW], hi[NTHR > 1 ? TPW : 1];
+        const int tw0 = wave * TPW;
         if constexpr (LAYOUT == WAGG_LAYOUT_TG) {
             if (lane < nu) {
                 const int64_t cell0 = pv.ucell[u0 + lane];
-                const int tw0 = wave * TPW;
-                vec4 v[TPW];
+                const int64_t lim = G - 1 - cell0;                   // >= 0
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const int tc = (tw0 + i < nt) ? tw0 + i : nt - 1;
                     const T *p = X + (t0 + tc) * ldx + cell0;
                     if (DBG & 1) v[i] = vec4{T(i), T(i), T(i), T(i)};
                     else if (VEC) v[i] = *reinterpret_cast<const vec4 *>(p);
-                    else {                                           // unaligned rows / ragged grid end
-                        const int64_t lim = G - 1 - cell0;           // >= 0
+                    else                                             // unaligned rows / ragged grid end
                         v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
-                    }
                 }
                 if (pv.xpow > 0) {
 #pragma unroll
@@ -212,85 +220,112 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                     for (int i = 0; i < TPW; ++i) {
                         const int tc = (tw0 + i < nt) ? tw0 + i : nt - 1;
                         const T *p2 = pv.X2 + (t0 + tc) * ldx + cell0;
-                        const int64_t lim = G - 1 - cell0;
-                        vec4 hi;
-                        if (VEC) hi = *reinterpret_cast<const vec4 *>(p2);
-                        else hi = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
+                        vec4 h;
+                        if (VEC) h = *reinterpret_cast<const vec4 *>(p2);
+                        else h = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
+                        if constexpr (NTHR > 1) { v[i] = v[i] + pv.xoff; hi[i] = h + pv.xoff; }   // kept for every threshold
+                        else {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[i][c] = snyder_edd1<T>(v[i][c] + pv.xoff, hi[c] + pv.xoff, pv.edd_thr);
+                            for (int cc = 0; cc < 4; ++cc) v[i][cc] = snyder_edd1<T>(v[i][cc] + pv.xoff, h[cc] + pv.xoff, pv.edd_thr[0]);
+                        }
                     }
                 }
-                if (!(DBG & 2)) {
-#pragma unroll
-                    for (int i = 0; i < TPW; ++i)
-                        *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = v[i];
-                } else {
-                    vec4 sum = vec4{T(0), T(0), T(0), T(0)};
-#pragma unroll
-                    for (int i = 0; i < TPW; ++i) sum += v[i];
-                    *reinterpret_cast<vec4 *>(&xs[tw0 * UROW + 4 * lane]) = sum;
-                }
-            }
-        } else {
-            for (int u = wave; u < 4 * nu; u += NWAVE) {
-                int64_t cell = (int64_t)pv.ucell[u0 + (u >> 2)] + (u & 3);
-                cell = cell < G ? cell : G - 1;
-                if (lane < TB) {
-                    T xv = lane_live ? X[cell * ldx + t0 + lane] : T(0);
-                    if (pv.xpow > 0) xv = xform1<T>(xv, pv.xoff, pv.xpow);
-                    else if (pv.xpow == XF_EDD)
-                        xv = snyder_edd1<T>(xv + pv.xoff, (lane_live ? pv.X2[cell * ldx + t0 + lane] : T(0)) + pv.xoff, pv.edd_thr);
-                    xs[lane * UROW + u] = xv;
-                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < (SEG_MAX + UC - 1) / UC; ++i) {
-            const int k = tid + UC * i;
-            if (k < ns) { sm_u[k] = (uint16_t)mu[i]; sm_w[k] = mw[i]; }
-        }
-        if (tid < ne) sm_er[tid] = er;
-        if (tid <= ne) sm_es[tid] = (uint16_t)es;
-        __syncthreads();
-        // ---- weighted group sums: one wave per region, lane = timestep; the (cell, weight) list
-        // is read from LDS at wave-uniform addresses (broadcast) ----
-        for (int el = wave; el < ne; el += NWAVE) {
-            const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[el]);
-            const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[el + 1]);
-            const int r = __builtin_amdgcn_readfirstlane(sm_er[el]);
-            T den = T(1);
-            if (!giant) den = pv.den[r];                         // in flight during the segment loop
-            T acc = T(0);
-            if (lane < TB && !(DBG & 4)) {
+        for (int k = 0; k < NTHR; ++k) {
+            if (NTHR > 1 && k >= pv.n_thr) break;
+            if (k > 0) __syncthreads();                              // the previous threshold's sums are done with xs
+            if constexpr (LAYOUT == WAGG_LAYOUT_TG) {
+                if (lane < nu) {
+                    if (!(DBG & 2)) {
+#pragma unroll
+                        for (int i = 0; i < TPW; ++i) {
+                            vec4 val = v[i];
+                            if constexpr (NTHR > 1) {
+#pragma unroll
+                                for (int cc = 0; cc < 4; ++cc) val[cc] = snyder_edd1<T>(v[i][cc], hi[i][cc], pv.edd_thr[k]);
+                            }
+                            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = val;
+                        }
+                    } else {
+                        vec4 sum = vec4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+                        for (int i = 0; i < TPW; ++i) sum += v[i];
+                        *reinterpret_cast<vec4 *>(&xs[tw0 * UROW + 4 * lane]) = sum;
+                    }
+                }
+            } else {
+                for (int u = wave; u < 4 * nu; u += NWAVE) {
+                    int64_t cell = (int64_t)pv.ucell[u0 + (u >> 2)] + (u & 3);
+                    cell = cell < G ? cell : G - 1;
+                    if (lane < TB) {
+                        T xv = lane_live ? X[cell * ldx + t0 + lane] : T(0);
+                        if (pv.xpow > 0) xv = xform1<T>(xv, pv.xoff, pv.xpow);
+                        else if (pv.xpow == XF_EDD)
+                            xv = snyder_edd1<T>(xv + pv.xoff, (lane_live ? pv.X2[cell * ldx + t0 + lane] : T(0)) + pv.xoff,
+                                                pv.edd_thr[k]);
+                        xs[lane * UROW + u] = xv;
+                    }
+                }
+            }
+            if (k == 0) {
+#pragma unroll
+                for (int i = 0; i < (SEG_MAX + UC - 1) / UC; ++i) {
+                    const int kk = tid + UC * i;
+                    if (kk < ns) { sm_u[kk] = (uint16_t)mu[i]; sm_w[kk] = mw[i]; }
+                }
+                if (tid < ne) sm_er[tid] = er;
+                if (tid <= ne) sm_es[tid] = (uint16_t)es;
+            }
+            __syncthreads();
+            // ---- weighted group sums: one wave per region, lane = timestep; the (cell, weight) list
+            // is read from LDS at wave-uniform addresses (broadcast) ----
+            T *outk = out + (NTHR > 1 ? (int64_t)k * pv.thr_pstride : 0);
+            for (int el = wave; el < ne; el += NWAVE) {
+                const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[el]);
+                const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[el + 1]);
+                const int r = __builtin_amdgcn_readfirstlane(sm_er[el]);
+                T den = T(1);
+                if (!giant) den = pv.den[r];                         // in flight during the segment loop
+                T acc = T(0);
+                if (lane < TB && !(DBG & 4)) {
 #pragma unroll 8
-                for (int s = s0; s < s1; ++s) {
-                    const int u = sm_u[s] & SEG_UMASK;
-                    const T w = sm_w[s];
-                    const T p = xs[lane * UROW + u] * w;        // aggregations.py:78 product
-                    acc += (p == p) ? p : T(0);                 // skipna: NaN product counts 0 (S6)
+                    for (int sgi = s0; sgi < s1; ++sgi) {
+                        const int u = sm_u[sgi] & SEG_UMASK;
+                        const T w = sm_w[sgi];
+                        const T p = xs[lane * UROW + u] * w;        // aggregations.py:78 product
+                        acc += (p == p) ? p : T(0);                 // skipna: NaN product counts 0 (S6)
+                    }
                 }
-            }
-            if (giant) {
-                giant_acc += acc;
-            } else if (lane_live) {
-                const T q = acc / den;                          // aggregations.py:77-80, S7
-                if constexpr (OUT_LAYOUT == WAGG_OUT_TR) out[(t0 + lane) * ldo + r] = q;
-                else out[(int64_t)r * ldo + t0 + lane] = q;
+                if (giant) {
+                    giant_acc[k] += acc;
+                } else if (lane_live) {
+                    const T q = acc / den;                          // aggregations.py:77-80, S7
+                    if constexpr (OUT_LAYOUT == WAGG_OUT_TR) outk[(t0 + lane) * ldo + r] = q;
+                    else outk[(int64_t)r * ldo + t0 + lane] = q;
+                }
             }
         }
         __syncthreads();
     }
     if (giant) {
-        if (lane < TB) red[wave * TB + lane] = giant_acc;
-        __syncthreads();
-        if (wave == 0 && lane_live) {
-            T s = red[lane];
 #pragma unroll
-            for (int w = 1; w < NWAVE; ++w) s += red[w * TB + lane];
-            const int r = pv.ent_region[pv.chunk_e_begin[c0]];
-            const T q = s / pv.den[r];
-            if constexpr (OUT_LAYOUT == WAGG_OUT_TR) out[(t0 + lane) * ldo + r] = q;
-            else out[(int64_t)r * ldo + t0 + lane] = q;
+        for (int k = 0; k < NTHR; ++k) {
+            if (NTHR > 1 && k >= pv.n_thr) break;
+            if (k > 0) __syncthreads();
+            if (lane < TB) red[wave * TB + lane] = giant_acc[k];
+            __syncthreads();
+            if (wave == 0 && lane_live) {
+                T sred = red[lane];
+#pragma unroll
+                for (int w = 1; w < NWAVE; ++w) sred += red[w * TB + lane];
+                const int r = pv.ent_region[pv.chunk_e_begin[c0]];
+                const T q = sred / pv.den[r];
+                T *outk = out + (NTHR > 1 ? (int64_t)k * pv.thr_pstride : 0);
+                if constexpr (OUT_LAYOUT == WAGG_OUT_TR) outk[(t0 + lane) * ldo + r] = q;
+                else outk[(int64_t)r * ldo + t0 + lane] = q;
+            }
         }
     }
 }
@@ -989,7 +1024,8 @@ __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_emp
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
-                         int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, T edd_thr = T(0)) {
+                         int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, const double *thr = nullptr,
+                         int n_thr = 0) {
     // nfuse > 1: powers 1..nfuse of (x + xoff) in one pass over X (fused tas_poly); power p goes to
     // out + (p - 1) * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
@@ -1007,7 +1043,11 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         }
     }
     PlanView<T> pv;
-    pv.xoff = xoff; pv.xpow = xpow; pv.X2 = X2; pv.edd_thr = edd_thr;
+    pv.xoff = xoff; pv.xpow = xpow; pv.X2 = X2;
+    pv.n_thr = n_thr > 0 ? n_thr : 1;
+    for (int k = 0; k < 4; ++k) pv.edd_thr[k] = (T)(thr && k < n_thr ? thr[k] : 0.0);
+    // planes of output: powers of the fused tas_poly, or thresholds of one degree-day pass
+    const int nplanes = xpow == XF_EDD ? pv.n_thr : nfuse;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
     pv.ucell = d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
@@ -1033,7 +1073,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     int64_t kpstride = pstride;
     if (via_ws) {
         ldws = (Ttot + 63) / 64 * 64;
-        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nfuse, stream));
+        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nplanes, stream));
         ws = static_cast<T *>(wsbuf.p);
         kout = ws;
         kldo = ldws;
@@ -1119,7 +1159,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         }
         pv.n_groups = d.g0_normal;          // what is left for the chunk-walking kernel: giant groups
     }
-    for (int pz = 0; pz < nfuse; ++pz) {      // per power: giant groups, transpose, empty regions
+    pv.thr_pstride = kpstride;
+    for (int pz = 0; pz < nfuse; ++pz) {      // per power: the groups the kernels above left over (giant ones)
     if (nfuse > 1) pv.xpow = pz + 1;
     if (pv.n_groups > 0) {
         const int64_t nblk = (int64_t)pv.n_groups * n_tb;
@@ -1129,7 +1170,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
 #define WAGG_LAUNCH(L, O, V)                                                                    \
         do {                                                                                     \
             auto kern = sparse_gather_kernel<T, TB, L, O, V>;                                    \
-            if (const char *dbg_ = getenv("WAGG_SPARSE_DBG")) {                                  \
+            if (xpow == XF_EDD && pv.n_thr > 1) kern = sparse_gather_kernel<T, TB, L, O, V, 0, 4>; \
+            else if (const char *dbg_ = getenv("WAGG_SPARSE_DBG")) {                                  \
                 switch (atoi(dbg_)) {                                                            \
                     case 1: kern = sparse_gather_kernel<T, TB, L, O, V, 1>; break;               \
                     case 2: kern = sparse_gather_kernel<T, TB, L, O, V, 2>; break;               \
@@ -1151,6 +1193,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
 #undef WAGG_LAUNCH
         WAGG_HIP(hipGetLastError());
     }
+    }
+    for (int pz = 0; pz < nplanes; ++pz) {    // per plane: transpose, regions without any kept row
     if (via_ws) {
         dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
         hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws + (int64_t)pz * kpstride, ldws,
@@ -1589,9 +1633,9 @@ static int apply_edd(const wagg_plan *plan, const T *tmin, const T *tmax, int64_
     const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : (int64_t)plan->info.R;
     WAGG_REQUIRE(n_thr == 1 || out_pstride >= orows * ldo, "out_pstride %lld overlaps the previous threshold",
                  (long long)out_pstride);
-    for (int i = 0; i < n_thr && rc == WAGG_OK; ++i)
+    for (int i = 0; i < n_thr && rc == WAGG_OK; i += 4)         // both fields are read once per four thresholds
         rc = launch_sparse<T, TB>(plan, tmin, Tn, ldx, layout, out + (int64_t)i * out_pstride, ldo, out_layout, st,
-                                  (T)offset, XF_EDD, 1, 0, tmax, (T)thr[i]);
+                                  (T)offset, XF_EDD, 1, out_pstride, tmax, thr + i, n_thr - i < 4 ? n_thr - i : 4);
     return rc;
 }
 }  // namespace wagg

@@ -84,7 +84,7 @@ def one_case(i, rng):
     elif kind == 1:                                                                   # degree days
         half = rng.uniform(0, 8, X.shape).astype(dtype)
         lo, hi = X - half, X + half
-        thr = [float(rng.uniform(5, 35)) for _ in range(int(rng.integers(1, 3)))]
+        thr = [float(rng.uniform(5, 35)) for _ in range(int(rng.integers(1, 7)))]        # 1..6: passes of four + a rest
         ge = plan.apply_edd(dev(lo), dev(hi), thr, offset=-273.15, layout=layout, out_layout=out_layout).cpu().numpy()
         ft = dtype
         for k, e in enumerate(thr):
