@@ -13,7 +13,8 @@ What it restates (reference = /root/reference, read as text; it cannot be import
   (:64-66 labels, :69-71 weights, :73 backup fill, :75-82 grouped sums and the division)
 * ``weighted_aggregate_grid_to_regions``    aggregations.py:87-124 (:121-122 = the two above)
 
-PARITY STATUS: the reference's own tests (tests/test_climate_toolbox.py:109-135) pin shapes and
+PARITY STATUS -- "parity unpinned" in the strict sense (no number produced by the reference
+exists for this path): the reference's own tests (tests/test_climate_toolbox.py:109-135) pin shapes and
 "no NaN" only, never a number, and the reference cannot run here.  The numbers are therefore
 pinned by (1) the semantics list S1-S12 of SURVEY.md section 8a, (2) three *independent*
 restatements below that must agree to 1e-12 on the reference's own test fixture (legacy-RNG

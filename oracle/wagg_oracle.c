@@ -11,7 +11,8 @@
  *     :77-80  numerator / denominator (IEEE division, no guard)
  * Label resolution (:27 exact match), backup fill (:73) and label factorisation happen on the
  * host before this point, exactly as for the HIP engine (see oracle/ref_numpy.py for those).
- * Parity status: see the header of oracle/ref_numpy.py ("pinned by restatement agreement").
+ * Parity status: "parity unpinned" in the strict sense (no reference-produced number exists); see
+ * the header of oracle/ref_numpy.py for what pins the numbers instead (restatement agreement).
  */
 #include <math.h>
 #include <stdint.h>
