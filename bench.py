@@ -131,6 +131,9 @@ def main():
     force_dist = os.environ.get("WAGG_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
     if use_dist:
+        # stdout carries exactly one line (the JSON below): keep RCCL's version banner off it
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ.pop("NCCL_DEBUG")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -289,7 +292,7 @@ def main():
             line["config"]["plan"] = main_res["plan"]
         if secondary:
             line["secondary"] = secondary
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
