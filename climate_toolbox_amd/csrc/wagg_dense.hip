@@ -66,8 +66,9 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // are all distinct within each group.
 //
 // DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
-// of the k-loop, bit2 = skip the per-tile barrier, bit4 = X pieces before the W pieces.  Results are wrong
-// with bit0 or bit2 set.
+// of the k-loop, bit2 = skip the per-tile barrier, bit3 = both waves of a SIMD issue their DMA
+// pieces at the same point, bit4 = X pieces before the W pieces.  Results are wrong with bit0 or
+// bit2 set.
 //
 // TILED (tile-sparse W, e.g. c5 "block-local" weights): only the non-empty (32-cell x 256-region)
 // tiles of W are stored, compacted per column tile; tile_kt[i] is the k-tile (= X tile) of stored
