@@ -28,7 +28,10 @@ class DataArray:
 
     @property
     def values(self):
-        return np.asarray(self._values)
+        v = self._values
+        if type(v).__module__.startswith("torch"):      # a device-resident buffer: copy out on demand
+            return v.detach().cpu().numpy()
+        return np.asarray(v)
 
     @property
     def shape(self):

@@ -54,7 +54,12 @@ def remove_leap_days(ds):
         out.coords[k] = minixr.DataArray(np.asarray(c.values)[keep], c.dims) if c.dims == ("time",) else c
     for k, v in ds.data_vars.items():
         if "time" in v.dims:
-            raw = np.compress(keep, np.asarray(v._values), axis=v.dims.index("time"))
+            if type(v._values).__module__.startswith("torch"):          # device-resident buffer
+                import torch
+                raw = v._values.index_select(v.dims.index("time"),
+                                             torch.from_numpy(np.flatnonzero(keep)).to(v._values.device))
+            else:
+                raw = np.compress(keep, np.asarray(v._values), axis=v.dims.index("time"))
             if isinstance(v, minixr.LazyArray):
                 out.data_vars[k] = minixr.LazyArray(raw, v.dims, lon_perm=v._lon_perm, xform=v._xform, name=k,
                                                     attrs=v.attrs)

@@ -749,3 +749,30 @@ def test_dropin_any_dim_order_and_label_types(torch_cuda, dims):
         if d != "hierid":
             np.testing.assert_array_equal(out[d].values, coords[d])
     _rel_ok(out.tas.values, ref, RTOL64)
+
+
+def test_dropin_accepts_device_resident_fields(torch_cuda):
+    """A variable whose buffer is a torch CUDA tensor is aggregated in place (no PCIe copy) -- also
+    through the lazy standardize / tas_poly wrappers and for a layout that needs a transpose."""
+    from climate_toolbox_amd import minixr, standardize_climate_data, tas_poly, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    lat, lon = np.arange(-29.5, 30, 1.0), np.arange(0.5, 120, 1.0)
+    time = np.arange("2000-02-01", "2000-04-01", dtype="datetime64[D]")        # holds a 29 February
+    tas = (288 + 6 * rng.standard_normal((len(time), len(lat), len(lon)))).astype(np.float32)
+    leap = int(np.flatnonzero(time == np.datetime64("2000-02-29"))[0])
+    n = 1500
+    for dims, order in ((("time", "lat", "lon"), (0, 1, 2)), (("lat", "time", "lon"), (1, 0, 2))):
+        dev = torch.from_numpy(np.ascontiguousarray(tas.transpose(order))).cuda()
+        ds = minixr.Dataset({"tas": (dims, dev)}, coords={"time": time, "lat": lat, "lon": lon})
+        ds = standardize_climate_data(ds)
+        ref_grid, ref_lon = O.convert_lons_split(np.delete(tas, leap, axis=0), ("time", "lat", "lon"), lon)
+        df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(ref_lon, n), "areawt": rng.uniform(0.1, 1, n),
+                           "hierid": rng.integers(0, 60, n)})
+        ref, _, labs = O.agg_scatter(O.tas_poly_values(ref_grid, 2), ("time", "lat", "lon"), lat, ref_lon,
+                                     df["lat"].values, df["lon"].values, df["areawt"].values, df["areawt"].values,
+                                     df["hierid"].values, group_dim="hierid")
+        out = weighted_aggregate_grid_to_regions(tas_poly(ds, 2, "t2"), "t2", "areawt", "hierid", df)
+        got = out.t2.values if dims[0] == "time" else np.moveaxis(out.t2.values, 0, 1)
+        _rel_ok(got, ref, RTOL32, scale=1.0)
