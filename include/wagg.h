@@ -190,7 +190,9 @@ int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);
 int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
 /* out[t, r] = sum_g nan0(X[t,g]) * W[g,r] / den[r], fp32 MFMA (v_mfma_f32_16x16x4_f32).
- * ksplit = 0 picks the k-slice count; otherwise a multiple of 8.                               */
+ * ksplit = 0 picks the k-slice count; otherwise a multiple of 8.  The plan owns the packed copy of
+ * X and the partial-sum slabs of an apply (hence the non-const handle): applies on ONE dense plan
+ * must be ordered on one stream; different plans are independent.                               */
 int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                          float *out_dev, int64_t ldo, int ksplit, void *stream);
 
