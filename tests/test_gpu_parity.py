@@ -776,3 +776,31 @@ def test_dropin_accepts_device_resident_fields(torch_cuda):
         out = weighted_aggregate_grid_to_regions(tas_poly(ds, 2, "t2"), "t2", "areawt", "hierid", df)
         got = out.t2.values if dims[0] == "time" else np.moveaxis(out.t2.values, 0, 1)
         _rel_ok(got, ref, RTOL32, scale=1.0)
+
+
+def test_integration_md_binding_runs_as_written(torch_cuda):
+    """The ctypes stub INTEGRATION.md proposes for the reference (section 2) is executed verbatim
+    against libwagg.so and checked against the oracle."""
+    import re
+    from climate_toolbox_amd import _lib
+    from oracle import ref_numpy as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# climate_toolbox/aggregations/_wagg.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libwagg.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    _lib.load()                                             # torch's HIP runtime first, like the product
+    ns = {}
+    exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    rng = np.random.default_rng(12)
+    lat, lon = np.arange(-10.0, 10.0, 1.0), np.arange(100.0, 130.0, 1.0)
+    vals = rng.standard_normal((6, len(lat) * len(lon)))
+    n = 300
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "popwt": np.where(rng.random(n) < 0.3, np.nan, rng.uniform(0, 2, n)),
+                       "ISO": rng.integers(0, 9, n)})
+    out, labels = ns["aggregate"](np.ascontiguousarray(vals), lat, lon, df, "popwt", "ISO")
+    ref, _, labs = O.agg_scatter(vals.reshape(6, len(lat), len(lon)), ("time", "lat", "lon"), lat, lon,
+                                 df["lat"].values, df["lon"].values, df["popwt"].values, df["areawt"].values,
+                                 df["ISO"].values, group_dim="ISO")
+    assert list(labels) == list(labs)
+    _rel_ok(out, ref, RTOL64)
