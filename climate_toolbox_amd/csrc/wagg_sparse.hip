@@ -642,8 +642,8 @@ struct LcLds {
 };
 
 // NPOW > 1 (fused tas_poly): the loaders park y = x + pv.xoff; the consumers raise each
-// fragment to the powers 1..NPOW in registers and keep NPOW accumulator sets, so X is read from HBM
-// once for all powers; power p is stored at out + (p - 1) * out_pstride.  A chunk whose |y| could
+// fragment to the powers pv.xpow .. pv.xpow + NPOW - 1 in registers and keep NPOW accumulator sets,
+// so X is read from HBM once for NPOW powers; the i-th of them is stored at out + i * out_pstride.  A chunk whose |y| could
 // overflow fp32 at the highest power (or holds +-inf) takes the exact path, like +-inf data does.
 template <bool VEC, int NPOW = 1>
 __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
@@ -915,6 +915,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 pw = af[g4 & 1];
+                        if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) pw = pw * af[g4 & 1];   // first power of this pass
 #pragma unroll
                         for (int pp = 0; pp < NPOW; ++pp) {
                             if (pp > 0) pw = pw * af[g4 & 1];          // y^(pp+1), transformations.py:188
@@ -962,6 +963,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     for (int q = s0; q < s1; ++q) {
                         const float y = im[lane * UROW + (sm_u[buf * LC_SEGS + q] & 0xff)], w = sm_w[buf * LC_SEGS + q];
                         float yp = y;
+                        if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) yp *= y;
 #pragma unroll
                         for (int pp = 0; pp < NPOW; ++pp) {
                             if (pp > 0) yp *= y;
@@ -1026,17 +1028,17 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
                          int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, const double *thr = nullptr,
                          int n_thr = 0) {
-    // nfuse > 1: powers 1..nfuse of (x + xoff) in one pass over X (fused tas_poly); power p goes to
-    // out + (p - 1) * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
+    // nfuse > 1: powers xpow .. xpow + nfuse - 1 of (x + xoff) in one pass over X (fused tas_poly);
+    // the i-th goes to out + i * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
     const auto &d = plan->d;
     if (nfuse > 1) {
         const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM") &&
                            !getenv("WAGG_SPARSE_NO_LC") && (int)plan->info.n_groups - d.g0_normal > 0 && Ttot > 0;
         if (!lc_ok || nfuse > 4) {
-            for (int p = 1; p <= nfuse; ++p) {
-                const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)(p - 1) * pstride, ldo,
-                                                    out_layout, stream, xoff, p);
+            for (int i = 0; i < nfuse; ++i) {
+                const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
+                                                    out_layout, stream, xoff, xpow + i);
                 if (rc != WAGG_OK) return rc;
             }
             return WAGG_OK;
@@ -1099,7 +1101,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
             if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
             // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
-            const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)nfuse) : 0.f;
+            const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)(xpow + nfuse - 1)) : 0.f;
             WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LcLds::total));
             unsigned long long *lc_stamps = nullptr;
             if (getenv("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
@@ -1161,7 +1163,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     }
     pv.thr_pstride = kpstride;
     for (int pz = 0; pz < nfuse; ++pz) {      // per power: the groups the kernels above left over (giant ones)
-    if (nfuse > 1) pv.xpow = pz + 1;
+    if (nfuse > 1) pv.xpow = xpow + pz;
     if (pv.n_groups > 0) {
         const int64_t nblk = (int64_t)pv.n_groups * n_tb;
         WAGG_REQUIRE(nblk < (int64_t)0x7fffffff, "grid too large: %lld", (long long)nblk);
@@ -1566,14 +1568,11 @@ static int apply_poly(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : (int64_t)plan->info.R;
     WAGG_REQUIRE(n_pow == 1 || out_pstride >= orows * ldo, "out_pstride %lld overlaps the previous power",
                  (long long)out_pstride);
-    int done = 0;
-    if (pow_first == 1 && n_pow > 1) {                        // one pass over X for powers 1..4
-        done = n_pow < 4 ? n_pow : 4;
-        rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out, ldo, out_layout, st, (T)offset, 1, done, out_pstride);
-    }
-    for (int i = done; i < n_pow && rc == WAGG_OK; ++i)
+    for (int i = 0; i < n_pow && rc == WAGG_OK; i += 4) {     // one pass over X per four powers
+        const int n = n_pow - i < 4 ? n_pow - i : 4;
         rc = launch_sparse<T, TB>(plan, X, Tn, ldx, layout, out + (int64_t)i * out_pstride, ldo, out_layout, st,
-                                  (T)offset, pow_first + i);
+                                  (T)offset, pow_first + i, n, out_pstride);
+    }
     return rc;
 }
 

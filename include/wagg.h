@@ -132,8 +132,8 @@ int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, 
  * p = pow_first .. pow_first + n_pow - 1 in ONE call:
  *   out_p[t, r] = sum_i (X[t, cell_i] + offset)^p * w_eff[i] / den[r].
  * The transform is evaluated in the data type while X is loaded (NaN stays NaN and is skipped
- * like any NaN product, S6), so the transformed grids are never written to memory; with
- * pow_first = 1, fp32 (time, gridcell) data is read from HBM once for up to four powers.  The i-th
+ * like any NaN product, S6), so the transformed grids are never written to memory; fp32
+ * (time, gridcell) data is read from HBM once per four consecutive powers.  The i-th
  * power is stored at out_dev + i * out_pstride (elements) with leading dimension ldo.  Powers must
  * lie in [1, 16]. */
 int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,

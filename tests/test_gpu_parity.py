@@ -522,6 +522,13 @@ def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layo
     for p in range(1, 5):
         ref = O.agg_coded(O.tas_poly_values(X, p), cell, code, w, Rn)
         _rel_ok(got[p - 1], ref, RTOL32 if dtype == np.float32 else RTOL64, scale=1.0)
+    # powers 3..8 (two fused passes that start above 1 where the loader/consumer kernel applies)
+    Xs = np.where(np.isfinite(X), np.clip(X, 273.15 - 3, 273.15 + 3), X).astype(dtype)     # |y| <= 3: y^8 stays tame
+    Xsd = torch.from_numpy(Xs if layout == "TG" else np.ascontiguousarray(Xs.T)).cuda()
+    hi = plan.apply_poly(Xsd, -273.15, 6, layout=layout, pow_first=3).cpu().numpy()
+    for i, p in enumerate(range(3, 9)):
+        _rel_ok(hi[i], O.agg_coded(O.tas_poly_values(Xs, p), cell, code, w, Rn),
+                RTOL32 if dtype == np.float32 else RTOL64, scale=1.0)
     # power 1 with offset 0 is the plain aggregation
     np.testing.assert_array_equal(plan.apply_poly(Xd, 0.0, 1, layout=layout)[0].cpu().numpy(),
                                   plan.apply(Xd, layout=layout).cpu().numpy())
