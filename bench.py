@@ -155,12 +155,12 @@ def main():
         plan = engine.SparsePlan(cell, codes, w_eff, G, len(uniq), row_len=a.nlon)
         Xs = X if dtype == "float32" else X.double()
         out = torch.empty((T, len(uniq)), dtype=Xs.dtype, device="cuda")
-        gathered = [None]
+        gathered = [torch.empty((T * world, len(uniq)), dtype=Xs.dtype, device="cuda") if use_dist and rank == 0 else None]
 
         def step():
             plan.apply(Xs, out=out)
             if use_dist:
-                gathered[0] = gather_time_shards(out, dst=0)
+                gather_time_shards(out, dst=0, out=gathered[0])
 
         engine.profile_enable(True)       # event records only, no synchronisation
         dt = timed_steps(torch, dist, step, a.steps, a.warmup, world)
@@ -202,12 +202,12 @@ def main():
     def run_dense():
         dense = engine.DensePlan.synth(G, R, seed=2)
         out = torch.empty((T, R), dtype=torch.float32, device="cuda")
-        gathered = [None]
+        gathered = [torch.empty((T * world, R), dtype=torch.float32, device="cuda") if use_dist and rank == 0 else None]
 
         def step():
             dense.apply(X, out=out, ksplit=a.ksplit)
             if use_dist:
-                gathered[0] = gather_time_shards(out, dst=0)
+                gather_time_shards(out, dst=0, out=gathered[0])
 
         engine.profile_enable(True)       # event records only (no sync): negligible next to 0.1 s
         dt = timed_steps(torch, dist, step, a.steps, a.warmup, world)

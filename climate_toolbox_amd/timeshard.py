@@ -19,10 +19,12 @@ def shard_bounds(T, world):
     return out
 
 
-def gather_time_shards(out_local, dst=0, rows=None, group=None):
+def gather_time_shards(out_local, dst=0, rows=None, group=None, out=None):
     """Gather per-rank (T_rank, R) blocks on `dst`; returns the (sum T_rank, R) tensor there and
     None elsewhere.  `rows` = per-rank row counts when they differ (ragged shards are padded to
-    the largest block for the collective and trimmed on arrival)."""
+    the largest block for the collective and trimmed on arrival).  With equal blocks, `out` (a
+    contiguous (world * T_rank, R) tensor on `dst`) receives the blocks in place: no temporaries,
+    no concatenation."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -37,6 +39,11 @@ def gather_time_shards(out_local, dst=0, rows=None, group=None):
         block = torch.zeros((mx,) + tuple(out_local.shape[1:]), dtype=out_local.dtype, device=out_local.device)
         block[: out_local.shape[0]] = out_local
     block = block.contiguous()
+    if rank == dst and out is not None and all(n == mx for n in rows):
+        if tuple(out.shape) != (world * mx,) + tuple(block.shape[1:]) or not out.is_contiguous() or out.dtype != block.dtype:
+            raise ValueError("out must be a contiguous %r tensor" % (((world * mx,) + tuple(block.shape[1:])),))
+        dist.gather(block, gather_list=[out[i * mx:(i + 1) * mx] for i in range(world)], dst=dst, group=group)
+        return out
     if rank == dst:
         parts = [torch.empty_like(block) for _ in range(world)]
         dist.gather(block, gather_list=parts, dst=dst, group=group)
