@@ -406,14 +406,12 @@ def _xforms(ds):
 # the reference's functions
 # ----------------------------------------------------------------------------------------------
 def _reindex_spatial_data_to_regions(ds, df):
-    """
-    Reindexes spatial and segment weight data to regions
-    Enables region index-based math operations
+    """Drop-in for aggregations.py:8-32.
 
-    Same contract as aggregations.py:8-32: every segment row ``i`` of ``df`` picks the grid cell
-    with ``lat == df.lat[i]`` and ``lon == df.lon[i]`` (exact match, KeyError otherwise); the new
-    dimension ``reshape_index`` replaces the first of the two indexed dims.  Returns a lazy
-    :class:`ReindexedDataset` (no gathered copy is made).
+    Every row ``i`` of the segment table ``df`` selects the grid cell whose labels equal
+    ``df.lat[i]`` / ``df.lon[i]`` exactly (``KeyError`` when a label is not on the grid); the new
+    ``reshape_index`` dimension takes the place of the first of the two indexed dims.  What comes
+    back is a lazy :class:`ReindexedDataset`: the cell index of every row, no gathered copy.
     """
     src_values, src_dims, coords, was_xr = _extract(ds)
     if "lat" not in coords or "lon" not in coords:
@@ -545,70 +543,36 @@ def _as_dataset(data_vars, rdims, coords, was_xr):
 def _aggregate_reindexed_data_to_regions(
     ds, variable, aggwt, agglev, weights, backup_aggwt="areawt"
 ):
-    """
-    Performs weighted avg for climate variable by region
+    """Drop-in for aggregations.py:35-84: the weighted regional mean of one variable.
 
-    Parameters
-    ----------
+    ds            what ``_reindex_spatial_data_to_regions`` returned (or any Dataset that already has
+                  a ``reshape_index`` dimension)
+    variable      data variable to average
+    aggwt         weights column of ``weights`` (popwt, areawt, cropwt, ...)
+    agglev        column of ``weights`` holding the region label of each segment row
+    weights       the segment table (pandas DataFrame)
+    backup_aggwt  column that stands in, row by row, wherever ``aggwt`` is not > 0
 
-    ds: ReindexedDataset (from ``_reindex_spatial_data_to_regions``) or any Dataset that already
-        carries a ``reshape_index`` dimension
-
-    variable: str
-        name of the data variable
-
-    aggwt: str
-        variable to weight by (i.e popwt, areawt, cropwt)
-
-    agglev: str
-        indicates which regional id scheme to select in the dataframe
-
-    weights: pd.DataFrame
-        pandas DataFrame of weights
-
-    backup_aggwt: str, optional
-        aggregation weight to use in regions with no aggwt data (default
-        'areawt')
-
-    Follows aggregations.py:64-82.  ``w_eff = w if w > 0 else backup`` per ROW (:73, S4), regions
-    are the sorted unique labels (:78, S3), ``out = sum(x*w_eff) / sum(w_eff)`` with NaN products
-    counted as 0 (S6) and IEEE division (S7).  Like the reference it also attaches ``agglev``
-    and ``aggwt`` to ``ds`` (:64-71).
+    ``w_eff = w if w > 0 else backup`` per ROW (:73, S4); regions are the sorted unique labels
+    (:78, S3); ``out = sum(x * w_eff) / sum(w_eff)`` with NaN products counted as 0 (S6) and IEEE
+    division (S7).  Like the reference it also attaches ``agglev`` and ``aggwt`` to ``ds`` (:64-71).
     """
     res, rdims, coords, was_xr = _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt)
     return _as_dataset({variable: res}, rdims, coords, was_xr)
 
 
 def weighted_aggregate_grid_to_regions(ds, variable, aggwt, agglev, weights=None):
-    """
-    Computes the weighted reshape of gridded data
+    """Drop-in for aggregations.py:87-124: gridded variable -> weighted regional means.
 
-    Parameters
-    ----------
-    ds : xr.Dataset (or minixr.Dataset)
-        Dataset to be aggregated. Must have 'lat' and 'lon' in the
-        coordinates.
+    ds        Dataset (xarray, or minixr here) with ``lat`` and ``lon`` coordinates
+    variable  which data variable to aggregate
+    aggwt     weighting column of the weights table, e.g. ``popwt`` or ``areawt``
+    agglev    region-label column of the weights table, e.g. ``ISO`` or ``hierid``
+    weights   the segment-weights DataFrame, or the path of its CSV.  As in the reference
+              (:118-119 vs :128) leaving it out cannot work -- no weights file is bundled -- and
+              raises TypeError.
 
-    variable : str
-        name of the variable to be aggregated
-
-    aggwt : str
-        Weighting variable (e.g. 'popwt', 'areawt'). This must be a column name
-        in the weights file.
-
-    agglev : str
-        Target regional aggregation level (e.g. 'ISO', 'hierid'). This must be
-        a column name in the weights file.
-
-    weights : pd.DataFrame (or str path to the weights CSV), optional
-        Regional aggregation weights.  As in the reference (aggregations.py:118-119 vs :128)
-        the ``None`` default cannot work -- there is no bundled weights file -- and raises
-        TypeError.
-
-    Returns
-    -------
-    ds: Dataset
-        weighted and averaged dataset based on agglev
+    Returns a Dataset holding ``variable`` on ``agglev`` (plus the dims that were carried through).
     """
     if weights is None:
         weights = prepare_spatial_weights_data()          # TypeError, like the reference
@@ -623,18 +587,12 @@ def weighted_aggregate_grid_to_regions(ds, variable, aggwt, agglev, weights=None
 
 @functools.lru_cache(maxsize=None)   # the reference memoises on the path (toolz.memoize, :127)
 def prepare_spatial_weights_data(weights_file):
-    """
-    Rescales the pix_cent_x colum values
+    """Drop-in for aggregations.py:127-152: load the segment-weights CSV at ``weights_file``.
 
-    Parameters
-    ----------
-    weights_file: str
-        location of file used for weighting
-
-    Mirrors aggregations.py:141-150: read the CSV, relabel pixel centres at 180.125 to -179.875
-    (:144), name the index ``reshape_index`` (:148), rename ``pix_cent_x/y`` to ``lon/lat``
-    (:150).  The reference's ``drop_duplicates()`` result is discarded (:147), so duplicates are
-    kept here too (they add, S5).
+    Pixel centres labelled 180.125 are relabelled -179.875 (:144), the index is named
+    ``reshape_index`` (:148), ``pix_cent_x/y`` become ``lon/lat`` (:150).  The reference's
+    ``drop_duplicates()`` result is discarded (:147), so duplicates are kept here too (they add, S5).
+    Memoised like the reference (``toolz.memoize``, :127).
     """
     df = pd.read_csv(weights_file)
     import ctypes as C

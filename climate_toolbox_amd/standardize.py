@@ -41,16 +41,12 @@ def _is_xarray(ds):
 
 def rename_coords_to_lon_and_lat(ds):
     """utils.py:43-57: latitude -> lat; longitude (or long) -> lon; drop ``z`` and squeeze."""
-    if _is_xarray(ds):
-        if "latitude" in ds.coords:
-            ds = ds.rename({"latitude": "lat"})
-        if "longitude" in ds.coords:
-            ds = ds.rename({"longitude": "lon"})
-        elif "long" in ds.coords:
-            ds = ds.rename({"long": "lon"})
-        if "z" in ds.coords:
-            ds = ds.drop_vars("z").squeeze()
-        return ds
+    if _is_xarray(ds):                                         # xarray present: its own rename/drop
+        names = {"latitude": "lat", "longitude": "lon"}
+        if "longitude" not in ds.coords:
+            names["long"] = "lon"
+        ds = ds.rename({k: v for k, v in names.items() if k in ds.coords})
+        return ds.drop_vars("z").squeeze() if "z" in ds.coords else ds
     ren = {}
     if "latitude" in ds.coords:
         ren["latitude"] = "lat"
@@ -112,23 +108,16 @@ def _relabel_sorted(ds, lon_name, relabel):
 
 
 def convert_lons_split(ds, lon_name="longitude"):
-    """Convert longitude from 0-360 to -180-180 (utils.py:33-40), lazily along ``lon``."""
+    """Drop-in for utils.py:33-40 (0..360 labels -> -180..180, ascending), lazily along ``lon``."""
     return _relabel_sorted(ds, lon_name, lambda v: (v + 180) % 360 - 180)
 
 
 def convert_lons_mono(ds, lon_name="longitude"):
-    """Convert longitude from -180-180 to 0-360 (utils.py:23-30), lazily along ``lon``."""
+    """Drop-in for utils.py:23-30 (-180..180 labels -> 0..360, ascending), lazily along ``lon``."""
     return _relabel_sorted(ds, lon_name, lambda v: v % 360)
 
 
 def standardize_climate_data(ds):
-    """
-    Read climate data and standardize units to:
-        - lon and lat,
-        - lon to -180 to 180 and
-
-    Same contract as io/io.py:6-24; no data is moved (see the module docstring).
-    """
-    ds = rename_coords_to_lon_and_lat(ds)
-    ds = convert_lons_split(ds, lon_name="lon")
-    return ds
+    """Drop-in for io/io.py:6-24: coordinate names become ``lat`` / ``lon`` and the longitudes run
+    from -180 to 180 in ascending order.  No data is moved (see the module docstring)."""
+    return convert_lons_split(rename_coords_to_lon_and_lat(ds), lon_name="lon")

@@ -100,14 +100,10 @@ def _describe(power):
 
 
 def tas_poly(ds, power, varname):
-    """
-    Daily average temperature (degrees C), raised to a power
+    """Drop-in for transformations.py:160-208: ``(tas - 273.15) ** power`` as variable ``varname``,
+    29 February dropped, ``time`` relabelled to YYYYDDD integers (at most 365 days per call).
 
-    Leap years are removed before counting days (uses a 365 day
-    calendar).
-
-    Same contract as transformations.py:160-208; the returned variable is lazy (see the module
-    docstring) and ``.values`` evaluates it on demand.
+    The returned variable is lazy (see the module docstring); ``.values`` evaluates it on demand.
     """
     if int(power) != power or power < 1:
         raise ValueError("power must be a positive integer, got %r" % (power,))
@@ -180,28 +176,21 @@ def _degree_days(tasmin, tasmax, terms, units):
 
 
 def snyder_edd(tasmin, tasmax, threshold):
-    r"""
-    Snyder exceedance degree days/cooling degree days
-
-    Same contract as transformations.py:7-93 (tasmin, tasmax: daily minimum / maximum temperature,
-    degrees C, as DataArrays of one Dataset; threshold in degrees C).  The result is a lazy
-    variable: assign it to a Dataset and hand that to ``weighted_aggregate_grid_to_regions`` -- the
-    degree days are evaluated on the GPU while both fields are loaded (``wagg_apply_edd_*``);
-    ``.values`` materialises the grid on demand.
+    """Drop-in for transformations.py:7-93: degree days above ``threshold`` of the sinusoid through
+    the daily (tasmin, tasmax) pair -- both DataArrays of one Dataset, in degrees C like the
+    threshold.  The result is a lazy variable: assign it to a Dataset and hand that to
+    ``weighted_aggregate_grid_to_regions`` -- the degree days are evaluated on the GPU while both
+    fields are loaded (``wagg_apply_edd_*``); ``.values`` materialises the grid on demand.
     """
-    # Check for unit agreement
-    assert _units(tasmin) == _units(tasmax)
+    assert _units(tasmin) == _units(tasmax)                    # :56, same units on both fields
     return _degree_days(tasmin, tasmax, [(1.0, float(threshold))],
                         "degreedays_{}{}".format(threshold, _units(tasmax)))
 
 
 def snyder_gdd(tasmin, tasmax, threshold_low, threshold_high):
-    r"""
-    Snyder growing degree days: EDD(threshold_low) - EDD(threshold_high)
-    (transformations.py:96-144).  Lazy like :func:`snyder_edd`; the aggregation of the difference is
-    the difference of the two aggregations.
+    """Drop-in for transformations.py:96-144: EDD(threshold_low) - EDD(threshold_high).  Lazy like
+    :func:`snyder_edd`; the aggregation of the difference is the difference of the two aggregations.
     """
-    # Check for unit agreement
-    assert _units(tasmin) == _units(tasmax)
+    assert _units(tasmin) == _units(tasmax)                    # :133
     return _degree_days(tasmin, tasmax, [(1.0, float(threshold_low)), (-1.0, float(threshold_high))],
                         "degreedays_{}-{}{}".format(threshold_low, threshold_high, _units(tasmax)))
