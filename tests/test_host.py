@@ -288,3 +288,22 @@ def test_tas_poly_removes_leap_day_and_rejects_long_years():
                              coords={"time": time, "lat": np.zeros(1), "lon": np.zeros(1)})
     with pytest.raises(ValueError):
         tas_poly(long_ds, 2, "p2")
+
+
+def test_to_netcdf_round_trip(tmp_path):
+    """region time series with string region labels, YYYYDDD time and attrs survive a
+    NetCDF-3 round trip."""
+    from climate_toolbox_amd import minixr
+    from climate_toolbox_amd.output import read_netcdf, to_netcdf
+    rng = np.random.default_rng(0)
+    labels = np.array(["USA.1.2", "CAN.10", "é-région"], dtype=object)
+    vals = rng.standard_normal((4, 3)).astype(np.float32)
+    ds = minixr.Dataset({"tas-poly-2": (("time", "hierid"), vals)},
+                        coords={"time": 2001000 + np.arange(1, 5), "hierid": labels})
+    ds["tas-poly-2"].attrs = {"units": "C^2", "variable": "tas-poly-2"}
+    path = to_netcdf(ds, str(tmp_path / "out.nc"))
+    back = read_netcdf(path)
+    np.testing.assert_array_equal(back["tas-poly-2"].values, vals)
+    assert back["tas-poly-2"].dims == ("time", "hierid") and back["tas-poly-2"].attrs["units"] == "C^2"
+    np.testing.assert_array_equal(back.time.values, 2001000 + np.arange(1, 5))
+    assert list(back.hierid.values) == list(labels)
