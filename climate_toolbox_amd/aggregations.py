@@ -352,12 +352,18 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
     key = h.hexdigest()
     plan = _PLAN_CACHE.get(key)
     if plan is None:
-        plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
         import torch
         free_bytes = torch.cuda.mem_get_info()[0]
-        if _prefer_dense(plan.info["n_ucells"], G, R, is_f32, layout, free_bytes):
-            plan.close()
+        # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
+        # form: go to the dense / tile-sparse form directly instead of building the sparse plan
+        # first just to read its statistics
+        if len(cell_idx) > 4 * DENSE_SWITCH * G and _prefer_dense(float("inf"), G, R, is_f32, layout, free_bytes):
             plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
+        else:
+            plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
+            if _prefer_dense(plan.info["n_ucells"], G, R, is_f32, layout, free_bytes):
+                plan.close()
+                plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
         _PLAN_CACHE[key] = plan
         while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
             _PLAN_CACHE.popitem(last=False)[1].close()
