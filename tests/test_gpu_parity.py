@@ -811,3 +811,38 @@ def test_integration_md_binding_runs_as_written(torch_cuda):
                                  df["ISO"].values, group_dim="ISO")
     assert list(labels) == list(labs)
     _rel_ok(out, ref, RTOL64)
+
+
+def test_c_abi_argument_errors_are_reported_not_crashed(torch_cuda):
+    """Every entry point returns a negative status with a message for bad arguments (no throw, no
+    exit, no launch): shapes, strides, ranges."""
+    import ctypes as C
+    from climate_toolbox_amd import _lib
+    from climate_toolbox_amd.engine import SparsePlan, DensePlan
+    torch = torch_cuda
+    L = _lib.load()
+    G, R = 100, 5
+    plan = SparsePlan(np.arange(50, dtype=np.int32), (np.arange(50) % R).astype(np.int32), np.ones(50), G, R)
+    X = torch.ones((4, G), dtype=torch.float32, device="cuda")
+    out = torch.empty((3, 4, R), dtype=torch.float32, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    def err(rc):
+        assert rc < 0
+        return L.wagg_last_error().decode()
+    assert "ldx" in err(L.wagg_apply_f32(plan._h, vp(X), 4, G - 1, 0, vp(out), R, 0, None))
+    assert "layout" in err(L.wagg_apply_f32(plan._h, vp(X), 4, G, 7, vp(out), R, 0, None))
+    assert "NULL" in err(L.wagg_apply_f32(None, vp(X), 4, G, 0, vp(out), R, 0, None)).upper()
+    assert "powers" in err(L.wagg_apply_poly_f32(plan._h, vp(X), 4, G, 0, 0.0, 1, 17, vp(out), R, 4 * R, 0, None))
+    assert "powers" in err(L.wagg_apply_poly_f32(plan._h, vp(X), 4, G, 0, 0.0, 0, 2, vp(out), R, 4 * R, 0, None))
+    assert "overlaps" in err(L.wagg_apply_poly_f32(plan._h, vp(X), 4, G, 0, 0.0, 1, 3, vp(out), R, R, 0, None))
+    thr = (C.c_double * 2)(10.0, 20.0)
+    assert "tasmax" in err(L.wagg_apply_edd_f32(plan._h, vp(X), None, 4, G, 0, 0.0, thr, 2, vp(out), R, 4 * R, 0, None))
+    assert "threshold" in err(L.wagg_apply_edd_f32(plan._h, vp(X), vp(X), 4, G, 0, 0.0, thr, 0, vp(out), R, 4 * R, 0, None))
+    h = C.c_void_p()
+    assert err(L.wagg_plan_create(None, None, None, 5, G, R, 0, 0, C.byref(h))) and not h.value
+    assert err(L.wagg_dense_create_synth(0, R, 1, C.byref(h))) and not h.value
+    dense = DensePlan.synth(64, 8, 1)
+    assert "ksplit" in err(L.wagg_dense_apply_f32(dense._h, vp(X), 4, 64, vp(out), 8, 3, None))
+    assert "ldx" in err(L.wagg_dense_apply_f32(dense._h, vp(X), 4, 63, vp(out), 8, 0, None))
+    # the plans are still usable afterwards
+    assert torch.isfinite(plan.apply(X)).all()
