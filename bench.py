@@ -104,6 +104,7 @@ def cpu_baseline_dense(T, G, R, seed_w):
 def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, T_sample):
     """The oracle's faithful single-threaded restatement (gather -> fp64 multiply -> group-sum ->
     divide, like the reference) on the first T_sample timesteps of the c2-real workload."""
+    import numpy as np
     from oracle import c_oracle
     c_oracle.segments(X_host[:1], cell, codes, w_eff, R)
     t0 = time.perf_counter()
@@ -111,7 +112,8 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, T_sample):
     dt = time.perf_counter() - t0
     return {"value": T_sample * G * R / dt, "unit": "gridcell-region-timesteps/s", "cores": 1, "kind": "port",
             "wall_s": round(dt, 3), "nnz_timesteps_per_s": T_sample * len(cell) / dt,
-            "sample": "oracle/wagg_oracle.c segments_f32, first %d of the timesteps, full segment table" % T_sample}
+            "sample": "oracle/wagg_oracle.c segments_%s, first %d of the timesteps, full segment table"
+                      % ("f32" if X_host.dtype == np.float32 else "f64", T_sample)}
 
 
 def main():
@@ -183,7 +185,7 @@ def main():
                          "algorithmic_bytes_per_launch": abytes},
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_sparse(X.cpu().numpy(), cell, codes, w_eff, Rr, G, min(T, 64))
+            res["cpu_baseline"] = cpu_baseline_sparse(Xs[:64].cpu().numpy(), cell, codes, w_eff, Rr, G, min(T, 64))
         if dtype == "float32" and world == 1:
             # fused tas_poly: (tas - 273.15)^p, p = 1..4, one pass over the field
             pout = torch.empty((4, T, Rr), dtype=Xs.dtype, device="cuda")
@@ -267,7 +269,8 @@ def main():
         secondary = []
         if world == 1 and not a.no_secondary:
             torch.cuda.empty_cache()
-            secondary.append(run_sparse("float32"))
+            secondary.append(run_sparse("float32"))          # c2-real: segment-table form, fp32, area weights
+            secondary.append(run_sparse("float64"))          # c3-real: fp64 data, pop weights with backup fill
     else:
         main_res = run_sparse("float32" if a.workload == "c2-real" else "float64")
         secondary = []
