@@ -1,22 +1,26 @@
-// Sparse path: coded segment table -> region-grouped gather plan -> one HIP kernel.
+// Sparse path: coded segment table -> region-grouped gather plan -> HIP kernels.
 //
 // Replaces aggregations.py:24-27 (gather) and :78-80 (grouped sums + division) of the reference
 // with   out[t,r] = sum_{i in r} X[t, cell_i] * w_i / den[r]   computed WITHOUT materialising
-// the (T x nseg) gathered copy.  Design (MI355X-first, HBM-bound):
+// the (T x nseg) gathered copy.  HBM-bound; what is in this file:
 //
-//   * host plan builder (below): coalesce duplicate (cell, region) rows, order regions along
-//     8-row latitude bands, pack neighbouring regions into GROUPS whose union of cells is at
-//     most UC=256 unique cells (one LDS "chunk"); regions larger than a chunk become "giant"
-//     groups that walk several chunks.
-//   * kernel: one 256-thread workgroup per (group, time block).  Thread u gathers the TB
-//     timesteps of unique cell u (consecutive lanes -> consecutive cells -> coalesced lines)
-//     with all TB loads in flight (64 KB of HBM requests per workgroup), parks them in an LDS
-//     image xs[u][t] (row stride TB+1 words: conflict-free for the lane-per-cell store and the
-//     lane-per-timestep read).  Then each wave owns one region at a time: lane = timestep, the
-//     segment list (u, w) is wave-uniform and comes through the scalar cache, one ds_read +
-//     one FMA per (segment, timestep).  The division by den[r] (aggregations.py:79-80) and the
-//     skipna rule (NaN product counts 0, S6) are fused; results are stored once, no atomics,
-//     bitwise reproducible.
+//   * host plan builder (wagg_plan_create): coalesce duplicate (cell, region) rows, order regions
+//     along 8-row latitude bands, pack neighbouring regions into GROUPS whose union of cells is at
+//     most 64 aligned 4-cell quads (UC = 256 cell slots: one LDS "chunk", one 16-byte load per
+//     quad and timestep); regions larger than a chunk become "giant" groups that walk several.
+//   * sparse_lc_kernel     fp32, (time, gridcell) data, single-chunk groups: 8 loader waves stream
+//                          items into a double-buffered LDS image, 4 consumer waves reduce them on
+//                          the matrix cores (up to four fused powers of the data per pass).
+//   * sparse_stream_kernel fp64 (and fp32 on request): persistent, software-pipelined, reduction by
+//                          v_readlane-broadcast segment lists.
+//   * sparse_gather_kernel the chunk-walking form: giant groups, (gridcell, time) data, two-field
+//                          degree-day transform (up to four thresholds per pass).
+//   * transpose / fill kernels for the (time, region) result layout and regions without rows.
+//
+// Common to all: the t-major LDS image xs[t][u] (row stride 260 elements), NaN products count 0
+// (S6), the division by den[r] (aggregations.py:79-80) is fused, results are stored once, no
+// atomics anywhere: bitwise reproducible.  DESIGN.md section (d) has the measurements behind the
+// shapes chosen here.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
