@@ -846,3 +846,36 @@ def test_c_abi_argument_errors_are_reported_not_crashed(torch_cuda):
     assert "ldx" in err(L.wagg_dense_apply_f32(dense._h, vp(X), 4, 63, vp(out), 8, 0, None))
     # the plans are still usable afterwards
     assert torch.isfinite(plan.apply(X)).all()
+
+
+def test_concurrent_applies_on_two_streams_share_one_plan(torch_cuda):
+    """include/wagg.h: a sparse plan is immutable, applies on distinct streams may overlap.  Two
+    streams aggregate different fields through one plan at the same time, many times over."""
+    from climate_toolbox_amd import synth
+    from climate_toolbox_amd.engine import SparsePlan
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(180, 360, R=2000, seed=3, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R, T = len(lat) * len(lon), len(uniq), 200
+    plan = SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    XA = 280 + 20 * torch.randn((T, G), device="cuda", generator=gen)
+    XB = 260 + 30 * torch.randn((T, G), device="cuda", generator=gen)
+    refA, refB = plan.apply(XA).clone(), plan.apply(XB).clone()
+    refP = plan.apply_poly(XB, -273.15, 3).clone()
+    torch.cuda.synchronize()
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    outsA, outsB, outsP = [], [], []
+    for _ in range(10):
+        with torch.cuda.stream(sA):
+            outsA.append(plan.apply(XA))
+        with torch.cuda.stream(sB):
+            outsB.append(plan.apply(XB))
+            outsP.append(plan.apply_poly(XB, -273.15, 3))
+    torch.cuda.synchronize()
+    for o in outsA:
+        assert torch.equal(o, refA)
+    for o in outsB:
+        assert torch.equal(o, refB)
+    for o in outsP:
+        assert torch.equal(o, refP)
