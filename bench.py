@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2-dense", choices=["c2-dense", "c2-real", "c3-real", "c5-block"])
+    ap.add_argument("--workload", default="c2-dense", choices=["c2-dense", "c2-real", "c3-real", "c5-block", "c5-uniform"])
     ap.add_argument("--T", type=int, default=365)
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
@@ -231,12 +231,14 @@ def main():
         dense.close()
         return res
 
-    def run_blocklocal():
-        """c5 in its block-local structure: every 64-cell run touches 256 regions, ~1 % of
-        G x R non-zero; tile-sparse MFMA form.  T defaults to one rank's share of 50 x 365 days."""
+    def run_blocklocal(uniform=False):
+        """c5, ~1 % of G x R non-zero, T defaults to one rank's share of 50 x 365 days.
+        block-local: every 64-cell run touches 256 regions -> tile-sparse MFMA form.  uniform: the
+        non-zeros sit at uniformly random positions -> no tile of W is empty, full dense form (the
+        worst case: 100x the algorithmic flops are executed)."""
         Tb = a.T if a.T != 365 else 2282
         Xb = engine.synth_field(Tb, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float32")
-        plan = engine.DensePlan.synth_blocklocal(G, R, seed=2)
+        plan = engine.DensePlan.synth(G, R, seed=2, fill=0.01) if uniform else engine.DensePlan.synth_blocklocal(G, R, seed=2)
         out = torch.empty((Tb, R), dtype=torch.float32, device="cuda")
 
         def step():
@@ -249,20 +251,20 @@ def main():
         kms = engine.profile_read()[a.warmup:]
         engine.profile_enable(False)
         kavg = sum(kms) / len(kms) * 1e-3
-        nnz = int(round(plan.info["n_tiles"] * 32 * 256 * 0.952))
+        nnz = int(0.01 * G * R) if uniform else int(round(plan.info["n_tiles"] * 32 * 256 * 0.952))
         flops = 2.0 * Tb * nnz
-        res = {"workload": "c5-block", "dtype": "f32", "T": Tb, "G": G, "R": R, "nnz": nnz,
+        res = {"workload": "c5-uniform" if uniform else "c5-block", "dtype": "f32", "T": Tb, "G": G, "R": R, "nnz": nnz,
                "value": Tb * world * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
                "ms_per_step": dt / a.steps * 1e3, "plan": dict(plan.info),
                "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                             "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                            "kernel": "dense_mfma_kernel<tiled>", "kernel_ms_avg": kavg * 1e3,
+                            "kernel": "dense_mfma_kernel" if uniform else "dense_mfma_kernel<tiled>", "kernel_ms_avg": kavg * 1e3,
                             "algorithmic_flops_per_launch": flops}}
         plan.close()
         return res
 
-    if a.workload == "c5-block":
-        main_res = run_blocklocal()
+    if a.workload in ("c5-block", "c5-uniform"):
+        main_res = run_blocklocal(uniform=a.workload == "c5-uniform")
         secondary = []
     elif a.workload == "c2-dense":
         main_res = run_dense()
@@ -284,7 +286,7 @@ def main():
             "config": {"workload": "%s: daily tas T=%d per GPU, 0.25deg grid %dx%d (G=%d), R=%d regions, "
                                    "%s, time axis sharded over %d GPU(s) + RCCL gather"
                                    % (main_res["workload"], main_res["T"], a.nlat, a.nlon, G, main_res["R"],
-                                      "block-local weights (~1 %% of G x R non-zero), fp32" if main_res["workload"] == "c5-block"
+                                      "%s weights (~1 %% of G x R non-zero), fp32" % main_res["workload"][3:] if main_res["workload"].startswith("c5-")
                                       else "area-weighted, %s" % main_res["dtype"], world),
                        "T_per_gpu": main_res["T"], "G": G, "R": main_res["R"], "parallelism": "time-shard x%d" % world},
             "roofline": main_res["roofline"],

@@ -20,7 +20,7 @@ EXPORTS = (
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
     "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
     "wagg_gather_f32", "wagg_gather_f64",
-    "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_get_info",
+    "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_create_synth_sparse", "wagg_dense_get_info",
     "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32",
     "wagg_synth_field_f32", "wagg_synth_field_f64",
 )
@@ -92,6 +92,7 @@ def load():
     L.wagg_dense_create_from_segments.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32,
                                                   C.POINTER(vp)]
     L.wagg_dense_create_synth_blocklocal.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
+    L.wagg_dense_create_synth_sparse.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_get_info.argtypes = [vp, C.POINTER(DenseInfo)]
     L.wagg_dense_destroy.argtypes = [vp]
     L.wagg_dense_get_den.argtypes = [vp, f64p]

@@ -312,7 +312,7 @@ __global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, i
 
 // synthetic W[g][r] = hash_u01(g R + r, seed) written straight into the packed order
 __global__ void dense_synth_w_kernel(f32x4 *__restrict__ Wp, int64_t G, int32_t R, int n_kt,
-                                     int64_t n_slots, uint32_t seed) {
+                                     int64_t n_slots, uint32_t seed, float fill) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
         const int slot = (int)(s % (D_WT / 4));
@@ -322,8 +322,11 @@ __global__ void dense_synth_w_kernel(f32x4 *__restrict__ Wp, int64_t G, int32_t 
         const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            v[c] = (r < R && g0 + c < G) ? hash_u01((uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r, seed) : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            const uint64_t id = (uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r;
+            const bool keep = r < R && g0 + c < G && (fill >= 1.0f || hash_u01(id, seed ^ 0x9e3779b9u) < fill);
+            v[c] = keep ? hash_u01(id, seed) : 0.f;
+        }
         Wp[s] = v;
     }
 }
@@ -520,12 +523,17 @@ static int pick_ksplit(int64_t items, int n_kt) {
 }  // namespace wagg
 
 extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out) {
+    return wagg_dense_create_synth_sparse(G, R, seed, 1.0, out);
+}
+
+extern "C" int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
     using namespace wagg;
+    WAGG_REQUIRE(fill > 0.0 && fill <= 1.0, "fill must be in (0, 1]");
     int rc = dense_alloc(G, R, out);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
     hipLaunchKernelGGL(dense_synth_w_kernel, dim3(256 * 32), dim3(256), 0, nullptr,
-                       reinterpret_cast<f32x4 *>(d->W.p), G, R, d->n_kt, d->w_slots(), seed);
+                       reinterpret_cast<f32x4 *>(d->W.p), G, R, d->n_kt, d->w_slots(), seed, (float)fill);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) rc = dense_finish_den(d); else { set_error("synth launch: %s", hipGetErrorString(e)); rc = WAGG_EHIP; }
     if (rc != WAGG_OK) { delete d; *out = nullptr; }

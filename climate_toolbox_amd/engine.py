@@ -185,11 +185,13 @@ class DensePlan:
         return cls(h, G, R)
 
     @classmethod
-    def synth(cls, G, R, seed):
+    def synth(cls, G, R, seed, fill=1.0):
+        """W[g, r] = hash_u01(g R + r, seed); with fill < 1 only that fraction of the entries, at
+        uniformly random positions (c5's uniform-random structure at fill = 0.01)."""
         require_gpu()
         h = C.c_void_p()
-        _lib.check(_lib.load().wagg_dense_create_synth(int(G), int(R), int(seed), C.byref(h)),
-                   "wagg_dense_create_synth")
+        _lib.check(_lib.load().wagg_dense_create_synth_sparse(int(G), int(R), int(seed), float(fill), C.byref(h)),
+                   "wagg_dense_create_synth_sparse")
         return cls(h, G, R)
 
     @classmethod

@@ -169,6 +169,10 @@ int wagg_gather_f64(const double *X_dev, int64_t T, int64_t ldx, int layout,
 /* synth: W[g,r] = hash_u01(g*R + r, seed) in [0,1), generated on device (never on host); this is
  * the c2-dense benchmark operand (1,036,800 x 24,378 = 101 GB).                                */
 int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out);
+/* the same with only a fraction `fill` of the entries non-zero, at uniformly random positions
+ * (kept where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill): c5's "uniform-random columns"
+ * structure at fill = 0.01 -- no tile of W is empty, so this stays in the full dense form.      */
+int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 /* from a host row-major (G, R) fp32 matrix (small cases / tests) */
 int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
 /* from a sparse plan's coded table, densified on device (weights that are not very sparse).

@@ -255,15 +255,21 @@ def agg_coded(X_TG, cell_idx, region_code, w_eff, R):
         return num / den[None, :]
 
 
-def dense_weights_oracle(G, R, seed):
+def dense_weights_oracle(G, R, seed, fill=1.0):
     """Counter-hash dense W[g,r] in U[0,1) -- must equal wagg_dense_synth on device bit for bit.
 
     32-bit finaliser (two xorshift-multiply rounds) of (g*R + r) ^ seed*0x9E3779B9, top 24 bits
-    scaled by 2^-24 so every value is exactly representable in fp32."""
+    scaled by 2^-24 so every value is exactly representable in fp32.  ``fill`` < 1 keeps only
+    the entries whose second hash (seed ^ 0x9e3779b9) is below it (wagg_dense_create_synth_sparse:
+    c5's uniform-random structure)."""
     g = np.arange(G, dtype=np.uint64)[:, None]
     r = np.arange(R, dtype=np.uint64)[None, :]
     idx = g * np.uint64(R) + r
-    return hash_u01(idx, seed)
+    W = hash_u01(idx, seed)
+    if fill < 1.0:
+        keep = hash_u01(idx, np.uint32(seed) ^ np.uint32(0x9e3779b9)) < np.float32(fill)
+        W = np.where(keep, W, np.float32(0)).astype(np.float32)
+    return W
 
 
 def hash_u01(idx, seed):

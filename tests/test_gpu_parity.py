@@ -261,6 +261,12 @@ def test_dense_synth_matches_oracle_hash(torch_cuda):
     np.testing.assert_array_equal(Xh, (np.float32(280.0) + np.float32(60.0) * (O.hash_u01(idx, 7) - np.float32(0.5))))
     got = plan.apply(X).cpu().numpy()
     _rel_ok(got, c_oracle.dense_synth(Xh, 0, G, R, 0, R, seed), RTOL32)
+    # c5's uniform-random structure: 5 % of the entries at random positions (still the full dense form)
+    sp = DensePlan.synth(G, R, seed, fill=0.05)
+    Ws = O.dense_weights_oracle(G, R, seed, fill=0.05)
+    assert sp.info["tiled"] == 0 and 0.04 < (Ws != 0).mean() < 0.06
+    np.testing.assert_allclose(sp.den, Ws.astype(np.float64).sum(0), rtol=1e-12)
+    _rel_ok(sp.apply(X).cpu().numpy(), O.agg_dense(Xh, Ws), RTOL32)
 
 
 def test_dense_from_segments_equals_sparse(torch_cuda):
