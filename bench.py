@@ -6,11 +6,23 @@ A "step" is one pass of the hot path over one batch: out[T, R] = (X[T, G] . W[G,
 Default workload (N=1) = BASELINE.json configs[1] in its dense north-star form ("c2-dense"):
 T=365 daily steps, 0.25-degree grid G=720x1440=1,036,800, R=24,378 impact regions, fp32, W a
 dense (gridcell x region) matrix generated on the device (101 GB, hash of (g, r, seed)); inputs
-are resident in HBM before the timed region.  The same run also times "c2-real" (the sparse
-segment-table form of the same config: ~4e5 segments, HBM-bound) and reports it under
-"secondary".  With --gpus N (launched by torch.distributed.run, one rank per GPU) the time axis is
-sharded: every rank aggregates its own 365-row shard (weak scaling) and the region time series
-are reassembled on rank 0 with an RCCL gather inside the timed region.
+are resident in HBM before the timed region.  The same run also times "c2-real" / "c3-real" (the
+sparse segment-table form of configs[1] / [2]) and reports them under "secondary".
+
+Workloads (--workload):
+  c1          configs[0]: 2-degree grid, 100 regions, fp64 -- the reference's own CPU-sized case; the
+              CPU oracle is timed on the FULL problem beside it
+  c2-dense    configs[1], dense north-star form (default)
+  c2-real     configs[1], segment-table form (HBM-bound)     c3-real  configs[2], fp64 + popwt
+  c4          configs[3]: 10,950 daily steps, dense form, time axis cut over the ranks ("strong")
+  c5-uniform  configs[4]: 50 x 365 rows, ~1 % non-zeros at uniformly random positions (entry-list form)
+  c5-block    configs[4]: the block-local structure (tile-sparse MFMA form)
+For c4/c5 the rows of a run are shard_bounds(T_total, --shards)[rank]; --shards defaults to the
+world size for c4 and to 8 for c5 (one rank's share of the 8-GPU job on a single GPU).
+
+With --gpus N (launched by torch.distributed.run, one rank per GPU) the time axis is sharded over
+the ranks and the region time series are reassembled on rank 0 with an RCCL gather that overlaps
+the next step's compute; the default workload is weak scaling (365 rows per rank).
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,7 +37,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
+PEAK_F64_MFMA_TFLOPS = 78.6     # half the fp32 rate
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+WORKLOADS = ["c1", "c2-dense", "c2-real", "c3-real", "c4", "c5-block", "c5-uniform"]
 
 
 def parse():
@@ -33,8 +47,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2-dense", choices=["c2-dense", "c2-real", "c3-real", "c5-block", "c5-uniform"])
-    ap.add_argument("--T", type=int, default=365)
+    ap.add_argument("--workload", default="c2-dense", choices=WORKLOADS)
+    ap.add_argument("--T", type=int, default=0, help="rows per rank (overrides the workload's own)")
+    ap.add_argument("--shards", type=int, default=0, help="c4/c5: cut T_total into this many shards, this rank takes its own")
     ap.add_argument("--nlat", type=int, default=720)
     ap.add_argument("--nlon", type=int, default=1440)
     ap.add_argument("--R", type=int, default=24378)
@@ -42,17 +57,24 @@ def parse():
     ap.add_argument("--land-frac", type=float, default=0.30, help="experiment knob for c2-real")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--diag-lib", action="store_true",
+                    help="load libwagg_diag.so (make diag): the build with the ablation knobs; timing experiments only")
     return ap.parse_args()
 
 
 def load_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
+    """(HBM bytes per launch, where that number comes from).  It is NOT measured by this run: it is
+    the figure tools/summarize_prof.py derived from separate rocprofv3 --pmc passes and committed to
+    profiles/traffic.json (PMC collection needs its own profiler runs, see profiles/README.md)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            e = json.load(f).get(workload)
+        if not e:
+            return None, None
+        return e.get("hbm_bytes_per_launch"), "profiles/traffic.json <- %s (%s)" % (e.get("source"), e.get("measured", "round 1"))
     except Exception:
-        return None
+        return None, None
 
 
 def sparse_algorithmic_bytes(T, G, R, nnz, b):
@@ -60,10 +82,11 @@ def sparse_algorithmic_bytes(T, G, R, nnz, b):
     return b * T * G + (b + 4) * nnz + 4 * (G + 1) + b * T * R + b * R
 
 
-def timed_steps(torch, dist, step, steps, warmup, world):
+def timed_steps(torch, dist, step, finish, steps, warmup, world):
     world = world if not (dist.is_available() and dist.is_initialized()) else max(world, 2)   # forced-dist rehearsal
     for _ in range(warmup):
         step()
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -71,6 +94,7 @@ def timed_steps(torch, dist, step, steps, warmup, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    finish()                               # every queued gather has completed
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -83,37 +107,52 @@ def timed_steps(torch, dist, step, steps, warmup, world):
     return dt
 
 
-def cpu_baseline_dense(T, G, R, seed_w):
+# ---- CPU baselines (rank 0, N = 1 only; bounded samples; the oracle is the thing timed here) -------
+def cpu_baseline_dense(T, G, R, seed_w, fill=1.0, blocklocal=False):
     """The oracle's dense restatement (oracle/wagg_oracle.c, kind "port") on a bounded window of
-    the same workload: all T rows x Gw cells x Rw regions, threads = OpenMP default."""
+    the same workload: Tw rows x Gw cells x Rw regions, threads = OpenMP default."""
     import numpy as np
     from oracle import c_oracle
-    Gw, Rw = min(G, 32768), min(R, 8192)
+    Tw, Gw, Rw = min(T, 365), min(G, 32768), min(R, 8192)
     rng = np.random.default_rng(0)
-    X = (280.0 + 30.0 * rng.standard_normal((T, Gw))).astype(np.float32)
-    c_oracle.dense_synth(X[:8], 0, min(Gw, 256), R, 0, min(Rw, 256), seed_w)     # warm
+    X = (280.0 + 30.0 * rng.standard_normal((Tw, Gw))).astype(np.float32)
+    c_oracle.dense_synth_sparse(X[:8], 0, min(Gw, 256), R, 0, min(Rw, 256), seed_w, fill, blocklocal)     # warm
     t0 = time.perf_counter()
-    c_oracle.dense_synth(X, 0, Gw, R, 0, Rw, seed_w)
+    c_oracle.dense_synth_sparse(X, 0, Gw, R, 0, Rw, seed_w, fill, blocklocal)
     dt = time.perf_counter() - t0
-    return {"value": T * Gw * Rw / dt, "unit": "gridcell-region-timesteps/s", "cores": c_oracle.threads(),
+    return {"value": Tw * Gw * Rw / dt, "unit": "gridcell-region-timesteps/s", "cores": c_oracle.threads(),
             "kind": "port", "wall_s": round(dt, 3),
-            "sample": "oracle/wagg_oracle.c dense (fp64 accumulate, OpenMP) on T=%d x %d cells x %d regions "
-                      "of the c2-dense operands (window of the 1,036,800 x 24,378 problem)" % (T, Gw, Rw)}
+            "sample": "oracle/wagg_oracle.c dense (fp64 accumulate, OpenMP; weights regenerated from the hashes, "
+                      "fill=%g%s) on %d rows x %d cells x %d regions of this workload's operands"
+                      % (fill, ", block-local" if blocklocal else "", Tw, Gw, Rw)}
 
 
-def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, T_sample):
+def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, T_sample, what):
     """The oracle's faithful single-threaded restatement (gather -> fp64 multiply -> group-sum ->
-    divide, like the reference) on the first T_sample timesteps of the c2-real workload."""
+    divide, like the reference) plus a best-effort CPU path (scipy CSR SpMM, also one thread) on
+    the first T_sample timesteps."""
     import numpy as np
+    import scipy.sparse as sp
     from oracle import c_oracle
     c_oracle.segments(X_host[:1], cell, codes, w_eff, R)
     t0 = time.perf_counter()
     c_oracle.segments(X_host[:T_sample], cell, codes, w_eff, R)
     dt = time.perf_counter() - t0
+    keep = (codes >= 0) & ~np.isnan(w_eff)
+    W = sp.coo_matrix((w_eff[keep], (cell[keep], codes[keep])), shape=(G, R)).tocsc()
+    Xs = np.nan_to_num(X_host[:T_sample].astype(np.float64), nan=0.0, posinf=np.inf, neginf=-np.inf)
+    t1 = time.perf_counter()
+    num = (W.T @ Xs.T).T
+    den = np.asarray(W.sum(axis=0)).ravel()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        num / den[None, :]
+    dtb = time.perf_counter() - t1
     return {"value": T_sample * G * R / dt, "unit": "gridcell-region-timesteps/s", "cores": 1, "kind": "port",
-            "wall_s": round(dt, 3), "nnz_timesteps_per_s": T_sample * len(cell) / dt,
-            "sample": "oracle/wagg_oracle.c segments_%s, first %d of the timesteps, full segment table"
-                      % ("f32" if X_host.dtype == np.float32 else "f64", T_sample)}
+            "wall_s": round(dt, 4), "nnz_timesteps_per_s": T_sample * len(cell) / dt,
+            "sample": "oracle/wagg_oracle.c segments_%s (single thread, like the reference), %s"
+                      % ("f32" if X_host.dtype == np.float32 else "f64", what),
+            "cpu_best": {"value": T_sample * G * R / dtb, "wall_s": round(dtb, 4), "cores": 1,
+                         "what": "scipy.sparse CSC^T @ X^T in fp64 (one thread), same sample"}}
 
 
 def main():
@@ -142,51 +181,77 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from climate_toolbox_amd import engine, synth
-    from climate_toolbox_amd.timeshard import gather_time_shards
+    from climate_toolbox_amd import _lib, engine, synth
+    if a.diag_lib:
+        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libwagg_diag.so")
+    from climate_toolbox_amd.timeshard import ShardedStep, shard_bounds
 
-    T, G, R = a.T, a.nlat * a.nlon, a.R
-    # every rank owns its own T-row shard of the global (T*world) x G field (weak scaling)
-    X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float32")
-    result = {}
+    G, R = a.nlat * a.nlon, a.R
+    scaling = "weak"
+    # rows of this rank
+    if a.workload in ("c4", "c5-block", "c5-uniform"):
+        T_total = 10950 if a.workload == "c4" else 50 * 365
+        shards = a.shards or (world if a.workload == "c4" or world > 1 else 8)
+        bounds = shard_bounds(T_total, max(shards, world))
+        rows_all = [e - s for s, e in bounds][:world]
+        T = a.T or rows_all[rank]
+        if a.T:
+            rows_all = [a.T] * world
+        scaling = "strong" if shards == world and not a.T else "weak"
+    else:
+        T = a.T or 365
+        rows_all = [T] * world
+    T_job = sum(rows_all)
 
-    def run_sparse(dtype):
-        lat, lon, df = synth.realistic_segments(nlat=a.nlat, nlon=a.nlon, R=R, seed=2, land_frac=a.land_frac)
-        wname = "areawt" if dtype == "float32" else "popwt"
-        cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, "hierid")
-        plan = engine.SparsePlan(cell, codes, w_eff, G, len(uniq), row_len=a.nlon)
-        Xs = X if dtype == "float32" else X.double()
-        out = torch.empty((T, len(uniq)), dtype=Xs.dtype, device="cuda")
-        gathered = [torch.empty((T * world, len(uniq)), dtype=Xs.dtype, device="cuda") if use_dist and rank == 0 else None]
+    def stepper(apply_fn, Rr, dtype):
+        return ShardedStep(apply_fn, lambda: torch.empty((T, Rr), dtype=dtype, device="cuda"), rows=rows_all, dst=0,
+                           distributed=use_dist)
 
-        def step():
-            plan.apply(Xs, out=out)
-            if use_dist:
-                gather_time_shards(out, dst=0, out=gathered[0])
+    def kernel_avg_ms(kms):
+        kms = kms[a.warmup:] if len(kms) > a.warmup else kms
+        return sum(kms) / max(1, len(kms))
 
+    def run_sparse(dtype, small=False):
+        if small:       # c1: the reference's 2-degree test grid, 100 block regions
+            lat, lon, tas, df = synth.c1_workload(T=T)
+            Gs, nlon = len(lat) * len(lon), len(lon)
+            wname, lev = "areawt", "hierid"
+            Xs = torch.from_numpy(np.ascontiguousarray(tas.reshape(T, Gs))).cuda()
+        else:
+            lat, lon, df = synth.realistic_segments(nlat=a.nlat, nlon=a.nlon, R=R, seed=2, land_frac=a.land_frac)
+            Gs, nlon = G, a.nlon
+            wname, lev = ("areawt" if dtype == "float32" else "popwt"), "hierid"
+            Xs = engine.synth_field(T, Gs, seed=1000 + rank, base=280.0, amp=60.0, dtype=dtype)
+        cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, lev)
+        plan = engine.SparsePlan(cell, codes, w_eff, Gs, len(uniq), row_len=nlon)
+        Rr = len(uniq)
+        st = stepper(lambda out: plan.apply(Xs, out=out), Rr, Xs.dtype)
         engine.profile_enable(True)       # event records only, no synchronisation
-        dt = timed_steps(torch, dist, step, a.steps, a.warmup, world)
-        kms = engine.profile_read()[a.warmup:]
+        dt = timed_steps(torch, dist, st.step, st.finish, a.steps, a.warmup, world)
+        kavg = kernel_avg_ms(engine.profile_read()) * 1e-3
         engine.profile_enable(False)
+        plan.status()
         b = 4 if dtype == "float32" else 8
         nnz = plan.info["nnz"]
-        Rr = len(uniq)
-        kavg = sum(kms) / len(kms) * 1e-3
-        abytes = sparse_algorithmic_bytes(T, G, Rr, nnz, b)
-        wl = "c2-real" if dtype == "float32" else "c3-real"
+        abytes = sparse_algorithmic_bytes(T, Gs, Rr, nnz, b)
+        wl = "c1" if small else ("c2-real" if dtype == "float32" else "c3-real")
+        traffic, tsrc = load_traffic(wl)
         res = {
-            "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "G": G, "R": Rr, "nnz": int(nnz),
-            "value": T * world * G * Rr * a.steps / dt, "unit": "gridcell-region-timesteps/s",
-            "ms_per_step": dt / a.steps * 1e3, "nnz_timesteps_per_s": T * world * nnz * a.steps / dt,
+            "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "G": Gs, "R": Rr, "nnz": int(nnz),
+            "value": T_job * Gs * Rr * a.steps / dt, "unit": "gridcell-region-timesteps/s",
+            "ms_per_step": dt / a.steps * 1e3, "nnz_timesteps_per_s": T_job * nnz * a.steps / dt,
             "plan": {k: int(v) for k, v in plan.info.items()},
             "roofline": {"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": load_traffic(wl),
-                         "kernel": "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel", "kernel_ms_avg": kavg * 1e3,
-                         "algorithmic_bytes_per_launch": abytes},
+                         "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
+                         "kernel": "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel<double>",
+                         "kernel_ms_avg": kavg * 1e3, "algorithmic_bytes_per_launch": abytes},
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_sparse(Xs[:64].cpu().numpy(), cell, codes, w_eff, Rr, G, min(T, 64))
-        if dtype == "float32" and world == 1:
+            Ts = T if small else min(T, 64)
+            res["cpu_baseline"] = cpu_baseline_sparse(Xs[:Ts].cpu().numpy(), cell, codes, w_eff, Rr, Gs, Ts,
+                                                      "the FULL problem (all %d timesteps)" % Ts if small else
+                                                      "first %d of the timesteps, full segment table" % Ts)
+        if dtype == "float32" and world == 1 and not small:
             # fused tas_poly: (tas - 273.15)^p, p = 1..4, one pass over the field
             pout = torch.empty((4, T, Rr), dtype=Xs.dtype, device="cuda")
             for _ in range(2):
@@ -197,98 +262,76 @@ def main():
                 plan.apply_poly(Xs, -273.15, 4, out=pout)
             torch.cuda.synchronize()
             pdt = (time.perf_counter() - t0) / a.steps
-            res["fused_tas_poly_1to4"] = {"ms_per_step": pdt * 1e3, "value": 4 * T * G * Rr / pdt,
+            res["fused_tas_poly_1to4"] = {"ms_per_step": pdt * 1e3, "value": 4 * T * Gs * Rr / pdt,
                                           "unit": "gridcell-region-timesteps/s (4 powers)"}
         return res
 
-    def run_dense():
-        dense = engine.DensePlan.synth(G, R, seed=2)
-        out = torch.empty((T, R), dtype=torch.float32, device="cuda")
-        gathered = [torch.empty((T * world, R), dtype=torch.float32, device="cuda") if use_dist and rank == 0 else None]
-
-        def step():
-            dense.apply(X, out=out, ksplit=a.ksplit)
-            if use_dist:
-                gather_time_shards(out, dst=0, out=gathered[0])
-
-        engine.profile_enable(True)       # event records only (no sync): negligible next to 0.1 s
-        dt = timed_steps(torch, dist, step, a.steps, a.warmup, world)
-        kms = engine.profile_read()[a.warmup:]
+    def run_dense_family(wl):
+        """c2-dense / c4 (full matrix), c5-uniform (entry lists), c5-block (tile-sparse)."""
+        X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float32")
+        if wl == "c5-uniform":
+            plan, fill, bl = engine.DensePlan.synth(G, R, seed=2, fill=0.01), 0.01, False
+        elif wl == "c5-block":
+            plan, fill, bl = engine.DensePlan.synth_blocklocal(G, R, seed=2), 0.952, True
+        else:
+            plan, fill, bl = engine.DensePlan.synth(G, R, seed=2), 1.0, False
+        st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), R, torch.float32)
+        engine.profile_enable(True)       # event records only (no sync)
+        dt = timed_steps(torch, dist, st.step, st.finish, a.steps, a.warmup, world)
+        kavg = kernel_avg_ms(engine.profile_read()) * 1e-3
         engine.profile_enable(False)
-        kavg = sum(kms) / len(kms) * 1e-3
-        flops = 2.0 * T * G * R
-        res = {
-            "workload": "c2-dense", "dtype": "f32", "T": T, "G": G, "R": R,
-            "value": T * world * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
-            "ms_per_step": dt / a.steps * 1e3,
-            "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": load_traffic("c2-dense"), "kernel": "dense_mfma_kernel",
-                         "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops},
-        }
-        if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_dense(T, G, R, 2)
-        dense.close()
-        return res
-
-    def run_blocklocal(uniform=False):
-        """c5, ~1 % of G x R non-zero, T defaults to one rank's share of 50 x 365 days.
-        block-local: every 64-cell run touches 256 regions -> tile-sparse MFMA form.  uniform: the
-        non-zeros sit at uniformly random positions -> no tile of W is empty, full dense form (the
-        worst case: 100x the algorithmic flops are executed)."""
-        Tb = a.T if a.T != 365 else 2282
-        Xb = engine.synth_field(Tb, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float32")
-        plan = engine.DensePlan.synth(G, R, seed=2, fill=0.01) if uniform else engine.DensePlan.synth_blocklocal(G, R, seed=2)
-        out = torch.empty((Tb, R), dtype=torch.float32, device="cuda")
-
-        def step():
-            plan.apply(Xb, out=out)
-            if use_dist:
-                gather_time_shards(out, dst=0)
-
-        engine.profile_enable(True)
-        dt = timed_steps(torch, dist, step, a.steps, a.warmup, world)
-        kms = engine.profile_read()[a.warmup:]
-        engine.profile_enable(False)
-        kavg = sum(kms) / len(kms) * 1e-3
-        nnz = int(0.01 * G * R) if uniform else int(round(plan.info["n_tiles"] * 32 * 256 * 0.952))
-        flops = 2.0 * Tb * nnz
-        res = {"workload": "c5-uniform" if uniform else "c5-block", "dtype": "f32", "T": Tb, "G": G, "R": R, "nnz": nnz,
-               "value": Tb * world * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
-               "ms_per_step": dt / a.steps * 1e3, "plan": dict(plan.info),
+        form = int(plan.info["form"])
+        if wl == "c5-uniform":
+            nnz = int(plan.info["nnz"])
+        elif wl == "c5-block":
+            nnz = int(round(plan.info["n_tiles"] * 32 * 256 * fill))
+        else:
+            nnz = G * R
+        flops = 2.0 * T * nnz                                   # algorithmic: 2 T nnz (dense: nnz = G R)
+        traffic, tsrc = load_traffic(wl)
+        kname = {0: "dense_mfma_kernel", 1: "dense_mfma_kernel<tiled>", 2: "spmm_kernel (vector ALU, entry lists)"}[form]
+        res = {"workload": wl, "dtype": "f32", "T": T, "G": G, "R": R, "nnz": nnz,
+               "value": T_job * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
+               "ms_per_step": dt / a.steps * 1e3, "plan": {k: int(v) for k, v in plan.info.items()},
                "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                            "kernel": "dense_mfma_kernel" if uniform else "dense_mfma_kernel<tiled>", "kernel_ms_avg": kavg * 1e3,
-                            "algorithmic_flops_per_launch": flops}}
+                            "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                            "traffic": traffic, "traffic_source": tsrc, "kernel": kname,
+                            "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops}}
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_dense(T, G, R, 2, fill, bl)
         plan.close()
         return res
 
-    if a.workload in ("c5-block", "c5-uniform"):
-        main_res = run_blocklocal(uniform=a.workload == "c5-uniform")
-        secondary = []
-    elif a.workload == "c2-dense":
-        main_res = run_dense()
-        secondary = []
-        if world == 1 and not a.no_secondary:
+    secondary = []
+    if a.workload in ("c2-dense", "c4", "c5-block", "c5-uniform"):
+        main_res = run_dense_family(a.workload)
+        if a.workload == "c2-dense" and world == 1 and not a.no_secondary:
             torch.cuda.empty_cache()
             secondary.append(run_sparse("float32"))          # c2-real: segment-table form, fp32, area weights
             secondary.append(run_sparse("float64"))          # c3-real: fp64 data, pop weights with backup fill
+    elif a.workload == "c1":
+        main_res = run_sparse("float64", small=True)
     else:
         main_res = run_sparse("float32" if a.workload == "c2-real" else "float64")
-        secondary = []
 
     if rank == 0:
+        wl = main_res["workload"]
+        what = {"c1": "2-degree grid, 100 block regions, area-weighted, f64 (the reference's CPU-sized case)",
+                "c2-dense": "area-weighted dense (gridcell x region) W, f32",
+                "c4": "30-year daily series, dense W, f32", "c2-real": "area-weighted segment table, f32",
+                "c3-real": "pop-weighted segment table with backup fill, f64",
+                "c5-uniform": "ensemble x time rows, ~1 % of G x R non-zero at uniformly random positions, f32",
+                "c5-block": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f32"}[wl]
         line = {
             "metric": "gridcell-region-timesteps/sec", "value": main_res["value"],
             "unit": "gridcell-region-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": main_res["dtype"], "data": "synthetic",
-            "config": {"workload": "%s: daily tas T=%d per GPU, 0.25deg grid %dx%d (G=%d), R=%d regions, "
-                                   "%s, time axis sharded over %d GPU(s) + RCCL gather"
-                                   % (main_res["workload"], main_res["T"], a.nlat, a.nlon, G, main_res["R"],
-                                      "%s weights (~1 %% of G x R non-zero), fp32" % main_res["workload"][3:] if main_res["workload"].startswith("c5-")
-                                      else "area-weighted, %s" % main_res["dtype"], world),
-                       "T_per_gpu": main_res["T"], "G": G, "R": main_res["R"], "parallelism": "time-shard x%d" % world},
+            "config": {"workload": "%s: daily tas, T=%d rows on this GPU (%d in the job), grid G=%d, R=%d regions, %s; "
+                                   "time axis sharded over %d GPU(s) + RCCL gather"
+                                   % (wl, main_res["T"], T_job, main_res["G"], main_res["R"], what, world),
+                       "T_per_gpu": main_res["T"], "T_job": T_job, "G": main_res["G"], "R": main_res["R"],
+                       "parallelism": "time-shard x%d" % world},
             "roofline": main_res["roofline"],
             "cpu_baseline": main_res.get("cpu_baseline"),
         }

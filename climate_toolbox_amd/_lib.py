@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
 
 EKEY = -6
+PLAN_NO_LC, PLAN_NO_STREAM = 1, 2
+FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
 
@@ -16,19 +18,23 @@ OUT_TR, OUT_RT = 0, 1
 EXPORTS = (
     "wagg_version", "wagg_device_count", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
     "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
-    "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den",
+    "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den", "wagg_plan_status",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
     "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
     "wagg_gather_f32", "wagg_gather_f64",
+    "wagg_transform_poly_f32", "wagg_transform_poly_f64", "wagg_transform_edd_f32", "wagg_transform_edd_f64",
+    "wagg_any_less_f32", "wagg_any_less_f64",
     "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_create_synth_sparse", "wagg_dense_get_info",
-    "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32",
+    "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32", "wagg_dense_apply_poly_f32",
+    "wagg_dense_apply_edd_f32", "wagg_dense_saw_inf",
     "wagg_synth_field_f32", "wagg_synth_field_f64",
 )
 
 
 class DenseInfo(C.Structure):
     _fields_ = [("G", C.c_int64), ("n_tiles", C.c_int64), ("w_bytes", C.c_int64),
-                ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32)]
+                ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32),
+                ("form", C.c_int32), ("reserved", C.c_int32), ("nnz", C.c_int64)]
 
 
 class WaggError(RuntimeError):
@@ -74,6 +80,7 @@ def load():
     L.wagg_plan_destroy.argtypes = [vp]
     L.wagg_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
     L.wagg_plan_get_den.argtypes = [vp, f64p]
+    L.wagg_plan_status.argtypes = [vp, vp]
     for name in ("wagg_apply_f32", "wagg_apply_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_poly_f32", "wagg_apply_poly_f64"):
@@ -87,6 +94,12 @@ def load():
     for name in ("wagg_gather_f32", "wagg_gather_f64"):
         getattr(L, name).argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, vp, C.c_int64,
                                      C.c_int, vp]
+    for name in ("wagg_transform_poly_f32", "wagg_transform_poly_f64"):
+        getattr(L, name).argtypes = [vp, C.c_int64, C.c_double, C.c_int, vp, vp]
+    for name in ("wagg_transform_edd_f32", "wagg_transform_edd_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_double, f64p, f64p, C.c_int, vp, vp]
+    for name in ("wagg_any_less_f32", "wagg_any_less_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int), vp]
     L.wagg_dense_create_synth.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.wagg_dense_create_host.argtypes = [f32p, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.wagg_dense_create_from_segments.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32,
@@ -97,6 +110,10 @@ def load():
     L.wagg_dense_destroy.argtypes = [vp]
     L.wagg_dense_get_den.argtypes = [vp, f64p]
     L.wagg_dense_apply_f32.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
+    L.wagg_dense_apply_poly_f32.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, vp, C.c_int64, C.c_int, vp]
+    L.wagg_dense_apply_edd_f32.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, vp, C.c_int64,
+                                           C.c_int, vp]
+    L.wagg_dense_saw_inf.argtypes = [vp, vp, C.POINTER(C.c_int)]
     L.wagg_synth_field_f32.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_float,
                                        C.c_float, vp]
     L.wagg_synth_field_f64.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_double,

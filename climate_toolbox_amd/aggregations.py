@@ -22,7 +22,7 @@ from collections import OrderedDict
 import numpy as np
 import pandas as pd
 
-from . import minixr
+from . import engine as _engine, minixr
 from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
 
 try:  # optional: return real xarray objects when the caller hands us xarray objects
@@ -34,7 +34,8 @@ __all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data",
            "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
 
 _PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
-_PLAN_CACHE_MAX = 8
+_PLAN_CACHE_MAX = 8                 # plans
+_PLAN_CACHE_MAX_FRAC = 0.5          # ... and at most this share of the device's memory (dense plans are GBs)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -261,14 +262,14 @@ class ReindexedDataset(minixr.Dataset):
         Xd = _to_device(X2)
         ci = torch.from_numpy(np.ascontiguousarray(cell)).cuda()
         out = _device_gather(Xd, ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
-        if name in self._xforms:
+        if name in self._xforms:                     # wagg_transform_poly_*: the kernels' own device function
             off, pw = self._xforms[name]
-            out = (out + off) ** pw
+            out = _engine.transform_poly(out, off, pw)
         if name in self._edds:
             hi, off, terms = self._edds[name]
             H2 = _flatten_for_device(hi, self._src_dims[name])[0]
             hig = _device_gather(_to_device(H2), ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
-            out = sum(c * minixr.snyder_edd_device(torch, out + off, hig + off, e) for c, e in terms)
+            out = _engine.transform_edd(out, hig, off, terms)
         return unflatten(out.cpu().numpy(), self._nseg)
 
 
@@ -340,8 +341,29 @@ def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes):
     faster -- provided it is an fp32 (time, gridcell) problem and W fits comfortably in HBM."""
     if not is_f32 or layout != "TG":
         return False
-    w_bytes = 4 * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
-    return n_ucells > DENSE_SWITCH * G and w_bytes < 0.6 * free_bytes
+    return n_ucells > DENSE_SWITCH * G and _dense_bytes(G, R) < 0.6 * free_bytes
+
+
+def _dense_bytes(G, R):
+    return 4 * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
+
+
+def _plan_bytes(plan):
+    return int(plan.info.get("w_bytes", 0)) if isinstance(plan, DensePlan) else 16 * int(plan.info.get("nnz", 0))
+
+
+def _evict_plans(byte_budget, keep):
+    """Close cached plans, oldest first, until at most ``keep`` remain and they hold no more than
+    ``byte_budget`` bytes of device memory; returns the bytes released."""
+    freed = 0
+    held = sum(_plan_bytes(p) for p in _PLAN_CACHE.values())
+    while _PLAN_CACHE and (len(_PLAN_CACHE) > keep or held > max(byte_budget, 0)):
+        _, old = _PLAN_CACHE.popitem(last=False)
+        b = _plan_bytes(old)
+        old.close()
+        held -= b
+        freed += b
+    return freed
 
 
 def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
@@ -353,7 +375,10 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         import torch
-        free_bytes = torch.cuda.mem_get_info()[0]
+        free_bytes, total_bytes = torch.cuda.mem_get_info()
+        # what the cached plans hold can be given back: evict (oldest first) before declining the
+        # dense form for lack of memory, and keep the cache under its byte budget
+        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - _dense_bytes(G, R), keep=_PLAN_CACHE_MAX - 1)
         # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
         # form: go to the dense / tile-sparse form directly instead of building the sparse plan
         # first just to read its statistics
@@ -365,8 +390,6 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
                 plan.close()
                 plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
         _PLAN_CACHE[key] = plan
-        while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
-            _PLAN_CACHE.popitem(last=False)[1].close()
     else:
         _PLAN_CACHE.move_to_end(key)
     return plan
@@ -511,24 +534,42 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             raise ValueError("tasmin and tasmax must have the same shape and dtype")
         Hd = _to_device(H2)
         coefs, thr = [c for c, _ in edd[2]], [e for _, e in edd[2]]
-        if isinstance(plan, DensePlan):
-            stack = [plan.apply(minixr.snyder_edd_device(torch, Xd + edd[1], Hd + edd[1], e)) for e in thr]
-        else:
-            stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
-        total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
-        for c, o in zip(coefs[1:], stack[1:]):
-            total = total + c * o
-        outs, single = [total], True
-    elif powers is None:
-        outs = [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
-    elif isinstance(plan, DensePlan):
-        # scattered weights in the dense MFMA form: the transform is one elementwise device pass
-        outs = [plan.apply((Xd + offset) ** int(p)) for p in powers]
-    else:
+
+    def run(plan):
+        """The device work for one plan form; returns the list of (T, R) / (R, T) result tensors."""
+        if edd is not None:
+            if isinstance(plan, DensePlan):     # the degree days are evaluated while X is packed
+                stack = [plan.apply_edd(Xd, Hd, e, offset=edd[1]) for e in thr]
+            else:
+                stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
+            total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
+            for c, o in zip(coefs[1:], stack[1:]):
+                total = total + c * o
+            return [total]
+        if powers is None:
+            return [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
+        if isinstance(plan, DensePlan):         # scattered weights: (x + offset)^p evaluated while X is packed
+            return [plan.apply_poly(Xd, offset, int(p)) for p in powers]
         lo, hi = int(min(powers)), int(max(powers))
         stack = plan.apply_poly(Xd, offset, hi - lo + 1, layout=layout, out_layout=out_layout, pow_first=lo)
-        outs = [stack[int(p) - lo] for p in powers]
+        return [stack[int(p) - lo] for p in powers]
+
+    outs = run(plan)
+    if isinstance(plan, DensePlan) and plan.saw_inf():
+        # +-inf in the (transformed) data: the dense forms multiply every (cell, region) pair of a
+        # stored tile, so inf * 0 would leak NaN into regions that do not own the cell.  The
+        # segment-table form confines it to the owning regions like the reference (S6): redo there.
+        exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
+        try:
+            outs = run(exact)
+            exact.status()
+        finally:
+            exact.close()
+    if edd is not None:
+        single = True
     res = [unflatten(o.cpu().numpy(), len(uniq)) for o in outs]
+    if isinstance(plan, SparsePlan):
+        plan.status()                                        # a device-side failure must not pass silently
     rdims = _result_dims(dims, agglev)
 
     coords = {}

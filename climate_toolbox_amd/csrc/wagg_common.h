@@ -43,6 +43,43 @@ __host__ __device__ inline float hash_u01(uint64_t idx, uint32_t seed) {
     return (float)(hash32(idx, seed) >> 8) * (1.0f / 16777216.0f);
 }
 
+// ---- grid-level transforms evaluated while the data is loaded ---------------------
+constexpr int XF_EDD = -1;
+
+// transformations.py:64-87, evaluated in the data type like the reference:
+//   tmin < e ? (tmax > e ? ((M - e)(pi/2 - theta) + w cos(theta)) / pi : 0) : M - e
+// (a NaN tasmin gives M - e = NaN, a NaN tasmax with tasmin < e gives 0 -- exactly what the two
+// nested xr.where calls select)
+template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T e) {
+    const T M = (tmax + tmin) / T(2), w = (tmax - tmin) / T(2);
+    if (!(tmin < e)) return M - e;
+    if (!(tmax > e)) return T(0);
+    const T pi = T(3.14159265358979323846);
+    // theta = arcsin(z) lies in [-pi/2, pi/2], where cos(theta) = sqrt((1 - z)(1 + z)) exactly
+    // (tmin < e < tmax puts z strictly inside (-1, 1)); this spares the general-argument cosine
+    const T z = (e - M) / w;
+    T theta, c;
+    if constexpr (sizeof(T) == 4) { theta = asinf(z); c = sqrtf((T(1) - z) * (T(1) + z)); }
+    else { theta = asin(z); c = sqrt((T(1) - z) * (T(1) + z)); }
+    return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
+}
+
+template <typename T> __device__ __forceinline__ T xform1(T x, T off, int pw) {
+    const T y = x + off;
+    T r = y;
+    for (int i = 1; i < pw; ++i) r *= y;
+    return r;
+}
+template <typename V, typename T> __device__ __forceinline__ V xform4(V v, T off, int pw) {
+    V r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = xform1<T>(v[c], off, pw);
+    return r;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per apply
+hipError_t allow_dynamic_lds(const void *kern, size_t bytes);
+
 // event ring behind wagg_profile_enable / wagg_profile_read (wagg_util.hip)
 void profile_mark(hipStream_t stream, bool begin);
 

@@ -29,7 +29,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "wagg_common.h"
+#include "wagg_dense_int.h"
 
 namespace wagg {
 
@@ -65,7 +65,7 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // rows {4-11} of the next; with f = i >> 1 the 16-byte positions (i & 1) * 8 + ((kq + 4h) ^ f)
 // are all distinct within each group.
 //
-// DBG is a diagnostic knob (WAGG_DENSE_DBG env, never set in production): bit0 = skip the LDS-DMA
+// DBG is a diagnostic knob (WAGG_DENSE_DBG env, read by the -DWAGG_DIAG build only): bit0 = skip the LDS-DMA
 // of the k-loop, bit2 = skip the per-tile barrier, bit3 = both waves of a SIMD issue their DMA
 // pieces at the same point, bit4 = X pieces before the W pieces.  Results are wrong with bit0 or
 // bit2 set.
@@ -262,9 +262,11 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 // bm = 16 MT rows), NaN -> 0 (S6), zero for rows >= T and cells >= G.  One thread per slot; the 8 slots of a row read one 128-byte
 // line of X.
 __global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
-                                    int n_kt, int bm, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp) {
+                                    int n_kt, int bm, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp,
+                                    PackXf xf, int *__restrict__ inf_flag) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int tile_slots = bm * 8;                         // bm rows x 8 pieces of 16 bytes
+    bool inf_seen = false;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
         const int slot = (int)(s % tile_slots);
         const int64_t tk = s / tile_slots;
@@ -272,20 +274,26 @@ __global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int6
         const int64_t mb = tk / n_kt;
         const int row = slot >> 3, p = (slot & 7) ^ ((row >> 1) & 7);
         const int64_t t = mb * bm + row, k0 = (int64_t)kt * D_BK + 4 * p;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
             const float *src = X + t * ldx + k0;
+            const float *src2 = xf.mode == XF_EDD ? xf.X2 + t * ldx + k0 : src;
             if (aligned && k0 + 4 <= G) {
                 v = *reinterpret_cast<const f32x4 *>(src);
+                if (xf.mode == XF_EDD) h = *reinterpret_cast<const f32x4 *>(src2);
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (k0 + c < G) v[c] = src[c];
+                for (int c = 0; c < 4; ++c) if (k0 + c < G) { v[c] = src[c]; h[c] = src2[c]; }
             }
+            // transform (tas_poly / snyder_edd), then NaN -> 0 (S6); cells >= G stay 0
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = nan0(v[c]);
+            for (int c = 0; c < 4; ++c) if (k0 + c < G) v[c] = pack_xf(xf, v[c], h[c], inf_seen);
         }
         Xp[s] = v;
     }
+    // the MFMA forms multiply every (cell, region) pair of a stored tile: +-inf data would turn the
+    // zero weights of other regions into NaN, so the caller is told (wagg_dense_saw_inf)
+    if (inf_seen) __hip_atomic_store(inf_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // float index of W[g][r] inside the packed matrix Wp[nt][kt][slot][4]
@@ -420,31 +428,9 @@ __global__ void dense_pack_w_kernel(const float *__restrict__ W, int64_t G, int3
 
 }  // namespace wagg
 
-struct wagg_dense {
-    int64_t G = 0;
-    int32_t R = 0;
-    int n_kt = 0, n_nt = 0;            // k tiles (32 cells) and column tiles (256 regions)
-    wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order
-    wagg::DevBuf<double> den64;
-    std::vector<double> den_host;
-    // tile-sparse form: only the non-empty (32-cell x 256-region) tiles of W are stored, grouped by
-    // column tile; tile_kt[i] = k tile of stored tile i (+2 padding entries), tile_off[nt][0..TS] =
-    // the column tile's run split into TS slices of equal length
-    bool tiled = false;
-    int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
-    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: one table per slice count 1, 2, 4, 8
-    static constexpr int TS = 8;
-    static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
-        int64_t at = 0;
-        for (int t = 1; t < ts; t *= 2) at += (int64_t)n_nt * (t + 1);
-        return at;
-    }
-    int64_t w_slots() const { return n_tiles * (wagg::D_WT / 4); }
-};
-
 namespace wagg {
 
-static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_tiles = -1) {
+static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_tiles = -1, bool spmm = false) {
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
@@ -454,9 +440,15 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     d->G = G; d->R = R;
     d->n_kt = (int)((G + D_BK - 1) / D_BK);
     d->n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
-    d->n_tiles = stored_tiles >= 0 ? stored_tiles : (int64_t)d->n_nt * d->n_kt;
-    d->tiled = stored_tiles >= 0;
-    hipError_t e = d->W.alloc((size_t)(d->w_slots() > 0 ? d->w_slots() : 1) * 4);
+    d->n_tiles = spmm ? 0 : (stored_tiles >= 0 ? stored_tiles : (int64_t)d->n_nt * d->n_kt);
+    d->tiled = !spmm && stored_tiles >= 0;
+    d->spmm = spmm;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { *d->inf_host = 0; e = hipHostGetDevicePointer((void **)&d->inf_dev, d->inf_host, 0); }
+    if (e == hipSuccess) e = d->W.alloc((size_t)(d->w_slots() > 0 ? d->w_slots() : 1) * 4);
     if (e == hipSuccess) e = d->den32.alloc((size_t)R);
     if (e == hipSuccess) e = d->den64.alloc((size_t)R);
     if (e != hipSuccess) {
@@ -507,6 +499,11 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
     return e;
 }
 
+// Below this share of non-zeros a W whose tiles are (almost) all occupied goes to the entry-list form
+// (wagg_spmm.hip): it runs at ~25 % of the fp32 peak on 2*T*nnz flops, the full MFMA form at ~90 % on
+// 2*T*G*R, so the break-even is near 25 % fill; 10 % keeps a safety margin for small problems.
+constexpr double SPMM_MAX_FILL = 0.10;
+
 static int pick_ksplit(int64_t items, int n_kt) {
     int best = 8;
     double best_eff = 0.0;
@@ -529,6 +526,13 @@ extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg
 extern "C" int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
     using namespace wagg;
     WAGG_REQUIRE(fill > 0.0 && fill <= 1.0, "fill must be in (0, 1]");
+    if (fill < SPMM_MAX_FILL) {             // scattered and sparse: entry lists instead of a matrix
+        int rc = dense_alloc(G, R, out, -1, true);
+        if (rc != WAGG_OK) return rc;
+        rc = spmm_build_synth(*out, seed, fill);
+        if (rc != WAGG_OK) { delete *out; *out = nullptr; }
+        return rc;
+    }
     int rc = dense_alloc(G, R, out);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
@@ -585,7 +589,9 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     WAGG_REQUIRE(d && info, "NULL argument");
     info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
     info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
-    info->w_bytes = d->w_slots() * 16;
+    info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 64 : d->w_slots() * 16;
+    info->form = d->spmm ? WAGG_FORM_ENTRIES : (d->tiled ? WAGG_FORM_TILES : WAGG_FORM_FULL);
+    info->nnz = d->spmm ? d->sp.nnz : -1;
     return WAGG_OK;
 }
 
@@ -642,10 +648,26 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
     std::vector<int64_t> tiles(keys);
     std::sort(tiles.begin(), tiles.end());
     tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
-    const bool tiled = (double)tiles.size() < 0.5 * (double)n_kt * (double)n_nt && !getenv("WAGG_DENSE_NO_TILED");
-    int rc = dense_alloc(G, R, out, tiled ? (int64_t)tiles.size() : -1);
+    bool tiled = (double)tiles.size() < 0.5 * (double)n_kt * (double)n_nt;
+#ifdef WAGG_DIAG
+    if (getenv("WAGG_DENSE_NO_TILED")) tiled = false;
+#endif
+    // tiles mostly occupied but few non-zeros in them (scattered weights): entry lists
+    const bool spmm = !tiled && (double)hc.size() < SPMM_MAX_FILL * (double)G * (double)R;
+    int rc = dense_alloc(G, R, out, tiled ? (int64_t)tiles.size() : -1, spmm);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
+    if (spmm) {
+        rc = spmm_build_from_coo(d, hc, hr, hw);
+        std::vector<float> den32s(den.size());
+        for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
+        hipError_t es = rc == WAGG_OK ? hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice) : hipSuccess;
+        if (es == hipSuccess && rc == WAGG_OK) es = hipMemcpy(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), hipMemcpyHostToDevice);
+        if (es != hipSuccess) { set_error("entry lists: %s", hipGetErrorString(es)); rc = WAGG_EHIP; }
+        if (rc != WAGG_OK) { delete d; *out = nullptr; return rc; }
+        d->den_host = den;
+        return WAGG_OK;
+    }
     DevBuf<int32_t> dc, dr; DevBuf<float> dw; DevBuf<int64_t> dat;
     hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * 4 * (size_t)d->w_slots());
     if (e == hipSuccess) e = dw.upload(hw);
@@ -695,15 +717,17 @@ extern "C" int wagg_dense_get_den(const wagg_dense *d, double *den_host) {
     return WAGG_OK;
 }
 
-extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
-                                    float *out_dev, int64_t ldo, int ksplit, void *stream) {
-    using namespace wagg;
+namespace wagg {
+static int dense_apply(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, const PackXf &xf,
+                       float *out_dev, int64_t ldo, int ksplit, void *stream) {
     WAGG_REQUIRE(d != nullptr, "dense plan is NULL");
     WAGG_REQUIRE(T >= 0, "T < 0");
     if (T == 0) return WAGG_OK;
     WAGG_REQUIRE(X_dev && out_dev, "X/out is NULL");
+    WAGG_REQUIRE(xf.mode != XF_EDD || xf.X2 != nullptr, "tasmax is NULL");
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
+    if (d->spmm) return spmm_apply(d, X_dev, T, ldx, xf, out_dev, ldo, (hipStream_t)stream);
     const int n_nt = d->n_nt, n_kt = d->n_kt;
     // row blocks: as few as possible (<= 368 rows each), evenly filled, 16 MT rows with MT from the
     // instantiated set -- T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
@@ -738,6 +762,7 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
         default: set_error("no kernel for MT=%d", MT); return WAGG_EINVAL;
     }
 #undef WAGG_PICK
+#ifdef WAGG_DIAG      // ablation variants (timing only; results are wrong with bit0 or bit2): tools/dense_ablate.sh
     if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
         switch (atoi(dbg)) {
             case 1: kern = dense_mfma_kernel<1>; break;
@@ -748,9 +773,11 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
             default: break;
         }
     }
-    WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#endif
+    WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));
+    const int aligned2 = aligned && (xf.mode != XF_EDD || (reinterpret_cast<uintptr_t>(xf.X2) & 15) == 0);
     hipLaunchKernelGGL(dense_pack_x_kernel, dim3(256 * 16), dim3(256), 0, st, X_dev, T, ldx, d->G, n_kt, bm, x_slots,
-                       aligned, reinterpret_cast<f32x4 *>(d->xp.p));
+                       aligned2, reinterpret_cast<f32x4 *>(d->xp.p), xf, d->inf_dev);
     WAGG_HIP(hipGetLastError());
     profile_mark(st, true);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, (const float *)d->xp.p,
@@ -762,5 +789,38 @@ extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T
     hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,
                        d->slabs.p, n_nt, S, bm, T, d->R, d->den32.p, out_dev, ldo);
     WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+}  // namespace wagg
+
+extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
+                                    float *out_dev, int64_t ldo, int ksplit, void *stream) {
+    return wagg::dense_apply(d, X_dev, T, ldx, wagg::PackXf{}, out_dev, ldo, ksplit, stream);
+}
+
+extern "C" int wagg_dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, double offset,
+                                         int power, float *out_dev, int64_t ldo, int ksplit, void *stream) {
+    using namespace wagg;
+    WAGG_REQUIRE(power >= 1 && power <= 16, "power must lie in [1, 16], got %d", power);
+    PackXf xf;
+    xf.mode = power; xf.off = (float)offset;
+    return dense_apply(d, X_dev, T, ldx, xf, out_dev, ldo, ksplit, stream);
+}
+
+extern "C" int wagg_dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+                                        int64_t ldx, double offset, double threshold, float *out_dev, int64_t ldo,
+                                        int ksplit, void *stream) {
+    using namespace wagg;
+    PackXf xf;
+    xf.mode = XF_EDD; xf.off = (float)offset; xf.thr = (float)threshold; xf.X2 = tasmax_dev;
+    return dense_apply(d, tasmin_dev, T, ldx, xf, out_dev, ldo, ksplit, stream);
+}
+
+extern "C" int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw) {
+    using namespace wagg;
+    WAGG_REQUIRE(d && saw, "NULL argument");
+    WAGG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *saw = *(volatile int *)d->inf_host;
+    *(volatile int *)d->inf_host = 0;
     return WAGG_OK;
 }

@@ -1,0 +1,85 @@
+// Internal layout of a dense-family plan (wagg_dense) shared by wagg_dense.hip (full / tile-sparse
+// MFMA forms) and wagg_spmm.hip (entry-list form for scattered weights).
+#pragma once
+#include "wagg_common.h"
+
+namespace wagg {
+
+// Element transform applied while X is packed for a dense-family apply: the packed
+// copy is the only place every element is touched, so tas_poly / snyder_edd cost no extra pass.
+struct PackXf {
+    int mode = 0;            // 0: identity; p > 0: (x + off)^p; XF_EDD: snyder_edd1(x + off, x2 + off, thr)
+    float off = 0.f, thr = 0.f;
+    const float *X2 = nullptr;   // tasmax (XF_EDD only), same shape and row stride as X
+};
+
+// transformed value with NaN -> 0 (S6); *inf_seen is set when the result is +-inf (the MFMA forms
+// multiply every pair of a stored tile, so the caller must redo such a field in an exact form)
+__device__ __forceinline__ float pack_xf(const PackXf &xf, float x, float x2, bool &inf_seen) {
+    float y = x;
+    if (xf.mode > 0) y = xform1<float>(x, xf.off, xf.mode);
+    else if (xf.mode == XF_EDD) y = snyder_edd1<float>(x + xf.off, x2 + xf.off, xf.thr);
+    inf_seen |= __builtin_isinf(y);
+    return y == y ? y : 0.0f;
+}
+
+// ---- entry-list ("SpMM") form: geometry shared by the builders and the kernel -------------------
+constexpr int SP_WAVES = 16;                 // waves per workgroup (1024 threads, one workgroup per CU)
+constexpr int SP_THREADS = SP_WAVES * 64;
+constexpr int SP_TB = 64;                    // timesteps per block = lanes of a wave
+constexpr int SP_KC = 256;                   // grid cells per LDS chunk (256 rows x 256 B = 64 KiB)
+constexpr int SP_ACC = 96;                   // accumulator registers per lane (v[32:127])
+constexpr int SP_RW_MAX = SP_ACC - 1;        // regions per wave; accumulator 95 swallows the padding entries
+constexpr int SP_TRASH = SP_ACC - 1;
+constexpr int SP_GROUP = 8;                  // entries per 64-byte group (one s_load_dwordx16)
+
+struct SpmmPlan {
+    int rw = 0;                              // regions per wave (<= SP_RW_MAX), region r = (rb * 16 + wave) * rw + j
+    int n_rb = 0;                            // region blocks of 16 * rw regions
+    int n_chunks = 0;                        // ceil(G / SP_KC)
+    int64_t nnz = 0, n_groups = 0;           // kept (cell, region) pairs; 8-entry groups incl. padding
+    DevBuf<uint2> ent;                       // [n_groups * 8 + 8]: .x = (cell_in_chunk << 8) | acc index, .y = weight bits
+    DevBuf<int32_t> grp_off;                 // [n_rb * n_chunks * 16 + 1]: first group of (rb, chunk, wave)
+};
+
+}  // namespace wagg
+
+struct wagg_dense {
+    int64_t G = 0;
+    int32_t R = 0;
+    int n_kt = 0, n_nt = 0;            // k tiles (32 cells) and column tiles (256 regions)
+    wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order
+    wagg::DevBuf<double> den64;
+    std::vector<double> den_host;
+    // tile-sparse form: only the non-empty (32-cell x 256-region) tiles of W are stored, grouped by
+    // column tile; tile_kt[i] = k tile of stored tile i (+2 padding entries), tile_off[nt][0..TS] =
+    // the column tile's run split into TS slices of equal length
+    bool tiled = false;
+    int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
+    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: one table per slice count 1, 2, 4, 8
+    static constexpr int TS = 8;
+    static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
+        int64_t at = 0;
+        for (int t = 1; t < ts; t *= 2) at += (int64_t)n_nt * (t + 1);
+        return at;
+    }
+    int64_t w_slots() const { return n_tiles * (8192 / 4); }   // 16-byte slots (one tile = 256 x 32 floats)
+    // entry-list form (scattered weights, e.g. <= 1 % non-zeros at random positions): no W matrix at all
+    bool spmm = false;
+    wagg::SpmmPlan sp;
+    int ncu = 256;
+    // +-inf seen in the (transformed) data of an apply in one of the MFMA forms: host-mapped word
+    int *inf_host = nullptr, *inf_dev = nullptr;
+    ~wagg_dense() { if (inf_host) (void)hipHostFree(inf_host); }
+};
+
+namespace wagg {
+// wagg_spmm.hip
+int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill);
+int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
+                        const std::vector<float> &w);
+int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const PackXf &xf, float *out, int64_t ldo,
+               hipStream_t stream);
+// wagg_dense.hip
+int dense_alloc_common(wagg_dense *d);
+}  // namespace wagg

@@ -25,10 +25,22 @@
 #include <cmath>
 #include <cstdlib>
 #include <numeric>
+#include <utility>
 
 #include "wagg_common.h"
 
 namespace wagg {
+
+// Diagnostic knobs (ablation switches, phase stamps) exist only in the -DWAGG_DIAG build
+// (`make diag` -> libwagg_diag.so, used by tools/*_ablate.sh); the production library reads no
+// environment variable on any path.
+#ifdef WAGG_DIAG
+static inline int diag_env(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+static inline bool diag_set(const char *name) { return getenv(name) != nullptr; }
+#else
+static inline constexpr int diag_env(const char *) { return 0; }
+static inline constexpr bool diag_set(const char *) { return false; }
+#endif
 
 constexpr int UC = 256;      // cell slots per LDS chunk == workgroup size
 constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of a wave)
@@ -65,6 +77,12 @@ struct wagg_plan {
     std::vector<double> den_host;
     wagg::SparsePlanDev d;
     int device = 0;
+    int ncu = 256;                 // compute units of `device` (read once, at plan creation)
+    int flags = 0;                 // WAGG_PLAN_* kernel-form switches, fixed at plan creation
+    // set by a kernel whose consumer-wave barrier timed out (host-mapped, so the host can read it
+    // without touching the stream); checked by the next apply, wagg_plan_status and the *_host_ forms
+    int *timeout_host = nullptr, *timeout_dev = nullptr;
+    ~wagg_plan() { if (timeout_host) (void)hipHostFree(timeout_host); }
 };
 
 namespace wagg {
@@ -88,39 +106,6 @@ template <typename T> struct PlanView {
     int n_thr;
     int64_t thr_pstride;         // output of threshold k goes to out + k * thr_pstride
 };
-constexpr int XF_EDD = -1;
-
-// transformations.py:64-87, evaluated in the data type like the reference:
-//   tmin < e ? (tmax > e ? ((M - e)(pi/2 - theta) + w cos(theta)) / pi : 0) : M - e
-// (a NaN tasmin gives M - e = NaN, a NaN tasmax with tasmin < e gives 0 -- exactly what the two
-// nested xr.where calls select)
-template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T e) {
-    const T M = (tmax + tmin) / T(2), w = (tmax - tmin) / T(2);
-    if (!(tmin < e)) return M - e;
-    if (!(tmax > e)) return T(0);
-    const T pi = T(3.14159265358979323846);
-    // theta = arcsin(z) lies in [-pi/2, pi/2], where cos(theta) = sqrt((1 - z)(1 + z)) exactly
-    // (tmin < e < tmax puts z strictly inside (-1, 1)); this spares the general-argument cosine
-    const T z = (e - M) / w;
-    T theta, c;
-    if constexpr (sizeof(T) == 4) { theta = asinf(z); c = sqrtf((T(1) - z) * (T(1) + z)); }
-    else { theta = asin(z); c = sqrt((T(1) - z) * (T(1) + z)); }
-    return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
-}
-
-template <typename T> __device__ __forceinline__ T xform1(T x, T off, int pw) {
-    const T y = x + off;
-    T r = y;
-    for (int i = 1; i < pw; ++i) r *= y;
-    return r;
-}
-template <typename V, typename T> __device__ __forceinline__ V xform4(V v, T off, int pw) {
-    V r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = xform1<T>(v[c], off, pw);
-    return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
@@ -655,8 +640,16 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                                                                   float *__restrict__ out, int64_t ldo,
                                                                   int n_norm, long long n_items,
                                                                   int *__restrict__ timeout_word,
-                                                                  unsigned long long *__restrict__ stamps, int knob,
+                                                                  unsigned long long *__restrict__ stamps_arg, int knob_arg,
                                                                   int64_t out_pstride = 0, float ylim = 0.f) {
+#ifdef WAGG_DIAG
+    const int knob = knob_arg;                       // ablation switches / phase stamps: diagnostic build only
+    unsigned long long *const stamps = stamps_arg;
+#else
+    constexpr int knob = 0;
+    constexpr unsigned long long *stamps = nullptr;
+    (void)knob_arg; (void)stamps_arg;
+#endif
     typedef float vec4 __attribute__((ext_vector_type(4)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -714,11 +707,13 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         };
         auto load_cell = [&](const StreamDesc &d) {
             const int c = pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
-            if (knob & 16) {                    // diagnostic: aligned 8 x 128-B patch instead of the chunk's quads
+#ifdef WAGG_DIAG      // timing-only address patterns on the 720 x 1440 grid (results are wrong)
+            if (knob & 16) {                    // aligned 8 x 128-B patch instead of the chunk's quads
                 const int rowlen = 1440, pc = (d.u0 >> 6) % 45, pr = ((d.u0 >> 6) / 45) % 90;
                 return (pr * 8 + (lane >> 3)) * rowlen + pc * 32 + (lane & 7) * 4;
             }
-            if (knob & 32) return ((d.u0 >> 6) % 4050) * 256 + lane * 4;      // diagnostic: 1 KB contiguous
+            if (knob & 32) return ((d.u0 >> 6) % 4050) * 256 + lane * 4;      // 1 KB contiguous
+#endif
             return c;
         };
         struct Regs { vec4 v[TPW]; int mu; float mw; int er, es; float ed; };
@@ -856,17 +851,30 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         const int ctid = tid - LC_LW * 64;                        // 0..255
         const int lr = lane & 15, kq = lane >> 4;
         int epoch = 0;
+        // A consumer wave whose barrier spin runs out marks the launch as failed (the host turns the
+        // word into WAGG_EHIP), stops computing and storing, and only keeps the workgroup barriers
+        // going so that the loaders drain; its partners then time out at their next arrival too.
         bool dead = false;
         auto cbarrier = [&]() {                                   // the 4 consumer waves only (bounded spin)
+            if (dead) return;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             epoch += LC_CW;
+            int gave_up = 0;
             if (lane == 0) {
-                __hip_atomic_fetch_add(ccnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                int spins = 0;
-                while (__hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
-                    if (++spins > (1 << 24)) { if (timeout_word) *timeout_word = 1; dead = true; break; }
+#ifdef WAGG_DIAG
+                if ((knob & 64) && cw == 3 && epoch > 8 * LC_CW) gave_up = 1;   // test hook: wave 3 stops arriving
+                else
+#endif
+                {
+                    __hip_atomic_fetch_add(ccnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    int spins = 0;
+                    while (__hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
+                        if (++spins > (1 << 24)) { gave_up = 1; break; }
+                    }
                 }
+                if (gave_up && timeout_word) __hip_atomic_store(timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            dead = __builtin_amdgcn_readfirstlane(gave_up) != 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         // the dense weight tile starts all-zero and is returned to all-zero after every pass
@@ -884,7 +892,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
             const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
             const bool exact = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);
-            if (knob & 1) continue;                               // diagnostic: consumers idle
+            if ((knob & 1) || dead) continue;                     // (knob: diagnostic build, consumers idle)
             if (!exact) {
                 for (int e0 = 0; e0 < ne; e0 += 16) {
                     // ---- dense weight tile of regions e0..e0+15: scatter the segments ----
@@ -894,6 +902,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                         if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = sm_w[buf * LC_SEGS + k];
                     }
                     cbarrier();
+                    if (dead) break;
                     stamp(0);                                     // consumer ph0: build the weight tile
                     // ---- out[t][e] = sum_u img[t][u] * Aw[e][u].  A = img (i = timestep), B = Aw^T
                     // (j = region); lane group kq = lane >> 4 walks cells 64 kq .. 64 kq + 63, so one
@@ -949,12 +958,14 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     }
                     stamp(1);                                     // ph1: MFMAs + stores
                     cbarrier();                                   // every wave is done reading the tile
+                    if (dead) break;
                     for (int k = ctid; k < ns; k += 256) {        // return the tile to all-zero
                         const int pu = sm_u[buf * LC_SEGS + k];
                         const int e = (pu >> 16) & 0xff;
                         if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = 0.f;
                     }
                     if (e0 + 16 < ne) cbarrier();                 // next pass scatters into a clean tile
+                    if (dead) break;
                     stamp(2);                                     // ph2: un-scatter + consumer barrier
                 }
             } else {
@@ -986,7 +997,6 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         }
         lds_only_barrier();                                       // matches the loaders' final barrier
         if (stamps && ctid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
-        (void)dead;
     }
 }
 
@@ -1027,6 +1037,31 @@ __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_emp
     else out[(int64_t)r * ldo + t] = q;
 }
 
+#ifdef WAGG_DIAG
+#define WAGG_DIAG_GATHER_VARIANTS(L, O, V)                                                       \
+            else switch (diag_env("WAGG_SPARSE_DBG")) {                                          \
+                case 1: kern = sparse_gather_kernel<T, TB, L, O, V, 1>; break;                   \
+                case 2: kern = sparse_gather_kernel<T, TB, L, O, V, 2>; break;                   \
+                case 4: kern = sparse_gather_kernel<T, TB, L, O, V, 4>; break;                   \
+                case 6: kern = sparse_gather_kernel<T, TB, L, O, V, 6>; break;                   \
+                case 7: kern = sparse_gather_kernel<T, TB, L, O, V, 7>; break;                   \
+                default: break;                                                                  \
+            }
+#else
+#define WAGG_DIAG_GATHER_VARIANTS(L, O, V)
+#endif
+
+// a consumer-wave barrier of an earlier sparse_lc_kernel launch on this plan timed out: its
+// results are incomplete (the dead waves stopped storing)
+static int check_timeout(const wagg_plan *plan) {
+    if (plan->timeout_host && *(volatile int *)plan->timeout_host != 0) {
+        set_error("sparse_lc_kernel: consumer-wave barrier timed out in an earlier apply on this plan; "
+                  "its results are incomplete");
+        return WAGG_EHIP;
+    }
+    return WAGG_OK;
+}
+
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
@@ -1036,9 +1071,10 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // the i-th goes to out + i * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
     const auto &d = plan->d;
+    if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
-        const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !getenv("WAGG_SPARSE_NO_STREAM") &&
-                           !getenv("WAGG_SPARSE_NO_LC") && (int)plan->info.n_groups - d.g0_normal > 0 && Ttot > 0;
+        const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
+                           (int)plan->info.n_groups - d.g0_normal > 0 && Ttot > 0;
         if (!lc_ok || nfuse > 4) {
             for (int i = 0; i < nfuse; ++i) {
                 const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
@@ -1089,15 +1125,13 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // aligned fast path: 16-byte aligned rows
     const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0);
     // two-field transforms (EDD) are implemented in the chunk-walking kernel only
-    const bool stream_path = layout == WAGG_LAYOUT_TG && xpow != XF_EDD && !getenv("WAGG_SPARSE_NO_STREAM");
+    const bool stream_path = layout == WAGG_LAYOUT_TG && xpow != XF_EDD && !(plan->flags & WAGG_PLAN_NO_STREAM);
     const int n_norm = (int)plan->info.n_groups - d.g0_normal;
     bool lc_done = false;
     if constexpr (sizeof(T) == 4) {
-        if (stream_path && n_norm > 0 && !getenv("WAGG_SPARSE_NO_LC")) {
+        if (stream_path && n_norm > 0 && !(plan->flags & WAGG_PLAN_NO_LC)) {
             // loader/consumer MFMA kernel over the single-chunk groups; one workgroup per CU
-            int dev = 0, ncu = 256;
-            WAGG_HIP(hipGetDevice(&dev));
-            WAGG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            const int ncu = plan->ncu;
             const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
             const long long nw = n_items < ncu ? n_items : ncu;
             auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
@@ -1106,13 +1140,13 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
             // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
             const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)(xpow + nfuse - 1)) : 0.f;
-            WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LcLds::total));
+            WAGG_HIP(allow_dynamic_lds((const void *)kern, LcLds::total));
             unsigned long long *lc_stamps = nullptr;
-            if (getenv("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
+            if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
             hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
-                               plan->info.G, kout, kldo, n_norm, n_items, (int *)nullptr, lc_stamps,
-                               getenv("WAGG_LC_KNOB") ? atoi(getenv("WAGG_LC_KNOB")) : 0, kpstride, ylim);
+                               plan->info.G, kout, kldo, n_norm, n_items, plan->timeout_dev, lc_stamps,
+                               diag_env("WAGG_LC_KNOB"), kpstride, ylim);
             profile_mark(stream, false);
             WAGG_HIP(hipGetLastError());
             if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
@@ -1132,23 +1166,23 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     }
     if (stream_path && n_norm > 0 && !lc_done) {
         // persistent pipelined kernel over the single-chunk groups; two workgroups per CU
-        int dev = 0, ncu = 256;
-        WAGG_HIP(hipGetDevice(&dev));
-        WAGG_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * n_tb;
         const long long nw = n_items < 2LL * ncu ? n_items : 2LL * ncu;
         const size_t shmem = SparseLds<T, TB>::total;
         auto kern = vec ? sparse_stream_kernel<T, TB, true> : sparse_stream_kernel<T, TB, false>;
         unsigned long long *stamps = nullptr;
-        const bool do_stamp = getenv("WAGG_SPARSE_STAMP") != nullptr;
+        const bool do_stamp = diag_set("WAGG_SPARSE_STAMP");
+#ifdef WAGG_DIAG
         if (do_stamp) {
             kern = sparse_stream_kernel<T, TB, true, true>;
             WAGG_HIP(hipMalloc((void **)&stamps, sizeof(unsigned long long) * 10 * (size_t)nw));
         }
-        WAGG_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+#endif
+        WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));
         profile_mark(stream, true);
         hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(STHREADS), shmem, stream, pv, X, Ttot, ldx, plan->info.G,
-                           kout, kldo, n_norm, n_items, stamps, do_stamp ? atoi(getenv("WAGG_SPARSE_STAMP")) : 0);
+                           kout, kldo, n_norm, n_items, stamps, diag_env("WAGG_SPARSE_STAMP"));
         profile_mark(stream, false);
         WAGG_HIP(hipGetLastError());
         if (do_stamp) {           // diagnostic: print mean cycles per stage and phase
@@ -1177,18 +1211,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         do {                                                                                     \
             auto kern = sparse_gather_kernel<T, TB, L, O, V>;                                    \
             if (xpow == XF_EDD && pv.n_thr > 1) kern = sparse_gather_kernel<T, TB, L, O, V, 0, 4>; \
-            else if (const char *dbg_ = getenv("WAGG_SPARSE_DBG")) {                                  \
-                switch (atoi(dbg_)) {                                                            \
-                    case 1: kern = sparse_gather_kernel<T, TB, L, O, V, 1>; break;               \
-                    case 2: kern = sparse_gather_kernel<T, TB, L, O, V, 2>; break;               \
-                    case 4: kern = sparse_gather_kernel<T, TB, L, O, V, 4>; break;               \
-                    case 6: kern = sparse_gather_kernel<T, TB, L, O, V, 6>; break;               \
-                    case 7: kern = sparse_gather_kernel<T, TB, L, O, V, 7>; break;               \
-                    default: break;                                                              \
-                }                                                                                \
-            }                                                                                    \
-            WAGG_HIP(hipFuncSetAttribute((const void *)kern,                                     \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+            WAGG_DIAG_GATHER_VARIANTS(L, O, V)                                                   \
+            WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));                              \
             if (!(stream_path && n_norm > 0)) profile_mark(stream, true);                        \
             hipLaunchKernelGGL(kern, grid, block, shmem, stream, pv, X, Ttot, ldx, plan->info.G, \
                                kout + (int64_t)pz * kpstride, kldo);                             \
@@ -1242,9 +1266,9 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                                 const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                 int64_t row_len, int flags, wagg_plan **out) {
     using namespace wagg;
-    (void)flags;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
+    WAGG_REQUIRE((flags & ~(WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) == 0, "unknown plan flags 0x%x", flags);
     WAGG_REQUIRE(nseg >= 0 && G > 0 && R >= 0, "bad sizes nseg=%lld G=%lld R=%d", (long long)nseg,
                  (long long)G, R);
     WAGG_REQUIRE(G < (int64_t)0x7fffffff, "G must fit int32");
@@ -1286,7 +1310,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         // regions are ordered along latitude bands of `band_rows` grid rows (column-major inside a
         // band): a chunk then covers ~band_rows rows x a run of columns
         int band_rows = 8;
-        if (const char *b = getenv("WAGG_BAND_ROWS")) { const int v = atoi(b); if (v >= 1 && v <= 1024) band_rows = v; }
+        if (const int v = diag_env("WAGG_BAND_ROWS")) { if (v >= 1 && v <= 1024) band_rows = v; }
         std::vector<int32_t> order, empty;
         std::vector<double> key_col((size_t)R, 0.0);
         std::vector<int64_t> key_band((size_t)R, 0);
@@ -1493,9 +1517,15 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         std::vector<float> seg_w32(seg_w.size()), den32(den.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
         for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
-        (void)hipGetDevice(&plan->device);
+        plan->flags = flags;
         auto &d = plan->d;
-        hipError_t he = hipSuccess;
+        hipError_t he = hipGetDevice(&plan->device);
+        if (he == hipSuccess) he = hipDeviceGetAttribute(&plan->ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
+        if (he == hipSuccess) he = hipHostMalloc((void **)&plan->timeout_host, sizeof(int), hipHostMallocMapped);
+        if (he == hipSuccess) {
+            *plan->timeout_host = 0;
+            he = hipHostGetDevicePointer((void **)&plan->timeout_dev, plan->timeout_host, 0);
+        }
         auto up = [&](auto &buf, const auto &h) { if (he == hipSuccess) he = buf.upload(h); };
         up(d.grp_chunk_begin, grp_chunk_begin); up(d.grp_giant, grp_giant);
         up(d.chunk_u_begin, chunk_u_begin); up(d.chunk_e_begin, chunk_e_begin);
@@ -1534,6 +1564,12 @@ extern "C" int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info) {
     WAGG_REQUIRE(plan && info, "NULL argument");
     *info = plan->info;
     return WAGG_OK;
+}
+
+extern "C" int wagg_plan_status(const wagg_plan *plan, void *stream) {
+    WAGG_REQUIRE(plan != nullptr, "plan is NULL");
+    WAGG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return wagg::check_timeout(plan);
 }
 
 extern "C" int wagg_plan_get_den(const wagg_plan *plan, double *den_host) {
@@ -1595,6 +1631,7 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     rc = fn(plan, dx.p, Tn, ldx, layout, dout.p, ldo, out_layout, nullptr);
     if (rc != WAGG_OK) return rc;
     WAGG_HIP(hipDeviceSynchronize());
+    if (int rc2 = check_timeout(plan)) return rc2;
     WAGG_HIP(hipMemcpy(out, dout.p, sizeof(T) * (size_t)(orows * ldo), hipMemcpyDeviceToHost));
     return WAGG_OK;
 }

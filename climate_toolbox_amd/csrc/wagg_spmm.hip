@@ -1,0 +1,444 @@
+// Entry-list ("SpMM") form of the dense-family plan: weights that are scattered all over the grid
+// but sparse -- BASELINE configs[4] "CSR <= 1 % nnz" with uniformly random columns.  Neither of the
+// other forms fits: the segment-table gather (wagg_sparse.hip) would move ~9 TB for one c5 rank
+// shard (every region is spread over the whole grid), and the MFMA forms (wagg_dense.hip) multiply
+// every (cell, region) pair of a tile, i.e. 100x the algorithmic 2*T*nnz flops.  Even with K
+// compacted per 16-region block a 16x16x4 MFMA tile is only ~6.7 % full, so the matrix pipe cannot
+// beat ~10 TF here.  This kernel does exactly 2*T*nnz flops on the vector ALU instead:
+//
+//   * lanes = timesteps.  A workgroup (16 waves, one per CU) owns 64 timesteps x (16 * rw) regions;
+//     every wave keeps rw <= 95 regions x 64 timesteps as ACCUMULATOR REGISTERS v[32:126] for the
+//     whole k loop (98k accumulators per CU: each byte of X that reaches the CU is used ~15 times).
+//   * X is packed once per apply as Xp[time block][cell][64 timesteps] (transform, NaN -> 0 and
+//     zero padding fused, like the MFMA forms' pack); a chunk of 256 cells is one contiguous 64 KiB
+//     run that goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one
+//     workgroup barrier per chunk.
+//   * W is never a matrix: per (region block, chunk, wave) a list of 8-byte entries
+//     (cell_in_chunk << 8 | accumulator, weight), padded to 8-entry groups.  The list is wave-uniform,
+//     so it is read through the SCALAR cache (s_load_dwordx16 = one group) and costs no vector
+//     instruction; one entry = v_bfi (LDS address) + ds_read_b32 (64 timesteps of the cell,
+//     conflict-free) + ONE v_fma_f32 whose accumulator register is picked by the entry itself
+//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[32 + M0[7:0]]).
+//   * bound: one ds_read_b32 per entry = 2 LDS cycles per 64 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
+//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops; the VALU does 2 instructions
+//     per entry and is half idle.
+//   * k is split into S slices so that every CU gets the same number of items; partial sums go to
+//     slabT[slice][region][time] (256-byte coalesced stores straight from the accumulators) and one
+//     reduce kernel adds the slices, divides by den[r] (aggregations.py:77-80) and transposes to
+//     (time, region).  No atomics: bitwise reproducible.
+//   * +-inf data stays exact (S6): only real (cell, region) pairs are multiplied; padding entries
+//     carry w = 0 into a trash accumulator.
+#include <algorithm>
+#include <cmath>
+
+#include "wagg_dense_int.h"
+
+namespace wagg {
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+constexpr int SP_BUF_BYTES = SP_KC * SP_TB * 4;           // 65,536: one X chunk in LDS
+constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB nobody reads: destination of the list warm-up loads
+constexpr int SP_LDS_BYTES = SP_SINK + 1024;
+static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
+
+// one entry: LDS address = (lo & 0xff00) | lanebuf, accumulator = lo & 0xff, weight = hi
+#define SP_BFI(T, LO) "v_bfi_b32 %[" T "], %[vmask], " LO ", %[lb]\n\t"
+#define SP_RD(T) "ds_read_b32 %[" T "], %[" T "]\n\t"
+#define SP_FMA(T, LO, HI, CNT)                                                                   \
+    "s_set_gpr_idx_idx " LO "\n\ts_waitcnt lgkmcnt(" CNT ")\n\tv_fma_f32 v32, %[" T "], " HI ", v32\n\t"
+// One group of 8 entries held in s[A..A+15]; the next group is fetched into s[B..B+15] meanwhile.
+// lgkmcnt: the SMEM may still be in flight beside the 8 LDS reads, so "read k has landed" is
+// lgkmcnt(7 - k) (LDS returns in order; an outstanding SMEM only makes the wait conservative).
+#define SP_GROUP_ASM(A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11, A12, A13, A14, A15, BRANGE)  \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                    \
+    "s_add_u32 %[off], %[off], 64\n\t"                                                            \
+    "s_load_dwordx16 " BRANGE ", %[ptr], %[off]\n\t"                                              \
+    SP_BFI("t0", A0) SP_BFI("t1", A2) SP_BFI("t2", A4) SP_BFI("t3", A6)                           \
+    SP_BFI("t4", A8) SP_BFI("t5", A10) SP_BFI("t6", A12) SP_BFI("t7", A14)                        \
+    SP_RD("t0") SP_RD("t1") SP_RD("t2") SP_RD("t3") SP_RD("t4") SP_RD("t5") SP_RD("t6") SP_RD("t7") \
+    "s_set_gpr_idx_on " A0 ", 0xc\n\ts_waitcnt lgkmcnt(7)\n\tv_fma_f32 v32, %[t0], " A1 ", v32\n\t" \
+    SP_FMA("t1", A2, A3, "6") SP_FMA("t2", A4, A5, "5") SP_FMA("t3", A6, A7, "4")                 \
+    SP_FMA("t4", A8, A9, "3") SP_FMA("t5", A10, A11, "2") SP_FMA("t6", A12, A13, "1")             \
+    SP_FMA("t7", A14, A15, "0")                                                                   \
+    "s_set_gpr_idx_off\n\t"                                                                       \
+    "s_sub_u32 %[n], %[n], 1\n\t"                                                                 \
+    "s_cmp_eq_u32 %[n], 0\n\t"                                                                    \
+    "s_cbranch_scc1 9f\n\t"
+
+__global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
+    const float *__restrict__ Xp, const uint2 *__restrict__ ent, const int32_t *__restrict__ grp_off,
+    float *__restrict__ slabT, int n_tb, int n_rb, int n_chunks, int cps, int rw, int64_t Gpad,
+    int64_t Tpad, int64_t Rpad, int n_items, int n_groups) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink; filled by LDS-DMA only
+    const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char *)lds;   // 0: the only LDS object
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-contiguous logical ids (speed only): the 16 region blocks of one (slice, time block) run on
+    // one XCD at about the same time, so its L2 serves their common X stream
+    const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
+    const int lid = (int)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
+    const int vmask = 0xff00;
+    const int voff16 = lane * 16;                    // LDS-DMA: 16 bytes per lane
+
+    for (int item = lid; item < n_items; item += (int)nblk) {
+        const int rb = item % n_rb;
+        const int tb = (item / n_rb) % n_tb;
+        const int ks = item / (n_rb * n_tb);
+        const int c0 = ks * cps;
+        const int c1 = c0 + cps < n_chunks ? c0 + cps : n_chunks;
+        f32x32 a0, a1, a2;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
+        // cell g of this time block starts at xbase + g * 256 bytes; this wave moves bytes
+        // [wave * 4096, wave * 4096 + 4096) of every 64 KiB chunk
+        const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * (SP_TB * 4) + wave * 4096;
+        const int32_t *goff = grp_off + ((int64_t)rb * n_chunks) * SP_WAVES + wave;
+
+        auto dma_chunk = [&](int c, int buf) {       // 4 x 1 KiB pieces of chunk c -> LDS buffer buf
+            const char *src = xbase + (int64_t)c * SP_BUF_BYTES;
+            const int l0 = lds0 + buf * SP_BUF_BYTES + wave * 4096;
+            int m0save, v1;
+            asm volatile(
+                "s_mov_b32 %[sv], m0\n\t"
+                "s_mov_b32 m0, %[l0]\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %[vo], %[src]\n\t"
+                "v_add_u32 %[v1], 0x400, %[vo]\n\t"
+                "s_add_u32 m0, %[l0], 0x400\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                "v_add_u32 %[v1], 0x800, %[vo]\n\t"
+                "s_add_u32 m0, %[l0], 0x800\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                "v_add_u32 %[v1], 0xc00, %[vo]\n\t"
+                "s_add_u32 m0, %[l0], 0xc00\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                "s_mov_b32 m0, %[sv]\n\t"
+                : [sv] "=&s"(m0save), [v1] "=&v"(v1)
+                : [l0] "s"(l0), [vo] "v"(voff16), [src] "s"(src)
+                : "memory", "scc");
+        };
+        auto warm_list = [&](int c) {                // pull the entry list of chunk c into L2 (no register written)
+            const int g0 = goff[(int64_t)c * SP_WAVES];
+            const char *src = reinterpret_cast<const char *>(ent) + (int64_t)g0 * 64;
+            const int lim = n_groups - g0;           // groups up to the end of the array (one padding group follows)
+            const int voff64 = (lane < lim ? lane : lim) * 64;   // one 64-byte line per lane, never past the allocation
+            const int sink = lds0 + SP_SINK;
+            int m0save;
+            asm volatile(
+                "s_mov_b32 %[sv], m0\n\t"
+                "s_mov_b32 m0, %[sink]\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dword %[vo], %[src]\n\t"
+                "s_mov_b32 m0, %[sv]\n\t"
+                : [sv] "=&s"(m0save)
+                : [sink] "s"(sink), [vo] "v"(voff64), [src] "s"(src)
+                : "memory");
+        };
+
+        if (c0 < c1) {
+            dma_chunk(c0, 0);
+            warm_list(c0);
+            if (c0 + 1 < c1) warm_list(c0 + 1);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        for (int c = c0; c < c1; ++c) {
+            const int buf = (c - c0) & 1;
+            if (c + 1 < c1) dma_chunk(c + 1, buf ^ 1);
+            if (c + 2 < c1) warm_list(c + 2);
+            const int g0 = goff[(int64_t)c * SP_WAVES], g1 = goff[(int64_t)c * SP_WAVES + 1];
+            int n = g1 - g0;
+            if (n > 0) {
+                const uint2 *ptr = ent + (int64_t)g0 * SP_GROUP;
+                const int lb = lds0 + lane * 4 + buf * SP_BUF_BYTES;
+                int off = 0, m0save, t0, t1, t2, t3, t4, t5, t6, t7;
+                asm volatile(
+                    "s_mov_b32 %[sv], m0\n\t"
+                    "s_load_dwordx16 s[36:51], %[ptr], 0x0\n\t"
+                    "1:\n\t"
+                    SP_GROUP_ASM("s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+                                 "s48", "s49", "s50", "s51", "s[52:67]")
+                    SP_GROUP_ASM("s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
+                                 "s64", "s65", "s66", "s67", "s[36:51]")
+                    "s_branch 1b\n\t"
+                    "9:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"                 // the look-ahead load must not land later
+                    "s_mov_b32 m0, %[sv]\n\t"
+                    : [n] "+s"(n), [off] "+s"(off), [sv] "=&s"(m0save), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
+                      "+{v[32:63]}"(a0), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2)
+                    : [ptr] "s"(ptr), [vmask] "v"(vmask), [lb] "v"(lb)
+                    : "memory", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+                      "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
+                      "s62", "s63", "s64", "s65", "s66", "s67");
+            }
+            // this wave's pieces of chunk c + 1 have landed and it is done reading chunk c
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // partial sums of this k slice: region r of the wave, 64 consecutive timesteps per store
+        float *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * SP_TB + lane;
+#pragma unroll
+        for (int j = 0; j < SP_RW_MAX; ++j) {
+            if (j < rw) *dst = j < 32 ? a0[j & 31] : (j < 64 ? a1[j & 31] : a2[j & 31]);
+            dst += Tpad;
+            asm volatile("" : "+v"(dst));            // one running pointer, not 95 hoisted offsets
+        }
+    }
+}
+
+// X (T x G, row stride ldx) -> Xp[time block][cell][64 timesteps]: transform (tas_poly / snyder_edd),
+// NaN -> 0 (S6), zeros for rows >= T and cells >= G.  64 x 64 tiles through LDS: both sides coalesced.
+__global__ __launch_bounds__(256) void spmm_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
+                                                          int64_t Gpad, PackXf xf, float *__restrict__ Xp) {
+    __shared__ float tile[64][65];
+    const int64_t g0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    bool inf_seen = false;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t t = t0 + i, g = g0 + tx;
+        float v = 0.f;
+        if (t < T && g < G) {
+            const float x = X[t * ldx + g];
+            v = pack_xf(xf, x, xf.mode == XF_EDD ? xf.X2[t * ldx + g] : 0.f, inf_seen);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4)
+        Xp[(((int64_t)blockIdx.y * Gpad + g0 + i) * SP_TB) + tx] = tile[tx][i];
+}
+
+// out[t, r] = sum_s slabT[s][r][t] / den[r]   (aggregations.py:77-80), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(const float *__restrict__ slabT, int S, int64_t Rpad, int64_t Tpad,
+                                                          int64_t T, int32_t R, const float *__restrict__ den,
+                                                          float *__restrict__ out, int64_t ldo) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i;
+        float s = 0.f;
+        if (r < Rpad) {
+            const float *p = slabT + r * Tpad + t0 + tx;
+            for (int k = 0; k < S; ++k) s += p[(int64_t)k * Rpad * Tpad];
+        }
+        tile[i][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t t = t0 + i, r = r0 + tx;
+        if (t < T && r < R) out[t * ldo + r] = tile[tx][i] / den[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// builders
+// ---------------------------------------------------------------------------------------------
+// synthetic W[g][r] = hash_u01(g R + r, seed) where hash_u01(g R + r, seed ^ 0x9e3779b9) < fill
+// (wagg_dense_create_synth_sparse).  One workgroup per (region block, chunk), one wave per list:
+// candidates are visited cell-major, kept ones are appended in that order (ballot + prefix count),
+// so the list -- and with it every fp32 sum -- is the same on every build.
+template <bool FILL>
+__global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32_t R, uint32_t seed, float fill, int rw,
+                                                                int n_chunks, int32_t *__restrict__ counts,
+                                                                const int32_t *__restrict__ grp_off, uint2 *__restrict__ ent) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x % n_chunks, rb = blockIdx.x / n_chunks;
+    const int64_t bucket = ((int64_t)rb * n_chunks + c) * SP_WAVES + wave;
+    const int64_t r_first = ((int64_t)rb * SP_WAVES + wave) * rw;
+    const int ncand = SP_KC * rw;
+    int64_t base = FILL ? (int64_t)grp_off[bucket] * SP_GROUP : 0;
+    int kept = 0;
+    for (int i0 = 0; i0 < ncand; i0 += 64) {
+        const int i = i0 + lane;
+        const int gl = i / rw, j = i - gl * rw;
+        const int64_t g = (int64_t)c * SP_KC + gl, r = r_first + j;
+        bool keep = false;
+        uint64_t id = 0;
+        if (i < ncand && g < G && r < R) {
+            id = (uint64_t)g * (uint64_t)R + (uint64_t)r;
+            keep = hash_u01(id, seed ^ 0x9e3779b9u) < fill;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (FILL && keep) {
+            const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+            ent[base + pos] = make_uint2((unsigned)(gl << 8 | j), __float_as_uint(hash_u01(id, seed)));
+        }
+        kept += __popcll(m);
+    }
+    if (FILL) {                                   // pad the last group: w = 0 into the trash accumulator
+        const int padded = (kept + SP_GROUP - 1) / SP_GROUP * SP_GROUP;
+        if (kept + lane < padded) ent[base + kept + lane] = make_uint2((unsigned)SP_TRASH, 0u);
+    } else if (lane == 0) {
+        counts[bucket] = kept;
+    }
+}
+
+// den[r] = sum_g W[g][r] in fp64, one wave per region, fixed summation order
+__global__ __launch_bounds__(256) void spmm_synth_den_kernel(int64_t G, int32_t R, uint32_t seed, float fill,
+                                                             double *__restrict__ den) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    double s = 0.0;
+    for (int64_t g = lane; g < G; g += 64) {
+        const uint64_t id = (uint64_t)g * (uint64_t)R + (uint64_t)r;
+        if (hash_u01(id, seed ^ 0x9e3779b9u) < fill) s += (double)hash_u01(id, seed);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) den[r] = s;
+}
+
+__global__ void spmm_den32_kernel(const double *__restrict__ den64, float *__restrict__ den32, int32_t R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) den32[r] = (float)den64[r];
+}
+
+static void spmm_geometry(wagg_dense *d) {
+    SpmmPlan &sp = d->sp;
+    sp.n_rb = (int)(((int64_t)d->R + SP_WAVES * SP_RW_MAX - 1) / (SP_WAVES * SP_RW_MAX));
+    sp.rw = (int)(((int64_t)d->R + (int64_t)sp.n_rb * SP_WAVES - 1) / ((int64_t)sp.n_rb * SP_WAVES));   // balanced, <= 95
+    sp.n_chunks = (int)((d->G + SP_KC - 1) / SP_KC);
+}
+
+// counts per (region block, chunk, wave) -> first 8-entry group of each list (+ total at the end)
+static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
+    SpmmPlan &sp = d->sp;
+    std::vector<int32_t> off(counts.size() + 1, 0);
+    int64_t groups = 0, nnz = 0;
+    for (size_t i = 0; i < counts.size(); ++i) {
+        off[i] = (int32_t)groups;
+        groups += (counts[i] + SP_GROUP - 1) / SP_GROUP;
+        nnz += counts[i];
+        WAGG_REQUIRE(groups < (int64_t)0x7fffffff, "entry list too long");
+    }
+    off[counts.size()] = (int32_t)groups;
+    sp.n_groups = groups;
+    sp.nnz = nnz;
+    WAGG_HIP(sp.grp_off.upload(off));
+    // one extra group at the end: the kernel's look-ahead load reads 64 bytes past the last list
+    WAGG_HIP(sp.ent.alloc((size_t)(groups + 1) * SP_GROUP));
+    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * SP_GROUP, 0, sizeof(uint2) * SP_GROUP));
+    return WAGG_OK;
+}
+
+int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
+    spmm_geometry(d);
+    SpmmPlan &sp = d->sp;
+    const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
+    WAGG_REQUIRE((int64_t)sp.n_rb * sp.n_chunks < (int64_t)0x7fffffff, "grid too large");
+    DevBuf<int32_t> dcounts;
+    WAGG_HIP(dcounts.alloc((size_t)n_buckets));
+    const dim3 grid((unsigned)((int64_t)sp.n_rb * sp.n_chunks));
+    hipLaunchKernelGGL((spmm_synth_kernel<false>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
+                       sp.n_chunks, dcounts.p, (const int32_t *)nullptr, (uint2 *)nullptr);
+    WAGG_HIP(hipGetLastError());
+    std::vector<int32_t> counts((size_t)n_buckets);
+    WAGG_HIP(hipMemcpy(counts.data(), dcounts.p, sizeof(int32_t) * counts.size(), hipMemcpyDeviceToHost));
+    if (int rc = spmm_offsets(d, counts)) return rc;
+    hipLaunchKernelGGL((spmm_synth_kernel<true>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
+                       sp.n_chunks, (int32_t *)nullptr, (const int32_t *)sp.grp_off.p, sp.ent.p);
+    WAGG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(spmm_synth_den_kernel, dim3((unsigned)((d->R + 3) / 4)), dim3(256), 0, nullptr, d->G, d->R, seed,
+                       (float)fill, d->den64.p);
+    hipLaunchKernelGGL(spmm_den32_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, nullptr, d->den64.p,
+                       d->den32.p, d->R);
+    WAGG_HIP(hipGetLastError());
+    d->den_host.resize((size_t)d->R);
+    WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
+    return WAGG_OK;
+}
+
+// coalesced (cell, region, weight) triples, sorted by (region, cell) -> entry lists (host side)
+int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
+                        const std::vector<float> &w) {
+    spmm_geometry(d);
+    SpmmPlan &sp = d->sp;
+    const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
+    const int wave_regions = sp.rw;
+    auto bucket_of = [&](size_t i) {
+        const int64_t wv = region[i] / wave_regions;            // global wave index = rb * 16 + wave
+        return ((wv / SP_WAVES) * sp.n_chunks + cell[i] / SP_KC) * SP_WAVES + wv % SP_WAVES;
+    };
+    try {
+        std::vector<int32_t> counts((size_t)n_buckets, 0);
+        for (size_t i = 0; i < cell.size(); ++i) counts[(size_t)bucket_of(i)]++;
+        if (int rc = spmm_offsets(d, counts)) return rc;
+        std::vector<int32_t> off((size_t)n_buckets);
+        {
+            int64_t g = 0;
+            for (int64_t b = 0; b < n_buckets; ++b) { off[(size_t)b] = (int32_t)g; g += (counts[(size_t)b] + SP_GROUP - 1) / SP_GROUP; }
+        }
+        std::vector<uint2> ent((size_t)sp.n_groups * SP_GROUP, make_uint2((unsigned)SP_TRASH, 0u));
+        std::vector<int32_t> cur((size_t)n_buckets, 0);
+        // visit the triples cell-major so that a list is ordered like the synthetic builder's
+        std::vector<size_t> order(cell.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cell[a] < cell[b]; });
+        for (size_t i : order) {
+            const int64_t b = bucket_of(i);
+            const unsigned lo = (unsigned)((cell[i] % SP_KC) << 8 | (region[i] % wave_regions));
+            unsigned wb;
+            std::memcpy(&wb, &w[i], 4);
+            ent[(size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++] = make_uint2(lo, wb);
+        }
+        if (!ent.empty()) WAGG_HIP(hipMemcpy(sp.ent.p, ent.data(), sizeof(uint2) * ent.size(), hipMemcpyHostToDevice));
+    } catch (const std::bad_alloc &) {
+        set_error("host allocation failed while building the entry lists");
+        return WAGG_ENOMEM;
+    }
+    return WAGG_OK;
+}
+
+int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const PackXf &xf, float *out, int64_t ldo,
+               hipStream_t st) {
+    const SpmmPlan &sp = d->sp;
+    const int n_tb = (int)((T + SP_TB - 1) / SP_TB);
+    const int64_t Tpad = (int64_t)n_tb * SP_TB, Gpad = (int64_t)sp.n_chunks * SP_KC;
+    const int64_t Rpad = (int64_t)sp.n_rb * SP_WAVES * sp.rw;
+    // k slices: enough items for every CU to get the same number (a multiple of the CU count where
+    // possible), at least ~16 chunks per slice
+    const int64_t base_items = (int64_t)n_tb * sp.n_rb;
+    int S = 1;
+    {
+        double best = -1.0;
+        for (int s = 1; s <= 64 && sp.n_chunks / s >= 16; ++s) {
+            const double waves = (double)(base_items * s) / d->ncu;
+            const double eff = waves / std::ceil(waves);
+            if (eff > best + 0.02) { best = eff; S = s; }
+            if (eff > 0.97 && base_items * s >= 4LL * d->ncu) break;
+        }
+    }
+    const int cps = (sp.n_chunks + S - 1) / S;
+    const int64_t n_items = base_items * S;
+    WAGG_REQUIRE(n_items < (int64_t)0x7fffffff, "grid too large");
+    const size_t need_x = (size_t)n_tb * (size_t)Gpad * SP_TB, need_s = (size_t)S * (size_t)Rpad * (size_t)Tpad;
+    if (d->xp.n < need_x) WAGG_HIP(d->xp.alloc(need_x));
+    if (d->slabs.n < need_s) WAGG_HIP(d->slabs.alloc(need_s));
+    hipLaunchKernelGGL(spmm_pack_x_kernel, dim3((unsigned)(Gpad / 64), (unsigned)n_tb), dim3(256), 0, st, X, T, ldx, d->G,
+                       Gpad, xf, d->xp.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel, SP_LDS_BYTES));
+    const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
+    profile_mark(st, true);
+    hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const float *)d->xp.p,
+                       (const uint2 *)sp.ent.p, (const int32_t *)sp.grp_off.p, d->slabs.p, n_tb, sp.n_rb, sp.n_chunks, cps,
+                       sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups);
+    profile_mark(st, false);
+    WAGG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)n_tb), dim3(256), 0, st,
+                       (const float *)d->slabs.p, S, Rpad, Tpad, T, d->R, (const float *)d->den32.p, out, ldo);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+
+}  // namespace wagg

@@ -1,5 +1,8 @@
 // Process-level entry points, the materialised gather (aggregations.py:27) and the synthetic
 // field generator shared with the oracle.
+#include <mutex>
+#include <utility>
+
 #include "wagg_common.h"
 
 namespace wagg {
@@ -11,6 +14,20 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device, not once per apply
+hipError_t allow_dynamic_lds(const void *kern, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &kd : done) if (kd.first == kern && kd.second == dev) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.emplace_back(kern, dev);
+    return e;
 }
 
 struct ProfRing {
@@ -97,9 +114,103 @@ static int synth_field(T *X, int64_t Ttot, int64_t G, int64_t ldx, uint32_t seed
     return WAGG_OK;
 }
 
+// Materialised grid-level transforms (the lazy variables' ``.values`` and the materialised
+// ``_reindex`` view): the same device functions the aggregation kernels evaluate on load.
+template <typename T>
+__global__ void xform_poly_kernel(const T *__restrict__ X, int64_t n, T off, int pw, T *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = xform1<T>(X[i], off, pw);                     // transformations.py:188
+}
+
+constexpr int XF_MAX_TERMS = 8;
+template <typename T> struct EddTerms { T coef[XF_MAX_TERMS], thr[XF_MAX_TERMS]; int n; };
+
+template <typename T>
+__global__ void xform_edd_kernel(const T *__restrict__ lo, const T *__restrict__ hi, int64_t n, T off,
+                                 EddTerms<T> tm, T *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T a = lo[i] + off, b = hi[i] + off;
+        T s = tm.coef[0] * snyder_edd1<T>(a, b, tm.thr[0]);   // transformations.py:64-87 (+ :138-140 for gdd)
+        for (int k = 1; k < tm.n; ++k) s += tm.coef[k] * snyder_edd1<T>(a, b, tm.thr[k]);
+        out[i] = s;
+    }
+}
+
+// any tasmax < tasmin?  (transformations.py:62, NaN compares false like the reference's `<`)
+template <typename T>
+__global__ void any_less_kernel(const T *__restrict__ a, const T *__restrict__ b, int64_t n, int *__restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool hit = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) hit |= a[i] < b[i];
+    if (__ballot(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T>
+static int transform_poly(const T *X, int64_t n, double offset, int power, T *out, void *stream) {
+    WAGG_REQUIRE(n >= 0 && power >= 1 && power <= 16, "bad arguments (n=%lld, power=%d)", (long long)n, power);
+    if (n == 0) return WAGG_OK;
+    WAGG_REQUIRE(X && out, "NULL pointer");
+    hipLaunchKernelGGL((xform_poly_kernel<T>), dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, X, n, (T)offset, power, out);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+
+template <typename T>
+static int transform_edd(const T *lo, const T *hi, int64_t n, double offset, const double *coefs,
+                         const double *thr, int n_terms, T *out, void *stream) {
+    WAGG_REQUIRE(n >= 0 && n_terms >= 1 && n_terms <= XF_MAX_TERMS && coefs && thr, "bad arguments");
+    if (n == 0) return WAGG_OK;
+    WAGG_REQUIRE(lo && hi && out, "NULL pointer");
+    EddTerms<T> tm;
+    tm.n = n_terms;
+    for (int k = 0; k < XF_MAX_TERMS; ++k) { tm.coef[k] = (T)(k < n_terms ? coefs[k] : 0.0); tm.thr[k] = (T)(k < n_terms ? thr[k] : 0.0); }
+    hipLaunchKernelGGL((xform_edd_kernel<T>), dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, lo, hi, n, (T)offset, tm, out);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+
+template <typename T>
+static int any_less(const T *a, const T *b, int64_t n, int *result, void *stream) {
+    WAGG_REQUIRE(n >= 0 && result, "bad arguments");
+    *result = 0;
+    if (n == 0) return WAGG_OK;
+    WAGG_REQUIRE(a && b, "NULL pointer");
+    DevBuf<int> flag;
+    WAGG_HIP(flag.alloc(1));
+    WAGG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL((any_less_kernel<T>), dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, a, b, n, flag.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipMemcpyAsync(result, flag.p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    WAGG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return WAGG_OK;
+}
+
 }  // namespace wagg
 
-extern "C" int wagg_version(void) { return 10000 * 0 + 100 * 1 + 0; }
+extern "C" int wagg_transform_poly_f32(const float *X, int64_t n, double offset, int power, float *out, void *stream) {
+    return wagg::transform_poly<float>(X, n, offset, power, out, stream);
+}
+extern "C" int wagg_transform_poly_f64(const double *X, int64_t n, double offset, int power, double *out, void *stream) {
+    return wagg::transform_poly<double>(X, n, offset, power, out, stream);
+}
+extern "C" int wagg_transform_edd_f32(const float *tasmin, const float *tasmax, int64_t n, double offset,
+                                      const double *coefs, const double *thresholds, int n_terms, float *out, void *stream) {
+    return wagg::transform_edd<float>(tasmin, tasmax, n, offset, coefs, thresholds, n_terms, out, stream);
+}
+extern "C" int wagg_transform_edd_f64(const double *tasmin, const double *tasmax, int64_t n, double offset,
+                                      const double *coefs, const double *thresholds, int n_terms, double *out, void *stream) {
+    return wagg::transform_edd<double>(tasmin, tasmax, n, offset, coefs, thresholds, n_terms, out, stream);
+}
+extern "C" int wagg_any_less_f32(const float *a, const float *b, int64_t n, int *result, void *stream) {
+    return wagg::any_less<float>(a, b, n, result, stream);
+}
+extern "C" int wagg_any_less_f64(const double *a, const double *b, int64_t n, int *result, void *stream) {
+    return wagg::any_less<double>(a, b, n, result, stream);
+}
+
+extern "C" int wagg_version(void) { return 10000 * 0 + 100 * 2 + 0; }
 
 extern "C" int wagg_device_count(void) {
     int n = 0;

@@ -55,7 +55,7 @@ def _check_X(X, layout):
 class SparsePlan:
     """Coded segment table -> device plan (wagg_plan_create).  Immutable after construction."""
 
-    def __init__(self, cell_idx, region_code, w_eff, G, R, row_len=0):
+    def __init__(self, cell_idx, region_code, w_eff, G, R, row_len=0, flags=0):
         require_gpu()
         L = _lib.load()
         ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
@@ -67,7 +67,7 @@ class SparsePlan:
         self.G, self.R = int(G), int(R)
         _lib.check(L.wagg_plan_create(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32),
                                       _np_ptr(we, C.c_double), len(ci), self.G, self.R,
-                                      int(row_len), 0, C.byref(self._h)), "wagg_plan_create")
+                                      int(row_len), int(flags), C.byref(self._h)), "wagg_plan_create")
         info = _lib.PlanInfo()
         _lib.check(L.wagg_plan_get_info(self._h, C.byref(info)), "wagg_plan_get_info")
         self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_ if k != "reserved"}
@@ -81,6 +81,11 @@ class SparsePlan:
             self._h = C.c_void_p()
 
     __del__ = close
+
+    def status(self, stream=None):
+        """Synchronise the stream and raise if any apply on this plan failed on the device
+        (``wagg_plan_status``)."""
+        _lib.check(_lib.load().wagg_plan_status(self._h, _stream_handle(stream)), "wagg_plan_status")
 
     def apply(self, X, layout="TG", out=None, out_layout="TR", stream=None):
         """out[t, r] on the device; asynchronous on torch's current stream (or `stream`)."""
@@ -222,7 +227,7 @@ class DensePlan:
 
     __del__ = close
 
-    def apply(self, X, out=None, ksplit=0, stream=None):
+    def _prep(self, X, out):
         import torch
         X = _check_X(X, "TG")
         if X.dtype != torch.float32:
@@ -232,10 +237,45 @@ class DensePlan:
         T = X.shape[0]
         if out is None:
             out = torch.empty((T, self.R), dtype=torch.float32, device=X.device)
+        elif tuple(out.shape) != (T, self.R) or out.dtype != torch.float32 or (self.R > 1 and out.stride(1) != 1):
+            raise ValueError("out must be a (%d, %d) float32 tensor with contiguous rows" % (T, self.R))
+        return X, T, out
+
+    def apply(self, X, out=None, ksplit=0, stream=None):
+        X, T, out = self._prep(X, out)
         _lib.check(_lib.load().wagg_dense_apply_f32(
             self._h, C.c_void_p(X.data_ptr()), T, _ld(X), C.c_void_p(out.data_ptr()),
             _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_f32")
         return out
+
+    def apply_poly(self, X, offset, power, out=None, ksplit=0, stream=None):
+        """Aggregate of (X + offset) ** power (``wagg_dense_apply_poly_f32``): the transform of
+        tas_poly (transformations.py:188) is evaluated while X is packed."""
+        X, T, out = self._prep(X, out)
+        _lib.check(_lib.load().wagg_dense_apply_poly_f32(
+            self._h, C.c_void_p(X.data_ptr()), T, _ld(X), float(offset), int(power), C.c_void_p(out.data_ptr()),
+            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_poly_f32")
+        return out
+
+    def apply_edd(self, tasmin, tasmax, threshold, offset=0.0, out=None, ksplit=0, stream=None):
+        """Aggregate of snyder_edd(tasmin + offset, tasmax + offset, threshold)
+        (``wagg_dense_apply_edd_f32``; transformations.py:64-87 evaluated while the fields are packed)."""
+        tasmin, T, out = self._prep(tasmin, out)
+        tasmax = _check_X(tasmax, "TG")
+        if tasmax.shape != tasmin.shape or tasmax.dtype != tasmin.dtype or _ld(tasmax) != _ld(tasmin):
+            raise ValueError("tasmin and tasmax must have the same shape, dtype and row stride")
+        _lib.check(_lib.load().wagg_dense_apply_edd_f32(
+            self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin), float(offset),
+            float(threshold), C.c_void_p(out.data_ptr()), _ld(out), int(ksplit), _stream_handle(stream)),
+            "wagg_dense_apply_edd_f32")
+        return out
+
+    def saw_inf(self, stream=None):
+        """True when an apply since the last call met +-inf in its (transformed) data in one of the MFMA
+        forms (``wagg_dense_saw_inf``; synchronises the stream and clears the note)."""
+        saw = C.c_int(0)
+        _lib.check(_lib.load().wagg_dense_saw_inf(self._h, _stream_handle(stream), C.byref(saw)), "wagg_dense_saw_inf")
+        return bool(saw.value)
 
 
 def gather(X, cell_idx_dev, layout="TG", out_layout="TR", stream=None):
@@ -254,6 +294,67 @@ def gather(X, cell_idx_dev, layout="TG", out_layout="TR", stream=None):
                   C.c_void_p(cell_idx_dev.data_ptr()), n, C.c_void_p(out.data_ptr()), max(1, shape[1]),
                   _OUTS[out_layout], _stream_handle(stream)), "wagg_gather")
     return out
+
+
+def _flat_dev(t):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.float64)):
+        raise TypeError("expected a float32/float64 CUDA tensor")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def transform_poly(X, offset, power, stream=None):
+    """(X + offset) ** power elementwise on the device (``wagg_transform_poly_*``; the arithmetic of
+    tas_poly, transformations.py:188, as the fused kernels evaluate it)."""
+    import torch
+    X = _flat_dev(X)
+    out = torch.empty_like(X)
+    L = _lib.load()
+    fn = L.wagg_transform_poly_f32 if X.dtype == torch.float32 else L.wagg_transform_poly_f64
+    _lib.check(fn(C.c_void_p(X.data_ptr()), X.numel(), float(offset), int(power), C.c_void_p(out.data_ptr()),
+                  _stream_handle(stream)), "wagg_transform_poly")
+    return out
+
+
+def transform_edd(tasmin, tasmax, offset, terms, stream=None):
+    """sum_k coef_k * snyder_edd(tasmin + offset, tasmax + offset, threshold_k) elementwise on the
+    device (``wagg_transform_edd_*``; transformations.py:64-87, :138-140)."""
+    import torch
+    lo, hi = _flat_dev(tasmin), _flat_dev(tasmax)
+    if lo.shape != hi.shape or lo.dtype != hi.dtype:
+        raise ValueError("tasmin and tasmax must have the same shape and dtype")
+    coefs = np.ascontiguousarray([c for c, _ in terms], dtype=np.float64)
+    thr = np.ascontiguousarray([e for _, e in terms], dtype=np.float64)
+    out = torch.empty_like(lo)
+    L = _lib.load()
+    fn = L.wagg_transform_edd_f32 if lo.dtype == torch.float32 else L.wagg_transform_edd_f64
+    _lib.check(fn(C.c_void_p(lo.data_ptr()), C.c_void_p(hi.data_ptr()), lo.numel(), float(offset),
+                  _np_ptr(coefs, C.c_double), _np_ptr(thr, C.c_double), len(coefs), C.c_void_p(out.data_ptr()),
+                  _stream_handle(stream)), "wagg_transform_edd")
+    return out
+
+
+def any_less(a, b, stream=None):
+    """True iff some a[i] < b[i] (``wagg_any_less_*``: the tasmax < tasmin check of
+    transformations.py:62); blocks."""
+    import torch
+    a, b = _flat_dev(a), _flat_dev(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("operands must have the same shape and dtype")
+    res = C.c_int(0)
+    L = _lib.load()
+    fn = L.wagg_any_less_f32 if a.dtype == torch.float32 else L.wagg_any_less_f64
+    _lib.check(fn(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), a.numel(), C.byref(res), _stream_handle(stream)),
+               "wagg_any_less")
+    return bool(res.value)
+
+
+def to_device(values):
+    """NumPy array (one pageable H2D copy) or CUDA tensor (as it is) -> CUDA tensor."""
+    import torch
+    if isinstance(values, torch.Tensor):
+        return values if values.is_cuda else values.cuda()
+    return torch.from_numpy(np.ascontiguousarray(values)).cuda()
 
 
 def synth_field(T, G, seed, base, amp, dtype="float32", device="cuda"):

@@ -96,38 +96,50 @@ class LazyArray(DataArray):
         self._edd = None if edd is None else (edd[0], float(edd[1]), [(float(c), float(e)) for c, e in edd[2]])
         self.attrs = dict(attrs or {})
 
+    def _replace(self, raw=None, dims=None, edd_raw=None, **over):
+        """Copy of this variable with another buffer / dims, keeping the lon permutation, the lazy
+        transform, the degree-day partner and the attrs (``edd_raw`` = the tasmax buffer after the
+        same edit as ``raw``; a lazy degree-day variable cannot be re-built without it)."""
+        edd = self._edd
+        if edd is not None and raw is not None:
+            if edd_raw is None:
+                raise ValueError("a lazy degree-day variable needs both of its buffers edited alike")
+            edd = (edd_raw, edd[1], edd[2])
+        kw = dict(lon_perm=self._lon_perm, xform=self._xform, name=self.name, attrs=self.attrs, edd=edd)
+        kw.update(over)
+        return LazyArray(self._values if raw is None else raw, self.dims if dims is None else dims, **kw)
+
+    def _ordered(self, buf):
+        """``buf`` (host array or device tensor, file order) with the lon permutation applied."""
+        if self._lon_perm is None or "lon" not in self.dims:
+            return buf
+        ax = self.dims.index("lon")
+        if _is_tensor(buf):
+            import torch
+            return buf.index_select(ax, torch.from_numpy(self._lon_perm).to(buf.device))
+        return np.take(np.asarray(buf), self._lon_perm, axis=ax)
+
     @property
     def values(self):
-        raw = np.asarray(self._values)
-        if self._lon_perm is not None and "lon" in self.dims:
-            raw = np.take(raw, self._lon_perm, axis=self.dims.index("lon"))
+        raw = self._ordered(self._values)
+        if self._xform is None and self._edd is None:
+            return raw.detach().cpu().numpy() if _is_tensor(raw) else np.asarray(raw)
+        # transforms are evaluated on the device by the kernels' own device functions
+        # (wagg_transform_*), never on the host
+        from . import engine
+        engine.require_gpu()
+        t = engine.to_device(raw)
         if self._xform is not None:
-            from .engine import require_gpu
-            torch = require_gpu()                       # evaluated on the device, like the fused path
             off, pw = self._xform
-            t = torch.from_numpy(np.ascontiguousarray(raw)).cuda()
-            raw = ((t + off) ** pw).cpu().numpy()
+            t = engine.transform_poly(t, off, pw)
         if self._edd is not None:
-            from .engine import require_gpu
-            torch = require_gpu()
             hi, off, terms = self._edd
-            hi = np.asarray(hi)
-            if self._lon_perm is not None and "lon" in self.dims:
-                hi = np.take(hi, self._lon_perm, axis=self.dims.index("lon"))
-            lo_t = torch.from_numpy(np.ascontiguousarray(raw)).cuda() + off
-            hi_t = torch.from_numpy(np.ascontiguousarray(hi)).cuda() + off
-            raw = sum(c * snyder_edd_device(torch, lo_t, hi_t, e) for c, e in terms).cpu().numpy()
-        return raw
+            t = engine.transform_edd(t, engine.to_device(self._ordered(hi)), off, terms)
+        return t.cpu().numpy()
 
 
-def snyder_edd_device(torch, tmin, tmax, e):
-    """transformations.py:64-87 with torch ops on device tensors (materialised ``.values`` only; the
-    aggregation evaluates the same formula inside its load stage, csrc/wagg_sparse.hip)."""
-    mean, width = (tmax + tmin) / 2, (tmax - tmin) / 2
-    theta = torch.asin((e - mean) / width)
-    inner = torch.where(tmax > e, ((mean - e) * (np.pi / 2 - theta) + width * torch.cos(theta)) / np.pi,
-                        torch.zeros_like(mean))
-    return torch.where(tmin < e, inner, mean - e)
+def _is_tensor(v):
+    return type(v).__module__.startswith("torch")
 
 
 class _Coords(dict):

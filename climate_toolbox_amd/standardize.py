@@ -25,10 +25,10 @@ __all__ = ["standardize_climate_data", "convert_lons_split", "convert_lons_mono"
            "rename_coords_to_lon_and_lat"]
 
 
-def LonSortedArray(raw, dims, perm, name=None, xform=None):
+def LonSortedArray(raw, dims, perm, name=None, xform=None, attrs=None, edd=None):
     """A data variable whose ``lon`` axis is logically re-ordered: element j along ``lon`` is
     column ``perm[j]`` of the stored buffer (a :class:`minixr.LazyArray`)."""
-    return minixr.LazyArray(raw, dims, lon_perm=perm, xform=xform, name=name)
+    return minixr.LazyArray(raw, dims, lon_perm=perm, xform=xform, name=name, attrs=attrs, edd=edd)
 
 
 def _is_xarray(ds):
@@ -59,14 +59,17 @@ def rename_coords_to_lon_and_lat(ds):
     def fix(arr):
         dims = tuple(ren.get(d, d) for d in arr.dims)
         raw = arr._values
+        squeeze = lambda b: b
         if drop_z:                                            # .drop('z').squeeze(): all size-1 dims go
             keep = [i for i, n in enumerate(raw.shape) if n != 1]
-            raw = np.asarray(raw).reshape([raw.shape[i] for i in keep])
+            squeeze = lambda b: b.reshape([b.shape[i] for i in keep])
+            raw = squeeze(raw)
             dims = tuple(dims[i] for i in keep)
-        perm, xf = getattr(arr, "_lon_perm", None), getattr(arr, "_xform", None)
-        if (perm is not None and "lon" in dims) or xf is not None:
-            return minixr.LazyArray(raw, dims, lon_perm=perm, xform=xf)
-        return minixr.DataArray(raw, dims)
+        if isinstance(arr, minixr.LazyArray):                 # lon order, transform, degree-day partner, attrs stay
+            return arr._replace(raw=raw, dims=dims, edd_raw=None if arr._edd is None else squeeze(arr._edd[0]))
+        out = minixr.DataArray(raw, dims)
+        out.attrs = dict(getattr(arr, "attrs", {}))
+        return out
 
     out = minixr.Dataset()
     for k, c in ds.coords.items():
@@ -98,9 +101,11 @@ def _relabel_sorted(ds, lon_name, relabel):
             prev = getattr(v, "_lon_perm", None)
             p = perm if prev is None else np.asarray(prev)[perm]
             if lon_name == "lon":
-                arr = LonSortedArray(v._values, v.dims, p, name=k, xform=getattr(v, "_xform", None))
+                arr = LonSortedArray(v._values, v.dims, p, name=k, xform=getattr(v, "_xform", None),
+                                     attrs=getattr(v, "attrs", None), edd=getattr(v, "_edd", None))
             else:                                             # a differently named axis: permute eagerly
                 arr = minixr.DataArray(np.take(v.values, perm, axis=v.dims.index(lon_name)), v.dims, name=k)
+                arr.attrs = dict(getattr(v, "attrs", {}))
         else:
             arr = v
         out.data_vars[k] = arr

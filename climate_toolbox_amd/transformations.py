@@ -54,27 +54,31 @@ def remove_leap_days(ds):
         out.coords[k] = minixr.DataArray(np.asarray(c.values)[keep], c.dims) if c.dims == ("time",) else c
     for k, v in ds.data_vars.items():
         if "time" in v.dims:
-            if type(v._values).__module__.startswith("torch"):          # device-resident buffer
-                import torch
-                raw = v._values.index_select(v.dims.index("time"),
-                                             torch.from_numpy(np.flatnonzero(keep)).to(v._values.device))
-            else:
-                raw = np.compress(keep, np.asarray(v._values), axis=v.dims.index("time"))
-            if isinstance(v, minixr.LazyArray):
-                out.data_vars[k] = minixr.LazyArray(raw, v.dims, lon_perm=v._lon_perm, xform=v._xform, name=k,
-                                                    attrs=v.attrs)
+            ax = v.dims.index("time")
+            raw = _compress(v._values, keep, ax)
+            if isinstance(v, minixr.LazyArray):            # keeps lon order, transform, degree-day partner, attrs
+                edd_raw = None if v._edd is None else _compress(v._edd[0], keep, ax)
+                out.data_vars[k] = v._replace(raw=raw, edd_raw=edd_raw, name=k)
             else:
                 out.data_vars[k] = minixr.DataArray(raw, v.dims, name=k)
+                out.data_vars[k].attrs = dict(getattr(v, "attrs", {}))
         else:
             out.data_vars[k] = v
     return out
+
+
+def _compress(buf, keep, axis):
+    if type(buf).__module__.startswith("torch"):          # device-resident buffer
+        import torch
+        return buf.index_select(axis, torch.from_numpy(np.flatnonzero(keep)).to(buf.device))
+    return np.compress(keep, np.asarray(buf), axis=axis)
 
 
 def convert_kelvin_to_celsius(df, temp_name):
     """Convert Kelvin to Celsius (utils.py:10-20) -- lazily: the variable keeps its Kelvin buffer
     and carries the offset, which the aggregation applies while loading."""
     v = df[temp_name]
-    if getattr(v, "_xform", None) is not None:
+    if getattr(v, "_xform", None) is not None or getattr(v, "_edd", None) is not None:
         raise ValueError("%r already carries a lazy transform" % (temp_name,))
     attrs = dict(getattr(v, "attrs", {}))
     attrs.update({"units": "C", "valid_min": -108.78788, "valid_max": 62.02828})
@@ -167,10 +171,12 @@ def _degree_days(tasmin, tasmax, terms, units):
     if (plo is None) != (phi is None) or (plo is not None and not np.array_equal(plo, phi)):
         raise ValueError("tasmin and tasmax must share their longitude order")
     # check to make sure tasmax > tasmin everywhere (transformations.py:62), on the device
-    from .engine import require_gpu
-    torch = require_gpu()
-    bad = (torch.from_numpy(np.ascontiguousarray(hi)).cuda() < torch.from_numpy(np.ascontiguousarray(lo)).cuda()).any()
-    assert not bool(bad), "values encountered where tasmin > tasmax"
+    # (wagg_any_less_*).  Host buffers are uploaded for this check and again by the aggregation:
+    # hand device tensors in to avoid both copies.
+    from . import engine
+    engine.require_gpu()
+    bad = engine.any_less(engine.to_device(hi), engine.to_device(lo))
+    assert not bad, "values encountered where tasmin > tasmax"
     return minixr.LazyArray(lo, tasmin.dims, lon_perm=plo, edd=(hi, off_lo, terms), name=tasmin.name,
                             attrs={"units": units})
 

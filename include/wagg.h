@@ -104,13 +104,22 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
  * region_code[i] rank of the row's label among the sorted unique labels, -1 = null label (S3)
  * w_eff[i]       fp64 weight after the per-row backup fill of :73; NaN rows leave both sums
  * row_len        cells per grid row (nlon); only a locality hint for grouping, 0 = unknown
+ * flags          0, or WAGG_PLAN_* bits that pin the kernel form for this plan (tests, ablations);
+ *                resolved here, once -- the library reads no environment variable
  * Host pointers; copied.  Duplicate (cell, region) rows add (S5).                              */
+#define WAGG_PLAN_NO_LC 1     /* fp32 (time, gridcell) data: persistent VALU kernel instead of the loader/consumer MFMA kernel */
+#define WAGG_PLAN_NO_STREAM 2 /* every group through the chunk-walking kernel */
 int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
                      int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
                      wagg_plan **out);
 int wagg_plan_destroy(wagg_plan *plan);
 int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info);
 int wagg_plan_get_den(const wagg_plan *plan, double *den_host /* R values */); /* :79 */
+/* Blocks until `stream` is idle, then reports whether any apply on this plan failed on the device
+ * (a consumer-wave barrier of the loader/consumer kernel timed out: WAGG_EHIP, results incomplete).
+ * The same check runs at the start of every later apply on the plan and inside the *_host_ forms,
+ * so a device-side failure always surfaces as a status, never as silent garbage.               */
+int wagg_plan_status(const wagg_plan *plan, void *stream);
 
 /* ---- apply: replaces aggregations.py:78-80 (and the gather of :27, fused) ------------------ */
 /* out[t, r] = sum_i X[t, cell_i] * w_i / den[r]; NaN products count as 0 (skipna, S6); den == 0
@@ -156,6 +165,21 @@ int wagg_apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const do
                        int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
                        double *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream);
 
+/* ---- materialised grid-level transforms (device buffers, elementwise) ------------------------ */
+/* What ``.values`` of a lazily transformed variable returns: out[i] = (X[i] + offset)^power
+ * (transformations.py:188), out[i] = sum_k coefs[k] * snyder_edd(tasmin[i] + offset, tasmax[i] + offset,
+ * thresholds[k]) (transformations.py:64-87; two terms with coefs +1/-1 = snyder_gdd, :138-140), with the
+ * device functions the fused aggregation kernels use.  n_terms <= 8.  wagg_any_less_* is the check of
+ * transformations.py:62 (``assert not (tasmax < tasmin).any()``): *result = 1 iff some a[i] < b[i]; blocks. */
+int wagg_transform_poly_f32(const float *X_dev, int64_t n, double offset, int power, float *out_dev, void *stream);
+int wagg_transform_poly_f64(const double *X_dev, int64_t n, double offset, int power, double *out_dev, void *stream);
+int wagg_transform_edd_f32(const float *tasmin_dev, const float *tasmax_dev, int64_t n, double offset,
+                           const double *coefs, const double *thresholds, int n_terms, float *out_dev, void *stream);
+int wagg_transform_edd_f64(const double *tasmin_dev, const double *tasmax_dev, int64_t n, double offset,
+                           const double *coefs, const double *thresholds, int n_terms, double *out_dev, void *stream);
+int wagg_any_less_f32(const float *a_dev, const float *b_dev, int64_t n, int *result, void *stream);
+int wagg_any_less_f64(const double *a_dev, const double *b_dev, int64_t n, int *result, void *stream);
+
 /* ---- materialised gather: what _reindex_spatial_data_to_regions returns (:27) -------------- */
 /* out[t, i] = X[t, cell_idx[i]] in out_layout (WAGG_OUT_TR: out[t*ldo+i], RT: out[i*ldo+t]).   */
 int wagg_gather_f32(const float *X_dev, int64_t T, int64_t ldx, int layout,
@@ -171,13 +195,17 @@ int wagg_gather_f64(const double *X_dev, int64_t T, int64_t ldx, int layout,
 int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out);
 /* the same with only a fraction `fill` of the entries non-zero, at uniformly random positions
  * (kept where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill): c5's "uniform-random columns"
- * structure at fill = 0.01 -- no tile of W is empty, so this stays in the full dense form.      */
+ * structure at fill = 0.01 -- no tile of W is empty, yet 99 % of every tile is.                 */
 int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
+/* (fill < 10 %: built directly as entry lists, WAGG_FORM_ENTRIES -- c5 at fill = 0.01; above that the
+ * full matrix is generated)                                                                        */
 /* from a host row-major (G, R) fp32 matrix (small cases / tests) */
 int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
-/* from a sparse plan's coded table, densified on device (weights that are not very sparse).
- * W is kept as (32-cell x 256-region) tiles; when fewer than half of them hold a non-zero only
- * those are stored and contracted ("tile-sparse": c5's block-local weights), else all of them.  */
+/* from a sparse plan's coded table (weights whose regions are scattered over the grid).  The form
+ * follows the structure: fewer than half of the (32-cell x 256-region) tiles occupied -> only those
+ * are stored and contracted by the MFMA kernel (WAGG_FORM_TILES: c5's block-local weights); tiles
+ * mostly occupied but under 10 % non-zeros -> entry lists and the vector-ALU kernel
+ * (WAGG_FORM_ENTRIES: c5's uniformly random weights); else the full matrix (WAGG_FORM_FULL).     */
 int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                     const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                     wagg_dense **out);
@@ -186,9 +214,15 @@ int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *regi
  * hash_u01(g*R + r, seed) where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill, else 0.  Generated on
  * the device in tile-sparse form (benchmark operand; the oracle regenerates it from the hashes).  */
 int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
+#define WAGG_FORM_FULL 0     /* every (32-cell x 256-region) tile of W stored, fp32 MFMA contraction            */
+#define WAGG_FORM_TILES 1    /* only the non-empty tiles ("tile-sparse": block-local weights), same MFMA kernel */
+#define WAGG_FORM_ENTRIES 2  /* no matrix: per-wave (cell, region, weight) lists, vector-ALU kernel (scattered,
+                                sparse weights: <= 10 % non-zeros spread over (almost) every tile)              */
 typedef struct wagg_dense_info {
-    int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles and their bytes in HBM */
+    int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles; bytes of W (or of the entry lists) in HBM */
     int32_t R, n_kt, n_nt, tiled;  /* k tiles, column tiles, 1 = tile-sparse form */
+    int32_t form, reserved;        /* WAGG_FORM_* */
+    int64_t nnz;                   /* entry-list form: kept (cell, region) pairs; else -1 */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);
@@ -199,6 +233,21 @@ int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
  * must be ordered on one stream; different plans are independent.                               */
 int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                          float *out_dev, int64_t ldo, int ksplit, void *stream);
+/* the same contraction of (X + offset)^power (tas_poly, transformations.py:188) and of
+ * snyder_edd(tasmin + offset, tasmax + offset, threshold) (transformations.py:64-87): the transform is
+ * evaluated while X is packed, the transformed grid is never written anywhere                    */
+int wagg_dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, double offset,
+                              int power, float *out_dev, int64_t ldo, int ksplit, void *stream);
+int wagg_dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+                             int64_t ldx, double offset, double threshold, float *out_dev, int64_t ldo,
+                             int ksplit, void *stream);
+/* The MFMA forms multiply every (cell, region) pair of a stored tile, so +-inf in the (transformed)
+ * data turns the zero weights of regions that do not own the cell into NaN, where the reference and
+ * the segment-table form confine it to the owning regions (S6).  The pack stage notes such data:
+ * this call synchronises `stream`, returns in *saw whether any apply since the last call met +-inf
+ * and clears the note; the caller then repeats that field through a wagg_plan.  (The entry-list
+ * form multiplies real pairs only and never sets it.)                                            */
+int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw);
 
 /* ---- synthetic data generators (device side, shared with the CPU oracle bit for bit) ------- */
 /* X[t*ldx + g] = base + amp * (hash_u01(t*G + g, seed) - 0.5)                                   */

@@ -34,6 +34,9 @@ def lib():
         L.wagg_oracle_dense_synth_f32.restype = C.c_int
         L.wagg_oracle_dense_synth_f32.argtypes = [C.POINTER(C.c_float)] + [C.c_int64] * 7 + [
             C.c_uint32, f64p]
+        L.wagg_oracle_dense_synth2_f32.restype = C.c_int
+        L.wagg_oracle_dense_synth2_f32.argtypes = [C.POINTER(C.c_float)] + [C.c_int64] * 7 + [
+            C.c_uint32, C.c_double, C.c_int, f64p]
         L.wagg_oracle_hash_u01.restype = C.c_float
         L.wagg_oracle_hash_u01.argtypes = [C.c_uint64, C.c_uint32]
         L.wagg_oracle_threads.restype = C.c_int
@@ -79,6 +82,20 @@ def dense_synth(X, g0, Gw, R_total, r0, Rw, seed):
                                           seed, _p(out, C.c_double))
     if rcode != 0:
         raise RuntimeError("wagg_oracle_dense_synth_f32 failed: %d" % rcode)
+    return out
+
+
+def dense_synth_sparse(X, g0, Gw, R_total, r0, Rw, seed, fill=1.0, blocklocal=False):
+    """Column window [r0, r0 + Rw) of the synthetic weights with a fraction ``fill`` of non-zeros
+    (c5: uniform-random, or block-local with ``blocklocal``), kept pairs only, fp64 accumulation."""
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    T, ldx = X.shape
+    out = np.empty((T, Rw), dtype=np.float64)
+    rcode = L.wagg_oracle_dense_synth2_f32(_p(X, C.c_float), T, ldx, g0, Gw, R_total, r0, Rw, seed,
+                                           float(fill), 1 if blocklocal else 0, _p(out, C.c_double))
+    if rcode != 0:
+        raise RuntimeError("wagg_oracle_dense_synth2_f32 failed: %d" % rcode)
     return out
 
 

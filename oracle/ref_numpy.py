@@ -300,7 +300,19 @@ def agg_dense(X_TG, W_GR):
 def convert_lons_split(values, dims, lon):
     """climate_toolbox/utils/utils.py:33-40: relabel ``(lon + 180) % 360 - 180``, then
     ``ds.sel(lon=np.sort(new))`` -- returns (values re-ordered along 'lon', sorted labels)."""
-    new = (np.asarray(lon, dtype=np.float64) + 180) % 360 - 180
+    new = (np.asarray(lon) + 180) % 360 - 180          # integer labels stay integers, like xarray
+    order = np.argsort(new, kind="stable")
+    return np.take(np.asarray(values), order, axis=tuple(dims).index("lon")), new[order]
+
+
+def convert_lons_mono_labels(lon):
+    """climate_toolbox/utils/utils.py:23-30: relabel ``lon % 360`` and sort ascending."""
+    return np.sort(np.asarray(lon) % 360)
+
+
+def convert_lons_mono(values, dims, lon):
+    """utils.py:23-30 on a data array: returns (values re-ordered along 'lon', sorted labels)."""
+    new = np.asarray(lon) % 360
     order = np.argsort(new, kind="stable")
     return np.take(np.asarray(values), order, axis=tuple(dims).index("lon")), new[order]
 

@@ -78,6 +78,61 @@ float wagg_oracle_hash_u01(uint64_t idx, uint32_t seed) {
     return (float)(hash32(idx, seed) >> 8) * (1.0f / 16777216.0f);
 }
 
+/* Dense form with structured sparsity: only a fraction `fill` of the entries is non-zero (kept where
+ * hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill; fill >= 1 keeps all) -- BASELINE configs[4], the c5
+ * "uniform-random columns" structure of include/wagg.h wagg_dense_create_synth_sparse -- and with
+ * blocklocal != 0 additionally only inside the 256-region column tile (97 * (g / 64)) mod
+ * ceil(R_total / 256) of each 64-cell run (wagg_dense_create_synth_blocklocal).  Unlike the engine's
+ * MFMA forms this multiplies kept pairs only, so +-inf data stays with the regions that own the cell
+ * (S6).  den comes from ALL G cells of the column window only when g0 == 0 and Gw == G; it is the
+ * window's own column sum otherwise (callers compare windows that span the whole grid). */
+int wagg_oracle_dense_synth2_f32(const float *X, int64_t T, int64_t ldx, int64_t g0, int64_t Gw,
+                                 int64_t R_total, int64_t r0, int64_t Rw, uint32_t seed, double fill,
+                                 int blocklocal, double *out) {
+    double *den = (double *)calloc((size_t)Rw, sizeof(double));
+    if (!den) return -2;
+    memset(out, 0, sizeof(double) * (size_t)T * (size_t)Rw);
+    enum { GB2 = 64 };
+    float *wblk = (float *)malloc(sizeof(float) * GB2 * (size_t)Rw);
+    if (!wblk) { free(den); return -2; }
+    const int64_t n_nt = (R_total + 255) / 256;
+    const float ffill = (float)fill;
+    for (int64_t gb = 0; gb < Gw; gb += GB2) {
+        int64_t gn = Gw - gb < GB2 ? Gw - gb : GB2;
+#pragma omp parallel for schedule(static)
+        for (int64_t gi = 0; gi < gn; ++gi) {
+            const int64_t g = g0 + gb + gi;
+            const int64_t owner = (97 * (g / 64)) % n_nt;
+            for (int64_t r = 0; r < Rw; ++r) {
+                const uint64_t id = (uint64_t)g * (uint64_t)R_total + (uint64_t)(r0 + r);
+                int keep = fill >= 1.0 || wagg_oracle_hash_u01(id, seed ^ 0x9e3779b9u) < ffill;
+                if (blocklocal && (r0 + r) / 256 != owner) keep = 0;
+                wblk[gi * Rw + r] = keep ? wagg_oracle_hash_u01(id, seed) : 0.0f;
+            }
+        }
+        for (int64_t gi = 0; gi < gn; ++gi)
+            for (int64_t r = 0; r < Rw; ++r) den[r] += (double)wblk[gi * Rw + r];
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < T; ++t) {
+            double *row = out + t * Rw;
+            for (int64_t gi = 0; gi < gn; ++gi) {
+                const float xf = X[t * ldx + g0 + gb + gi];
+                const float *wr = wblk + gi * Rw;
+                for (int64_t r = 0; r < Rw; ++r) {
+                    if (wr[r] == 0.0f) continue;             /* no segment row for this pair */
+                    const double p = (double)xf * (double)wr[r];
+                    if (!isnan(p)) row[r] += p;              /* skipna (S6) */
+                }
+            }
+        }
+    }
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t r = 0; r < Rw; ++r) out[t * Rw + r] /= den[r];
+    free(wblk);
+    free(den);
+    return 0;
+}
+
 /* Dense form (X . W) / (1^T W) with W[g,r] = hash_u01(g*R_total + r0 + r, seed) generated on the
  * fly for the column window [r0, r0+Rw) and the row window [g0, g0+Gw) -- the CPU comparator of
  * the c2-dense workload on a bounded sample.  fp32 inputs, fp64 accumulation, threads = OpenMP.

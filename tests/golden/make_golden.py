@@ -6,6 +6,18 @@ fixtures bit for bit (legacy global RandomState stream, tests/test_climate_toolb
 lat/lon/clim_data and :86-106 for weights, drawn in that order after np.random.seed(42));
 expected outputs come from oracle/ref_numpy.py and are stored only when its three independent
 restatements agree to 1e-12 relative.  Known-answer cases carry hand-computed expectations.
+
+reference_held.npz is different: it holds the numeric expectations the reference's OWN tests pin for
+the helpers either side of the path, i.e. inputs and expected outputs read off
+/root/reference/tests/test_climate_toolbox.py (data, not code):
+  :180-187  convert_lons_mono   lon [-156.6, -38.48]  -> [203.4, 321.52]
+  :190-197  convert_lons_split  longitude [300, 320]  -> [-60, -40]
+  :242-262  snyder_edd  tmin (278.902, 278.23163), tmax (280.4963, 280.7887), threshold 273.15 + 8:
+            sum == 0.0 exactly, units "degreedays_281.15K"
+  :265-290  snyder_gdd  same fields, thresholds 273.15 + 1 / 273.15 + 8: sum == approx(11, rel 0.1),
+            units "degreedays_274.15-281.15K"
+These are the only reference-held numbers on or next to the path; the oracle is checked against
+them in tests/test_oracle.py and the HIP path in tests/test_gpu_parity.py.
 """
 import os
 import sys
@@ -84,6 +96,28 @@ def main():
             [False] * 8 + [True]), expect_areawt=exp_area, expect_popwt=exp_pop,
         labels=np.array(["a", "b", "c", "z0"]))
     print("kat_small.npz written")
+
+    # ---- numbers the reference's own tests hold (tests/test_climate_toolbox.py:177-290) -------
+    held = dict(
+        mono_lon=np.array([-156.6, -38.48]), mono_expect=np.array([203.4, 321.52]),          # :181-182
+        split_lon=np.array([300, 320]), split_expect=np.array([-60, -40]),                   # :191-192
+        edd_tmin=np.array([278.902, 278.23163]), edd_tmax=np.array([280.4963, 280.7887]),    # :245,252
+        edd_units_in=np.array("K"),
+        edd_threshold=np.array(273.15 + 8), edd_sum=np.array(0.0),                           # :257-262
+        edd_units=np.array("degreedays_281.15K"),
+        gdd_threshold_low=np.array(273.15 + 1), gdd_threshold_high=np.array(273.15 + 8),     # :283-284
+        gdd_sum_approx=np.array(11.0), gdd_sum_rel=np.array(0.1),                            # :290
+        gdd_units=np.array("degreedays_274.15-281.15K"),
+    )
+    # the oracle must reproduce every one of them before they are stored
+    np.testing.assert_array_equal(O.convert_lons_mono_labels(held["mono_lon"]), held["mono_expect"])
+    np.testing.assert_array_equal(O.convert_lons_split(np.zeros(2), ("lon",), held["split_lon"])[1], held["split_expect"])
+    assert O.snyder_edd_values(held["edd_tmin"], held["edd_tmax"], float(held["edd_threshold"])).sum() == 0.0
+    g = O.snyder_gdd_values(held["edd_tmin"], held["edd_tmax"], float(held["gdd_threshold_low"]),
+                            float(held["gdd_threshold_high"])).sum()
+    assert abs(g - 11.0) <= 0.1 * 11.0, g
+    np.savez_compressed(os.path.join(HERE, "reference_held.npz"), **held)
+    print("reference_held.npz written (gdd sum by the oracle = %r)" % g)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,351 @@
+"""GPU parity tests added in round 2 (run with -m gpu on an MI355X): the numbers the reference's own
+tests hold, the weights-CSV path, the entry-list form for scattered weights (c5 "uniform"), c5 at
+its full rank-shard size, transforms in the dense-family pack stage, +-inf routing, and the
+device-failure status.  Every comparison goes through the C-ABI; the oracle is only the checker."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from tests.test_gpu_parity import RTOL32, RTOL64, _rel_ok
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------
+# numbers the reference's own tests hold (tests/golden/reference_held.npz)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reference_held_snyder_vectors_lazy_and_fused(torch_cuda, golden_dir, dtype):
+    """tests/test_climate_toolbox.py:242-290 through BOTH paths: the lazy variable's ``.values``
+    (wagg_transform_edd_*) and the fused aggregation (wagg_apply_edd_*) over a one-region plan that
+    covers the two cells: snyder_edd sums to exactly 0.0, snyder_gdd to ~11, units strings equal."""
+    from climate_toolbox_amd import minixr, snyder_edd, snyder_gdd, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    h = np.load(os.path.join(golden_dir, "reference_held.npz"), allow_pickle=False)
+    lat, lon = np.array([-33.625]), np.array([286.125, 286.375])                 # the test's coordinates
+    tmin = h["edd_tmin"].astype(dtype).reshape(1, 1, 2)
+    tmax = h["edd_tmax"].astype(dtype).reshape(1, 1, 2)
+    ds = minixr.Dataset({"tmin": (("time", "lat", "lon"), tmin), "tmax": (("time", "lat", "lon"), tmax)},
+                        coords={"time": np.arange(1), "lat": lat, "lon": lon})
+    ds["tmin"].attrs["units"] = ds["tmax"].attrs["units"] = str(h["edd_units_in"])
+    thr, lo, hi = float(h["edd_threshold"]), float(h["gdd_threshold_low"]), float(h["gdd_threshold_high"])
+    edd = snyder_edd(ds.tmin, ds.tmax, threshold=thr)
+    gdd = snyder_gdd(ds.tmin, ds.tmax, threshold_low=lo, threshold_high=hi)
+    assert edd.attrs["units"] == str(h["edd_units"])                              # :261
+    assert gdd.attrs["units"] == str(h["gdd_units"]) and gdd.attrs["units"] != str(h["edd_units"])   # :288-289
+    # lazy .values (device transform kernel)
+    assert edd.values.sum() == float(h["edd_sum"]) == 0.0                         # :262
+    assert gdd.values.sum() == pytest.approx(float(h["gdd_sum_approx"]), float(h["gdd_sum_rel"]))   # :290
+    np.testing.assert_allclose(gdd.values, O.snyder_gdd_values(tmin, tmax, lo, hi), rtol=1e-6)
+    # fused: one region owning both cells with unit weights -> mean = sum / 2
+    ds["edd"], ds["gdd"] = edd, gdd
+    df = pd.DataFrame({"lat": [lat[0], lat[0]], "lon": lon, "areawt": [1.0, 1.0], "hierid": ["r", "r"]})
+    out_e = weighted_aggregate_grid_to_regions(ds, "edd", "areawt", "hierid", df)
+    out_g = weighted_aggregate_grid_to_regions(ds, "gdd", "areawt", "hierid", df)
+    assert out_e.edd.values.shape == (1, 1) and out_e.edd.values[0, 0] * 2 == 0.0
+    assert out_g.gdd.values[0, 0] * 2 == pytest.approx(float(h["gdd_sum_approx"]), float(h["gdd_sum_rel"]))
+    np.testing.assert_allclose(out_g.gdd.values[0, 0] * 2, O.snyder_gdd_values(tmin, tmax, lo, hi).sum(), rtol=1e-6)
+
+
+def test_reference_held_convert_lons_then_aggregate(torch_cuda, golden_dir):
+    """tests/test_climate_toolbox.py:180-197 on a dataset that carries data: the relabelled, sorted
+    longitudes equal the held vectors and the lazily re-ordered field aggregates like the eagerly
+    re-ordered one."""
+    from climate_toolbox_amd import convert_lons_mono, convert_lons_split, minixr, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    h = np.load(os.path.join(golden_dir, "reference_held.npz"), allow_pickle=False)
+    rng = np.random.default_rng(0)
+    for fn, oracle_fn, lon_in, expect, name in (
+            (convert_lons_mono, O.convert_lons_mono, h["mono_lon"], h["mono_expect"], "lon"),
+            (convert_lons_split, O.convert_lons_split, h["split_lon"].astype(np.float64), h["split_expect"].astype(np.float64), "lon")):
+        lat = np.array([10.0, 20.0, 30.0])
+        tas = rng.standard_normal((4, 3, 2))
+        ds = fn(minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": np.arange(4), "lat": lat, name: lon_in}),
+                lon_name=name)
+        np.testing.assert_array_equal(ds.lon.values, expect)
+        vals, labs = oracle_fn(tas, ("time", "lat", "lon"), lon_in)
+        np.testing.assert_array_equal(ds.tas.values, vals)
+        df = pd.DataFrame({"lat": lat[[0, 1, 2, 1]], "lon": expect[[0, 1, 1, 0]], "areawt": [1.0, 2.0, 3.0, 4.0],
+                           "hierid": [1, 1, 2, 2]})
+        out = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+        ref, _, _ = O.agg_scatter(vals, ("time", "lat", "lon"), lat, labs, df["lat"].values, df["lon"].values,
+                                  df["areawt"].values, df["areawt"].values, df["hierid"].values, group_dim="hierid")
+        _rel_ok(out.tas.values, ref, RTOL64)
+
+
+# ---------------------------------------------------------------------------------------------
+# prepare_spatial_weights_data through the drop-in (aggregations.py:127-152 -> :118-124)
+# ---------------------------------------------------------------------------------------------
+def test_weights_csv_path_with_dateline_pixel(torch_cuda, tmp_path):
+    """``weights`` given as the path of the CSV (aggregations.py:108): pix_cent_x/pix_cent_y columns,
+    a pixel centre at 180.125 that must land on the grid's -179.875 column (:144), duplicate rows
+    kept (the reference discards drop_duplicates' result, :147)."""
+    from climate_toolbox_amd import minixr, prepare_spatial_weights_data, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    lat = -89.875 + 0.25 * np.arange(720)[300:340]
+    lon = -179.875 + 0.25 * np.arange(1440)[:48]
+    rng = np.random.default_rng(5)
+    tas = (280 + 10 * rng.standard_normal((6, len(lat), len(lon)))).astype(np.float32)
+    rows = [(180.125, lat[3], 0.7, 1.5, "USA.1", "USA"), (-179.625, lat[3], 0.2, np.nan, "USA.1", "USA"),
+            (180.125, lat[4], 0.5, 0.0, "RUS.9", "RUS"), (-170.125, lat[20], 0.9, 2.0, "RUS.9", "RUS"),
+            (-170.125, lat[20], 0.9, 2.0, "RUS.9", "RUS"), (-168.375, lat[39], 0.4, 0.3, "FJI.2", "FJI")]
+    csv = tmp_path / "segment_weights.csv"
+    pd.DataFrame(rows, columns=["pix_cent_x", "pix_cent_y", "areawt", "popwt", "hierid", "ISO"]).to_csv(csv, index=False)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": np.arange(6), "lat": lat, "lon": lon})
+    df = prepare_spatial_weights_data(str(csv))
+    assert list(df.columns[:2]) == ["lon", "lat"] and df.index.names == ["reshape_index"]
+    assert (df["lon"].values[[0, 2]] == -179.875).all() and len(df) == 6
+    for aggwt, agglev in (("areawt", "hierid"), ("popwt", "ISO")):
+        out = weighted_aggregate_grid_to_regions(ds, "tas", aggwt, agglev, weights=str(csv))
+        seg_lon = np.where(np.array([r[0] for r in rows]) == 180.125, -179.875, [r[0] for r in rows])
+        ref, rdims, labs = O.agg_scatter(tas, ("time", "lat", "lon"), lat, lon, np.array([r[1] for r in rows]), seg_lon,
+                                         np.array([r[3] if aggwt == "popwt" else r[2] for r in rows], dtype=float),
+                                         np.array([r[2] for r in rows]), np.array([r[4] if agglev == "hierid" else r[5] for r in rows], dtype=object),
+                                         group_dim=agglev)
+        assert out.tas.dims == rdims and list(out[agglev].values) == list(labs)
+        _rel_ok(out.tas.values, ref, RTOL32)
+    # a pixel that is not on the grid raises KeyError like Dataset.sel (S1)
+    bad = tmp_path / "bad.csv"
+    pd.DataFrame([(0.125, lat[0], 1.0, 1.0, "X", "X")], columns=["pix_cent_x", "pix_cent_y", "areawt", "popwt", "hierid", "ISO"]).to_csv(bad, index=False)
+    with pytest.raises(KeyError):
+        weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", weights=str(bad))
+
+
+# ---------------------------------------------------------------------------------------------
+# entry-list form (wagg_spmm.hip): scattered, sparse weights
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,G,R,fill", [(185, 64 * 96, 300, 0.01), (64, 256, 17, 0.05), (1, 300, 5, 0.09),
+                                        (130, 5000, 1600, 0.02), (400, 1537, 96, 0.03)])
+def test_entry_list_form_synth_vs_oracle(torch_cuda, T, G, R, fill):
+    """wagg_dense_create_synth_sparse below 10 % fill builds entry lists on the device; every
+    region-timestep against the fp64 oracle on the regenerated matrix (ragged T, G, R; two region
+    blocks at R = 1600)."""
+    from climate_toolbox_amd import _lib
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    seed = 11
+    W = O.dense_weights_oracle(G, R, seed, fill)
+    plan = DensePlan.synth(G, R, seed, fill=fill)
+    assert plan.info["form"] == _lib.FORM_ENTRIES and plan.info["nnz"] == int((W != 0).sum())
+    np.testing.assert_allclose(plan.den, W.astype(np.float64).sum(0), rtol=1e-12)
+    rng = np.random.default_rng(3)
+    X = (280 + 20 * rng.standard_normal((T, G))).astype(np.float32)
+    X[0, G // 2] = np.nan
+    ref = O.agg_dense(X, W)
+    Xd = torch.from_numpy(X).cuda()
+    got = plan.apply(Xd).cpu().numpy()
+    _rel_ok(got, ref, RTOL32)
+    np.testing.assert_array_equal(plan.apply(Xd).cpu().numpy(), got)              # bitwise reproducible
+    # the same weights handed over as a segment table take the same form and give the same bits
+    gi, ri = np.nonzero(W)
+    seg = DensePlan.from_segments(gi.astype(np.int32), ri.astype(np.int32), W[gi, ri].astype(np.float64), G, R)
+    if len(gi) < 0.1 * G * R and seg.info["tiled"] == 0:
+        assert seg.info["form"] == _lib.FORM_ENTRIES
+        np.testing.assert_allclose(seg.apply(Xd).cpu().numpy(), got, rtol=1e-6, equal_nan=True)
+    # transforms in the pack stage: (x - 273.15)^2 and one degree-day threshold
+    _rel_ok(plan.apply_poly(Xd, -273.15, 2).cpu().numpy(), O.agg_dense(O.tas_poly_values(X, 2), W), RTOL32)
+    Xhi = X + np.float32(6.0)
+    edd = O.snyder_edd_values(X + np.float32(-273.15), Xhi + np.float32(-273.15), 10.0)
+    _rel_ok(plan.apply_edd(Xd, torch.from_numpy(Xhi).cuda(), 10.0, offset=-273.15).cpu().numpy(),
+            O.agg_dense(edd, W), RTOL32, scale=0.05)
+    assert not plan.saw_inf()
+
+
+def test_entry_list_form_keeps_inf_with_the_owning_regions(torch_cuda):
+    """+-inf data (S6): the entry-list form multiplies real (cell, region) pairs only, so an inf
+    reaches exactly the regions that own the cell -- like the reference and the segment-table form."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    T, G, R = 70, 2048, 200
+    nnz = int(0.02 * G * R)
+    flat = rng.choice(G * R, size=nnz, replace=False)
+    cell, code = (flat // R).astype(np.int32), (flat % R).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, nnz)
+    X = (280 + 15 * rng.standard_normal((T, G))).astype(np.float32)
+    X[3, 17] = np.inf
+    X[5, 900] = -np.inf
+    X[6, 901] = np.nan
+    ref = O.agg_coded(X, cell, code, w, R)
+    plan = DensePlan.from_segments(cell, code, w, G, R)
+    assert plan.info["form"] == 2
+    got = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    assert np.isinf(ref).sum() > 0 and np.isinf(ref).sum() < 0.1 * ref.size
+    _rel_ok(got, ref, RTOL32)
+
+
+def test_dropin_routes_inf_around_the_mfma_forms(torch_cuda):
+    """the drop-in picks the dense MFMA form for scattered weights by itself; a field with
+    +-inf (also one that only overflows after the fused power) must still come out as in the
+    reference -- inf confined to the regions that own the cell -- not as NaN everywhere."""
+    from climate_toolbox_amd import aggregations as A, minixr, tas_poly_aggregate
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(3)
+    nlat, nlon, R, T = 48, 96, 40, 30
+    lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0
+    n = int(0.3 * nlat * nlon * R)                              # dense-ish random table -> full MFMA form
+    flat = rng.choice(nlat * nlon * R, size=n, replace=False)
+    cell, lab = flat // R, flat % R
+    df = pd.DataFrame({"lat": lat[cell // nlon], "lon": lon[cell % nlon], "areawt": rng.uniform(0.1, 1, n), "hierid": lab})
+    tas = (280 + 10 * rng.standard_normal((T, nlat, nlon))).astype(np.float32)
+    tas[2, 5, 7] = np.inf
+    tas[4, 9, 1] = -np.inf
+    tas[4, 9, 2] = np.nan
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": pd.date_range("2001-01-01", periods=T).values, "lat": lat, "lon": lon})
+    A._PLAN_CACHE.clear()
+    out = A.weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    assert any(isinstance(p, DensePlan) and p.info["form"] == 0 for p in A._PLAN_CACHE.values())
+    args = (("time", "lat", "lon"), lat, lon, df["lat"].values, df["lon"].values, df["areawt"].values, df["areawt"].values, df["hierid"].values)
+    ref = O.agg_scatter(tas, *args, group_dim="hierid")[0]
+    assert np.isinf(ref).any() and np.isfinite(ref).any()
+    _rel_ok(out.tas.values, ref, RTOL32)
+    # overflow only after the transform: 1e13 ** 3 is inf in fp32
+    tas2 = tas.copy()
+    tas2[2, 5, 7] = 1.0e13
+    tas2[4, 9, 1] = 280.0
+    ds2 = minixr.Dataset({"tas": (("time", "lat", "lon"), tas2)}, coords=ds.coords)
+    outp = tas_poly_aggregate(ds2, [1, 3], "areawt", "hierid", df)
+    for p in (1, 3):
+        refp = O.agg_scatter(O.tas_poly_values(tas2, p), *args, group_dim="hierid")[0]
+        _rel_ok(outp["tas-poly-%d" % p].values, refp, RTOL32, scale=1e-3 if p == 1 else 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] at its full rank-shard size (T = 2,282 of 18,250 rows, G = 1,036,800,
+# R = 24,378, ~2.53e8 non-zeros), both structures of SURVEY 8d
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("structure", ["uniform", "block_local"])
+def test_c5_full_size_rank_shard(torch_cuda, structure):
+    from climate_toolbox_amd import _lib, engine
+    from climate_toolbox_amd.timeshard import shard_bounds
+    from oracle import c_oracle, ref_numpy as O
+    torch = torch_cuda
+    G, R, seed = 720 * 1440, 24378, 2
+    bounds = shard_bounds(50 * 365, 8)
+    T = bounds[0][1] - bounds[0][0]
+    assert T == 2282 and bounds[-1][1] - bounds[-1][0] == 2281
+    uniform = structure == "uniform"
+    fill = 0.01 if uniform else 0.952
+    plan = engine.DensePlan.synth(G, R, seed, fill=fill) if uniform else engine.DensePlan.synth_blocklocal(G, R, seed, fill=fill)
+    assert plan.info["form"] == (_lib.FORM_ENTRIES if uniform else _lib.FORM_TILES)
+    if uniform:
+        assert abs(plan.info["nnz"] - 0.01 * G * R) < 2e-4 * G * R         # ~2.53e8 kept pairs
+    X = engine.synth_field(T, G, seed=1000, base=280.0, amp=60.0)
+    got = plan.apply(X)
+    rows = torch.from_numpy(np.r_[0:6, 1140:1146, T - 6:T]).cuda()          # first / middle / ragged last time block
+    Xr = X[rows].cpu().numpy()
+    for r0 in (0, 11111, R - 16):                                           # column windows over ALL 1,036,800 cells
+        ref = c_oracle.dense_synth_sparse(Xr, 0, G, R, r0, 16, seed, fill=fill, blocklocal=not uniform)
+        _rel_ok(got[rows][:, r0:r0 + 16].cpu().numpy(), ref, RTOL32)
+    # denominators against the hashes
+    r = 777
+    idx = np.arange(G, dtype=np.uint64) * np.uint64(R) + np.uint64(r)
+    keep = O.hash_u01(idx, np.uint32(seed) ^ np.uint32(0x9e3779b9)) < np.float32(fill)
+    if not uniform:
+        keep &= ((97 * (np.arange(G) // 64)) % ((R + 255) // 256)) == r // 256
+    np.testing.assert_allclose(plan.den[r], O.hash_u01(idx, seed)[keep].astype(np.float64).sum(), rtol=1e-12)
+    # size-independent properties over all 24,378 regions
+    const = plan.apply(torch.full((3, G), 7.25, dtype=torch.float32, device="cuda")).cpu().numpy()
+    np.testing.assert_allclose(const, 7.25, rtol=2e-5)                      # constant field -> constant
+    assert torch.equal(plan.apply(X * 2.0), got * 2.0)                      # exact linearity in 2x
+    short = plan.apply(X[:100].contiguous())                                # rows are independent of the block they sit in
+    np.testing.assert_allclose(short.cpu().numpy(), got[:100].cpu().numpy(), rtol=2e-6)   # (k is sliced differently)
+    plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# transforms inside the MFMA forms' pack stage, and the +-inf note
+# ---------------------------------------------------------------------------------------------
+def test_mfma_forms_pack_stage_transforms_and_inf_note(torch_cuda):
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    T, G, R = 100, 64 * 30 + 7, 300
+    Wf = rng.uniform(0, 1, (G, R)).astype(np.float32)
+    Wb = O.blocklocal_weights_oracle(G, R, 5)
+    X = (285 + 12 * rng.standard_normal((T, G))).astype(np.float32)
+    X[9, 4] = np.nan
+    Xhi = X + rng.uniform(0, 9, X.shape).astype(np.float32)
+    Xd, Hd = torch.from_numpy(X).cuda(), torch.from_numpy(Xhi).cuda()
+    for W, plan in ((Wf, DensePlan.from_host(Wf)), (Wb, DensePlan.synth_blocklocal(G, R, 5))):
+        _rel_ok(plan.apply_poly(Xd, -273.15, 3).cpu().numpy(), O.agg_dense(O.tas_poly_values(X, 3), W), RTOL32, scale=1.0)
+        edd = O.snyder_edd_values(X + np.float32(-273.15), Xhi + np.float32(-273.15), 14.0)
+        _rel_ok(plan.apply_edd(Xd, Hd, 14.0, offset=-273.15).cpu().numpy(), O.agg_dense(edd, W), RTOL32, scale=0.05)
+        assert not plan.saw_inf()
+        Xi = Xd.clone()
+        Xi[3, 100] = float("inf")
+        plan.apply(Xi)
+        assert plan.saw_inf() and not plan.saw_inf()                         # noted once, then cleared
+        plan.apply_poly(torch.full_like(Xd, 1.0e13), 0.0, 3)                  # overflows in the transform
+        assert plan.saw_inf()
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel-form flags and the device-failure status
+# ---------------------------------------------------------------------------------------------
+def test_plan_flags_pin_the_kernel_form(torch_cuda):
+    """WAGG_PLAN_NO_LC / NO_STREAM (wagg_plan_create flags): the three fp32 kernels agree."""
+    from climate_toolbox_amd import _lib, synth
+    from climate_toolbox_amd.engine import SparsePlan
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G = len(lat) * len(lon)
+    X = torch.from_numpy((280 + np.random.default_rng(1).standard_normal((130, G))).astype(np.float32)).cuda()
+    outs = []
+    for flags in (0, _lib.PLAN_NO_LC, _lib.PLAN_NO_STREAM):
+        plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=flags)
+        outs.append(plan.apply(X).cpu().numpy())
+        plan.status()
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-6)
+    np.testing.assert_allclose(outs[2], outs[0], rtol=2e-6)
+    with pytest.raises(_lib.WaggError):
+        SparsePlan(cell, code, w, G, len(uniq), flags=64)
+
+
+def test_consumer_barrier_timeout_surfaces_as_an_error(torch_cuda):
+    """a consumer-wave barrier that times out inside sparse_lc_kernel must turn
+    into WAGG_EHIP, never into silent garbage.  Forced in the diagnostic build only (libwagg_diag.so,
+    WAGG_LC_KNOB bit 6: consumer wave 3 stops arriving), in a child process."""
+    diag = os.path.join(ROOT, "climate_toolbox_amd", "lib", "libwagg_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("diagnostic library not built (make -C climate_toolbox_amd/csrc diag)")
+    code = r'''
+import numpy as np, torch
+from climate_toolbox_amd import _lib, synth
+_lib.LIB_PATH = %r
+from climate_toolbox_amd.engine import SparsePlan
+lat, lon, df = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=False)
+cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+G = len(lat) * len(lon)
+plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon))
+X = torch.ones((640, G), dtype=torch.float32, device="cuda")
+plan.apply(X)
+try:
+    plan.status()
+except _lib.WaggError as e:
+    print("STATUS-ERROR", e)
+try:
+    plan.apply(X)
+except _lib.WaggError as e:
+    print("APPLY-ERROR", e)
+''' % diag
+    env = dict(os.environ, WAGG_LC_KNOB="64", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "STATUS-ERROR" in r.stdout and "APPLY-ERROR" in r.stdout and "timed out" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

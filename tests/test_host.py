@@ -1,5 +1,7 @@
 """Host-side logic of the drop-in (label lookup, backup fill inputs, factorisation, layout
 bookkeeping, weights CSV preparation) -- everything that runs before the C-ABI.  CPU only."""
+import os
+
 import numpy as np
 import pandas as pd
 import pytest
@@ -307,3 +309,13 @@ def test_to_netcdf_round_trip(tmp_path):
     assert back["tas-poly-2"].dims == ("time", "hierid") and back["tas-poly-2"].attrs["units"] == "C^2"
     np.testing.assert_array_equal(back.time.values, 2001000 + np.arange(1, 5))
     assert list(back.hierid.values) == list(labels)
+
+
+def test_convert_lons_on_the_vectors_the_reference_tests_hold(golden_dir):
+    """tests/test_climate_toolbox.py:180-197 through the drop-in functions (host logic only)."""
+    from climate_toolbox_amd import convert_lons_mono, convert_lons_split, minixr
+    h = np.load(os.path.join(golden_dir, "reference_held.npz"), allow_pickle=False)
+    ds = convert_lons_mono(minixr.Dataset(coords={"lon": h["mono_lon"]}), lon_name="lon")
+    np.testing.assert_array_equal(ds.lon.values, h["mono_expect"])
+    ds = convert_lons_split(minixr.Dataset(coords={"longitude": h["split_lon"]}))
+    np.testing.assert_array_equal(ds.longitude.values, h["split_expect"])

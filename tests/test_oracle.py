@@ -147,3 +147,21 @@ def test_dense_hash_and_dense_oracle_agree():
     np.testing.assert_allclose(got, ref, rtol=1e-12)
     win = c_oracle.dense_synth(X, 0, G, R, 4, 5, seed)                 # column window
     np.testing.assert_allclose(win, ref[:, 4:9], rtol=1e-12)
+
+
+def test_oracle_reproduces_the_numbers_the_reference_tests_hold(golden_dir):
+    """tests/golden/reference_held.npz = the numeric expectations of the reference's own tests for
+    the helpers either side of the path (tests/test_climate_toolbox.py:177-290)."""
+    h = np.load(os.path.join(golden_dir, "reference_held.npz"), allow_pickle=False)
+    np.testing.assert_array_equal(O.convert_lons_mono_labels(h["mono_lon"]), h["mono_expect"])          # :180-187
+    vals, labs = O.convert_lons_split(np.arange(2.0), ("lon",), h["split_lon"])
+    np.testing.assert_array_equal(labs, h["split_expect"])                                               # :190-197
+    np.testing.assert_array_equal(vals, np.arange(2.0))
+    edd = O.snyder_edd_values(h["edd_tmin"], h["edd_tmax"], float(h["edd_threshold"]))
+    assert edd.sum() == float(h["edd_sum"]) == 0.0                                                       # :262
+    gdd = O.snyder_gdd_values(h["edd_tmin"], h["edd_tmax"], float(h["gdd_threshold_low"]),
+                              float(h["gdd_threshold_high"]))
+    assert gdd.sum() == pytest.approx(float(h["gdd_sum_approx"]), float(h["gdd_sum_rel"]))               # :290
+    # fp32 fields give the same answers (both cells lie in the "tmax < e" / "tmin >= e" branches)
+    assert O.snyder_edd_values(h["edd_tmin"].astype(np.float32), h["edd_tmax"].astype(np.float32),
+                               float(h["edd_threshold"])).sum() == 0.0

@@ -50,13 +50,28 @@ def _worker(rank, world, port, T, q):
 
         got = aggregate_time_sharded(apply_fn, torch.from_numpy(X[s:e]), rows=rows, dst=0)
         # equal blocks: the in-place form (what bench.py uses) gathers into a preallocated tensor
+        # the in-place form (what bench.py uses): blocks land in their rows of a preallocated
+        # tensor, for equal and for ragged shards alike
+        from climate_toolbox_amd.timeshard import ShardedStep, gather_time_shards
+        buf = torch.full((T, R), -1.0, dtype=torch.float64) if rank == 0 else None
+        res = gather_time_shards(apply_fn(torch.from_numpy(X[s:e])), dst=0, rows=rows, out=buf)
         inplace_ok = True
-        if len(set(rows)) == 1:
-            from climate_toolbox_amd.timeshard import gather_time_shards
-            buf = torch.full((T, R), -1.0, dtype=torch.float64) if rank == 0 else None
-            res = gather_time_shards(apply_fn(torch.from_numpy(X[s:e])), dst=0, out=buf)
-            if rank == 0:
-                inplace_ok = res is buf and bool(np.array_equal(buf.numpy(), got.numpy()))
+        if rank == 0:
+            inplace_ok = res is buf and bool(np.array_equal(buf.numpy(), got.numpy()))
+        # bench.py's step object: double-buffered results, the gather of step k queued
+        # asynchronously and overlapped with the compute of step k + 1
+        scale = [1.0]
+
+        def write(out):
+            out.copy_(apply_fn(torch.from_numpy(X[s:e])) * scale[0])
+
+        stepper = ShardedStep(write, lambda: torch.empty((e - s, R), dtype=torch.float64), rows=rows, dst=0)
+        for k in range(3):
+            scale[0] = float(k + 1)
+            stepper.step()
+        final = stepper.finish()
+        if rank == 0:
+            inplace_ok = inplace_ok and bool(np.allclose(final.numpy(), 3.0 * got.numpy(), rtol=1e-15, atol=0))
         if rank == 0:
             ref = O.agg_coded(X, cell, code, w, R)
             q.put(("ok", bool(np.array_equal(got.numpy(), ref)) and inplace_ok, tuple(got.shape)))

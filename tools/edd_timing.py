@@ -4,7 +4,7 @@ grids on the device first and aggregating the result, on c2-real.  Run on the GP
 import json, sys, time
 import numpy as np, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from climate_toolbox_amd import synth, minixr
+from climate_toolbox_amd import engine, synth
 from climate_toolbox_amd.engine import SparsePlan, synth_field
 
 lat, lon, df = synth.realistic_segments(string_labels=False)
@@ -24,7 +24,7 @@ for K in (1, 3):
 o1 = torch.empty((T, R), dtype=torch.float32, device="cuda")
 def unfused():
     a, b = tmin - 273.15, tmax - 273.15
-    plan.apply(minixr.snyder_edd_device(torch, a, b, 30.0), out=o1)
+    plan.apply(engine.transform_edd(a, b, 0.0, [(1.0, 30.0)]), out=o1)
 for _ in range(2): unfused()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5): unfused()
