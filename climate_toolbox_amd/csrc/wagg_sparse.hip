@@ -862,7 +862,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             int gave_up = 0;
             if (lane == 0) {
 #ifdef WAGG_DIAG
-                if ((knob & 64) && cw == 3 && epoch > 8 * LC_CW) gave_up = 1;   // test hook: wave 3 stops arriving
+                if ((knob & 64) && cw == 3 && epoch > LC_CW) gave_up = 1;       // test hook: wave 3 stops arriving
                 else
 #endif
                 {
@@ -1514,6 +1514,13 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                 if ((q >> 4) != s64) { s64 = q >> 4; ++plan->info.n_sectors64; }
             }
         }
+#ifdef WAGG_DIAG
+        if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
+            fprintf(stderr, "[wagg plan] band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld\n",
+                    band_rows, (long long)plan->info.n_chunks, (long long)plan->info.n_groups, (long long)n_giant,
+                    (long long)plan->info.n_ucells, (long long)plan->info.n_lines128, (long long)plan->info.n_sectors64,
+                    (long long)nnz);
+#endif
         std::vector<float> seg_w32(seg_w.size()), den32(den.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
         for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];

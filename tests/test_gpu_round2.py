@@ -264,7 +264,7 @@ def test_c5_full_size_rank_shard(torch_cuda, structure):
     np.testing.assert_allclose(const, 7.25, rtol=2e-5)                      # constant field -> constant
     assert torch.equal(plan.apply(X * 2.0), got * 2.0)                      # exact linearity in 2x
     short = plan.apply(X[:100].contiguous())                                # rows are independent of the block they sit in
-    np.testing.assert_allclose(short.cpu().numpy(), got[:100].cpu().numpy(), rtol=2e-6)   # (k is sliced differently)
+    np.testing.assert_allclose(short.cpu().numpy(), got[:100].cpu().numpy(), rtol=2e-5)   # (k is sliced differently)
     plan.close()
 
 
@@ -335,7 +335,7 @@ lat, lon, df = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=Fa
 cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
 G = len(lat) * len(lon)
 plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon))
-X = torch.ones((640, G), dtype=torch.float32, device="cuda")
+X = torch.ones((1920, G), dtype=torch.float32, device="cuda")
 plan.apply(X)
 try:
     plan.status()
