@@ -27,6 +27,8 @@ EXPORTS = (
     "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_create_synth_sparse", "wagg_dense_get_info",
     "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32", "wagg_dense_apply_poly_f32",
     "wagg_dense_apply_edd_f32", "wagg_dense_saw_inf",
+    "wagg_dense_create_synth_f64", "wagg_dense_create_host_f64", "wagg_dense_create_from_segments_f64",
+    "wagg_dense_create_synth_blocklocal_f64", "wagg_dense_apply_f64", "wagg_dense_apply_poly_f64", "wagg_dense_apply_edd_f64",
     "wagg_synth_field_f32", "wagg_synth_field_f64",
 )
 
@@ -34,7 +36,7 @@ EXPORTS = (
 class DenseInfo(C.Structure):
     _fields_ = [("G", C.c_int64), ("n_tiles", C.c_int64), ("w_bytes", C.c_int64),
                 ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32),
-                ("form", C.c_int32), ("reserved", C.c_int32), ("nnz", C.c_int64)]
+                ("form", C.c_int32), ("elem_bytes", C.c_int32), ("nnz", C.c_int64)]
 
 
 class WaggError(RuntimeError):
@@ -114,6 +116,14 @@ def load():
     L.wagg_dense_apply_edd_f32.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, vp, C.c_int64,
                                            C.c_int, vp]
     L.wagg_dense_saw_inf.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    L.wagg_dense_create_synth_f64.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
+    L.wagg_dense_create_synth_blocklocal_f64.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
+    L.wagg_dense_create_host_f64.argtypes = [f64p, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.wagg_dense_create_from_segments_f64.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.wagg_dense_apply_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
+    L.wagg_dense_apply_poly_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, vp, C.c_int64, C.c_int, vp]
+    L.wagg_dense_apply_edd_f64.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, vp, C.c_int64,
+                                           C.c_int, vp]
     L.wagg_synth_field_f32.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_float,
                                        C.c_float, vp]
     L.wagg_synth_field_f64.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_double,

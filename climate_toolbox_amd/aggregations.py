@@ -337,15 +337,16 @@ def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes):
     """Device-form choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
     per timestep; when regions are scattered all over the grid (e.g. <=1 % non-zeros at random
     columns: every region is a multi-chunk "giant") that is many times the grid itself and the
-    dense (gridcell x region) MFMA contraction, whose cost does not depend on the structure, is
-    faster -- provided it is an fp32 (time, gridcell) problem and W fits comfortably in HBM."""
-    if not is_f32 or layout != "TG":
+    dense-family forms (MFMA contraction of the stored tiles in fp32 or fp64, entry lists for very
+    sparse fp32 tables), whose cost does not depend on where a region's cells lie, are faster --
+    provided it is a (time, gridcell) problem and, in the worst case, the full W fits comfortably."""
+    if layout != "TG":
         return False
-    return n_ucells > DENSE_SWITCH * G and _dense_bytes(G, R) < 0.6 * free_bytes
+    return n_ucells > DENSE_SWITCH * G and _dense_bytes(G, R, is_f32) < 0.6 * free_bytes
 
 
-def _dense_bytes(G, R):
-    return 4 * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
+def _dense_bytes(G, R, is_f32=True):
+    return (4 if is_f32 else 8) * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
 
 
 def _plan_bytes(plan):
@@ -378,17 +379,18 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
         free_bytes, total_bytes = torch.cuda.mem_get_info()
         # what the cached plans hold can be given back: evict (oldest first) before declining the
         # dense form for lack of memory, and keep the cache under its byte budget
-        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - _dense_bytes(G, R), keep=_PLAN_CACHE_MAX - 1)
+        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - _dense_bytes(G, R, is_f32), keep=_PLAN_CACHE_MAX - 1)
         # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
         # form: go to the dense / tile-sparse form directly instead of building the sparse plan
         # first just to read its statistics
+        dt = "float32" if is_f32 else "float64"
         if len(cell_idx) > 4 * DENSE_SWITCH * G and _prefer_dense(float("inf"), G, R, is_f32, layout, free_bytes):
-            plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
+            plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
         else:
             plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
             if _prefer_dense(plan.info["n_ucells"], G, R, is_f32, layout, free_bytes):
                 plan.close()
-                plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R)
+                plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
         _PLAN_CACHE[key] = plan
     else:
         _PLAN_CACHE.move_to_end(key)

@@ -33,24 +33,45 @@
 
 namespace wagg {
 
-constexpr int D_MT = 23;                 // most 16-row MFMA tiles per workgroup (T = 365 -> 23)
-constexpr int D_BM = D_MT * 16;          // 368 rows
+constexpr int D_MT = 23;                 // most 16-row MFMA tiles per workgroup (fp32; T = 365 -> 23)
 constexpr int D_BN = 256;                // 8 waves x 32 columns
-constexpr int D_BK = 32;                 // k depth of one LDS tile = 8 MFMA k-steps
+constexpr int D_ROWB = 128;              // bytes of one tile row = 8 pieces of 16 bytes: 32 floats or 16 doubles of k
 constexpr int D_THREADS = 512;
-constexpr int D_WT = D_BN * D_BK;        // floats per packed W tile (32,768 B)
-constexpr int D_WPIECES = D_WT / 256;    // 32 one-KiB pieces: 4 per wave
-static_assert(D_WPIECES == 32, "4 W pieces per wave");
-// a workgroup owns MT x 16 rows (MT <= 23, chosen per T so that the row blocks are evenly filled)
-constexpr int d_xt(int mt) { return mt * 16 * D_BK; }            // floats per packed X tile (MT = 23: 47,104 B)
-constexpr int d_buf_bytes(int mt) { return (d_xt(mt) + D_WT) * 4; }   // per LDS buffer, two buffers (MT = 23: 79,872 B)
+constexpr int D_WTB = D_BN * D_ROWB;     // bytes per packed W tile (32,768 B)
+constexpr int D_WSLOTS = D_WTB / 16;     // 16-byte slots per W tile (2,048)
+static_assert(D_WTB / 1024 == 32, "4 one-KiB W pieces per wave");
+// a workgroup owns MT x 16 rows (chosen per T so that the row blocks are evenly filled)
+constexpr int d_xt_bytes(int mt) { return mt * 16 * D_ROWB; }             // packed X tile (MT = 23: 47,104 B)
+constexpr int d_buf_bytes(int mt) { return d_xt_bytes(mt) + D_WTB; }      // per LDS buffer, two buffers (MT = 23: 79,872 B)
 static_assert(2 * d_buf_bytes(D_MT) <= 160 * 1024, "LDS budget");
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
 
-__device__ __forceinline__ float nan0(float v) { return v == v ? v : 0.0f; }
+// Everything below is written once for both data types.  The tile geometry is the same in BYTES
+// (rows of 8 x 16-byte pieces, 256-column W tiles, the DMA schedule, the bank-conflict-free piece
+// swizzle); what changes with the type is the k depth of a tile (32 floats / 16 doubles), the
+// matrix instruction (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: 4 k per instruction either
+// way, half the rate in fp64), the accumulator size (4 / 8 registers per 16x16 block, hence at most
+// 23 / 11 row blocks per workgroup) and the C/D register -> row map.
+template <typename T> struct DT;
+template <> struct DT<float> {
+    typedef f32x4 vec;                                   // one 16-byte piece
+    typedef f32x4 acc;
+    static constexpr int EPP = 4, BK = 32, MT_MAX = 23;  // elements per piece, k per tile, row blocks
+    static __device__ __forceinline__ acc mfma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int kq, int reg) { return kq * 4 + reg; }   // C/D: row = 4 (lane >> 4) + reg
+};
+template <> struct DT<double> {
+    typedef f64x2 vec;
+    typedef f64x4 acc;
+    static constexpr int EPP = 2, BK = 16, MT_MAX = 11;
+    static __device__ __forceinline__ acc mfma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int crow(int kq, int reg) { return kq + 4 * reg; }   // f64 C/D: row = (lane >> 4) + 4 reg
+};
 
 // Position of (row, piece p) inside a packed tile, in 16-byte slots.  The same involution is
 // applied by the packers (source side) and by the fragment reads.
@@ -75,13 +96,17 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // tile i and tile_off[nt][ks] .. tile_off[nt][ks+1] the run of stored tiles that block (nt, ks)
 // contracts.  The k index of tile t+2 is fetched by a plain vector load at the start of tile t
 // (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
-template <int DBG = 0, bool TILED = false, int MT = D_MT>
+template <typename T, int DBG = 0, bool TILED = false, int MT = D_MT>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
-    const float *__restrict__ Xp, const float *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
-    int kt_per_slice, float *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
+    const T *__restrict__ Xp, const T *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
+    int kt_per_slice, T *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
     const int32_t *__restrict__ tile_off = nullptr) {
+    static_assert(MT <= DT<T>::MT_MAX, "accumulators of MT row blocks must fit the register file");
+    typedef typename DT<T>::vec vec_t;
+    typedef typename DT<T>::acc acc_t;
+    constexpr int KS = DT<T>::EPP;                   // MFMA k-steps fed by one 16-byte fragment read
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][BUF_BYTES]
-    constexpr int XT4 = d_xt(MT) * 4;                // bytes of the packed X tile (MT x 16 rows x 128 B)
+    constexpr int XT4 = d_xt_bytes(MT);              // bytes of the packed X tile (MT x 16 rows x 128 B)
     constexpr int BUF_BYTES = d_buf_bytes(MT);
     constexpr int XPIECES = XT4 / 1024;              // 2 MT one-KiB pieces
     constexpr int NXP = (XPIECES + 7) / 8;           // X pieces per wave (the last round may be partial)
@@ -117,12 +142,12 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
     // moves W pieces wave + 8 i (i < 4) and X pieces wave + 8 i (i < NXP, those below XPIECES)
     const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
-    const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * (D_WT * 4) + lane * 16;
+    const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * D_WTB + lane * 16;
 #define WAGG_DMA_X(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * XT4 + (q) * 1024),          \
                                      (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0)
 #define WAGG_DMA_W(q, tile, buf)                                                                  \
-    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * (D_WT * 4) + (q) * 1024),   \
+    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * D_WTB + (q) * 1024),   \
                                      (lptr_t)(lds + (buf) * BUF_BYTES + XT4 + (q) * 1024), 16, 0, 0)
     // piece i of this wave: W pieces (HBM, longest latency) first, then the X pieces (served by the
     // XCD's L2); DBG bit4 = X first
@@ -143,9 +168,9 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     } while (0)
     static_assert(DPB <= 5, "at most five DMA pieces per row block (MT = 1: 4 W + 1 X)");
 
-    f32x4 acc[MT][2];
+    acc_t acc[MT][2];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = acc_t{0, 0, 0, 0};
 
     if (ntiles > 0) {
         WAGG_DMA_PIECE(0, x_first, 0, 0); WAGG_DMA_PIECE(1, x_first, 0, 0);
@@ -170,20 +195,20 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     // One 16-row block = 16 MFMAs: k-steps 0..7 x the wave's two 16-column blocks.  k-steps 0..3
     // come from the first fragment read (h = 0), 4..7 from the second.
 #define WAGG_MFMA(RB, CB, A, B, c) \
-    acc[RB][CB] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c], B[c], acc[RB][CB], 0, 0, 0)
+    acc[RB][CB] = DT<T>::mfma(A[c], B[c], acc[RB][CB])
 #define WAGG_MFMA_REST7(RB, A, B0, B1)                                                            \
     do {                                                                                          \
         WAGG_MFMA(RB, 1, A, B1, 0);                                                               \
-        _Pragma("unroll") for (int c = 1; c < 4; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
+        _Pragma("unroll") for (int c = 1; c < KS; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
     } while (0)
 #define WAGG_MFMA8(RB, A, B0, B1)                                                                 \
     do {                                                                                          \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
+        _Pragma("unroll") for (int c = 0; c < KS; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
     } while (0)
 #define WAGG_READ_A(D0, D1, RB)                                                                   \
     do {                                                                                          \
-        D0 = *reinterpret_cast<const f32x4 *>(img + frag0 + (RB) * 2048);                         \
-        D1 = *reinterpret_cast<const f32x4 *>(img + frag1 + (RB) * 2048);                         \
+        D0 = *reinterpret_cast<const vec_t *>(img + frag0 + (RB) * 2048);                         \
+        D1 = *reinterpret_cast<const vec_t *>(img + frag1 + (RB) * 2048);                         \
     } while (0)
     // Row block RB.  The fragment reads of the NEXT block are issued right behind the first MFMA
     // of the current one: hipcc's s_waitcnt for the current fragments (always a full lgkmcnt(0)
@@ -229,11 +254,11 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
             const int zero = 0;
             asm volatile("global_load_dword %0, %1, %2" : "=v"(ktn_v) : "v"(zero), "s"(pa) : "memory");
         }
-        f32x4 b00, b01, b10, b11, aA0, aA1, aB0, aB1;
-        b00 = *reinterpret_cast<const f32x4 *>(img + boff + frag0);
-        b01 = *reinterpret_cast<const f32x4 *>(img + boff + frag1);
-        b10 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag0);
-        b11 = *reinterpret_cast<const f32x4 *>(img + boff + 2048 + frag1);
+        vec_t b00, b01, b10, b11, aA0, aA1, aB0, aB1;
+        b00 = *reinterpret_cast<const vec_t *>(img + boff + frag0);
+        b01 = *reinterpret_cast<const vec_t *>(img + boff + frag1);
+        b10 = *reinterpret_cast<const vec_t *>(img + boff + 2048 + frag0);
+        b11 = *reinterpret_cast<const vec_t *>(img + boff + 2048 + frag1);
         WAGG_READ_A(aA0, aA1, 0);
         WAGG_BLOCK(0); WAGG_BLOCK(1); WAGG_BLOCK(2); WAGG_BLOCK(3); WAGG_BLOCK(4); WAGG_BLOCK(5);
         WAGG_BLOCK(6); WAGG_BLOCK(7); WAGG_BLOCK(8); WAGG_BLOCK(9); WAGG_BLOCK(10); WAGG_BLOCK(11);
@@ -247,23 +272,26 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
         if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     }
 
-    // C/D map of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
-    float *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * (MT * 16)) * D_BN;
+    // C/D map: col = lane & 15, row = DT<T>::crow(lane >> 4, reg) (it differs between the f32 and f64 forms)
+    T *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * (MT * 16)) * D_BN;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                slab[(m * 16 + kq * 4 + r) * D_BN + wave * 32 + cb * 16 + lr] = acc[m][cb][r];
+                slab[(m * 16 + DT<T>::crow(kq, r)) * D_BN + wave * 32 + cb * 16 + lr] = acc[m][cb][r];
 }
 
-// X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one f32x4 per slot; a row block has
-// bm = 16 MT rows), NaN -> 0 (S6), zero for rows >= T and cells >= G.  One thread per slot; the 8 slots of a row read one 128-byte
-// line of X.
-__global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
-                                    int n_kt, int bm, int64_t n_slots, int aligned, f32x4 *__restrict__ Xp,
-                                    PackXf xf, int *__restrict__ inf_flag) {
+// X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one 16-byte piece per slot; a row block has
+// bm = 16 MT rows), transform (tas_poly / snyder_edd), NaN -> 0 (S6), zero for rows >= T and cells >= G.
+// One thread per slot; the 8 slots of a row read one 128-byte line of X.
+template <typename T>
+__global__ void dense_pack_x_kernel(const T *__restrict__ X, int64_t Tn, int64_t ldx, int64_t G,
+                                    int n_kt, int bm, int64_t n_slots, int aligned, typename DT<T>::vec *__restrict__ Xp,
+                                    PackXfT<T> xf, int *__restrict__ inf_flag) {
+    typedef typename DT<T>::vec vec_t;
+    constexpr int E = DT<T>::EPP;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int tile_slots = bm * 8;                         // bm rows x 8 pieces of 16 bytes
     bool inf_seen = false;
@@ -273,21 +301,23 @@ __global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int6
         const int kt = (int)(tk % n_kt);
         const int64_t mb = tk / n_kt;
         const int row = slot >> 3, p = (slot & 7) ^ ((row >> 1) & 7);
-        const int64_t t = mb * bm + row, k0 = (int64_t)kt * D_BK + 4 * p;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
-        if (t < T) {
-            const float *src = X + t * ldx + k0;
-            const float *src2 = xf.mode == XF_EDD ? xf.X2 + t * ldx + k0 : src;
-            if (aligned && k0 + 4 <= G) {
-                v = *reinterpret_cast<const f32x4 *>(src);
-                if (xf.mode == XF_EDD) h = *reinterpret_cast<const f32x4 *>(src2);
+        const int64_t t = mb * bm + row, k0 = (int64_t)kt * DT<T>::BK + E * p;
+        vec_t v, h;
+#pragma unroll
+        for (int c = 0; c < E; ++c) { v[c] = T(0); h[c] = T(0); }
+        if (t < Tn) {
+            const T *src = X + t * ldx + k0;
+            const T *src2 = xf.mode == XF_EDD ? xf.X2 + t * ldx + k0 : src;
+            if (aligned && k0 + E <= G) {
+                v = *reinterpret_cast<const vec_t *>(src);
+                if (xf.mode == XF_EDD) h = *reinterpret_cast<const vec_t *>(src2);
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (k0 + c < G) { v[c] = src[c]; h[c] = src2[c]; }
+                for (int c = 0; c < E; ++c) if (k0 + c < G) { v[c] = src[c]; h[c] = src2[c]; }
             }
-            // transform (tas_poly / snyder_edd), then NaN -> 0 (S6); cells >= G stay 0
+            // transform, then NaN -> 0 (S6); cells >= G stay 0
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (k0 + c < G) v[c] = pack_xf(xf, v[c], h[c], inf_seen);
+            for (int c = 0; c < E; ++c) if (k0 + c < G) v[c] = pack_xf<T>(xf, v[c], h[c], inf_seen);
         }
         Xp[s] = v;
     }
@@ -296,60 +326,73 @@ __global__ void dense_pack_x_kernel(const float *__restrict__ X, int64_t T, int6
     if (inf_seen) __hip_atomic_store(inf_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// float index of W[g][r] inside the packed matrix Wp[nt][kt][slot][4]
+// element index of W[g][r] inside the packed matrix Wp[nt][kt][slot][EPP]
+template <typename T>
 __host__ __device__ __forceinline__ int64_t wp_index(int64_t g, int64_t r, int n_kt) {
-    const int64_t nt = r / D_BN, kt = g / D_BK;
-    const int cl = (int)(r % D_BN), kk = (int)(g % D_BK);
-    return ((nt * n_kt + kt) * (D_WT / 4) + tile_slot(cl, kk >> 2)) * 4 + (kk & 3);
+    constexpr int E = DT<T>::EPP, BK = DT<T>::BK;
+    const int64_t nt = r / D_BN, kt = g / BK;
+    const int cl = (int)(r % D_BN), kk = (int)(g % BK);
+    return ((nt * n_kt + kt) * D_WSLOTS + tile_slot(cl, kk / E)) * E + (kk % E);
 }
 
 // out[t, r] = sum_s slab[mb][nt][s][t_local][c] / den[r]        (aggregations.py:77-80 fused)
-__global__ void dense_reduce_kernel(const float *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
-                                    int32_t R, const float *__restrict__ den,
-                                    float *__restrict__ out, int64_t ldo) {
+template <typename T>
+__global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
+                                    int32_t R, const T *__restrict__ den, T *__restrict__ out, int64_t ldo) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t t = blockIdx.y;
     if (r >= R) return;
     const int mb = (int)(t / bm), tl = (int)(t % bm);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    const float *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
-    float s = 0.f;
+    const T *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
+    T s = T(0);
     for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
     out[t * ldo + r] = s / den[r];
 }
 
+// (slot, element) of a packed W tile -> (column inside the tile, k inside the tile)
+template <typename T> __device__ __forceinline__ void slot_to_ck(int slot, int &cl, int &k0) {
+    cl = slot >> 3;
+    k0 = DT<T>::EPP * ((slot & 7) ^ ((cl >> 1) & 7));
+}
+
 // synthetic W[g][r] = hash_u01(g R + r, seed) written straight into the packed order
-__global__ void dense_synth_w_kernel(f32x4 *__restrict__ Wp, int64_t G, int32_t R, int n_kt,
+template <typename T>
+__global__ void dense_synth_w_kernel(typename DT<T>::vec *__restrict__ Wp, int64_t G, int32_t R, int n_kt,
                                      int64_t n_slots, uint32_t seed, float fill) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
-        const int slot = (int)(s % (D_WT / 4));
-        const int64_t tk = s / (D_WT / 4);
+        const int64_t tk = s / D_WSLOTS;
         const int64_t kt = tk % n_kt, nt = tk / n_kt;
-        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
-        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
-        f32x4 v;
+        int cl, kl;
+        slot_to_ck<T>((int)(s % D_WSLOTS), cl, kl);
+        const int64_t r = nt * D_BN + cl, g0 = kt * DT<T>::BK + kl;
+        typename DT<T>::vec v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < DT<T>::EPP; ++c) {
             const uint64_t id = (uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r;
             const bool keep = r < R && g0 + c < G && (fill >= 1.0f || hash_u01(id, seed ^ 0x9e3779b9u) < fill);
-            v[c] = keep ? hash_u01(id, seed) : 0.f;
+            v[c] = keep ? (T)hash_u01(id, seed) : T(0);
         }
         Wp[s] = v;
     }
 }
 
 // column sums in fp64 (plan time): one block per (column tile, strip of k tiles); thread = slot
-__global__ void dense_colsum_kernel(const f32x4 *__restrict__ Wp, int32_t R, int n_kt, int kt_per_block,
+template <typename T>
+__global__ void dense_colsum_kernel(const typename DT<T>::vec *__restrict__ Wp, int32_t R, int n_kt, int kt_per_block,
                                     double *__restrict__ den) {
     const int nt = blockIdx.x;
     const int ktb = blockIdx.y * kt_per_block;
     const int kte = ktb + kt_per_block < n_kt ? ktb + kt_per_block : n_kt;
-    for (int slot = threadIdx.x; slot < D_WT / 4; slot += blockDim.x) {
+    for (int slot = threadIdx.x; slot < D_WSLOTS; slot += blockDim.x) {
         double s = 0.0;
         for (int kt = ktb; kt < kte; ++kt) {
-            const f32x4 v = Wp[((int64_t)nt * n_kt + kt) * (D_WT / 4) + slot];
-            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+            const typename DT<T>::vec v = Wp[((int64_t)nt * n_kt + kt) * D_WSLOTS + slot];
+            double sv = 0.0;
+#pragma unroll
+            for (int c = 0; c < DT<T>::EPP; ++c) sv += (double)v[c];
+            s += sv;
         }
         const int64_t r = (int64_t)nt * D_BN + (slot >> 3);
         if (r < R) atomicAdd(&den[r], s);
@@ -361,15 +404,16 @@ __global__ void dense_den32_kernel(const double *__restrict__ den64, float *__re
     if (r < R) den32[r] = (float)den64[r];
 }
 
-__global__ void dense_scatter_kernel(float *__restrict__ Wp, int n_kt, const int32_t *__restrict__ cell,
-                                     const int32_t *__restrict__ region, const float *__restrict__ w,
-                                     int64_t n) {
+template <typename T>
+__global__ void dense_scatter_kernel(T *__restrict__ Wp, int n_kt, const int32_t *__restrict__ cell,
+                                     const int32_t *__restrict__ region, const T *__restrict__ w, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) Wp[wp_index(cell[i], region[i], n_kt)] = w[i];
+    if (i < n) Wp[wp_index<T>(cell[i], region[i], n_kt)] = w[i];
 }
 
-__global__ void dense_scatter_at_kernel(float *__restrict__ Wp, const int64_t *__restrict__ at,
-                                        const float *__restrict__ w, int64_t n) {
+template <typename T>
+__global__ void dense_scatter_at_kernel(T *__restrict__ Wp, const int64_t *__restrict__ at,
+                                        const T *__restrict__ w, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) Wp[at[i]] = w[i];
 }
@@ -377,51 +421,56 @@ __global__ void dense_scatter_at_kernel(float *__restrict__ Wp, const int64_t *_
 // synthetic "block-local" weights: every run of 64 cells touches the 256 regions of
 // ONE column tile, nt = (97 run) mod n_nt; inside, W[g][r] = hash_u01(g R + r, seed) where a second
 // hash is below `fill`, else 0.  Stored tile i holds k tile kt_of[i] of column tile nt_of[i].
-__global__ void dense_synth_blocklocal_kernel(f32x4 *__restrict__ Wp, const int32_t *__restrict__ tile_kt,
+template <typename T>
+__global__ void dense_synth_blocklocal_kernel(typename DT<T>::vec *__restrict__ Wp, const int32_t *__restrict__ tile_kt,
                                               const int32_t *__restrict__ tile_nt, int64_t n_tiles, int64_t G,
                                               int32_t R, uint32_t seed, float fill) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n_slots = n_tiles * (D_WT / 4);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n_slots = n_tiles * D_WSLOTS;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
-        const int slot = (int)(s % (D_WT / 4));
-        const int64_t ti = s / (D_WT / 4);
+        const int64_t ti = s / D_WSLOTS;
         const int64_t kt = tile_kt[ti], nt = tile_nt[ti];
-        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
-        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
-        f32x4 v;
+        int cl, kl;
+        slot_to_ck<T>((int)(s % D_WSLOTS), cl, kl);
+        const int64_t r = nt * D_BN + cl, g0 = kt * DT<T>::BK + kl;
+        typename DT<T>::vec v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < DT<T>::EPP; ++c) {
             const uint64_t id = (uint64_t)(g0 + c) * (uint64_t)R + (uint64_t)r;
-            v[c] = (r < R && g0 + c < G && hash_u01(id, seed ^ 0x9e3779b9u) < fill) ? hash_u01(id, seed) : 0.f;
+            v[c] = (r < R && g0 + c < G && hash_u01(id, seed ^ 0x9e3779b9u) < fill) ? (T)hash_u01(id, seed) : T(0);
         }
         Wp[s] = v;
     }
 }
 
 // column sums of the tile-sparse form: one block per stored tile
-__global__ void dense_colsum_tiled_kernel(const f32x4 *__restrict__ Wp, const int32_t *__restrict__ tile_nt,
+template <typename T>
+__global__ void dense_colsum_tiled_kernel(const typename DT<T>::vec *__restrict__ Wp, const int32_t *__restrict__ tile_nt,
                                           int32_t R, double *__restrict__ den) {
     const int64_t ti = blockIdx.x;
-    for (int slot = threadIdx.x; slot < D_WT / 4; slot += blockDim.x) {
-        const f32x4 v = Wp[ti * (D_WT / 4) + slot];
-        const double s = ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    for (int slot = threadIdx.x; slot < D_WSLOTS; slot += blockDim.x) {
+        const typename DT<T>::vec v = Wp[ti * D_WSLOTS + slot];
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < DT<T>::EPP; ++c) s += (double)v[c];
         const int64_t r = (int64_t)tile_nt[ti] * D_BN + (slot >> 3);
         if (r < R && s != 0.0) atomicAdd(&den[r], s);
     }
 }
 
 // plain row-major W (G x R) -> packed order (small matrices handed over by the host)
-__global__ void dense_pack_w_kernel(const float *__restrict__ W, int64_t G, int32_t R, int n_kt,
-                                    int64_t n_slots, f32x4 *__restrict__ Wp) {
+template <typename T>
+__global__ void dense_pack_w_kernel(const T *__restrict__ W, int64_t G, int32_t R, int n_kt,
+                                    int64_t n_slots, typename DT<T>::vec *__restrict__ Wp) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += stride) {
-        const int slot = (int)(s % (D_WT / 4));
-        const int64_t tk = s / (D_WT / 4);
+        const int64_t tk = s / D_WSLOTS;
         const int64_t kt = tk % n_kt, nt = tk / n_kt;
-        const int cl = slot >> 3, p = (slot & 7) ^ ((cl >> 1) & 7);
-        const int64_t r = nt * D_BN + cl, g0 = kt * D_BK + 4 * p;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int cl, kl;
+        slot_to_ck<T>((int)(s % D_WSLOTS), cl, kl);
+        const int64_t r = nt * D_BN + cl, g0 = kt * DT<T>::BK + kl;
+        typename DT<T>::vec v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (r < R && g0 + c < G) v[c] = W[(g0 + c) * R + r];
+        for (int c = 0; c < DT<T>::EPP; ++c) v[c] = (r < R && g0 + c < G) ? W[(g0 + c) * R + r] : T(0);
         Wp[s] = v;
     }
 }
@@ -430,15 +479,18 @@ __global__ void dense_pack_w_kernel(const float *__restrict__ W, int64_t G, int3
 
 namespace wagg {
 
+template <typename T>
 static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_tiles = -1, bool spmm = false) {
+    constexpr int BK = DT<T>::BK;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
-    WAGG_REQUIRE((G + D_BK - 1) / D_BK < (int64_t)0x7fffffff / 8, "G too large");
+    WAGG_REQUIRE((G + BK - 1) / BK < (int64_t)0x7fffffff / 8, "G too large");
     wagg_dense *d = new (std::nothrow) wagg_dense();
     if (!d) { set_error("host allocation failed"); return WAGG_ENOMEM; }
     d->G = G; d->R = R;
-    d->n_kt = (int)((G + D_BK - 1) / D_BK);
+    d->f64 = sizeof(T) == 8;
+    d->n_kt = (int)((G + BK - 1) / BK);
     d->n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
     d->n_tiles = spmm ? 0 : (stored_tiles >= 0 ? stored_tiles : (int64_t)d->n_nt * d->n_kt);
     d->tiled = !spmm && stored_tiles >= 0;
@@ -460,18 +512,24 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     return WAGG_OK;
 }
 
-static int dense_finish_den(wagg_dense *d) {
-    WAGG_HIP(hipMemset(d->den64.p, 0, sizeof(double) * (size_t)d->R));
-    const int kt_per_block = 128;
-    dim3 grid((unsigned)d->n_nt, (unsigned)((d->n_kt + kt_per_block - 1) / kt_per_block));
-    hipLaunchKernelGGL(dense_colsum_kernel, grid, dim3(512), 0, nullptr,
-                       reinterpret_cast<const f32x4 *>(d->W.p), d->R, d->n_kt, kt_per_block, d->den64.p);
+static int dense_den_to_host(wagg_dense *d) {
     hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, nullptr,
                        d->den64.p, d->den32.p, d->R);
     WAGG_HIP(hipGetLastError());
     d->den_host.resize((size_t)d->R);
     WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
     return WAGG_OK;
+}
+
+template <typename T>
+static int dense_finish_den(wagg_dense *d) {
+    typedef typename DT<T>::vec vec_t;
+    WAGG_HIP(hipMemset(d->den64.p, 0, sizeof(double) * (size_t)d->R));
+    const int kt_per_block = 128;
+    dim3 grid((unsigned)d->n_nt, (unsigned)((d->n_kt + kt_per_block - 1) / kt_per_block));
+    hipLaunchKernelGGL((dense_colsum_kernel<T>), grid, dim3(512), 0, nullptr,
+                       reinterpret_cast<const vec_t *>(d->W.p), d->R, d->n_kt, kt_per_block, d->den64.p);
+    return dense_den_to_host(d);
 }
 
 // stored-tile lists of the tile-sparse form from the sorted keys nt * n_kt + kt
@@ -500,8 +558,8 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
 }
 
 // Below this share of non-zeros a W whose tiles are (almost) all occupied goes to the entry-list form
-// (wagg_spmm.hip): it runs at ~25 % of the fp32 peak on 2*T*nnz flops, the full MFMA form at ~90 % on
-// 2*T*G*R, so the break-even is near 25 % fill; 10 % keeps a safety margin for small problems.
+// (wagg_spmm.hip, fp32): it does 2*T*nnz flops on the vector ALU where the full MFMA form does 2*T*G*R at
+// ~90 % of the matrix peak, so the break-even is well above this; 10 % keeps a safety margin.
 constexpr double SPMM_MAX_FILL = 0.10;
 
 static int pick_ksplit(int64_t items, int n_kt) {
@@ -517,46 +575,42 @@ static int pick_ksplit(int64_t items, int n_kt) {
     return best;
 }
 
-}  // namespace wagg
-
-extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out) {
-    return wagg_dense_create_synth_sparse(G, R, seed, 1.0, out);
-}
-
-extern "C" int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
-    using namespace wagg;
+template <typename T>
+static int create_synth(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    typedef typename DT<T>::vec vec_t;
     WAGG_REQUIRE(fill > 0.0 && fill <= 1.0, "fill must be in (0, 1]");
-    if (fill < SPMM_MAX_FILL) {             // scattered and sparse: entry lists instead of a matrix
-        int rc = dense_alloc(G, R, out, -1, true);
+    if (fill < SPMM_MAX_FILL && sizeof(T) == 4) {       // scattered and sparse: entry lists instead of a matrix
+        int rc = dense_alloc<float>(G, R, out, -1, true);
         if (rc != WAGG_OK) return rc;
         rc = spmm_build_synth(*out, seed, fill);
         if (rc != WAGG_OK) { delete *out; *out = nullptr; }
         return rc;
     }
-    int rc = dense_alloc(G, R, out);
+    int rc = dense_alloc<T>(G, R, out);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    hipLaunchKernelGGL(dense_synth_w_kernel, dim3(256 * 32), dim3(256), 0, nullptr,
-                       reinterpret_cast<f32x4 *>(d->W.p), G, R, d->n_kt, d->w_slots(), seed, (float)fill);
+    hipLaunchKernelGGL((dense_synth_w_kernel<T>), dim3(256 * 32), dim3(256), 0, nullptr,
+                       reinterpret_cast<vec_t *>(d->W.p), G, R, d->n_kt, d->w_slots(), seed, (float)fill);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) rc = dense_finish_den(d); else { set_error("synth launch: %s", hipGetErrorString(e)); rc = WAGG_EHIP; }
+    if (e == hipSuccess) rc = dense_finish_den<T>(d); else { set_error("synth launch: %s", hipGetErrorString(e)); rc = WAGG_EHIP; }
     if (rc != WAGG_OK) { delete d; *out = nullptr; }
     return rc;
 }
 
-extern "C" int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill,
-                                                  wagg_dense **out) {
-    using namespace wagg;
+template <typename T>
+static int create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    typedef typename DT<T>::vec vec_t;
+    constexpr int BK = DT<T>::BK;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0 && fill > 0.0 && fill <= 1.0, "bad arguments");
-    const int n_kt = (int)((G + D_BK - 1) / D_BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
-    // run j (64 cells = k tiles 2j, 2j+1) touches column tile (97 j) mod n_nt
+    const int n_kt = (int)((G + BK - 1) / BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    // run j (64 cells = 64 / BK consecutive k tiles) touches column tile (97 j) mod n_nt
     std::vector<int64_t> tiles;
     tiles.reserve((size_t)n_kt);
-    for (int kt = 0; kt < n_kt; ++kt) tiles.push_back((int64_t)(((int64_t)97 * (kt / 2)) % n_nt) * n_kt + kt);
+    for (int kt = 0; kt < n_kt; ++kt) tiles.push_back((int64_t)(((int64_t)97 * (kt / (64 / BK))) % n_nt) * n_kt + kt);
     std::sort(tiles.begin(), tiles.end());
-    int rc = dense_alloc(G, R, out, (int64_t)tiles.size());
+    int rc = dense_alloc<T>(G, R, out, (int64_t)tiles.size());
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
     std::vector<int32_t> ntv;
@@ -564,66 +618,55 @@ extern "C" int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t
     hipError_t e = dense_set_tiles(d, tiles, &ntv);
     if (e == hipSuccess) e = dnt.upload(ntv);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(dense_synth_blocklocal_kernel, dim3(256 * 16), dim3(256), 0, nullptr,
-                           reinterpret_cast<f32x4 *>(d->W.p), d->tile_kt.p, dnt.p, d->n_tiles, G, R, seed, (float)fill);
+        hipLaunchKernelGGL((dense_synth_blocklocal_kernel<T>), dim3(256 * 16), dim3(256), 0, nullptr,
+                           reinterpret_cast<vec_t *>(d->W.p), d->tile_kt.p, dnt.p, d->n_tiles, G, R, seed, (float)fill);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemset(d->den64.p, 0, sizeof(double) * (size_t)R);
     if (e == hipSuccess && d->n_tiles > 0) {
-        hipLaunchKernelGGL(dense_colsum_tiled_kernel, dim3((unsigned)d->n_tiles), dim3(512), 0, nullptr,
-                           reinterpret_cast<const f32x4 *>(d->W.p), dnt.p, R, d->den64.p);
+        hipLaunchKernelGGL((dense_colsum_tiled_kernel<T>), dim3((unsigned)d->n_tiles), dim3(512), 0, nullptr,
+                           reinterpret_cast<const vec_t *>(d->W.p), dnt.p, R, d->den64.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nullptr, d->den64.p,
-                           d->den32.p, R);
-        e = hipGetLastError();
-    }
-    d->den_host.resize((size_t)R);
-    if (e == hipSuccess) e = hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)R, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { set_error("block-local synth: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
-    return WAGG_OK;
-}
-
-extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
-    WAGG_REQUIRE(d && info, "NULL argument");
-    info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
-    info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
-    info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 64 : d->w_slots() * 16;
-    info->form = d->spmm ? WAGG_FORM_ENTRIES : (d->tiled ? WAGG_FORM_TILES : WAGG_FORM_FULL);
-    info->nnz = d->spmm ? d->sp.nnz : -1;
-    return WAGG_OK;
-}
-
-extern "C" int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out) {
-    using namespace wagg;
-    WAGG_REQUIRE(W_host != nullptr, "W_host is NULL");
-    int rc = dense_alloc(G, R, out);
-    if (rc != WAGG_OK) return rc;
-    wagg_dense *d = *out;
-    DevBuf<float> plain;
-    hipError_t e = plain.alloc((size_t)(G * R));
-    if (e == hipSuccess) e = hipMemcpy(plain.p, W_host, sizeof(float) * (size_t)(G * R), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(dense_pack_w_kernel, dim3(256 * 8), dim3(256), 0, nullptr, plain.p, G, R, d->n_kt,
-                           d->w_slots(), reinterpret_cast<f32x4 *>(d->W.p));
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { set_error("dense upload: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
-    rc = dense_finish_den(d);
+    rc = dense_den_to_host(d);
     if (rc != WAGG_OK) { delete d; *out = nullptr; }
     return rc;
 }
 
-extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
-                                               const double *w_eff, int64_t nseg, int64_t G, int32_t R,
-                                               wagg_dense **out) {
-    using namespace wagg;
+template <typename T>
+static int create_host(const T *W_host, int64_t G, int32_t R, wagg_dense **out) {
+    typedef typename DT<T>::vec vec_t;
+    WAGG_REQUIRE(W_host != nullptr, "W_host is NULL");
+    int rc = dense_alloc<T>(G, R, out);
+    if (rc != WAGG_OK) return rc;
+    wagg_dense *d = *out;
+    DevBuf<T> plain;
+    hipError_t e = plain.alloc((size_t)(G * R));
+    if (e == hipSuccess) e = hipMemcpy(plain.p, W_host, sizeof(T) * (size_t)(G * R), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((dense_pack_w_kernel<T>), dim3(256 * 8), dim3(256), 0, nullptr, (const T *)plain.p, G, R, d->n_kt,
+                           d->w_slots(), reinterpret_cast<vec_t *>(d->W.p));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { set_error("dense upload: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
+    rc = dense_finish_den<T>(d);
+    if (rc != WAGG_OK) { delete d; *out = nullptr; }
+    return rc;
+}
+
+template <typename T>
+static int create_from_segments(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff, int64_t nseg,
+                                int64_t G, int32_t R, wagg_dense **out) {
+    constexpr int BK = DT<T>::BK, E = DT<T>::EPP;
+    WAGG_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
     WAGG_REQUIRE(nseg == 0 || (cell_idx && region_code && w_eff), "NULL segment arrays");
+    WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
     struct Seg { int32_t region, cell; double w; };
     std::vector<Seg> segs;
-    std::vector<double> den((size_t)(R > 0 ? R : 0), 0.0);
+    std::vector<double> den((size_t)R, 0.0);
     for (int64_t i = 0; i < nseg; ++i) {
         const int32_t r = region_code[i];
         if (r < 0) continue;
@@ -634,17 +677,17 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
     }
     std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
         return a.region != b.region ? a.region < b.region : a.cell < b.cell; });
-    std::vector<int32_t> hc, hr; std::vector<float> hw;
+    std::vector<int32_t> hc, hr; std::vector<T> hw;
     for (size_t i = 0; i < segs.size();) {
         double s = 0; size_t j = i;
         while (j < segs.size() && segs[j].region == segs[i].region && segs[j].cell == segs[i].cell) s += segs[j++].w;
-        hc.push_back(segs[i].cell); hr.push_back(segs[i].region); hw.push_back((float)s);
+        hc.push_back(segs[i].cell); hr.push_back(segs[i].region); hw.push_back((T)s);
         i = j;
     }
-    // which (32-cell x 256-region) tiles of W hold anything?  Few -> tile-sparse form
-    const int n_kt = (int)((G + D_BK - 1) / D_BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    // which (BK-cell x 256-region) tiles of W hold anything?  Few -> tile-sparse form
+    const int n_kt = (int)((G + BK - 1) / BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
     std::vector<int64_t> keys(hc.size());
-    for (size_t i = 0; i < hc.size(); ++i) keys[i] = (int64_t)(hr[i] / D_BN) * n_kt + hc[i] / D_BK;
+    for (size_t i = 0; i < hc.size(); ++i) keys[i] = (int64_t)(hr[i] / D_BN) * n_kt + hc[i] / BK;
     std::vector<int64_t> tiles(keys);
     std::sort(tiles.begin(), tiles.end());
     tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
@@ -652,51 +695,57 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
 #ifdef WAGG_DIAG
     if (getenv("WAGG_DENSE_NO_TILED")) tiled = false;
 #endif
-    // tiles mostly occupied but few non-zeros in them (scattered weights): entry lists
-    const bool spmm = !tiled && (double)hc.size() < SPMM_MAX_FILL * (double)G * (double)R;
-    int rc = dense_alloc(G, R, out, tiled ? (int64_t)tiles.size() : -1, spmm);
+    int rc = WAGG_OK;
+    if constexpr (sizeof(T) == 4) {
+        // tiles mostly occupied but few non-zeros in them (scattered weights): entry lists
+        if (!tiled && (double)hc.size() < SPMM_MAX_FILL * (double)G * (double)R) {
+            rc = dense_alloc<float>(G, R, out, -1, true);
+            if (rc != WAGG_OK) return rc;
+            wagg_dense *d = *out;
+            rc = spmm_build_from_coo(d, hc, hr, hw);
+            std::vector<float> den32s(den.size());
+            for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
+            hipError_t es = rc == WAGG_OK ? hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice) : hipSuccess;
+            if (es == hipSuccess && rc == WAGG_OK) es = hipMemcpy(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), hipMemcpyHostToDevice);
+            if (es != hipSuccess) { set_error("entry lists: %s", hipGetErrorString(es)); rc = WAGG_EHIP; }
+            if (rc != WAGG_OK) { delete d; *out = nullptr; return rc; }
+            d->den_host = den;
+            return WAGG_OK;
+        }
+    }
+    rc = dense_alloc<T>(G, R, out, tiled ? (int64_t)tiles.size() : -1);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    if (spmm) {
-        rc = spmm_build_from_coo(d, hc, hr, hw);
-        std::vector<float> den32s(den.size());
-        for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
-        hipError_t es = rc == WAGG_OK ? hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice) : hipSuccess;
-        if (es == hipSuccess && rc == WAGG_OK) es = hipMemcpy(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), hipMemcpyHostToDevice);
-        if (es != hipSuccess) { set_error("entry lists: %s", hipGetErrorString(es)); rc = WAGG_EHIP; }
-        if (rc != WAGG_OK) { delete d; *out = nullptr; return rc; }
-        d->den_host = den;
-        return WAGG_OK;
-    }
-    DevBuf<int32_t> dc, dr; DevBuf<float> dw; DevBuf<int64_t> dat;
-    hipError_t e = hipMemset(d->W.p, 0, sizeof(float) * 4 * (size_t)d->w_slots());
+    DevBuf<int32_t> dc, dr; DevBuf<T> dw; DevBuf<int64_t> dat;
+    hipError_t e = hipMemset(d->W.p, 0, 16 * (size_t)d->w_slots());
     if (e == hipSuccess) e = dw.upload(hw);
     if (tiled) {
         std::vector<int64_t> at(hc.size());
         for (size_t i = 0; i < hc.size(); ++i) {
             const int64_t ti = std::lower_bound(tiles.begin(), tiles.end(), keys[i]) - tiles.begin();
-            const int cl = hr[i] % D_BN, kk = hc[i] % D_BK;
-            at[i] = (ti * (D_WT / 4) + tile_slot(cl, kk >> 2)) * 4 + (kk & 3);
+            const int cl = hr[i] % D_BN, kk = hc[i] % BK;
+            at[i] = (ti * D_WSLOTS + tile_slot(cl, kk / E)) * E + (kk % E);
         }
         if (e == hipSuccess) e = dat.upload(at);
         if (e == hipSuccess) e = dense_set_tiles(d, tiles);
         if (e == hipSuccess && !hc.empty()) {
-            hipLaunchKernelGGL(dense_scatter_at_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                               d->W.p, dat.p, dw.p, (int64_t)hc.size());
+            hipLaunchKernelGGL((dense_scatter_at_kernel<T>), dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
+                               reinterpret_cast<T *>(d->W.p), (const int64_t *)dat.p, (const T *)dw.p, (int64_t)hc.size());
             e = hipGetLastError();
         }
     } else {
         if (e == hipSuccess) e = dc.upload(hc);
         if (e == hipSuccess) e = dr.upload(hr);
         if (e == hipSuccess && !hc.empty()) {
-            hipLaunchKernelGGL(dense_scatter_kernel, dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                               d->W.p, d->n_kt, dc.p, dr.p, dw.p, (int64_t)hc.size());
+            hipLaunchKernelGGL((dense_scatter_kernel<T>), dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
+                               reinterpret_cast<T *>(d->W.p), d->n_kt, (const int32_t *)dc.p, (const int32_t *)dr.p,
+                               (const T *)dw.p, (int64_t)hc.size());
             e = hipGetLastError();
         }
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { set_error("densify: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
-    // denominators from the fp64 segment sums (aggregations.py:79), not from the fp32 matrix
+    // denominators from the fp64 segment sums (aggregations.py:79), not from the stored matrix
     std::vector<float> den32(den.size());
     for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
     e = hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice);
@@ -706,36 +755,57 @@ extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const in
     return WAGG_OK;
 }
 
-extern "C" int wagg_dense_destroy(wagg_dense *d) {
-    delete d;
-    return WAGG_OK;
+template <typename T, bool TILED, int MT>
+static const void *mfma_kernel_ptr() { return (const void *)dense_mfma_kernel<T, 0, TILED, MT>; }
+
+// the kernel instantiated for MT row blocks (fp32: 1..6, 8, 10, ..., 20, 21, 22, 23; fp64: 1..6, 8, 10, 11)
+template <typename T>
+static const void *pick_mfma_kernel(int MT, bool tiled) {
+#define WAGG_PICK(M) case M: return tiled ? mfma_kernel_ptr<T, true, M>() : mfma_kernel_ptr<T, false, M>()
+    if constexpr (sizeof(T) == 4) {
+        switch (MT) {
+            WAGG_PICK(1); WAGG_PICK(2); WAGG_PICK(3); WAGG_PICK(4); WAGG_PICK(5); WAGG_PICK(6); WAGG_PICK(8);
+            WAGG_PICK(10); WAGG_PICK(12); WAGG_PICK(14); WAGG_PICK(16); WAGG_PICK(18); WAGG_PICK(20);
+            WAGG_PICK(21); WAGG_PICK(22); WAGG_PICK(23);
+            default: return nullptr;
+        }
+    } else {
+        switch (MT) {
+            WAGG_PICK(1); WAGG_PICK(2); WAGG_PICK(3); WAGG_PICK(4); WAGG_PICK(5); WAGG_PICK(6); WAGG_PICK(8);
+            WAGG_PICK(10); WAGG_PICK(11);
+            default: return nullptr;
+        }
+    }
+#undef WAGG_PICK
 }
 
-extern "C" int wagg_dense_get_den(const wagg_dense *d, double *den_host) {
-    WAGG_REQUIRE(d && den_host, "NULL argument");
-    std::memcpy(den_host, d->den_host.data(), sizeof(double) * (size_t)d->R);
-    return WAGG_OK;
-}
-
-namespace wagg {
-static int dense_apply(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, const PackXf &xf,
-                       float *out_dev, int64_t ldo, int ksplit, void *stream) {
+template <typename T>
+static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, const PackXfT<T> &xf,
+                       T *out_dev, int64_t ldo, int ksplit, void *stream) {
+    typedef typename DT<T>::vec vec_t;
     WAGG_REQUIRE(d != nullptr, "dense plan is NULL");
-    WAGG_REQUIRE(T >= 0, "T < 0");
-    if (T == 0) return WAGG_OK;
+    WAGG_REQUIRE(d->f64 == (sizeof(T) == 8), "this plan holds %s weights: use the matching wagg_dense_apply_*",
+                 d->f64 ? "fp64" : "fp32");
+    WAGG_REQUIRE(Tn >= 0, "T < 0");
+    if (Tn == 0) return WAGG_OK;
     WAGG_REQUIRE(X_dev && out_dev, "X/out is NULL");
     WAGG_REQUIRE(xf.mode != XF_EDD || xf.X2 != nullptr, "tasmax is NULL");
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
-    if (d->spmm) return spmm_apply(d, X_dev, T, ldx, xf, out_dev, ldo, (hipStream_t)stream);
+    if constexpr (sizeof(T) == 4) {
+        if (d->spmm) return spmm_apply(d, X_dev, Tn, ldx, xf, out_dev, ldo, (hipStream_t)stream);
+    }
     const int n_nt = d->n_nt, n_kt = d->n_kt;
-    // row blocks: as few as possible (<= 368 rows each), evenly filled, 16 MT rows with MT from the
-    // instantiated set -- T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
-    const int n_mb = (int)((T + D_BM - 1) / D_BM);
-    const int rows = (int)((T + n_mb - 1) / n_mb);
-    static const int mts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 21, 22, 23};
-    int MT = D_MT;
-    for (int m : mts) if (m * 16 >= rows) { MT = m; break; }
+    // row blocks: as few as possible (<= MT_MAX x 16 rows each), evenly filled, 16 MT rows with MT from the
+    // instantiated set -- fp32: T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
+    constexpr int BM_MAX = DT<T>::MT_MAX * 16;
+    const int n_mb = (int)((Tn + BM_MAX - 1) / BM_MAX);
+    const int rows = (int)((Tn + n_mb - 1) / n_mb);
+    static const int mts32[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 21, 22, 23};
+    static const int mts64[] = {1, 2, 3, 4, 5, 6, 8, 10, 11};
+    int MT = DT<T>::MT_MAX;
+    if constexpr (sizeof(T) == 4) { for (int m : mts32) if (m * 16 >= rows) { MT = m; break; } }
+    else { for (int m : mts64) if (m * 16 >= rows) { MT = m; break; } }
     const int bm = MT * 16;
     int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
     if (d->tiled) {               // fewest slices (1, 2, 4, 8) that still give >= 4 workgroups per CU
@@ -744,76 +814,152 @@ static int dense_apply(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx
     }
     const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
-    WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && T <= 65535, "grid too large");
-    const size_t need = (size_t)n_nt * n_mb * S * bm * D_BN;
+    WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && Tn <= 65535, "grid too large");
+    const size_t need = (size_t)n_nt * n_mb * S * bm * D_BN * (sizeof(T) / 4);     // DevBuf<float>: 4-byte units
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
     const int64_t x_slots = (int64_t)n_mb * n_kt * bm * 8;
     if (d->xp.n < (size_t)x_slots * 4) WAGG_HIP(d->xp.alloc((size_t)x_slots * 4));
-    const int aligned = (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0);
+    const int aligned = ((ldx * sizeof(T)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(X_dev) & 15) == 0) &&
+                        (xf.mode != XF_EDD || (reinterpret_cast<uintptr_t>(xf.X2) & 15) == 0);
     const size_t shmem = 2 * (size_t)d_buf_bytes(MT);
     hipStream_t st = (hipStream_t)stream;
-    typedef void (*kern_t)(const float *, const float *, int, int, int, int, int, float *, const int32_t *, const int32_t *);
-    kern_t kern = nullptr;
-#define WAGG_PICK(M) case M: kern = d->tiled ? (kern_t)dense_mfma_kernel<0, true, M> : (kern_t)dense_mfma_kernel<0, false, M>; break
-    switch (MT) {
-        WAGG_PICK(1); WAGG_PICK(2); WAGG_PICK(3); WAGG_PICK(4); WAGG_PICK(5); WAGG_PICK(6); WAGG_PICK(8);
-        WAGG_PICK(10); WAGG_PICK(12); WAGG_PICK(14); WAGG_PICK(16); WAGG_PICK(18); WAGG_PICK(20);
-        WAGG_PICK(21); WAGG_PICK(22); WAGG_PICK(23);
-        default: set_error("no kernel for MT=%d", MT); return WAGG_EINVAL;
-    }
-#undef WAGG_PICK
+    const void *kern = pick_mfma_kernel<T>(MT, d->tiled);
+    if (!kern) { set_error("no kernel for MT=%d", MT); return WAGG_EINVAL; }
 #ifdef WAGG_DIAG      // ablation variants (timing only; results are wrong with bit0 or bit2): tools/dense_ablate.sh
-    if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
-        switch (atoi(dbg)) {
-            case 1: kern = dense_mfma_kernel<1>; break;
-            case 4: kern = dense_mfma_kernel<4>; break;
-            case 5: kern = dense_mfma_kernel<5>; break;
-            case 8: kern = dense_mfma_kernel<8>; break;
-            case 16: kern = dense_mfma_kernel<16>; break;
-            default: break;
+    if constexpr (sizeof(T) == 4) {
+        if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
+            switch (atoi(dbg)) {
+                case 1: kern = (const void *)dense_mfma_kernel<float, 1>; break;
+                case 4: kern = (const void *)dense_mfma_kernel<float, 4>; break;
+                case 5: kern = (const void *)dense_mfma_kernel<float, 5>; break;
+                case 8: kern = (const void *)dense_mfma_kernel<float, 8>; break;
+                case 16: kern = (const void *)dense_mfma_kernel<float, 16>; break;
+                default: break;
+            }
         }
     }
 #endif
-    WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));
-    const int aligned2 = aligned && (xf.mode != XF_EDD || (reinterpret_cast<uintptr_t>(xf.X2) & 15) == 0);
-    hipLaunchKernelGGL(dense_pack_x_kernel, dim3(256 * 16), dim3(256), 0, st, X_dev, T, ldx, d->G, n_kt, bm, x_slots,
-                       aligned2, reinterpret_cast<f32x4 *>(d->xp.p), xf, d->inf_dev);
+    WAGG_HIP(allow_dynamic_lds(kern, shmem));
+    hipLaunchKernelGGL((dense_pack_x_kernel<T>), dim3(256 * 16), dim3(256), 0, st, X_dev, Tn, ldx, d->G, n_kt, bm, x_slots,
+                       aligned, reinterpret_cast<vec_t *>(d->xp.p), xf, d->inf_dev);
     WAGG_HIP(hipGetLastError());
+    const T *xp = reinterpret_cast<const T *>(d->xp.p), *wp = reinterpret_cast<const T *>(d->W.p);
+    T *slabs = reinterpret_cast<T *>(d->slabs.p);
+    int n_kt_a = n_kt, n_nt_a = n_nt, n_mb_a = n_mb, S_a = S, kps = kt_per_slice;
+    const int32_t *tkt = d->tile_kt.p;
+    const int32_t *toff = d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr;
+    void *args[] = {&xp, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff};
     profile_mark(st, true);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(D_THREADS), shmem, st, (const float *)d->xp.p,
-                       (const float *)d->W.p, n_kt, n_nt, n_mb, S, kt_per_slice, d->slabs.p,
-                       (const int32_t *)d->tile_kt.p,
-                       (const int32_t *)(d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr));
+    WAGG_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
     profile_mark(st, false);
-    WAGG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)((d->R + 255) / 256), (unsigned)T), dim3(256), 0, st,
-                       d->slabs.p, n_nt, S, bm, T, d->R, d->den32.p, out_dev, ldo);
+    const T *den;
+    if constexpr (sizeof(T) == 4) den = d->den32.p; else den = d->den64.p;
+    hipLaunchKernelGGL((dense_reduce_kernel<T>), dim3((unsigned)((d->R + 255) / 256), (unsigned)Tn), dim3(256), 0, st,
+                       (const T *)slabs, n_nt, S, bm, Tn, d->R, den, out_dev, ldo);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }
+
+template <typename T>
+static int apply_poly(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, double offset, int power, T *out_dev,
+                      int64_t ldo, int ksplit, void *stream) {
+    WAGG_REQUIRE(power >= 1 && power <= 16, "power must lie in [1, 16], got %d", power);
+    PackXfT<T> xf;
+    xf.mode = power; xf.off = (T)offset;
+    return dense_apply<T>(d, X_dev, Tn, ldx, xf, out_dev, ldo, ksplit, stream);
+}
+
+template <typename T>
+static int apply_edd(wagg_dense *d, const T *tasmin, const T *tasmax, int64_t Tn, int64_t ldx, double offset,
+                     double threshold, T *out_dev, int64_t ldo, int ksplit, void *stream) {
+    PackXfT<T> xf;
+    xf.mode = XF_EDD; xf.off = (T)offset; xf.thr = (T)threshold; xf.X2 = tasmax;
+    return dense_apply<T>(d, tasmin, Tn, ldx, xf, out_dev, ldo, ksplit, stream);
+}
+
 }  // namespace wagg
+
+extern "C" int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **out) {
+    return wagg::create_synth<float>(G, R, seed, 1.0, out);
+}
+extern "C" int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    return wagg::create_synth<float>(G, R, seed, fill, out);
+}
+extern "C" int wagg_dense_create_synth_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    return wagg::create_synth<double>(G, R, seed, fill, out);
+}
+extern "C" int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    return wagg::create_synth_blocklocal<float>(G, R, seed, fill, out);
+}
+extern "C" int wagg_dense_create_synth_blocklocal_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
+    return wagg::create_synth_blocklocal<double>(G, R, seed, fill, out);
+}
+extern "C" int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out) {
+    return wagg::create_host<float>(W_host, G, R, out);
+}
+extern "C" int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32_t R, wagg_dense **out) {
+    return wagg::create_host<double>(W_host, G, R, out);
+}
+extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
+                                               const double *w_eff, int64_t nseg, int64_t G, int32_t R,
+                                               wagg_dense **out) {
+    return wagg::create_from_segments<float>(cell_idx, region_code, w_eff, nseg, G, R, out);
+}
+extern "C" int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
+                                                   const double *w_eff, int64_t nseg, int64_t G, int32_t R,
+                                                   wagg_dense **out) {
+    return wagg::create_from_segments<double>(cell_idx, region_code, w_eff, nseg, G, R, out);
+}
+
+extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
+    using namespace wagg;
+    WAGG_REQUIRE(d && info, "NULL argument");
+    info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
+    info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
+    info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 64 : d->w_slots() * 16;
+    info->form = d->spmm ? WAGG_FORM_ENTRIES : (d->tiled ? WAGG_FORM_TILES : WAGG_FORM_FULL);
+    info->elem_bytes = d->f64 ? 8 : 4;
+    info->nnz = d->spmm ? d->sp.nnz : -1;
+    return WAGG_OK;
+}
+
+extern "C" int wagg_dense_destroy(wagg_dense *d) {
+    delete d;
+    return WAGG_OK;
+}
+
+extern "C" int wagg_dense_get_den(const wagg_dense *d, double *den_host) {
+    using namespace wagg;
+    WAGG_REQUIRE(d && den_host, "NULL argument");
+    std::memcpy(den_host, d->den_host.data(), sizeof(double) * (size_t)d->R);
+    return WAGG_OK;
+}
 
 extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                                     float *out_dev, int64_t ldo, int ksplit, void *stream) {
-    return wagg::dense_apply(d, X_dev, T, ldx, wagg::PackXf{}, out_dev, ldo, ksplit, stream);
+    return wagg::dense_apply<float>(d, X_dev, T, ldx, wagg::PackXfT<float>{}, out_dev, ldo, ksplit, stream);
 }
-
+extern "C" int wagg_dense_apply_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx,
+                                    double *out_dev, int64_t ldo, int ksplit, void *stream) {
+    return wagg::dense_apply<double>(d, X_dev, T, ldx, wagg::PackXfT<double>{}, out_dev, ldo, ksplit, stream);
+}
 extern "C" int wagg_dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, double offset,
                                          int power, float *out_dev, int64_t ldo, int ksplit, void *stream) {
-    using namespace wagg;
-    WAGG_REQUIRE(power >= 1 && power <= 16, "power must lie in [1, 16], got %d", power);
-    PackXf xf;
-    xf.mode = power; xf.off = (float)offset;
-    return dense_apply(d, X_dev, T, ldx, xf, out_dev, ldo, ksplit, stream);
+    return wagg::apply_poly<float>(d, X_dev, T, ldx, offset, power, out_dev, ldo, ksplit, stream);
 }
-
+extern "C" int wagg_dense_apply_poly_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx, double offset,
+                                         int power, double *out_dev, int64_t ldo, int ksplit, void *stream) {
+    return wagg::apply_poly<double>(d, X_dev, T, ldx, offset, power, out_dev, ldo, ksplit, stream);
+}
 extern "C" int wagg_dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
                                         int64_t ldx, double offset, double threshold, float *out_dev, int64_t ldo,
                                         int ksplit, void *stream) {
-    using namespace wagg;
-    PackXf xf;
-    xf.mode = XF_EDD; xf.off = (float)offset; xf.thr = (float)threshold; xf.X2 = tasmax_dev;
-    return dense_apply(d, tasmin_dev, T, ldx, xf, out_dev, ldo, ksplit, stream);
+    return wagg::apply_edd<float>(d, tasmin_dev, tasmax_dev, T, ldx, offset, threshold, out_dev, ldo, ksplit, stream);
+}
+extern "C" int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+                                        int64_t ldx, double offset, double threshold, double *out_dev, int64_t ldo,
+                                        int ksplit, void *stream) {
+    return wagg::apply_edd<double>(d, tasmin_dev, tasmax_dev, T, ldx, offset, threshold, out_dev, ldo, ksplit, stream);
 }
 
 extern "C" int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw) {

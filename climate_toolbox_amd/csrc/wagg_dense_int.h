@@ -7,20 +7,22 @@ namespace wagg {
 
 // Element transform applied while X is packed for a dense-family apply: the packed
 // copy is the only place every element is touched, so tas_poly / snyder_edd cost no extra pass.
-struct PackXf {
+template <typename T> struct PackXfT {
     int mode = 0;            // 0: identity; p > 0: (x + off)^p; XF_EDD: snyder_edd1(x + off, x2 + off, thr)
-    float off = 0.f, thr = 0.f;
-    const float *X2 = nullptr;   // tasmax (XF_EDD only), same shape and row stride as X
+    T off = T(0), thr = T(0);
+    const T *X2 = nullptr;   // tasmax (XF_EDD only), same shape and row stride as X
 };
+typedef PackXfT<float> PackXf;
 
 // transformed value with NaN -> 0 (S6); *inf_seen is set when the result is +-inf (the MFMA forms
 // multiply every pair of a stored tile, so the caller must redo such a field in an exact form)
-__device__ __forceinline__ float pack_xf(const PackXf &xf, float x, float x2, bool &inf_seen) {
-    float y = x;
-    if (xf.mode > 0) y = xform1<float>(x, xf.off, xf.mode);
-    else if (xf.mode == XF_EDD) y = snyder_edd1<float>(x + xf.off, x2 + xf.off, xf.thr);
+template <typename T>
+__device__ __forceinline__ T pack_xf(const PackXfT<T> &xf, T x, T x2, bool &inf_seen) {
+    T y = x;
+    if (xf.mode > 0) y = xform1<T>(x, xf.off, xf.mode);
+    else if (xf.mode == XF_EDD) y = snyder_edd1<T>(x + xf.off, x2 + xf.off, xf.thr);
     inf_seen |= __builtin_isinf(y);
-    return y == y ? y : 0.0f;
+    return y == y ? y : T(0);
 }
 
 // ---- entry-list ("SpMM") form: geometry shared by the builders and the kernel -------------------
@@ -47,8 +49,9 @@ struct SpmmPlan {
 struct wagg_dense {
     int64_t G = 0;
     int32_t R = 0;
-    int n_kt = 0, n_nt = 0;            // k tiles (32 cells) and column tiles (256 regions)
-    wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order
+    int n_kt = 0, n_nt = 0;            // k tiles (32 cells in fp32, 16 in fp64) and column tiles (256 regions)
+    bool f64 = false;                  // element type of W / X / slabs: fp32 (default) or fp64 (the *_f64 constructors)
+    wagg::DevBuf<float> W, den32, slabs, xp;     // W and xp in packed tile order (sized in 4-byte units for both types)
     wagg::DevBuf<double> den64;
     std::vector<double> den_host;
     // tile-sparse form: only the non-empty (32-cell x 256-region) tiles of W are stored, grouped by

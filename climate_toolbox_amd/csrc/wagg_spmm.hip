@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void spmm_pack_x_kernel(const float *__restric
         float v = 0.f;
         if (t < T && g < G) {
             const float x = X[t * ldx + g];
-            v = pack_xf(xf, x, xf.mode == XF_EDD ? xf.X2[t * ldx + g] : 0.f, inf_seen);
+            v = pack_xf<float>(xf, x, xf.mode == XF_EDD ? xf.X2[t * ldx + g] : 0.f, inf_seen);
         }
         tile[i][tx] = v;
     }

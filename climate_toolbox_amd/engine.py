@@ -169,7 +169,10 @@ class SparsePlan:
 
 
 class DensePlan:
-    """(gridcell x region) fp32 weight matrix resident in HBM + MFMA contraction."""
+    """Dense-family plan: W as a (gridcell x region) matrix resident in HBM contracted on the matrix
+    cores (full or tile-sparse form; fp32 or fp64 weights), or per-wave entry lists for scattered,
+    sparse weights (fp32).  ``info["form"]`` says which (``_lib.FORM_*``), ``dtype`` the element type
+    the plan serves ("float32" / "float64")."""
 
     def __init__(self, handle, G, R):
         self._h, self.G, self.R = handle, int(G), int(R)
@@ -179,45 +182,60 @@ class DensePlan:
         inf = _lib.DenseInfo()
         _lib.check(_lib.load().wagg_dense_get_info(self._h, C.byref(inf)), "wagg_dense_get_info")
         self.info = {k: int(getattr(inf, k)) for k, _ in _lib.DenseInfo._fields_}
+        self.dtype = "float64" if self.info["elem_bytes"] == 8 else "float32"
+
+    @staticmethod
+    def _is64(dtype):
+        return str(dtype).endswith("float64") or dtype is np.float64
 
     @classmethod
-    def synth_blocklocal(cls, G, R, seed, fill=0.952):
+    def synth_blocklocal(cls, G, R, seed, fill=0.952, dtype="float32"):
         """c5's block-local weights, generated on the device in tile-sparse form."""
         require_gpu()
         h = C.c_void_p()
-        _lib.check(_lib.load().wagg_dense_create_synth_blocklocal(int(G), int(R), int(seed), float(fill), C.byref(h)),
-                   "wagg_dense_create_synth_blocklocal")
+        L = _lib.load()
+        fn = L.wagg_dense_create_synth_blocklocal_f64 if cls._is64(dtype) else L.wagg_dense_create_synth_blocklocal
+        _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth_blocklocal")
         return cls(h, G, R)
 
     @classmethod
-    def synth(cls, G, R, seed, fill=1.0):
+    def synth(cls, G, R, seed, fill=1.0, dtype="float32"):
         """W[g, r] = hash_u01(g R + r, seed); with fill < 1 only that fraction of the entries, at
-        uniformly random positions (c5's uniform-random structure at fill = 0.01)."""
+        uniformly random positions (c5's uniform-random structure at fill = 0.01: entry lists)."""
         require_gpu()
         h = C.c_void_p()
-        _lib.check(_lib.load().wagg_dense_create_synth_sparse(int(G), int(R), int(seed), float(fill), C.byref(h)),
-                   "wagg_dense_create_synth_sparse")
+        L = _lib.load()
+        fn = L.wagg_dense_create_synth_f64 if cls._is64(dtype) else L.wagg_dense_create_synth_sparse
+        _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth")
         return cls(h, G, R)
 
     @classmethod
     def from_host(cls, W):
+        """From a host (G, R) matrix; a float64 array makes an fp64 plan, anything else fp32."""
         require_gpu()
-        W = np.ascontiguousarray(W, dtype=np.float32)
+        W = np.asarray(W)
         h = C.c_void_p()
-        _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1],
-                                                      C.byref(h)), "wagg_dense_create_host")
+        if W.dtype == np.float64:
+            W = np.ascontiguousarray(W)
+            _lib.check(_lib.load().wagg_dense_create_host_f64(_np_ptr(W, C.c_double), W.shape[0], W.shape[1], C.byref(h)),
+                       "wagg_dense_create_host_f64")
+        else:
+            W = np.ascontiguousarray(W, dtype=np.float32)
+            _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1], C.byref(h)),
+                       "wagg_dense_create_host")
         return cls(h, W.shape[0], W.shape[1])
 
     @classmethod
-    def from_segments(cls, cell_idx, region_code, w_eff, G, R):
+    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32"):
         require_gpu()
         ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
         rc = np.ascontiguousarray(region_code, dtype=np.int32)
         we = np.ascontiguousarray(w_eff, dtype=np.float64)
         h = C.c_void_p()
-        _lib.check(_lib.load().wagg_dense_create_from_segments(
-            _np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
-            int(R), C.byref(h)), "wagg_dense_create_from_segments")
+        L = _lib.load()
+        fn = L.wagg_dense_create_from_segments_f64 if cls._is64(dtype) else L.wagg_dense_create_from_segments
+        _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
+                      int(R), C.byref(h)), "wagg_dense_create_from_segments")
         return cls(h, G, R)
 
     def close(self):
@@ -230,44 +248,48 @@ class DensePlan:
     def _prep(self, X, out):
         import torch
         X = _check_X(X, "TG")
-        if X.dtype != torch.float32:
-            raise TypeError("dense path is fp32")
+        want = torch.float64 if self.dtype == "float64" else torch.float32
+        if X.dtype != want:
+            raise TypeError("this dense plan serves %s data, got %s" % (self.dtype, X.dtype))
         if X.shape[1] != self.G:
             raise ValueError("X has %d grid cells, plan expects %d" % (X.shape[1], self.G))
         T = X.shape[0]
         if out is None:
-            out = torch.empty((T, self.R), dtype=torch.float32, device=X.device)
-        elif tuple(out.shape) != (T, self.R) or out.dtype != torch.float32 or (self.R > 1 and out.stride(1) != 1):
-            raise ValueError("out must be a (%d, %d) float32 tensor with contiguous rows" % (T, self.R))
+            out = torch.empty((T, self.R), dtype=want, device=X.device)
+        elif tuple(out.shape) != (T, self.R) or out.dtype != want or (self.R > 1 and out.stride(1) != 1):
+            raise ValueError("out must be a (%d, %d) %s tensor with contiguous rows" % (T, self.R, self.dtype))
         return X, T, out
+
+    def _fn(self, stem):
+        return getattr(_lib.load(), stem + ("_f64" if self.dtype == "float64" else "_f32"))
 
     def apply(self, X, out=None, ksplit=0, stream=None):
         X, T, out = self._prep(X, out)
-        _lib.check(_lib.load().wagg_dense_apply_f32(
+        _lib.check(self._fn("wagg_dense_apply")(
             self._h, C.c_void_p(X.data_ptr()), T, _ld(X), C.c_void_p(out.data_ptr()),
-            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_f32")
+            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply")
         return out
 
     def apply_poly(self, X, offset, power, out=None, ksplit=0, stream=None):
-        """Aggregate of (X + offset) ** power (``wagg_dense_apply_poly_f32``): the transform of
+        """Aggregate of (X + offset) ** power (``wagg_dense_apply_poly_*``): the transform of
         tas_poly (transformations.py:188) is evaluated while X is packed."""
         X, T, out = self._prep(X, out)
-        _lib.check(_lib.load().wagg_dense_apply_poly_f32(
+        _lib.check(self._fn("wagg_dense_apply_poly")(
             self._h, C.c_void_p(X.data_ptr()), T, _ld(X), float(offset), int(power), C.c_void_p(out.data_ptr()),
-            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_poly_f32")
+            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_poly")
         return out
 
     def apply_edd(self, tasmin, tasmax, threshold, offset=0.0, out=None, ksplit=0, stream=None):
         """Aggregate of snyder_edd(tasmin + offset, tasmax + offset, threshold)
-        (``wagg_dense_apply_edd_f32``; transformations.py:64-87 evaluated while the fields are packed)."""
+        (``wagg_dense_apply_edd_*``; transformations.py:64-87 evaluated while the fields are packed)."""
         tasmin, T, out = self._prep(tasmin, out)
         tasmax = _check_X(tasmax, "TG")
         if tasmax.shape != tasmin.shape or tasmax.dtype != tasmin.dtype or _ld(tasmax) != _ld(tasmin):
             raise ValueError("tasmin and tasmax must have the same shape, dtype and row stride")
-        _lib.check(_lib.load().wagg_dense_apply_edd_f32(
+        _lib.check(self._fn("wagg_dense_apply_edd")(
             self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin), float(offset),
             float(threshold), C.c_void_p(out.data_ptr()), _ld(out), int(ksplit), _stream_handle(stream)),
-            "wagg_dense_apply_edd_f32")
+            "wagg_dense_apply_edd")
         return out
 
     def saw_inf(self, stream=None):

@@ -218,10 +218,20 @@ int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, doub
 #define WAGG_FORM_TILES 1    /* only the non-empty tiles ("tile-sparse": block-local weights), same MFMA kernel */
 #define WAGG_FORM_ENTRIES 2  /* no matrix: per-wave (cell, region, weight) lists, vector-ALU kernel (scattered,
                                 sparse weights: <= 10 % non-zeros spread over (almost) every tile)              */
+/* The *_f64 constructors build the same forms with fp64 weights for fp64 data (the reference's own
+ * arithmetic type, aggregations.py:73-80): tiles are (16-cell x 256-region), the contraction runs on
+ * v_mfma_f64_16x16x4_f64 (wagg_dense_apply_f64).  A plan serves one element type; the entry-list form
+ * is fp32 only (an fp64 table that would take it becomes a full or tile-sparse fp64 matrix).        */
+int wagg_dense_create_synth_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
+int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32_t R, wagg_dense **out);
+int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
+                                        const double *w_eff, int64_t nseg, int64_t G, int32_t R,
+                                        wagg_dense **out);
+int wagg_dense_create_synth_blocklocal_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 typedef struct wagg_dense_info {
     int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles; bytes of W (or of the entry lists) in HBM */
     int32_t R, n_kt, n_nt, tiled;  /* k tiles, column tiles, 1 = tile-sparse form */
-    int32_t form, reserved;        /* WAGG_FORM_* */
+    int32_t form, elem_bytes;      /* WAGG_FORM_*; 4 = fp32 plan, 8 = fp64 plan */
     int64_t nnz;                   /* entry-list form: kept (cell, region) pairs; else -1 */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
@@ -233,6 +243,9 @@ int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
  * must be ordered on one stream; different plans are independent.                               */
 int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                          float *out_dev, int64_t ldo, int ksplit, void *stream);
+/* fp64 data on an fp64 plan: out = sum_g nan0(X[t,g]) * W[g,r] / den[r] on v_mfma_f64_16x16x4_f64 */
+int wagg_dense_apply_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx,
+                         double *out_dev, int64_t ldo, int ksplit, void *stream);
 /* the same contraction of (X + offset)^power (tas_poly, transformations.py:188) and of
  * snyder_edd(tasmin + offset, tasmax + offset, threshold) (transformations.py:64-87): the transform is
  * evaluated while X is packed, the transformed grid is never written anywhere                    */
@@ -240,6 +253,11 @@ int wagg_dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int6
                               int power, float *out_dev, int64_t ldo, int ksplit, void *stream);
 int wagg_dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
                              int64_t ldx, double offset, double threshold, float *out_dev, int64_t ldo,
+                             int ksplit, void *stream);
+int wagg_dense_apply_poly_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx, double offset,
+                              int power, double *out_dev, int64_t ldo, int ksplit, void *stream);
+int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+                             int64_t ldx, double offset, double threshold, double *out_dev, int64_t ldo,
                              int ksplit, void *stream);
 /* The MFMA forms multiply every (cell, region) pair of a stored tile, so +-inf in the (transformed)
  * data turns the zero weights of regions that do not own the cell into NaN, where the reference and

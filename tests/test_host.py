@@ -137,7 +137,8 @@ def test_dense_form_choice():
     G, R, GB = 1036800, 24378, 1 << 30
     assert not A._prefer_dense(1.4 * G, G, R, True, "TG", 250 * GB)        # c2-real: compact regions
     assert A._prefer_dense(240 * G, G, R, True, "TG", 250 * GB)            # c5 uniform-random columns
-    assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB)       # fp64 stays on the gather form
+    assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB)       # fp64: 202 GB of W would not fit
+    assert A._prefer_dense(240 * G, G, 4000, False, "TG", 250 * GB)        # ... a smaller fp64 problem takes the f64 MFMA form
     assert not A._prefer_dense(240 * G, G, R, True, "GT", 250 * GB)        # fixture layout stays too
     assert not A._prefer_dense(240 * G, G, R, True, "TG", 100 * GB)        # 101 GB of W must fit
 
