@@ -16,7 +16,8 @@ Workloads (--workload):
   c2-real     configs[1], segment-table form (HBM-bound)     c3-real  configs[2], fp64 + popwt
   c4          configs[3]: 10,950 daily steps, dense form, time axis cut over the ranks ("strong")
   c5-uniform  configs[4]: 50 x 365 rows, ~1 % non-zeros at uniformly random positions (entry-list form)
-  c5-block    configs[4]: the block-local structure (tile-sparse MFMA form)
+  c5-block    configs[4]: the block-local structure (tile-sparse MFMA form); c5-block-f64: the same in fp64
+              (v_mfma_f64_16x16x4_f64)
 For c4/c5 the rows of a run are shard_bounds(T_total, --shards)[rank]; --shards defaults to the
 world size for c4 and to 8 for c5 (one rank's share of the 8-GPU job on a single GPU).
 
@@ -39,7 +40,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
 PEAK_F64_MFMA_TFLOPS = 78.6     # half the fp32 rate
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-WORKLOADS = ["c1", "c2-dense", "c2-real", "c3-real", "c4", "c5-block", "c5-uniform"]
+WORKLOADS = ["c1", "c2-dense", "c2-real", "c3-real", "c4", "c5-block", "c5-uniform", "c5-block-f64"]
 
 
 def parse():
@@ -189,7 +190,7 @@ def main():
     G, R = a.nlat * a.nlon, a.R
     scaling = "weak"
     # rows of this rank
-    if a.workload in ("c4", "c5-block", "c5-uniform"):
+    if a.workload in ("c4", "c5-block", "c5-uniform", "c5-block-f64"):
         T_total = 10950 if a.workload == "c4" else 50 * 365
         shards = a.shards or (world if a.workload == "c4" or world > 1 else 8)
         bounds = shard_bounds(T_total, max(shards, world))
@@ -268,14 +269,15 @@ def main():
 
     def run_dense_family(wl):
         """c2-dense / c4 (full matrix), c5-uniform (entry lists), c5-block (tile-sparse)."""
-        X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float32")
+        f64 = wl.endswith("-f64")
+        X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float64" if f64 else "float32")
         if wl == "c5-uniform":
             plan, fill, bl = engine.DensePlan.synth(G, R, seed=2, fill=0.01), 0.01, False
-        elif wl == "c5-block":
-            plan, fill, bl = engine.DensePlan.synth_blocklocal(G, R, seed=2), 0.952, True
+        elif wl.startswith("c5-block"):
+            plan, fill, bl = engine.DensePlan.synth_blocklocal(G, R, seed=2, dtype="float64" if f64 else "float32"), 0.952, True
         else:
             plan, fill, bl = engine.DensePlan.synth(G, R, seed=2), 1.0, False
-        st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), R, torch.float32)
+        st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), R, X.dtype)
         engine.profile_enable(True)       # event records only (no sync)
         dt = timed_steps(torch, dist, st.step, st.finish, a.steps, a.warmup, world)
         kavg = kernel_avg_ms(engine.profile_read()) * 1e-3
@@ -283,18 +285,21 @@ def main():
         form = int(plan.info["form"])
         if wl == "c5-uniform":
             nnz = int(plan.info["nnz"])
-        elif wl == "c5-block":
-            nnz = int(round(plan.info["n_tiles"] * 32 * 256 * fill))
+        elif wl.startswith("c5-block"):
+            nnz = int(round(plan.info["n_tiles"] * (16 if f64 else 32) * 256 * fill))
         else:
             nnz = G * R
         flops = 2.0 * T * nnz                                   # algorithmic: 2 T nnz (dense: nnz = G R)
         traffic, tsrc = load_traffic(wl)
         kname = {0: "dense_mfma_kernel", 1: "dense_mfma_kernel<tiled>", 2: "spmm_kernel (vector ALU, entry lists)"}[form]
-        res = {"workload": wl, "dtype": "f32", "T": T, "G": G, "R": R, "nnz": nnz,
+        if f64:
+            kname = kname.replace("dense_mfma_kernel", "dense_mfma_kernel<double>")
+        peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
+        res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "G": G, "R": R, "nnz": nnz,
                "value": T_job * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
                "ms_per_step": dt / a.steps * 1e3, "plan": {k: int(v) for k, v in plan.info.items()},
-               "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / PEAK_F32_MFMA_TFLOPS,
+               "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": peak,
+                            "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / peak,
                             "traffic": traffic, "traffic_source": tsrc, "kernel": kname,
                             "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops}}
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -303,7 +308,7 @@ def main():
         return res
 
     secondary = []
-    if a.workload in ("c2-dense", "c4", "c5-block", "c5-uniform"):
+    if a.workload in ("c2-dense", "c4", "c5-block", "c5-uniform", "c5-block-f64"):
         main_res = run_dense_family(a.workload)
         if a.workload == "c2-dense" and world == 1 and not a.no_secondary:
             torch.cuda.empty_cache()
@@ -321,7 +326,8 @@ def main():
                 "c4": "30-year daily series, dense W, f32", "c2-real": "area-weighted segment table, f32",
                 "c3-real": "pop-weighted segment table with backup fill, f64",
                 "c5-uniform": "ensemble x time rows, ~1 % of G x R non-zero at uniformly random positions, f32",
-                "c5-block": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f32"}[wl]
+                "c5-block": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f32",
+                "c5-block-f64": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f64"}[wl]
         line = {
             "metric": "gridcell-region-timesteps/sec", "value": main_res["value"],
             "unit": "gridcell-region-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -30,17 +30,18 @@ constexpr int SP_WAVES = 16;                 // waves per workgroup (1024 thread
 constexpr int SP_THREADS = SP_WAVES * 64;
 constexpr int SP_TB = 64;                    // timesteps per block = lanes of a wave
 constexpr int SP_KC = 256;                   // grid cells per LDS chunk (256 rows x 256 B = 64 KiB)
-constexpr int SP_ACC = 96;                   // accumulator registers per lane (v[32:127])
-constexpr int SP_RW_MAX = SP_ACC - 1;        // regions per wave; accumulator 95 swallows the padding entries
+constexpr int SP_ACC = 88;                   // accumulator registers per lane (v[40:127])
+constexpr int SP_RW_MAX = SP_ACC - 1;        // regions per wave; the last accumulator swallows the padding entries
 constexpr int SP_TRASH = SP_ACC - 1;
-constexpr int SP_GROUP = 8;                  // entries per 64-byte group (one s_load_dwordx16)
+constexpr int SP_GROUP = 8;                  // entries per 64-byte group, stored as [8 x lo][8 x weight]
+constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list (a wave loads 5 x 64 entries from its list start)
 
 struct SpmmPlan {
     int rw = 0;                              // regions per wave (<= SP_RW_MAX), region r = (rb * 16 + wave) * rw + j
     int n_rb = 0;                            // region blocks of 16 * rw regions
     int n_chunks = 0;                        // ceil(G / SP_KC)
     int64_t nnz = 0, n_groups = 0;           // kept (cell, region) pairs; 8-entry groups incl. padding
-    DevBuf<uint2> ent;                       // [n_groups * 8 + 8]: .x = (cell_in_chunk << 8) | acc index, .y = weight bits
+    DevBuf<uint2> ent;                       // [(n_groups + pad) * 8] entries: lo = (cell_in_chunk << 8) | acc index, weight bits
     DevBuf<int32_t> grp_off;                 // [n_rb * n_chunks * 16 + 1]: first group of (rb, chunk, wave)
 };
 

@@ -7,21 +7,24 @@
 // beat ~10 TF here.  This kernel does exactly 2*T*nnz flops on the vector ALU instead:
 //
 //   * lanes = timesteps.  A workgroup (16 waves, one per CU) owns 64 timesteps x (16 * rw) regions;
-//     every wave keeps rw <= 95 regions x 64 timesteps as ACCUMULATOR REGISTERS v[32:126] for the
+//     every wave keeps rw <= 87 regions x 64 timesteps as ACCUMULATOR REGISTERS v[40:126] for the
 //     whole k loop (98k accumulators per CU: each byte of X that reaches the CU is used ~15 times).
 //   * X is packed once per apply as Xp[time block][cell][64 timesteps] (transform, NaN -> 0 and
 //     zero padding fused, like the MFMA forms' pack); a chunk of 256 cells is one contiguous 64 KiB
 //     run that goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one
 //     workgroup barrier per chunk.
 //   * W is never a matrix: per (region block, chunk, wave) a list of 8-byte entries
-//     (cell_in_chunk << 8 | accumulator, weight), padded to 8-entry groups.  The list is wave-uniform,
-//     so it is read through the SCALAR cache (s_load_dwordx16 = one group) and costs no vector
-//     instruction; one entry = v_bfi (LDS address) + ds_read_b32 (64 timesteps of the cell,
+//     (cell_in_chunk << 8 | accumulator, weight), padded to 8-entry groups stored as [8 x lo][8 x weight].
+//     A wave loads its whole list for the chunk with coalesced vector loads up front (lane j <- entry
+//     j; the scalar cache was tried first and is latency/throughput-bound at ~870 cycles per 64-byte
+//     line: 104 ms per c5 rank shard) and broadcasts entry after entry into SGPRs with v_readlane;
+//     one entry = 2 v_readlane + v_bfi (LDS address) + ds_read_b32 (64 timesteps of the cell,
 //     conflict-free) + ONE v_fma_f32 whose accumulator register is picked by the entry itself
-//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[32 + M0[7:0]]).
+//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[32 + M0[7:0]]).  The loop is
+//     generated (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc).
 //   * bound: one ds_read_b32 per entry = 2 LDS cycles per 64 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
-//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops; the VALU does 2 instructions
-//     per entry and is half idle.
+//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops, and 4 vector instructions per
+//     entry put the VALU at about the same limit.
 //   * k is split into S slices so that every CU gets the same number of items; partial sums go to
 //     slabT[slice][region][time] (256-byte coalesced stores straight from the accumulators) and one
 //     reduce kernel adds the slices, divides by den[r] (aggregations.py:77-80) and transposes to
@@ -36,37 +39,17 @@
 namespace wagg {
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int SP_BUF_BYTES = SP_KC * SP_TB * 4;           // 65,536: one X chunk in LDS
 constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB nobody reads: destination of the list warm-up loads
 constexpr int SP_LDS_BYTES = SP_SINK + 1024;
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
 
-// one entry: LDS address = (lo & 0xff00) | lanebuf, accumulator = lo & 0xff, weight = hi
-#define SP_BFI(T, LO) "v_bfi_b32 %[" T "], %[vmask], " LO ", %[lb]\n\t"
-#define SP_RD(T) "ds_read_b32 %[" T "], %[" T "]\n\t"
-#define SP_FMA(T, LO, HI, CNT)                                                                   \
-    "s_set_gpr_idx_idx " LO "\n\ts_waitcnt lgkmcnt(" CNT ")\n\tv_fma_f32 v32, %[" T "], " HI ", v32\n\t"
-// One group of 8 entries held in s[A..A+15]; the next group is fetched into s[B..B+15] meanwhile.
-// lgkmcnt: the SMEM may still be in flight beside the 8 LDS reads, so "read k has landed" is
-// lgkmcnt(7 - k) (LDS returns in order; an outstanding SMEM only makes the wait conservative).
-#define SP_GROUP_ASM(A0, A1, A2, A3, A4, A5, A6, A7, A8, A9, A10, A11, A12, A13, A14, A15, BRANGE)  \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                    \
-    "s_add_u32 %[off], %[off], 64\n\t"                                                            \
-    "s_load_dwordx16 " BRANGE ", %[ptr], %[off]\n\t"                                              \
-    SP_BFI("t0", A0) SP_BFI("t1", A2) SP_BFI("t2", A4) SP_BFI("t3", A6)                           \
-    SP_BFI("t4", A8) SP_BFI("t5", A10) SP_BFI("t6", A12) SP_BFI("t7", A14)                        \
-    SP_RD("t0") SP_RD("t1") SP_RD("t2") SP_RD("t3") SP_RD("t4") SP_RD("t5") SP_RD("t6") SP_RD("t7") \
-    "s_set_gpr_idx_on " A0 ", 0xc\n\ts_waitcnt lgkmcnt(7)\n\tv_fma_f32 v32, %[t0], " A1 ", v32\n\t" \
-    SP_FMA("t1", A2, A3, "6") SP_FMA("t2", A4, A5, "5") SP_FMA("t3", A6, A7, "4")                 \
-    SP_FMA("t4", A8, A9, "3") SP_FMA("t5", A10, A11, "2") SP_FMA("t6", A12, A13, "1")             \
-    SP_FMA("t7", A14, A15, "0")                                                                   \
-    "s_set_gpr_idx_off\n\t"                                                                       \
-    "s_sub_u32 %[n], %[n], 1\n\t"                                                                 \
-    "s_cmp_eq_u32 %[n], 0\n\t"                                                                    \
-    "s_cbranch_scc1 9f\n\t"
+#include "wagg_spmm_asm.inc"
 
 __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
-    const float *__restrict__ Xp, const uint2 *__restrict__ ent, const int32_t *__restrict__ grp_off,
+    const float *__restrict__ Xp, const uint32_t *__restrict__ ent, const int32_t *__restrict__ grp_off,
     float *__restrict__ slabT, int n_tb, int n_rb, int n_chunks, int cps, int rw, int64_t Gpad,
     int64_t Tpad, int64_t Rpad, int n_items, int n_groups) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink; filled by LDS-DMA only
@@ -79,7 +62,6 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
     const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned q8 = nblk >> 3, r8 = nblk & 7u;
     const int lid = (int)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
-    const int vmask = 0xff00;
     const int voff16 = lane * 16;                    // LDS-DMA: 16 bytes per lane
 
     for (int item = lid; item < n_items; item += (int)nblk) {
@@ -88,15 +70,17 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         const int ks = item / (n_rb * n_tb);
         const int c0 = ks * cps;
         const int c1 = c0 + cps < n_chunks ? c0 + cps : n_chunks;
-        f32x32 a0, a1, a2;
+        f32x8 b0;                                    // accumulators 0-7   v[40:47]
+        f32x16 b1;                                   //              8-23  v[48:63]
+        f32x32 a1, a2;                               //              24-55 v[64:95], 56-87 v[96:127]
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
+        for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; if (j < 8) b0[j] = 0.f; if (j < 16) b1[j] = 0.f; }
         // cell g of this time block starts at xbase + g * 256 bytes; this wave moves bytes
         // [wave * 4096, wave * 4096 + 4096) of every 64 KiB chunk
         const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * (SP_TB * 4) + wave * 4096;
         const int32_t *goff = grp_off + ((int64_t)rb * n_chunks) * SP_WAVES + wave;
 
-        auto dma_chunk = [&](int c, int buf) {       // 4 x 1 KiB pieces of chunk c -> LDS buffer buf
+        auto dma_chunk = [&](int c, int buf) {       // 4 x 1 KiB pieces of chunk c -> LDS buffer buf (item prologue)
             const char *src = xbase + (int64_t)c * SP_BUF_BYTES;
             const int l0 = lds0 + buf * SP_BUF_BYTES + wave * 4096;
             int m0save, v1;
@@ -122,60 +106,31 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
                 : [l0] "s"(l0), [vo] "v"(voff16), [src] "s"(src)
                 : "memory", "scc");
         };
-        auto warm_list = [&](int c) {                // pull the entry list of chunk c into L2 (no register written)
-            const int g0 = goff[(int64_t)c * SP_WAVES];
-            const char *src = reinterpret_cast<const char *>(ent) + (int64_t)g0 * 64;
-            const int lim = n_groups - g0;           // groups up to the end of the array (one padding group follows)
-            const int voff64 = (lane < lim ? lane : lim) * 64;   // one 64-byte line per lane, never past the allocation
-            const int sink = lds0 + SP_SINK;
-            int m0save;
-            asm volatile(
-                "s_mov_b32 %[sv], m0\n\t"
-                "s_mov_b32 m0, %[sink]\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dword %[vo], %[src]\n\t"
-                "s_mov_b32 m0, %[sv]\n\t"
-                : [sv] "=&s"(m0save)
-                : [sink] "s"(sink), [vo] "v"(voff64), [src] "s"(src)
-                : "memory");
-        };
 
         if (c0 < c1) {
             dma_chunk(c0, 0);
-            warm_list(c0);
-            if (c0 + 1 < c1) warm_list(c0 + 1);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         for (int c = c0; c < c1; ++c) {
             const int buf = (c - c0) & 1;
-            if (c + 1 < c1) dma_chunk(c + 1, buf ^ 1);
-            if (c + 2 < c1) warm_list(c + 2);
+            // everything of this chunk in ONE statement (the entry loads' destination registers must not be
+            // touched by compiler-generated code while the loads are in flight): entry loads of chunk c,
+            // LDS-DMA of chunk c + 1 (the last chunk re-loads itself: harmless), list warm-up for chunk c + 2,
+            // then the entries
+            const int cn = c + 1 < c1 ? c + 1 : c, cw = c + 2 < c1 ? c + 2 : c1 - 1;
             const int g0 = goff[(int64_t)c * SP_WAVES], g1 = goff[(int64_t)c * SP_WAVES + 1];
+            const int gw = goff[(int64_t)cw * SP_WAVES];
             int n = g1 - g0;
-            if (n > 0) {
-                const uint2 *ptr = ent + (int64_t)g0 * SP_GROUP;
-                const int lb = lds0 + lane * 4 + buf * SP_BUF_BYTES;
-                int off = 0, m0save, t0, t1, t2, t3, t4, t5, t6, t7;
-                asm volatile(
-                    "s_mov_b32 %[sv], m0\n\t"
-                    "s_load_dwordx16 s[36:51], %[ptr], 0x0\n\t"
-                    "1:\n\t"
-                    SP_GROUP_ASM("s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
-                                 "s48", "s49", "s50", "s51", "s[52:67]")
-                    SP_GROUP_ASM("s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
-                                 "s64", "s65", "s66", "s67", "s[36:51]")
-                    "s_branch 1b\n\t"
-                    "9:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"                 // the look-ahead load must not land later
-                    "s_mov_b32 m0, %[sv]\n\t"
-                    : [n] "+s"(n), [off] "+s"(off), [sv] "=&s"(m0save), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
-                      [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7),
-                      "+{v[32:63]}"(a0), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2)
-                    : [ptr] "s"(ptr), [vmask] "v"(vmask), [lb] "v"(lb)
-                    : "memory", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
-                      "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
-                      "s62", "s63", "s64", "s65", "s66", "s67");
-            }
+            const uint64_t ptr = reinterpret_cast<uint64_t>(ent + (int64_t)g0 * (2 * SP_GROUP));
+            const char *src = xbase + (int64_t)cn * SP_BUF_BYTES;
+            const char *wsrc = reinterpret_cast<const char *>(ent) + (int64_t)gw * 64;
+            const int l0 = lds0 + (buf ^ 1) * SP_BUF_BYTES + wave * 4096;
+            const int bufbit = lds0 + buf * SP_BUF_BYTES, sink = lds0 + SP_SINK, wlim = n_groups - gw;
+            asm volatile(SPMM_CHUNK_ASM
+                         : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2)
+                         : [plo] "s"((uint32_t)ptr), [phi] "s"((uint32_t)(ptr >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0),
+                           [src] "s"(src), [wsrc] "s"(wsrc), [wlim] "s"(wlim), [sink] "s"(sink)
+                         : "memory", "scc", SPMM_CHUNK_CLOBBERS);
             // this wave's pieces of chunk c + 1 have landed and it is done reading chunk c
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -183,7 +138,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         float *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * SP_TB + lane;
 #pragma unroll
         for (int j = 0; j < SP_RW_MAX; ++j) {
-            if (j < rw) *dst = j < 32 ? a0[j & 31] : (j < 64 ? a1[j & 31] : a2[j & 31]);
+            if (j < rw) *dst = j < 8 ? b0[j & 7] : (j < 24 ? b1[(j - 8) & 15] : (j < 56 ? a1[(j - 24) & 31] : a2[(j - 56) & 31]));
             dst += Tpad;
             asm volatile("" : "+v"(dst));            // one running pointer, not 95 hoisted offsets
         }
@@ -249,7 +204,7 @@ __global__ __launch_bounds__(256) void spmm_reduce_kernel(const float *__restric
 template <bool FILL>
 __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32_t R, uint32_t seed, float fill, int rw,
                                                                 int n_chunks, int32_t *__restrict__ counts,
-                                                                const int32_t *__restrict__ grp_off, uint2 *__restrict__ ent) {
+                                                                const int32_t *__restrict__ grp_off, uint32_t *__restrict__ ent) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x % n_chunks, rb = blockIdx.x / n_chunks;
     const int64_t bucket = ((int64_t)rb * n_chunks + c) * SP_WAVES + wave;
@@ -269,14 +224,21 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32
         }
         const unsigned long long m = __ballot(keep);
         if (FILL && keep) {
-            const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
-            ent[base + pos] = make_uint2((unsigned)(gl << 8 | j), __float_as_uint(hash_u01(id, seed)));
+            const int64_t pos = base + kept + __popcll(m & ((1ull << lane) - 1ull));
+            uint32_t *grp = ent + (pos >> 3) * 16 + (pos & 7);       // group = [8 x lo][8 x weight]
+            grp[0] = (unsigned)(gl << 8 | j);
+            grp[8] = __float_as_uint(hash_u01(id, seed));
         }
         kept += __popcll(m);
     }
     if (FILL) {                                   // pad the last group: w = 0 into the trash accumulator
         const int padded = (kept + SP_GROUP - 1) / SP_GROUP * SP_GROUP;
-        if (kept + lane < padded) ent[base + kept + lane] = make_uint2((unsigned)SP_TRASH, 0u);
+        if (kept + lane < padded) {
+            const int64_t pos = base + kept + lane;
+            uint32_t *grp = ent + (pos >> 3) * 16 + (pos & 7);
+            grp[0] = (unsigned)SP_TRASH;
+            grp[8] = 0u;
+        }
     } else if (lane == 0) {
         counts[bucket] = kept;
     }
@@ -325,9 +287,9 @@ static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
     sp.n_groups = groups;
     sp.nnz = nnz;
     WAGG_HIP(sp.grp_off.upload(off));
-    // one extra group at the end: the kernel's look-ahead load reads 64 bytes past the last list
-    WAGG_HIP(sp.ent.alloc((size_t)(groups + 1) * SP_GROUP));
-    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * SP_GROUP, 0, sizeof(uint2) * SP_GROUP));
+    // six 64-entry blocks of padding at the end: a wave always loads five blocks from its list start
+    WAGG_HIP(sp.ent.alloc((size_t)(groups + SP_PAD_GROUPS) * SP_GROUP));
+    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * SP_GROUP, 0, sizeof(uint2) * SP_GROUP * SP_PAD_GROUPS));
     return WAGG_OK;
 }
 
@@ -340,13 +302,13 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
     WAGG_HIP(dcounts.alloc((size_t)n_buckets));
     const dim3 grid((unsigned)((int64_t)sp.n_rb * sp.n_chunks));
     hipLaunchKernelGGL((spmm_synth_kernel<false>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
-                       sp.n_chunks, dcounts.p, (const int32_t *)nullptr, (uint2 *)nullptr);
+                       sp.n_chunks, dcounts.p, (const int32_t *)nullptr, (uint32_t *)nullptr);
     WAGG_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)n_buckets);
     WAGG_HIP(hipMemcpy(counts.data(), dcounts.p, sizeof(int32_t) * counts.size(), hipMemcpyDeviceToHost));
     if (int rc = spmm_offsets(d, counts)) return rc;
     hipLaunchKernelGGL((spmm_synth_kernel<true>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
-                       sp.n_chunks, (int32_t *)nullptr, (const int32_t *)sp.grp_off.p, sp.ent.p);
+                       sp.n_chunks, (int32_t *)nullptr, (const int32_t *)sp.grp_off.p, (uint32_t *)sp.ent.p);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(spmm_synth_den_kernel, dim3((unsigned)((d->R + 3) / 4)), dim3(256), 0, nullptr, d->G, d->R, seed,
                        (float)fill, d->den64.p);
@@ -378,7 +340,9 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
             int64_t g = 0;
             for (int64_t b = 0; b < n_buckets; ++b) { off[(size_t)b] = (int32_t)g; g += (counts[(size_t)b] + SP_GROUP - 1) / SP_GROUP; }
         }
-        std::vector<uint2> ent((size_t)sp.n_groups * SP_GROUP, make_uint2((unsigned)SP_TRASH, 0u));
+        std::vector<uint32_t> ent((size_t)sp.n_groups * 2 * SP_GROUP, 0u);     // group = [8 x lo][8 x weight]
+        for (int64_t g = 0; g < sp.n_groups; ++g)
+            for (int k = 0; k < SP_GROUP; ++k) ent[(size_t)g * 16 + k] = (unsigned)SP_TRASH;
         std::vector<int32_t> cur((size_t)n_buckets, 0);
         // visit the triples cell-major so that a list is ordered like the synthetic builder's
         std::vector<size_t> order(cell.size());
@@ -389,9 +353,11 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
             const unsigned lo = (unsigned)((cell[i] % SP_KC) << 8 | (region[i] % wave_regions));
             unsigned wb;
             std::memcpy(&wb, &w[i], 4);
-            ent[(size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++] = make_uint2(lo, wb);
+            const size_t pos = (size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++;
+            ent[(pos >> 3) * 16 + (pos & 7)] = lo;
+            ent[(pos >> 3) * 16 + 8 + (pos & 7)] = wb;
         }
-        if (!ent.empty()) WAGG_HIP(hipMemcpy(sp.ent.p, ent.data(), sizeof(uint2) * ent.size(), hipMemcpyHostToDevice));
+        if (!ent.empty()) WAGG_HIP(hipMemcpy(sp.ent.p, ent.data(), sizeof(uint32_t) * ent.size(), hipMemcpyHostToDevice));
     } catch (const std::bad_alloc &) {
         set_error("host allocation failed while building the entry lists");
         return WAGG_ENOMEM;
@@ -431,7 +397,7 @@ int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const Pack
     const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
     profile_mark(st, true);
     hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const float *)d->xp.p,
-                       (const uint2 *)sp.ent.p, (const int32_t *)sp.grp_off.p, d->slabs.p, n_tb, sp.n_rb, sp.n_chunks, cps,
+                       (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, d->slabs.p, n_tb, sp.n_rb, sp.n_chunks, cps,
                        sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups);
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
