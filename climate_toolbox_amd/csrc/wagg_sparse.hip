@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 #include <utility>
 
@@ -82,7 +83,33 @@ struct wagg_plan {
     // set by a kernel whose consumer-wave barrier timed out (host-mapped, so the host can read it
     // without touching the stream); checked by the next apply, wagg_plan_status and the *_host_ forms
     int *timeout_host = nullptr, *timeout_dev = nullptr;
-    ~wagg_plan() { if (timeout_host) (void)hipHostFree(timeout_host); }
+    // Region-major staging buffers of the (time, region) output form, one per stream that has applied
+    // this plan (kept until the plan is destroyed).  A stream-ordered hipMallocAsync / hipFreeAsync pair
+    // per apply made every call block for the whole kernel (0.28 ms enqueue against 0.01 ms without).
+    struct Staging { hipStream_t stream; void *p; size_t bytes; };
+    mutable std::mutex ws_mu;
+    mutable std::vector<Staging> ws;
+    void *staging(hipStream_t st, size_t bytes) const {
+        std::lock_guard<std::mutex> lock(ws_mu);
+        for (Staging &w : ws)
+            if (w.stream == st) {
+                if (w.bytes >= bytes) return w.p;
+                (void)hipStreamSynchronize(st);              // the old buffer may still be in use on this stream
+                (void)hipFree(w.p);
+                w.p = nullptr; w.bytes = 0;
+                if (hipMalloc(&w.p, bytes) != hipSuccess) return nullptr;
+                w.bytes = bytes;
+                return w.p;
+            }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        ws.push_back({st, p, bytes});
+        return p;
+    }
+    ~wagg_plan() {
+        if (timeout_host) (void)hipHostFree(timeout_host);
+        for (Staging &w : ws) if (w.p) (void)hipFree(w.p);
+    }
 };
 
 namespace wagg {
@@ -1007,19 +1034,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void transpose_rt_to_tr_kernel(const T *__restrict__ in, int64_t ldi,
                                                                 int64_t R, int64_t Ttot,
                                                                 T *__restrict__ out, int64_t ldo) {
+    // the staging buffer has 16-byte aligned rows of ldi = 64 k elements (zero-padded reads are harmless:
+    // only t < Ttot is stored), so the region-major side is read with 16-byte loads
+    constexpr int V = 16 / sizeof(T);                            // elements per load: 4 floats / 2 doubles
+    typedef T vecv __attribute__((ext_vector_type(V)));
     __shared__ T tile[64][65];
     const int64_t r0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    constexpr int TQ = 64 / V;                                   // vector columns per tile row
+    const int tq = threadIdx.x % TQ, ry = threadIdx.x / TQ;
+#pragma unroll
+    for (int i = ry; i < 64; i += 256 / TQ) {
+        const int64_t r = r0 + i;
+        if (r < R) {
+            const vecv v = *reinterpret_cast<const vecv *>(in + r * ldi + t0 + V * tq);
+#pragma unroll
+            for (int c = 0; c < V; ++c) tile[V * tq + c][i] = v[c];
+        }
+    }
+    __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 64; i += 4) {
-        const int64_t r = r0 + ty + i, t = t0 + tx;
-        if (r < R && t < Ttot) tile[ty + i][tx] = in[r * ldi + t];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {
         const int64_t t = t0 + ty + i, r = r0 + tx;
-        if (r < R && t < Ttot) out[t * ldo + r] = tile[tx][ty + i];
+        if (r < R && t < Ttot) out[t * ldo + r] = tile[ty + i][tx];
     }
 }
 
@@ -1101,12 +1138,6 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const int64_t n_tb = (Ttot + TB - 1) / TB;
     // (T x R) results: gather kernel writes region-major into a stream-ordered workspace, then
     // one transpose; (R x T) results go straight to the caller's buffer
-    struct AsyncBuf {       // stream-ordered workspace, returned to the pool on every exit path
-        void *p = nullptr;
-        hipStream_t s = nullptr;
-        ~AsyncBuf() { if (p) (void)hipFreeAsync(p, s); }
-    } wsbuf;
-    wsbuf.s = stream;
     T *ws = nullptr;
     int64_t ldws = 0;
     T *kout = out;
@@ -1115,8 +1146,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     int64_t kpstride = pstride;
     if (via_ws) {
         ldws = (Ttot + 63) / 64 * 64;
-        WAGG_HIP(hipMallocAsync(&wsbuf.p, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nplanes, stream));
-        ws = static_cast<T *>(wsbuf.p);
+        ws = static_cast<T *>(plan->staging(stream, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nplanes));
+        if (!ws) { set_error("staging buffer of %.1f MB: allocation failed", (double)(sizeof(T) * ldws * plan->info.R * nplanes) * 1e-6); return WAGG_ENOMEM; }
         kout = ws;
         kldo = ldws;
         kpstride = ldws * (int64_t)plan->info.R;
