@@ -28,20 +28,24 @@ __device__ __forceinline__ T pack_xf(const PackXfT<T> &xf, T x, T x2, bool &inf_
 // ---- entry-list ("SpMM") form: geometry shared by the builders and the kernel -------------------
 constexpr int SP_WAVES = 16;                 // waves per workgroup (1024 threads, one workgroup per CU)
 constexpr int SP_THREADS = SP_WAVES * 64;
-constexpr int SP_TB = 64;                    // timesteps per block = lanes of a wave
-constexpr int SP_KC = 256;                   // grid cells per LDS chunk (256 rows x 256 B = 64 KiB)
-constexpr int SP_ACC = 88;                   // accumulator registers per lane (v[40:127])
-constexpr int SP_RW_MAX = SP_ACC - 1;        // regions per wave; the last accumulator swallows the padding entries
-constexpr int SP_TRASH = SP_ACC - 1;
+constexpr int SP_NT = 2;                     // timesteps per lane
+constexpr int SP_TB = 64 * SP_NT;            // timesteps per block (one wave covers them all)
+constexpr int SP_ROW = SP_TB * 4;            // bytes of one cell's row in LDS (512)
+constexpr int SP_KC = 128;                   // grid cells per LDS chunk (128 rows x 512 B = 64 KiB)
+constexpr int SP_ACC = 88;                   // accumulator registers per lane (v[40:127]) = 44 pairs
+constexpr int SP_RW_MAX = SP_ACC / SP_NT - 1;   // regions per wave (43); the last pair swallows the padding entries
+constexpr int SP_TRASH = SP_NT * SP_RW_MAX;  // accumulator index (register offset) of the trash pair
 constexpr int SP_GROUP = 8;                  // entries per 64-byte group, stored as [8 x lo][8 x weight]
-constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list (a wave loads 5 x 64 entries from its list start)
+constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list (a wave loads 2 x 64 entries from its list start)
+// entry.lo = (cell_in_chunk << 9) | accumulator register offset (2 j for the wave's region j)
+__host__ __device__ inline unsigned sp_entry_lo(int cell_in_chunk, int j) { return (unsigned)(cell_in_chunk << 9 | SP_NT * j); }
 
 struct SpmmPlan {
     int rw = 0;                              // regions per wave (<= SP_RW_MAX), region r = (rb * 16 + wave) * rw + j
     int n_rb = 0;                            // region blocks of 16 * rw regions
     int n_chunks = 0;                        // ceil(G / SP_KC)
     int64_t nnz = 0, n_groups = 0;           // kept (cell, region) pairs; 8-entry groups incl. padding
-    DevBuf<uint2> ent;                       // [(n_groups + pad) * 8] entries: lo = (cell_in_chunk << 8) | acc index, weight bits
+    DevBuf<uint2> ent;                       // [(n_groups + pad) * 8] entries (sp_entry_lo, weight bits), group-interleaved
     DevBuf<int32_t> grp_off;                 // [n_rb * n_chunks * 16 + 1]: first group of (rb, chunk, wave)
 };
 

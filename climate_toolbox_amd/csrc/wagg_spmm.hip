@@ -6,11 +6,12 @@
 // compacted per 16-region block a 16x16x4 MFMA tile is only ~6.7 % full, so the matrix pipe cannot
 // beat ~10 TF here.  This kernel does exactly 2*T*nnz flops on the vector ALU instead:
 //
-//   * lanes = timesteps.  A workgroup (16 waves, one per CU) owns 64 timesteps x (16 * rw) regions;
-//     every wave keeps rw <= 87 regions x 64 timesteps as ACCUMULATOR REGISTERS v[40:126] for the
-//     whole k loop (98k accumulators per CU: each byte of X that reaches the CU is used ~15 times).
-//   * X is packed once per apply as Xp[time block][cell][64 timesteps] (transform, NaN -> 0 and
-//     zero padding fused, like the MFMA forms' pack); a chunk of 256 cells is one contiguous 64 KiB
+//   * lanes = timesteps, two per lane.  A workgroup (16 waves, one per CU) owns 128 timesteps x (16 * rw)
+//     regions; every wave keeps rw <= 43 regions x 128 timesteps as ACCUMULATOR REGISTER PAIRS
+//     v[40:125] for the whole k loop (90k accumulators per CU: each byte of X that reaches the CU is
+//     used ~7 times).
+//   * X is packed once per apply as Xp[time block][cell][128 timesteps] (transform, NaN -> 0 and
+//     zero padding fused, like the MFMA forms' pack); a chunk of 128 cells is one contiguous 64 KiB
 //     run that goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one
 //     workgroup barrier per chunk.
 //   * W is never a matrix: per (region block, chunk, wave) a list of 8-byte entries
@@ -18,13 +19,15 @@
 //     A wave loads its whole list for the chunk with coalesced vector loads up front (lane j <- entry
 //     j; the scalar cache was tried first and is latency/throughput-bound at ~870 cycles per 64-byte
 //     line: 104 ms per c5 rank shard) and broadcasts entry after entry into SGPRs with v_readlane;
-//     one entry = 2 v_readlane + v_bfi (LDS address) + ds_read_b32 (64 timesteps of the cell,
-//     conflict-free) + ONE v_fma_f32 whose accumulator register is picked by the entry itself
-//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[32 + M0[7:0]]).  The loop is
-//     generated (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc).
-//   * bound: one ds_read_b32 per entry = 2 LDS cycles per 64 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
-//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops, and 4 vector instructions per
-//     entry put the VALU at about the same limit.
+//     one entry = 2 v_readlane + v_bfi (LDS address) + ds_read_b64 (2 x 64 timesteps of the cell,
+//     conflict-free) + ONE v_pk_fma_f32 whose accumulator pair is picked by the entry itself
+//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[40 + M0[7:0] ...]).  The loop is
+//     generated (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc); the next chunk's list is loaded into
+//     a second register set while this chunk's entries are processed.
+//   * bound: a wave64 vector instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU),
+//     so 4 vector instructions per entry = 16 cycles per 128 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
+//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops; the LDS (one ds_read_b64 per
+//     entry) is at half of its rate there.
 //   * k is split into S slices so that every CU gets the same number of items; partial sums go to
 //     slabT[slice][region][time] (256-byte coalesced stores straight from the accumulators) and one
 //     reduce kernel adds the slices, divides by den[r] (aggregations.py:77-80) and transposes to
@@ -41,7 +44,7 @@ namespace wagg {
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-constexpr int SP_BUF_BYTES = SP_KC * SP_TB * 4;           // 65,536: one X chunk in LDS
+constexpr int SP_BUF_BYTES = SP_KC * SP_ROW;              // 65,536: one X chunk in LDS
 constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB nobody reads: destination of the list warm-up loads
 constexpr int SP_LDS_BYTES = SP_SINK + 1024;
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
@@ -70,87 +73,112 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         const int ks = item / (n_rb * n_tb);
         const int c0 = ks * cps;
         const int c1 = c0 + cps < n_chunks ? c0 + cps : n_chunks;
-        f32x8 b0;                                    // accumulators 0-7   v[40:47]
-        f32x16 b1;                                   //              8-23  v[48:63]
-        f32x32 a1, a2;                               //              24-55 v[64:95], 56-87 v[96:127]
+        f32x8 b0;                                    // accumulator registers 0-7   v[40:47]   (region j = registers 2j, 2j+1)
+        f32x16 b1;                                   //                       8-23  v[48:63]
+        f32x32 a1, a2;                               //                       24-55 v[64:95], 56-87 v[96:127]
 #pragma unroll
         for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; if (j < 8) b0[j] = 0.f; if (j < 16) b1[j] = 0.f; }
-        // cell g of this time block starts at xbase + g * 256 bytes; this wave moves bytes
+        // cell g of this time block starts at xbase + g * 512 bytes; this wave moves bytes
         // [wave * 4096, wave * 4096 + 4096) of every 64 KiB chunk
-        const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * (SP_TB * 4) + wave * 4096;
+        const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * SP_ROW + wave * 4096;
         const int32_t *goff = grp_off + ((int64_t)rb * n_chunks) * SP_WAVES + wave;
 
-        auto dma_chunk = [&](int c, int buf) {       // 4 x 1 KiB pieces of chunk c -> LDS buffer buf (item prologue)
-            const char *src = xbase + (int64_t)c * SP_BUF_BYTES;
-            const int l0 = lds0 + buf * SP_BUF_BYTES + wave * 4096;
-            int m0save, v1;
-            asm volatile(
-                "s_mov_b32 %[sv], m0\n\t"
-                "s_mov_b32 m0, %[l0]\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %[vo], %[src]\n\t"
-                "v_add_u32 %[v1], 0x400, %[vo]\n\t"
-                "s_add_u32 m0, %[l0], 0x400\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
-                "v_add_u32 %[v1], 0x800, %[vo]\n\t"
-                "s_add_u32 m0, %[l0], 0x800\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
-                "v_add_u32 %[v1], 0xc00, %[vo]\n\t"
-                "s_add_u32 m0, %[l0], 0xc00\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %[v1], %[src]\n\t"
-                "s_mov_b32 m0, %[sv]\n\t"
-                : [sv] "=&s"(m0save), [v1] "=&v"(v1)
-                : [l0] "s"(l0), [vo] "v"(voff16), [src] "s"(src)
-                : "memory", "scc");
-        };
-
         if (c0 < c1) {
-            dma_chunk(c0, 0);
+            {   // chunk c0 -> LDS buffer 0 (4 x 1 KiB pieces per wave)
+                const char *src = xbase + (int64_t)c0 * SP_BUF_BYTES;
+                const int l0 = lds0 + wave * 4096;
+                int m0save, v1;
+                asm volatile(
+                    "s_mov_b32 %[sv], m0\n\t"
+                    "s_mov_b32 m0, %[l0]\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %[vo], %[src]\n\t"
+                    "v_add_u32 %[v1], 0x400, %[vo]\n\t"
+                    "s_add_u32 m0, %[l0], 0x400\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                    "v_add_u32 %[v1], 0x800, %[vo]\n\t"
+                    "s_add_u32 m0, %[l0], 0x800\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                    "v_add_u32 %[v1], 0xc00, %[vo]\n\t"
+                    "s_add_u32 m0, %[l0], 0xc00\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %[v1], %[src]\n\t"
+                    "s_mov_b32 m0, %[sv]\n\t"
+                    : [sv] "=&s"(m0save), [v1] "=&v"(v1)
+                    : [l0] "s"(l0), [vo] "v"(voff16), [src] "s"(src)
+                    : "memory", "scc");
+            }
+            // ... and its entry list -> register set A.  From here to the end of the chunk loop the list
+            // registers live ACROSS statements: nothing but scalar code may sit between two of them
+            // (tools/check_spmm_codegen.py checks the compiled kernel).
+            const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * (2 * SP_GROUP));
+            asm volatile(SPMM_LOAD_LIST_ASM : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32))
+                         : "memory", SPMM_CHUNK_CLOBBERS);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        for (int c = c0; c < c1; ++c) {
-            const int buf = (c - c0) & 1;
-            // everything of this chunk in ONE statement (the entry loads' destination registers must not be
-            // touched by compiler-generated code while the loads are in flight): entry loads of chunk c,
-            // LDS-DMA of chunk c + 1 (the last chunk re-loads itself: harmless), list warm-up for chunk c + 2,
-            // then the entries
-            const int cn = c + 1 < c1 ? c + 1 : c, cw = c + 2 < c1 ? c + 2 : c1 - 1;
-            const int g0 = goff[(int64_t)c * SP_WAVES], g1 = goff[(int64_t)c * SP_WAVES + 1];
-            const int gw = goff[(int64_t)cw * SP_WAVES];
-            int n = g1 - g0;
-            const uint64_t ptr = reinterpret_cast<uint64_t>(ent + (int64_t)g0 * (2 * SP_GROUP));
-            const char *src = xbase + (int64_t)cn * SP_BUF_BYTES;
-            const char *wsrc = reinterpret_cast<const char *>(ent) + (int64_t)gw * 64;
-            const int l0 = lds0 + (buf ^ 1) * SP_BUF_BYTES + wave * 4096;
-            const int bufbit = lds0 + buf * SP_BUF_BYTES, sink = lds0 + SP_SINK, wlim = n_groups - gw;
-            asm volatile(SPMM_CHUNK_ASM
-                         : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2)
-                         : [plo] "s"((uint32_t)ptr), [phi] "s"((uint32_t)(ptr >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0),
-                           [src] "s"(src), [wsrc] "s"(wsrc), [wlim] "s"(wlim), [sink] "s"(sink)
-                         : "memory", "scc", SPMM_CHUNK_CLOBBERS);
-            // this wave's pieces of chunk c + 1 have landed and it is done reading chunk c
+        // Chunks go in PAIRS, statement A then statement B, straight-line (an if/else between the two
+        // statements makes the compiler shuffle the pinned accumulators through scratch); an odd count is
+        // padded with an empty chunk (n = 0: its statement only re-issues harmless loads).
+        auto chunk_args = [&](int c, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, const char *&wsrc,
+                              int &l0, int &bufbit, int &wlim) {
+            const bool real = c < c1;
+            const int cc = real ? c : c1 - 1;
+            // next chunk (the last one re-loads itself: harmless), list warm-up three chunks ahead
+            const int cn = cc + 1 < c1 ? cc + 1 : cc, cw = cc + 3 < c1 ? cc + 3 : c1 - 1;
+            const int g0 = goff[(int64_t)cc * SP_WAVES], g1 = goff[(int64_t)cc * SP_WAVES + 1];
+            const int gn = goff[(int64_t)cn * SP_WAVES], gw = goff[(int64_t)cw * SP_WAVES];
+            n = real ? g1 - g0 : 0;
+            pc = reinterpret_cast<uint64_t>(ent + (int64_t)g0 * (2 * SP_GROUP));
+            pn = reinterpret_cast<uint64_t>(ent + (int64_t)gn * (2 * SP_GROUP));
+            src = xbase + (int64_t)cn * SP_BUF_BYTES;
+            wsrc = reinterpret_cast<const char *>(ent) + (int64_t)gw * 64;
+            l0 = lds0 + (par ^ 1) * SP_BUF_BYTES + wave * 4096;
+            bufbit = lds0 + par * SP_BUF_BYTES;
+            wlim = n_groups - gw;
+        };
+        const int sink = lds0 + SP_SINK;
+#define SPMM_CHUNK_STMT(ASM)                                                                                  \
+        asm volatile(ASM                                                                                      \
+                     : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2) \
+                     : [cplo] "s"((uint32_t)pc), [cphi] "s"((uint32_t)(pc >> 32)), [nplo] "s"((uint32_t)pn),   \
+                       [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src),  \
+                       [wsrc] "s"(wsrc), [wlim] "s"(wlim), [sink] "s"(sink)                                   \
+                     : "memory", "scc", SPMM_CHUNK_CLOBBERS)
+        for (int c = c0; c < c1; c += 2) {
+            int n, l0, bufbit, wlim;
+            uint64_t pc, pn;
+            const char *src, *wsrc;
+            chunk_args(c, 0, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_A);               // this chunk's list in set A, the next one's -> B
+            // this wave's pieces of the next chunk and the next list have landed; it is done reading this chunk
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            chunk_args(c + 1, 1, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_B);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // partial sums of this k slice: region r of the wave, 64 consecutive timesteps per store
-        float *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * SP_TB + lane;
+#undef SPMM_CHUNK_STMT
+        // partial sums of this k slice: region j of the wave, 128 consecutive timesteps (two per lane) per store
+        float *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * SP_TB + 2 * lane;
 #pragma unroll
         for (int j = 0; j < SP_RW_MAX; ++j) {
-            if (j < rw) *dst = j < 8 ? b0[j & 7] : (j < 24 ? b1[(j - 8) & 15] : (j < 56 ? a1[(j - 24) & 31] : a2[(j - 56) & 31]));
+            const int q = 2 * j;
+            const float lo = q < 8 ? b0[q & 7] : (q < 24 ? b1[(q - 8) & 15] : (q < 56 ? a1[(q - 24) & 31] : a2[(q - 56) & 31]));
+            const float hi = q + 1 < 8 ? b0[(q + 1) & 7] : (q + 1 < 24 ? b1[(q - 7) & 15] : (q + 1 < 56 ? a1[(q - 23) & 31] : a2[(q - 55) & 31]));
+            if (j < rw) *reinterpret_cast<float2 *>(dst) = make_float2(lo, hi);
             dst += Tpad;
-            asm volatile("" : "+v"(dst));            // one running pointer, not 95 hoisted offsets
+            asm volatile("" : "+v"(dst));            // one running pointer, not 43 hoisted offsets
         }
     }
 }
 
-// X (T x G, row stride ldx) -> Xp[time block][cell][64 timesteps]: transform (tas_poly / snyder_edd),
+// X (T x G, row stride ldx) -> Xp[time block][cell][128 timesteps]: transform (tas_poly / snyder_edd),
 // NaN -> 0 (S6), zeros for rows >= T and cells >= G.  64 x 64 tiles through LDS: both sides coalesced.
 __global__ __launch_bounds__(256) void spmm_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
                                                           int64_t Gpad, PackXf xf, float *__restrict__ Xp) {
     __shared__ float tile[64][65];
-    const int64_t g0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    const int64_t g0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;      // blockIdx.y counts 64-timestep halves
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     bool inf_seen = false;
 #pragma unroll 4
@@ -164,9 +192,10 @@ __global__ __launch_bounds__(256) void spmm_pack_x_kernel(const float *__restric
         tile[i][tx] = v;
     }
     __syncthreads();
+    const int64_t tb = t0 / SP_TB, toff = t0 % SP_TB;
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4)
-        Xp[(((int64_t)blockIdx.y * Gpad + g0 + i) * SP_TB) + tx] = tile[tx][i];
+        Xp[((tb * Gpad + g0 + i) * SP_TB) + toff + tx] = tile[tx][i];
 }
 
 // out[t, r] = sum_s slabT[s][r][t] / den[r]   (aggregations.py:77-80), 64 x 64 tiles through LDS
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32
         if (FILL && keep) {
             const int64_t pos = base + kept + __popcll(m & ((1ull << lane) - 1ull));
             uint32_t *grp = ent + (pos >> 3) * 16 + (pos & 7);       // group = [8 x lo][8 x weight]
-            grp[0] = (unsigned)(gl << 8 | j);
+            grp[0] = sp_entry_lo(gl, j);
             grp[8] = __float_as_uint(hash_u01(id, seed));
         }
         kept += __popcll(m);
@@ -350,7 +379,7 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cell[a] < cell[b]; });
         for (size_t i : order) {
             const int64_t b = bucket_of(i);
-            const unsigned lo = (unsigned)((cell[i] % SP_KC) << 8 | (region[i] % wave_regions));
+            const unsigned lo = sp_entry_lo(cell[i] % SP_KC, region[i] % wave_regions);
             unsigned wb;
             std::memcpy(&wb, &w[i], 4);
             const size_t pos = (size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++;
@@ -390,8 +419,8 @@ int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const Pack
     const size_t need_x = (size_t)n_tb * (size_t)Gpad * SP_TB, need_s = (size_t)S * (size_t)Rpad * (size_t)Tpad;
     if (d->xp.n < need_x) WAGG_HIP(d->xp.alloc(need_x));
     if (d->slabs.n < need_s) WAGG_HIP(d->slabs.alloc(need_s));
-    hipLaunchKernelGGL(spmm_pack_x_kernel, dim3((unsigned)(Gpad / 64), (unsigned)n_tb), dim3(256), 0, st, X, T, ldx, d->G,
-                       Gpad, xf, d->xp.p);
+    hipLaunchKernelGGL(spmm_pack_x_kernel, dim3((unsigned)(Gpad / 64), (unsigned)(n_tb * (SP_TB / 64))), dim3(256), 0, st, X, T,
+                       ldx, d->G, Gpad, xf, d->xp.p);
     WAGG_HIP(hipGetLastError());
     WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel, SP_LDS_BYTES));
     const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
@@ -401,7 +430,7 @@ int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const Pack
                        sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups);
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)n_tb), dim3(256), 0, st,
+    hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)(Tpad / 64)), dim3(256), 0, st,
                        (const float *)d->slabs.p, S, Rpad, Tpad, T, d->R, (const float *)d->den32.p, out, ldo);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;

@@ -1,141 +1,180 @@
 #!/usr/bin/env python3
 """Generates climate_toolbox_amd/csrc/wagg_spmm_asm.inc: the per-(wave, chunk) inner loop of the
-entry-list kernel (wagg_spmm.hip) as one inline-asm string, SPMM_CHUNK_ASM.
+entry-list kernel (wagg_spmm.hip) as inline-asm strings.
 
-Why generated: the loop is unrolled over 5 blocks x 8 groups x 8 entries with static lane numbers
-(v_readlane) and a two-stage software pipeline; writing 2,400 instructions by hand invites slips.
+Why generated: the loop is unrolled over blocks x groups x entries with static lane numbers
+(v_readlane) and a two-stage software pipeline; writing ~1,500 instructions by hand invites slips.
 
-What one invocation does (one wave, one 256-cell chunk whose X tile is already in LDS):
-  1. issues ALL entry loads of this chunk's list (5 blocks of 64 entries: lane j <- entry j, the
-     8-byte entries stored as groups of [8 x lo][8 x weight]), then the 4 LDS-DMA pieces of the NEXT
-     chunk's X tile and one warm-up load for the list two chunks ahead -- so every later wait on an
-     entry block is a COUNTED vmcnt that leaves the DMA in flight;
-  2. per entry: two v_readlane (entry -> SGPRs), v_bfi (LDS address), ds_read_b32 (64 timesteps of the
-     cell), s_set_gpr_idx_idx + ONE v_fma_f32 into the accumulator register the entry names
-     (v[40 + (lo & 0xff)]), group g+1's reads in flight while group g is accumulated;
-  3. lists longer than 40 groups (never at 1 % fill) finish in a plain one-group-at-a-time loop.
+Geometry (must match wagg_dense_int.h): a wave's 64 lanes hold NT = 2 timesteps each (a 128-timestep
+block), a chunk is KC = 128 grid cells x 512 B = 64 KiB of LDS, accumulators are register PAIRS
+v[40 + 2j : 41 + 2j] for the wave's region j (j < 44; pair 43 swallows the padding entries).
 
-Private registers (clobbered, hard-coded): v3 entry-load lane offset, v[4:8] / v[9:13] lo / weight
-of blocks 0-4, v[14:21] / v[22:29] the two LDS-read sets, v30 lane*4 | buffer bit, v31 0xff00;
-s[36:51] / s[52:67] the two entry sets, s68 saved M0, s[70:71] list pointer.  Accumulators v[40:127]
-are in/out operands of the statement.
+SPMM_LOAD_LIST_ASM    (item prologue) loads the first chunk's list into register set A.
+SPMM_CHUNK_ASM_A / _B one wave, one chunk whose X tile is already in LDS, the list of THIS chunk in set
+                      A (B), in order:
+  1. issues the loads of the NEXT chunk's list into the other set (consumed by the next statement: the
+     C++ between two statements is scalar-only, which tools/check_spmm_codegen.py verifies on the
+     compiled kernel), the 4 LDS-DMA pieces of the next chunk's X tile, one L2 warm-up load for the list
+     three chunks ahead -- all retired by the `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
+  2. per entry: two v_readlane (entry -> SGPRs), v_bfi (LDS address), ds_read_b64 (2 x 64 timesteps of
+     the cell), s_set_gpr_idx_idx + v_pk_fma_f32 (or two v_fma_f32) into the accumulator pair the entry
+     names (VGPR index mode), half-group h+1's reads in flight while half-group h is accumulated;
+  3. lists longer than 16 groups (never at 1 % fill) finish in a one-group-at-a-time loop.
+
+Private registers (clobbered, hard-coded): v3 entry-load lane offset; set A = v[4:5] lo, v[6:7] weights
+of blocks 0-1, set B = v[8:9], v[10:11]; v12 lane, v13 scratch; v[14:21] / v[22:29] the two LDS-read sets
+(4 register pairs each); v30 lane*8 | buffer bit; v31 0xfe00; s[36:43] / s[44:51] the two half-group
+entry sets; s68 saved M0; s[70:71] list pointer.
 """
 import os
+import sys
 
-N_BLOCKS, GROUPS_PER_BLOCK = 5, 8
-SA, SB = 36, 52          # SGPR sets
-TA, TB = 14, 22          # VGPR temp sets
-LO0, HI0 = 4, 9          # entry block registers
-VO, LB, VMASK = 3, 30, 31
-ACC0 = 40                # first accumulator register: v[40:127] = 88 accumulators
-N_VM_AFTER = 4 + 1       # vector-memory ops issued after the entry loads: 4 DMA pieces + 1 warm-up
-
-
-def issue(g, S, T, out):
-    b, base = divmod(g, GROUPS_PER_BLOCK)
-    base *= 8
-    if base == 0:            # first group of a block: its two loads must have landed
-        out.append("s_waitcnt vmcnt(%d)" % (2 * (N_BLOCKS - 1 - b) + N_VM_AFTER))
-    for k in range(8):
-        out.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k, LO0 + b, base + k))
-        out.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, HI0 + b, base + k))
-    for k in range(8):
-        out.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + k, VMASK, S + 2 * k, LB))
-    for k in range(8):
-        out.append("ds_read_b32 v%d, v%d" % (T + k, T + k))
+N_BLOCKS = 2                 # 64-entry blocks loaded per list (16 groups); longer lists take the slow loop
+SA, SB = 36, 44              # SGPR half-group sets (4 entries x (lo, w))
+TP, TQ = 14, 22              # VGPR temp sets: 4 pairs each
+SETS = {"A": (4, 6), "B": (8, 10)}     # (first lo register, first weight register) of a list set
+VO, LANE, SCR, LB, VMASK = 3, 12, 13, 30, 31
+ACC0 = 40
+MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
+PK = int(os.environ.get("SPMM_PK", "1"))   # 1: v_pk_fma_f32, 0: two v_fma_f32
 
 
-def fma(S, T, younger, out):
-    """accumulate one group; `younger` = LDS reads issued after this group's (next group's 8, or 0)"""
-    for k in range(8):
-        out.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % (S + 2 * k))
-        out.append("s_waitcnt lgkmcnt(%d)" % (7 - k + younger))
-        out.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0, T + k, S + 2 * k + 1, ACC0))
-    out.append("s_set_gpr_idx_off")
+def lane_regs(o, with_lb):
+    o.append("v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE)
+    o.append("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE))
+    o.append("v_lshrrev_b32 v%d, 3, v%d" % (SCR, LANE))
+    o.append("v_and_b32 v%d, 7, v%d" % (VO, LANE))
+    o.append("v_lshlrev_b32 v%d, 6, v%d" % (SCR, SCR))
+    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VO, VO, SCR))      # (lane >> 3) * 64 + (lane & 7) * 4
+    if with_lb:
+        o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
+        o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))        # lane * 8 | buffer bit
+        o.append("v_mov_b32 v%d, 0x%x" % (VMASK, MASK))
 
 
-def main():
+def load_list(o, which):
+    lo0, hi0 = SETS[which]
+    for b in range(N_BLOCKS):
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (lo0 + b, VO, 512 * b))
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (hi0 + b, VO, 512 * b + 32))
+
+
+def issue(h, which, S, T, o):
+    """half-group h (4 entries): entry -> SGPRs, LDS address, read"""
+    lo0, hi0 = SETS[which]
+    b, base = divmod(4 * h, 64)
+    for k in range(4):
+        o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k, lo0 + b, base + k))
+        o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, hi0 + b, base + k))
+    for k in range(4):
+        o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, LB))
+    for k in range(4):
+        o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
+
+
+def fma(S, T, younger, o):
+    for k in range(4):
+        o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % (S + 2 * k))
+        o.append("s_waitcnt lgkmcnt(%d)" % (3 - k + younger))
+        if PK:
+            o.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[0,1,0]"
+                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, S + 2 * k, S + 2 * k + 1, ACC0, ACC0 + 1))
+        else:
+            o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0, T + 2 * k, S + 2 * k + 1, ACC0))
+            o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0 + 1, T + 2 * k + 1, S + 2 * k + 1, ACC0 + 1))
+    o.append("s_set_gpr_idx_off")
+
+
+def chunk(cur, nxt):
     o = []
     o.append("s_mov_b32 s68, m0")
-    o.append("s_mov_b32 s70, %[plo]")
-    o.append("s_mov_b32 s71, %[phi]")
-    # lane-derived registers
-    o.append("v_mbcnt_lo_u32_b32 v14, -1, 0")
-    o.append("v_mbcnt_hi_u32_b32 v14, -1, v14")              # v14 = lane
-    o.append("v_lshrrev_b32 v15, 3, v14")
-    o.append("v_and_b32 v16, 7, v14")
-    o.append("v_lshlrev_b32 v15, 6, v15")
-    o.append("v_lshl_or_b32 v%d, v16, 2, v15" % VO)          # (lane >> 3) * 64 + (lane & 7) * 4
-    o.append("v_lshlrev_b32 v%d, 2, v14" % LB)
-    o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))     # lane * 4 | buffer bit
-    o.append("v_mov_b32 v%d, 0xff00" % VMASK)
-    # 1. entry loads of this chunk's list
-    for b in range(N_BLOCKS):
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (LO0 + b, VO, 512 * b))
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (HI0 + b, VO, 512 * b + 32))
-    # the next chunk's X tile: 4 x 1 KiB LDS-DMA pieces of this wave
-    o.append("v_lshlrev_b32 v15, 4, v14")                    # lane * 16
+    o.append("s_mov_b32 s70, %[nplo]")
+    o.append("s_mov_b32 s71, %[nphi]")
+    lane_regs(o, True)
+    load_list(o, nxt)                                          # 1. the NEXT chunk's list
+    o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))         # lane * 16: LDS-DMA of the next X tile
     for i in range(4):
         if i:
-            o.append("v_add_u32 v16, 0x%x, v15" % (0x400 * i))
+            o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
         o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
         o.append("s_nop 0")
-        o.append("global_load_lds_dwordx4 v%d, %%[src]" % (16 if i else 15))
-    # warm-up of the list two chunks ahead (into the sink; one 64-byte line per lane, clamped)
-    o.append("v_min_u32 v17, %[wlim], v14")
-    o.append("v_lshlrev_b32 v17, 6, v17")
+        o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
+    o.append("v_min_u32 v%d, %%[wlim], v%d" % (SCR, LANE))     # L2 warm-up, one 64-byte line per lane
+    o.append("v_lshlrev_b32 v%d, 6, v%d" % (SCR, SCR))
     o.append("s_mov_b32 m0, %[sink]")
     o.append("s_nop 0")
-    o.append("global_load_lds_dword v17, %[wsrc]")
-    # 2. the pipelined groups
-    o.append("s_cmp_eq_u32 %[n], 0")
+    o.append("global_load_lds_dword v%d, %%[wsrc]" % SCR)
+    o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
     o.append("s_cbranch_scc1 8f")
-    n_groups = N_BLOCKS * GROUPS_PER_BLOCK
-    issue(0, SA, TA, o)
-    for g in range(n_groups):
-        S, T = (SA, TA) if g % 2 == 0 else (SB, TB)
-        S2, T2 = (SB, TB) if g % 2 == 0 else (SA, TA)
-        last = g == n_groups - 1
+    n_half = N_BLOCKS * 16
+    issue(0, cur, SA, TP, o)
+    for h in range(n_half):
+        S, T = (SA, TP) if h % 2 == 0 else (SB, TQ)
+        S2, T2 = (SB, TQ) if h % 2 == 0 else (SA, TP)
+        last = h == n_half - 1
         if not last:
-            issue(g + 1, S2, T2, o)
-        fma(S, T, 0 if last else 8, o)
-        o.append("s_sub_u32 %[n], %[n], 1")
-        o.append("s_cmp_eq_u32 %[n], 0")
-        o.append("s_cbranch_scc1 8f")
-    # 3. overflow: one group at a time
-    o.append("s_add_u32 s70, s70, %d" % (64 * n_groups))
-    o.append("s_addc_u32 s71, s71, 0")
+            issue(h + 1, cur, S2, T2, o)
+        fma(S, T, 0 if last else 4, o)
+        if h % 2 == 1:                                         # a whole group done
+            o.append("s_sub_u32 %[n], %[n], 1")
+            o.append("s_cmp_eq_u32 %[n], 0")
+            o.append("s_cbranch_scc1 8f")
+    # 3. overflow: one group at a time from behind the loaded blocks (uses the current set's registers)
+    lo0, hi0 = SETS[cur]
+    o.append("s_add_u32 s70, %%[cplo], %d" % (512 * N_BLOCKS))
+    o.append("s_addc_u32 s71, %[cphi], 0")
     o.append("7:")
-    o.append("global_load_dword v%d, v%d, s[70:71] offset:0" % (LO0, VO))
-    o.append("global_load_dword v%d, v%d, s[70:71] offset:32" % (HI0, VO))
+    o.append("global_load_dword v%d, v%d, s[70:71] offset:0" % (lo0, VO))
+    o.append("global_load_dword v%d, v%d, s[70:71] offset:32" % (hi0, VO))
     o.append("s_waitcnt vmcnt(0)")
-    for k in range(8):
-        o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k, LO0, k))
-        o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k + 1, HI0, k))
-    for k in range(8):
-        o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TA + k, VMASK, SA + 2 * k, LB))
-    for k in range(8):
-        o.append("ds_read_b32 v%d, v%d" % (TA + k, TA + k))
-    fma(SA, TA, 0, o)
+    for hh in range(2):
+        for k in range(4):
+            o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k, lo0, 4 * hh + k))
+            o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k + 1, hi0, 4 * hh + k))
+        for k in range(4):
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TP + 2 * k, VMASK, SA + 2 * k, LB))
+        for k in range(4):
+            o.append("ds_read_b64 v[%d:%d], v%d" % (TP + 2 * k, TP + 2 * k + 1, TP + 2 * k))
+        fma(SA, TP, 0, o)
     o.append("s_add_u32 s70, s70, 64")
     o.append("s_addc_u32 s71, s71, 0")
     o.append("s_sub_u32 %[n], %[n], 1")
     o.append("s_cmp_eq_u32 %[n], 0")
     o.append("s_cbranch_scc0 7b")
     o.append("8:")
-    o.append("s_waitcnt lgkmcnt(0)")          # reads issued for a group past the end are never consumed
+    o.append("s_waitcnt lgkmcnt(0)")          # reads issued for a half-group past the end are never consumed
     o.append("s_mov_b32 m0, s68")
+    return o
+
+
+def prologue():
+    o = []
+    o.append("s_mov_b32 s70, %[nplo]")
+    o.append("s_mov_b32 s71, %[nphi]")
+    lane_regs(o, False)
+    load_list(o, "A")
+    return o
+
+
+def emit(f, name, lines):
+    f.write("#define %s \\\n" % name)
+    for line in lines:
+        f.write('    "%s\\n\\t" \\\n' % line)
+    f.write('    ""\n')
+
+
+def main():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "climate_toolbox_amd", "csrc",
                         "wagg_spmm_asm.inc")
+    a, b, p = chunk("A", "B"), chunk("B", "A"), prologue()
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_spmm_asm.py -- do not edit; see that script for the register map.\n")
-        f.write("#define SPMM_CHUNK_ASM \\\n")
-        for line in o:
-            f.write('    "%s\\n\\t" \\\n' % line)
-        f.write('    ""\n')
+        f.write("// GENERATED by tools/gen_spmm_asm.py (SPMM_PK=%d) -- do not edit; see that script for the register map.\n" % PK)
+        emit(f, "SPMM_LOAD_LIST_ASM", p)
+        emit(f, "SPMM_CHUNK_ASM_A", a)
+        emit(f, "SPMM_CHUNK_ASM_B", b)
         clob = ["v%d" % i for i in range(3, 32)] + ["s%d" % i for i in range(36, 72)]
         f.write("#define SPMM_CHUNK_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
-    print("wrote", path, len(o), "instructions")
+    print("wrote", path, len(a), "instructions per chunk statement", file=sys.stderr)
 
 
 if __name__ == "__main__":
