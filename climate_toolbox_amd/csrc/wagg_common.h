@@ -64,6 +64,33 @@ template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T
     return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
 }
 
+// fp32: the same function with the slow parts replaced -- v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE
+// division and square-root sequences, and arcsin by Abramowitz & Stegun 4.4.46,
+//   asin|z| = pi/2 - sqrt(1 - |z|) (a0 + a1 |z| + ... + a7 |z|^7),  |error| <= 2e-8,
+// all three cases evaluated and selected (no divergent branches): ~35 vector instructions instead of ~100.
+// The degree days differ from the libm evaluation by ~1e-7 relative (tolerance of the fp32 path: 1e-4);
+// NaN / inf behave as in the generic form (a NaN tasmin gives NaN, a NaN tasmax below the threshold 0).
+template <> __device__ __forceinline__ float snyder_edd1<float>(float tmin, float tmax, float e) {
+    const float M = 0.5f * (tmax + tmin), w = 0.5f * (tmax - tmin);
+    const float d = M - e;
+    const float z = -d * __builtin_amdgcn_rcpf(w);                     // (e - M) / w, strictly inside (-1, 1) in the band
+    const float az = __builtin_fabsf(z);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, az, 0.0066700901f);
+    p = __builtin_fmaf(p, az, -0.0170881256f);
+    p = __builtin_fmaf(p, az, 0.0308918810f);
+    p = __builtin_fmaf(p, az, -0.0501743046f);
+    p = __builtin_fmaf(p, az, 0.0889789874f);
+    p = __builtin_fmaf(p, az, -0.2145988016f);
+    p = __builtin_fmaf(p, az, 1.5707963050f);
+    const float acos_az = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.0f - az, 0.0f)) * p;   // pi/2 - asin|z|
+    const float pi = 3.14159265358979323846f;
+    const float quarter = z >= 0.0f ? acos_az : pi - acos_az;         // pi/2 - theta
+    const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf((1.0f - z) * (1.0f + z), 0.0f));   // cos(theta)
+    const float inner = (d * quarter + w * c) * (1.0f / pi);
+    return !(tmin < e) ? d : (!(tmax > e) ? 0.0f : inner);
+}
+
 template <typename T> __device__ __forceinline__ T xform1(T x, T off, int pw) {
     const T y = x + off;
     T r = y;

@@ -661,7 +661,11 @@ struct LcLds {
 // fragment to the powers pv.xpow .. pv.xpow + NPOW - 1 in registers and keep NPOW accumulator sets,
 // so X is read from HBM once for NPOW powers; the i-th of them is stored at out + i * out_pstride.  A chunk whose |y| could
 // overflow fp32 at the highest power (or holds +-inf) takes the exact path, like +-inf data does.
-template <bool VEC, int NPOW = 1>
+// EDD (fused Snyder degree days): the loaders stream BOTH fields (tasmin = X, tasmax = pv.X2)
+// and keep them in registers; one stage per threshold: they park snyder_edd1(tasmin + xoff, tasmax + xoff,
+// thr[k]) (transformations.py:64-87) into the image buffer and the consumers reduce it into output plane
+// k, so the two fields are read from HBM once for up to four thresholds.
+template <bool VEC, int NPOW = 1, bool EDD = false>
 __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
                                                                   int64_t Ttot, int64_t ldx, int64_t G,
                                                                   float *__restrict__ out, int64_t ldo,
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 #endif
             return c;
         };
-        struct Regs { vec4 v[TPW]; int mu; float mw; int er, es; float ed; };
+        struct Regs { vec4 v[TPW]; vec4 h[EDD ? TPW : 1]; int mu; float mw; int er, es; float ed; };
         static_assert(LC_SEGS <= LC_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
             // small metadata loads first, the rows last (vmcnt retires in order)
@@ -770,6 +774,47 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                 }
                 if (i + 1 < cnt) p += ldx;
             }
+            if constexpr (EDD) {                                  // the second field: tasmax
+                const float *p2 = pv.X2 + (t0 + rbase) * ldx + cell0;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    if (VEC) R.h[i] = *reinterpret_cast<const vec4 *>(p2);
+                    else {
+                        const int64_t lim = G - 1 - cell0;
+                        R.h[i] = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
+                    }
+                    if (i + 1 < cnt) p2 += ldx;
+                }
+            }
+        };
+        auto park_meta = [&](const Regs &R, const StreamDesc &d, int tb, int buf, int plane) {
+            if (!(knob & 2)) {
+            if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
+            if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
+            if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
+            }
+            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; hdr[buf * 16 + 4] = plane; }
+        };
+        // degree days of threshold k from the two fields held in registers (they stay untouched for the
+        // next threshold): NaN values count 0 (S6), +-inf values send the chunk to the exact path
+        auto park_edd = [&](const Regs &R, const StreamDesc &d, int tb, int buf, int k) {
+            float *im = img + buf * LC_TB * UROW;
+            const float e = k == 0 ? pv.edd_thr[0] : (k == 1 ? pv.edd_thr[1] : (k == 2 ? pv.edd_thr[2] : pv.edd_thr[3]));
+            bool inf_seen = false;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                vec4 val;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float y = snyder_edd1<float>(R.v[i][c] + pv.xoff, R.h[EDD ? i : 0][c] + pv.xoff, e);
+                    inf_seen |= __builtin_amdgcn_classf(y, 0x204);
+                    val[c] = (y == y) ? y : 0.0f;
+                }
+                *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = val;
+            }
+            const bool inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
+            if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;
+            park_meta(R, d, tb, buf, k);
         };
         auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
             float *im = img + buf * LC_TB * UROW;
@@ -808,12 +853,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;      // every wave, every item: no reset needed
 #pragma unroll
             for (int i = 0; i < TPW; ++i) *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = R.v[i];
-            if (!(knob & 2)) {
-            if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
-            if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
-            if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
-            }
-            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; }
+            park_meta(R, d, tb, buf, 0);
         };
         // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
         Item itq[3];
@@ -848,7 +888,9 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         };
         { Ahead a; ahead_load(a); ahead_commit(a); }              // queue now describes items 1, 2, 3
         // two register sets alternate: while one item is parked, the next one's loads are in flight
-        auto lstage = [&](Regs &Rcur, Regs &Rnext, int st, int pbuf) {
+        const int K = EDD ? pv.n_thr : 1;                         // stages per item (one per degree-day threshold)
+        int sbuf = 0;                                             // image buffer of the next stage
+        auto lstage = [&](Regs &Rcur, Regs &Rnext, int st) {
             // Rcur holds item st (in flight since the previous call); item st+1 goes to Rnext
             const StreamDesc dn = dq[0];
             const int tbn = itq[0].tb;
@@ -857,18 +899,45 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             stamp(-1);
             if (more) { ahead_load(a); issue(Rnext, dn, cellq[0], tbn); }
             stamp(0);                                             // loader ph0: issue (blocked at VMEM)
-            park(Rcur, dPark, tbPark, pbuf);
-            stamp(2);                                             // ph2: wait for item st + park
-            if (more) { dPark = dn; tbPark = tbn; ahead_commit(a); }
-            stamp(1);                                             // ph1: queue rotation (must not wait for rows)
-            lds_only_barrier();                                   // item st is in buffer pbuf
-            stamp(3);                                             // ph3: waiting for the consumers
+            for (int k = 0; k < K; ++k) {
+                park(Rcur, dPark, tbPark, sbuf);
+                stamp(2);                                         // ph2: wait for item st + park
+                if (k + 1 == K && more) { dPark = dn; tbPark = tbn; ahead_commit(a); }
+                stamp(1);                                         // ph1: queue rotation (must not wait for rows)
+                lds_only_barrier();                               // stage (st, k) is in buffer sbuf
+                stamp(3);                                         // ph3: waiting for the consumers
+                sbuf ^= 1;
+            }
         };
-        // item st is parked during call st (into buffer st & 1); consumers reduce item st after it.
-        // The buffer is free: its previous tenant (item st-2) was reduced before barrier st-1.
-        for (int st = 0; st < nst; st += 2) {
-            lstage(RA, RB, st, 0);
-            if (st + 1 < nst) lstage(RB, RA, st + 1, 1);
+        // Degree days: ONE register set (the two fields of an item are 64 registers per lane; a second set does not
+        // fit the 168-register budget of three waves per SIMD -- tried: 400-500 spills).  The next item's loads are
+        // issued right behind the last threshold's park, so they overlap that stage's barrier and reduction only.
+        auto lstage_edd = [&](Regs &R, int st) {
+            const bool more = st + 1 < nst;
+            for (int k = 0; k < K; ++k) {
+                park_edd(R, dPark, tbPark, sbuf, k);
+                if (k + 1 == K && more) {
+                    const StreamDesc dn = dq[0];
+                    const int tbn = itq[0].tb;
+                    Ahead a;
+                    ahead_load(a);
+                    issue(R, dn, cellq[0], tbn);
+                    dPark = dn; tbPark = tbn;
+                    ahead_commit(a);
+                }
+                lds_only_barrier();
+                sbuf ^= 1;
+            }
+        };
+        // Stage s = st * K + k is parked into buffer s & 1; the consumers reduce it after the barrier.
+        // The buffer is free: its previous tenant (stage s - 2) was reduced before barrier s - 1.
+        if constexpr (EDD) {
+            for (int st = 0; st < nst; ++st) lstage_edd(RA, st);
+        } else {
+            for (int st = 0; st < nst; st += 2) {
+                lstage(RA, RB, st);
+                if (st + 1 < nst) lstage(RB, RA, st + 1);
+            }
         }
         lds_only_barrier();                                       // consumers finish the last item
         if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
@@ -907,11 +976,14 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         // the dense weight tile starts all-zero and is returned to all-zero after every pass
         for (int i = ctid * 4; i < 16 * LC_AROW; i += 256 * 4)
             *reinterpret_cast<vec4 *>(&aw[i]) = vec4{0.f, 0.f, 0.f, 0.f};
-        for (int st = 0; st < nst; ++st) {
+        const int nstages = nst * (EDD ? pv.n_thr : 1);
+        for (int st = 0; st < nstages; ++st) {
             stamp(-1);
-            lds_only_barrier();                                   // item st has been parked
+            lds_only_barrier();                                   // stage st has been parked
             stamp(3);                                             // consumer ph3: waiting for the loaders
             const int buf = st & 1;
+            // degree days: the stage's threshold selects the output plane
+            const int64_t plane_off = EDD ? (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 4]) * out_pstride : 0;
             const float *im = img + buf * LC_TB * UROW;
             const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
             const int ns = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 1]);
@@ -973,7 +1045,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 #pragma unroll
                         for (int pp = 0; pp < NPOW; ++pp) {
                             const f32x4 acc = accp[pp][0] + accp[pp][1];
-                            float *op = out + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+                            float *op = out + plane_off + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
                             const f32x4 qv = {acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den};   // :77-80
                             if (out_vec && tl + 3 < nt) {
                                 *reinterpret_cast<f32x4 *>(op) = qv;
@@ -1016,7 +1088,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     if (lane < nt) {
 #pragma unroll
                         for (int pp = 0; pp < NPOW; ++pp)
-                            out[(int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] =
+                            out[plane_off + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] =
                                 accx[pp] / sm_ed[buf * LC_ENT + e];
                     }
                 }
@@ -1154,9 +1226,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     }
     pv.chunk_desc = d.chunk_desc.p; pv.g0_normal = d.g0_normal; pv.c0_normal = d.c0_normal;
     // aligned fast path: 16-byte aligned rows
-    const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0);
-    // two-field transforms (EDD) are implemented in the chunk-walking kernel only
-    const bool stream_path = layout == WAGG_LAYOUT_TG && xpow != XF_EDD && !(plan->flags & WAGG_PLAN_NO_STREAM);
+    const bool vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((ldx * sizeof(T)) % 16 == 0) &&
+                     (xpow != XF_EDD || (reinterpret_cast<uintptr_t>(X2) & 15) == 0);
+    // degree days (two fields): fp32 (time, gridcell) data in the loader/consumer kernel, everything else in the
+    // chunk-walking kernel
+    const bool edd = xpow == XF_EDD;
+    const bool stream_path = layout == WAGG_LAYOUT_TG && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
     const int n_norm = (int)plan->info.n_groups - d.g0_normal;
     bool lc_done = false;
     if constexpr (sizeof(T) == 4) {
@@ -1166,6 +1241,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
             const long long nw = n_items < ncu ? n_items : ncu;
             auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
+            if (edd) kern = vec ? sparse_lc_kernel<true, 1, true> : sparse_lc_kernel<false, 1, true>;
             if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
             if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
             if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
@@ -1195,7 +1271,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             lc_done = true;
         }
     }
-    if (stream_path && n_norm > 0 && !lc_done) {
+    if (stream_path && n_norm > 0 && !lc_done && !edd) {
         // persistent pipelined kernel over the single-chunk groups; two workgroups per CU
         const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * n_tb;
@@ -1229,7 +1305,9 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                     sum[3] / stages, (sum[4] + sum[9]) / stages, sum[9] / stages, sum[5] / stages);
         }
         pv.n_groups = d.g0_normal;          // what is left for the chunk-walking kernel: giant groups
+        lc_done = true;                     // (a dominant kernel has been launched and timed)
     }
+    const bool main_done = lc_done;
     pv.thr_pstride = kpstride;
     for (int pz = 0; pz < nfuse; ++pz) {      // per power: the groups the kernels above left over (giant ones)
     if (nfuse > 1) pv.xpow = xpow + pz;
@@ -1244,10 +1322,10 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (xpow == XF_EDD && pv.n_thr > 1) kern = sparse_gather_kernel<T, TB, L, O, V, 0, 4>; \
             WAGG_DIAG_GATHER_VARIANTS(L, O, V)                                                   \
             WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));                              \
-            if (!(stream_path && n_norm > 0)) profile_mark(stream, true);                        \
+            if (!main_done) profile_mark(stream, true);                                          \
             hipLaunchKernelGGL(kern, grid, block, shmem, stream, pv, X, Ttot, ldx, plan->info.G, \
                                kout + (int64_t)pz * kpstride, kldo);                             \
-            if (!(stream_path && n_norm > 0)) profile_mark(stream, false);                       \
+            if (!main_done) profile_mark(stream, false);                                         \
         } while (0)
         if (layout == WAGG_LAYOUT_TG) { if (vec) WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, true); else WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, false); }
         else WAGG_LAUNCH(WAGG_LAYOUT_GT, WAGG_OUT_RT, false);
