@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
 EKEY = -6
 PLAN_NO_LC, PLAN_NO_STREAM = 1, 2
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
+HOST_PIN, HOST_WHOLE = 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
 
@@ -20,6 +21,7 @@ EXPORTS = (
     "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
     "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den", "wagg_plan_status",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
+    "wagg_apply_host_ex_f32", "wagg_apply_host_ex_f64", "wagg_dense_apply_host_f32", "wagg_dense_apply_host_f64",
     "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
     "wagg_gather_f32", "wagg_gather_f64",
     "wagg_transform_poly_f32", "wagg_transform_poly_f64", "wagg_transform_edd_f32", "wagg_transform_edd_f64",
@@ -93,6 +95,10 @@ def load():
                                      C.c_int64, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_host_f32", "wagg_apply_host_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int]
+    for name in ("wagg_apply_host_ex_f32", "wagg_apply_host_ex_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, C.c_int]
+    for name in ("wagg_dense_apply_host_f32", "wagg_dense_apply_host_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int]
     for name in ("wagg_gather_f32", "wagg_gather_f64"):
         getattr(L, name).argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, vp, C.c_int64,
                                      C.c_int, vp]

@@ -524,11 +524,33 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     X2, layout, _, unflatten = _flatten_for_device(values, dims)
     is_f32 = str(X2.dtype).endswith("float32")
     plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout)
-    # host-resident data: one pageable H2D copy (measured 51.7 GB/s on the MI355X box: 29 ms for the
-    # 1.5 GB c2 field, ~100x the kernel; a pinned double-buffered variant was 13x SLOWER because the
-    # pageable -> pinned host memcpy runs at ~4 GB/s), the kernels, one D2H copy of the result
-    Xd = _to_device(X2)
     out_layout = "TR" if layout == "TG" else "RT"
+    if (not _is_device_tensor(X2)) and layout == "TG" and powers is None and edd is None:
+        # Host-resident (time, gridcell) field, plain aggregation: the C-ABI streams it through the device
+        # in row blocks, the arrays page-locked in place for the call (wagg_apply_host_ex_* /
+        # wagg_dense_apply_host_*): the H2D of block i+1 overlaps the kernels of block i and the device
+        # never holds the whole field.  PCIe-bound for the segment-table form (49 GB/s of X, ~100x the
+        # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
+        from ._lib import HOST_PIN
+        X2c = np.ascontiguousarray(X2)
+        host_out = plan.apply_host(X2c, flags=HOST_PIN)
+        if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
+            exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
+            try:
+                host_out = exact.apply_host(X2c, flags=HOST_PIN)
+            finally:
+                exact.close()
+        res0 = unflatten(host_out, len(uniq))
+        rdims = _result_dims(dims, agglev)
+        coords = {}
+        for d in rdims:
+            if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+                coords[d] = np.asarray(carried[d].values)
+        coords[agglev] = uniq
+        return res0, rdims, coords, was_xr
+    # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
+    # kernels, one D2H copy of the result
+    Xd = _to_device(X2)
     if edd is not None:
         # Snyder degree days: sum of coef * EDD(threshold), both fields loaded once per threshold
         H2 = _flatten_for_device(edd[0], dims)[0]

@@ -110,6 +110,79 @@ hipError_t allow_dynamic_lds(const void *kern, size_t bytes);
 // event ring behind wagg_profile_enable / wagg_profile_read (wagg_util.hip)
 void profile_mark(hipStream_t stream, bool begin);
 
+// ---- host-resident (time, gridcell) data: row-block pipeline ----------------------------
+// X_host is cut into blocks of whole rows; the H2D copy of block i+1 (copy stream) overlaps the kernels
+// of block i (compute stream), results return block by block, and the device holds two blocks instead of
+// the whole field.  With WAGG_HOST_PIN the caller's arrays are page-locked in place for the duration of
+// the call (hipHostRegister), which makes the copies truly asynchronous; pageable arrays are staged by
+// the runtime and overlap only partly.  apply(X_dev, rows, out_dev, stream) launches one block.
+template <typename T, typename ApplyFn>
+int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int64_t ldo, int64_t R, int flags,
+                     int64_t quantum, ApplyFn apply) {
+    if (Tn == 0) return WAGG_OK;
+    // ~256 MiB of X per block in whole multiples of `quantum` rows (the row count one launch handles well:
+    // 64 for the segment-table kernels, a full 368 / 176-row block for the MFMA forms, whose W is streamed
+    // once per launch), at least two blocks when there are >= 2 quanta of rows
+    int64_t B = ((int64_t)256 << 20) / (int64_t)(ldx * sizeof(T));
+    B = B < quantum ? quantum : B / quantum * quantum;
+    if (Tn >= 2 * quantum && B > (Tn + 1) / 2) B = ((Tn + 1) / 2 + quantum - 1) / quantum * quantum;
+    if (B > Tn) B = Tn;
+    const int64_t nb = (Tn + B - 1) / B;
+    const size_t xbytes = sizeof(T) * (size_t)(Tn * ldx), obytes = sizeof(T) * (size_t)(Tn * ldo);
+    bool pin_x = false, pin_o = false;
+    if (flags & WAGG_HOST_PIN) {
+        pin_x = hipHostRegister(const_cast<T *>(X_host), xbytes, hipHostRegisterDefault) == hipSuccess;
+        pin_o = hipHostRegister(out_host, obytes, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();            // a failed registration is not an error: the copies are staged instead
+    }
+    struct Guard {              // everything acquired here is released on every exit path
+        const void *rx = nullptr; void *ro = nullptr;
+        hipStream_t sc = nullptr, sk = nullptr;
+        hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+        void *dx[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+        ~Guard() {
+            if (sc) (void)hipStreamSynchronize(sc);
+            if (sk) (void)hipStreamSynchronize(sk);
+            for (int b = 0; b < 2; ++b) {
+                if (ready[b]) (void)hipEventDestroy(ready[b]);
+                if (done[b]) (void)hipEventDestroy(done[b]);
+                if (dx[b]) (void)hipFree(dx[b]);
+                if (dout[b]) (void)hipFree(dout[b]);
+            }
+            if (sc) (void)hipStreamDestroy(sc);
+            if (sk) (void)hipStreamDestroy(sk);
+            if (rx) (void)hipHostUnregister(const_cast<void *>(rx));
+            if (ro) (void)hipHostUnregister(ro);
+        }
+    } g;
+    if (pin_x) g.rx = X_host;
+    if (pin_o) g.ro = out_host;
+    WAGG_HIP(hipStreamCreateWithFlags(&g.sc, hipStreamNonBlocking));
+    WAGG_HIP(hipStreamCreateWithFlags(&g.sk, hipStreamNonBlocking));
+    for (int b = 0; b < 2 && b < nb; ++b) {
+        WAGG_HIP(hipEventCreateWithFlags(&g.ready[b], hipEventDisableTiming));
+        WAGG_HIP(hipEventCreateWithFlags(&g.done[b], hipEventDisableTiming));
+        WAGG_HIP(hipMalloc(&g.dx[b], sizeof(T) * (size_t)(B * ldx)));
+        WAGG_HIP(hipMalloc(&g.dout[b], sizeof(T) * (size_t)(B * ldo)));
+    }
+    (void)R;
+    for (int64_t i = 0; i < nb; ++i) {
+        const int b = (int)(i & 1);
+        const int64_t r0 = i * B, rows = Tn - r0 < B ? Tn - r0 : B;
+        if (i >= 2) WAGG_HIP(hipStreamWaitEvent(g.sc, g.done[b], 0));       // block i-2 no longer uses this buffer
+        WAGG_HIP(hipMemcpyAsync(g.dx[b], X_host + r0 * ldx, sizeof(T) * (size_t)(rows * ldx), hipMemcpyHostToDevice, g.sc));
+        WAGG_HIP(hipEventRecord(g.ready[b], g.sc));
+        WAGG_HIP(hipStreamWaitEvent(g.sk, g.ready[b], 0));
+        const int rc = apply(static_cast<const T *>(g.dx[b]), rows, static_cast<T *>(g.dout[b]), g.sk);
+        if (rc != WAGG_OK) return rc;
+        WAGG_HIP(hipMemcpyAsync(out_host + r0 * ldo, g.dout[b], sizeof(T) * (size_t)(rows * ldo), hipMemcpyDeviceToHost, g.sk));
+        WAGG_HIP(hipEventRecord(g.done[b], g.sk));
+    }
+    WAGG_HIP(hipStreamSynchronize(g.sc));
+    WAGG_HIP(hipStreamSynchronize(g.sk));
+    return WAGG_OK;
+}
+
 template <typename T>
 struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime)
     T *p = nullptr;

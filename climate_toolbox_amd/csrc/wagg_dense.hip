@@ -980,6 +980,42 @@ extern "C" int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev,
     return wagg::apply_edd<double>(d, tasmin_dev, tasmax_dev, T, ldx, offset, threshold, out_dev, ldo, ksplit, stream);
 }
 
+namespace wagg {
+template <typename T>
+static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int64_t ldo, int flags) {
+    WAGG_REQUIRE(d != nullptr, "dense plan is NULL");
+    WAGG_REQUIRE(Tn >= 0, "T < 0");
+    if (Tn == 0) return WAGG_OK;
+    WAGG_REQUIRE(X_host && out_host, "X/out is NULL");
+    WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
+    if (flags & WAGG_HOST_WHOLE) {
+        DevBuf<T> dx, dout;
+        WAGG_HIP(dx.alloc((size_t)(Tn * ldx)));
+        WAGG_HIP(dout.alloc((size_t)(Tn * ldo)));
+        WAGG_HIP(hipMemcpy(dx.p, X_host, sizeof(T) * (size_t)(Tn * ldx), hipMemcpyHostToDevice));
+        const int rc = dense_apply<T>(d, dx.p, Tn, ldx, PackXfT<T>{}, dout.p, ldo, 0, nullptr);
+        if (rc != WAGG_OK) return rc;
+        WAGG_HIP(hipDeviceSynchronize());
+        WAGG_HIP(hipMemcpy(out_host, dout.p, sizeof(T) * (size_t)(Tn * ldo), hipMemcpyDeviceToHost));
+        return WAGG_OK;
+    }
+    return stream_host_rows<T>(X_host, Tn, ldx, out_host, ldo, d->R, flags, d->spmm ? SP_TB : DT<T>::MT_MAX * 16,
+                               [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
+                                   return dense_apply<T>(d, xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
+                               });
+}
+}  // namespace wagg
+
+extern "C" int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int64_t ldx,
+                                         float *out_host, int64_t ldo, int flags) {
+    return wagg::dense_apply_host<float>(d, X_host, T, ldx, out_host, ldo, flags);
+}
+extern "C" int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
+                                         double *out_host, int64_t ldo, int flags) {
+    return wagg::dense_apply_host<double>(d, X_host, T, ldx, out_host, ldo, flags);
+}
+
 extern "C" int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw) {
     using namespace wagg;
     WAGG_REQUIRE(d && saw, "NULL argument");

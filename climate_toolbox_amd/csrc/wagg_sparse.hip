@@ -1734,9 +1734,18 @@ static int apply_poly(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
 
 template <typename T, typename F>
 static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, T *out,
-                      int64_t ldo, int out_layout, F fn) {
+                      int64_t ldo, int out_layout, int flags, F fn) {
     int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
     if (rc != WAGG_OK || Tn == 0) return rc;
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
+    if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
+        rc = stream_host_rows<T>(X, Tn, ldx, out, ldo, plan->info.R, flags, 64,
+                                 [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
+                                     return fn(plan, xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
+                                 });
+        if (rc != WAGG_OK) return rc;
+        return check_timeout(plan);
+    }
     const int64_t xrows = layout == WAGG_LAYOUT_TG ? Tn : plan->info.G;
     const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : plan->info.R;
     DevBuf<T> dx, dout;
@@ -1755,11 +1764,19 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
 
 extern "C" int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                                    int layout, float *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, wagg_apply_f32);
+    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN, wagg_apply_f32);
+}
+extern "C" int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
+                                      int layout, float *out_host, int64_t ldo, int out_layout, int flags) {
+    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, wagg_apply_f32);
 }
 extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                    int layout, double *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, wagg_apply_f64);
+    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN, wagg_apply_f64);
+}
+extern "C" int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
+                                      int layout, double *out_host, int64_t ldo, int out_layout, int flags) {
+    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, wagg_apply_f64);
 }
 
 extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,

@@ -153,8 +153,11 @@ class SparsePlan:
                    "wagg_apply_edd")
         return out
 
-    def apply_host(self, X, layout="TG", out_layout="TR"):
-        """Blocking host-buffer form (wagg_apply_host_*): numpy in, numpy out."""
+    def apply_host(self, X, layout="TG", out_layout="TR", flags=0):
+        """Blocking host-buffer form (wagg_apply_host_ex_*): numpy in, numpy out.  (time, gridcell) data
+        is streamed through the device in row blocks (H2D of block i+1 overlapping the kernels of block
+        i); ``flags``: ``_lib.HOST_PIN`` page-locks the arrays for the call, ``_lib.HOST_WHOLE`` copies
+        the whole field at once."""
         X = np.ascontiguousarray(X)
         if X.dtype not in (np.float32, np.float64) or X.ndim != 2:
             raise TypeError("X must be a 2-D float32/float64 array")
@@ -162,9 +165,9 @@ class SparsePlan:
         shape = (T, self.R) if out_layout == "TR" else (self.R, T)
         out = np.empty(shape, dtype=X.dtype)
         L = _lib.load()
-        fn = L.wagg_apply_host_f32 if X.dtype == np.float32 else L.wagg_apply_host_f64
+        fn = L.wagg_apply_host_ex_f32 if X.dtype == np.float32 else L.wagg_apply_host_ex_f64
         _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], _LAYOUTS[layout],
-                      C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout]), "wagg_apply_host")
+                      C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout], int(flags)), "wagg_apply_host")
         return out
 
 
@@ -290,6 +293,19 @@ class DensePlan:
             self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin), float(offset),
             float(threshold), C.c_void_p(out.data_ptr()), _ld(out), int(ksplit), _stream_handle(stream)),
             "wagg_dense_apply_edd")
+        return out
+
+    def apply_host(self, X, flags=0):
+        """Host-resident (time, gridcell) array through the plan in row blocks (``wagg_dense_apply_host_*``):
+        numpy in, numpy out; flags as for :meth:`SparsePlan.apply_host`."""
+        want = np.float64 if self.dtype == "float64" else np.float32
+        X = np.ascontiguousarray(X)
+        if X.dtype != want or X.ndim != 2 or X.shape[1] != self.G:
+            raise TypeError("X must be a (T, %d) %s array" % (self.G, self.dtype))
+        out = np.empty((X.shape[0], self.R), dtype=want)
+        _lib.check(self._fn("wagg_dense_apply_host")(self._h, C.c_void_p(X.ctypes.data), X.shape[0], X.shape[1],
+                                                     C.c_void_p(out.ctypes.data), max(1, self.R), int(flags)),
+                   "wagg_dense_apply_host")
         return out
 
     def saw_inf(self, stream=None):

@@ -129,11 +129,27 @@ int wagg_apply_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t
                    float *out_dev, int64_t ldo, int out_layout, void *stream);
 int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
                    double *out_dev, int64_t ldo, int out_layout, void *stream);
-/* blocking convenience forms on host buffers (hipMalloc + H2D + apply + D2H inside) */
+/* Blocking forms on host buffers.  (time, gridcell) data with a (time, region) result is
+ * streamed through the device in row blocks of ~256 MiB: the H2D copy of block i+1 overlaps the kernels
+ * of block i on a second stream, results return block by block, the device holds two blocks at a time
+ * (host arrays of c4 / c5 size, 45-76 GB, need no device copy of the whole field).  flags:
+ *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister) so that the
+ *                    copies are truly asynchronous; without it pageable memory is staged by the runtime
+ *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
+ * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN.  Measured on one MI355X (tools/host_path_timing.py):
+ * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks,
+ * 33 ms pageable blocks); a dense 1,369-row shard takes 602 ms whole and 523 ms in pinned blocks (the copies
+ * hide behind the 490 ms of MFMA work; pageable blocks 601 ms: staged copies do not overlap).           */
+#define WAGG_HOST_PIN 1
+#define WAGG_HOST_WHOLE 2
 int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                         int layout, float *out_host, int64_t ldo, int out_layout);
 int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                         int layout, double *out_host, int64_t ldo, int out_layout);
+int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
+                           int layout, float *out_host, int64_t ldo, int out_layout, int flags);
+int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
+                           int layout, double *out_host, int64_t ldo, int out_layout, int flags);
 
 /* ---- fused grid-level transform ---------------------------------------------- */
 /* Replaces  tas_poly  (climate_toolbox/transformations/transformations.py:160-208, the arithmetic
@@ -259,6 +275,11 @@ int wagg_dense_apply_poly_f64(wagg_dense *d, const double *X_dev, int64_t T, int
 int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
                              int64_t ldx, double offset, double threshold, double *out_dev, int64_t ldo,
                              int ksplit, void *stream);
+/* host-resident (time, gridcell) data through a dense-family plan, row-block pipeline as wagg_apply_host_ex_* */
+int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int64_t ldx,
+                              float *out_host, int64_t ldo, int flags);
+int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
+                              double *out_host, int64_t ldo, int flags);
 /* The MFMA forms multiply every (cell, region) pair of a stored tile, so +-inf in the (transformed)
  * data turns the zero weights of regions that do not own the cell into NaN, where the reference and
  * the segment-table form confine it to the owning regions (S6).  The pack stage notes such data:

@@ -464,3 +464,65 @@ def test_c5_like_fp64_tile_sparse_at_scale(torch_cuda):
     np.testing.assert_allclose(const, 7.25, rtol=1e-13)
     assert torch.equal(plan.apply(X * 2.0), got * 2.0)
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# host-resident data: row-block pipeline of the C-ABI
+# ---------------------------------------------------------------------------------------------
+def test_host_streaming_forms_agree_with_the_device_apply(torch_cuda):
+    """wagg_apply_host_ex_* / wagg_dense_apply_host_*: whole-field copy, pageable row blocks and
+    page-locked row blocks give the bits of the device-resident apply (several blocks, ragged last
+    block, padded rows, both dtypes); (gridcell, time) data takes the whole-copy path."""
+    from climate_toolbox_amd import _lib, synth
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(360, 720, R=3000, seed=9, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R = len(lat) * len(lon), len(uniq)
+    plan = SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    rng = np.random.default_rng(4)
+    T = 700                                                    # 259,200 cells x 4 B: 256 MiB ~ 258 rows -> 3 blocks
+    for dtype in (np.float32, np.float64):
+        X = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+        X[3, 1000] = np.nan
+        ref = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+        for flags in (_lib.HOST_WHOLE, 0, _lib.HOST_PIN):
+            np.testing.assert_array_equal(plan.apply_host(X, flags=flags), ref)
+        XT = np.ascontiguousarray(X[:40].T)                    # (gridcell, time): whole-copy path
+        np.testing.assert_array_equal(plan.apply_host(XT, layout="GT", out_layout="RT", flags=_lib.HOST_PIN),
+                                      plan.apply(torch.from_numpy(XT).cuda(), layout="GT", out_layout="RT").cpu().numpy())
+    with pytest.raises(_lib.WaggError):
+        plan.apply_host(X, flags=64)
+    # dense-family plan: blocks are whole 368-row launches
+    Gd, Rd, Td = 4096, 300, 1000
+    W = rng.uniform(0, 1, (Gd, Rd)).astype(np.float32)
+    Xd = (280 + 20 * rng.standard_normal((Td, Gd))).astype(np.float32)
+    dplan = DensePlan.from_host(W)
+    refd = dplan.apply(torch.from_numpy(Xd).cuda()).cpu().numpy()
+    for flags in (_lib.HOST_WHOLE, 0, _lib.HOST_PIN):
+        np.testing.assert_allclose(dplan.apply_host(Xd, flags=flags), refd, rtol=2e-6)
+
+
+def test_dropin_streams_host_fields_through_the_pipeline(torch_cuda):
+    """A plain aggregation of a NumPy-backed (time, lat, lon) variable goes through the row-block
+    pipeline (no whole-field device copy) and matches the oracle; a device-resident variable and a lazily
+    transformed one take the device path and give the same numbers."""
+    from climate_toolbox_amd import minixr, weighted_aggregate_grid_to_regions
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(6)
+    lat, lon = np.arange(-44.5, 45, 1.0), np.arange(-89.5, 90, 1.0)
+    T, n = 130, 4000
+    tas = (280 + 10 * rng.standard_normal((T, len(lat), len(lon)))).astype(np.float32)
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "hierid": rng.integers(0, 60, n)})
+    ref = O.agg_scatter(tas, ("time", "lat", "lon"), lat, lon, df["lat"].values, df["lon"].values, df["areawt"].values,
+                        df["areawt"].values, df["hierid"].values, group_dim="hierid")[0]
+    coords = {"time": np.arange(T), "lat": lat, "lon": lon}
+    host = weighted_aggregate_grid_to_regions(minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords=coords),
+                                              "tas", "areawt", "hierid", df).tas.values
+    dev = weighted_aggregate_grid_to_regions(
+        minixr.Dataset({"tas": minixr.DataArray(torch.from_numpy(tas).cuda(), ("time", "lat", "lon"))}, coords=coords),
+        "tas", "areawt", "hierid", df).tas.values
+    _rel_ok(host, ref, RTOL32)
+    np.testing.assert_array_equal(host, dev)
