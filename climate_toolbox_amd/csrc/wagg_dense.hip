@@ -389,10 +389,12 @@ __global__ void dense_synth_w_kernel(typename DT<T>::vec *__restrict__ Wp, int64
     }
 }
 
-// column sums in fp64 (plan time): one block per (column tile, strip of k tiles); thread = slot
+// column sums in fp64 (plan time): one block per (column tile, strip of k tiles); thread = slot.  Every slot
+// writes its own partial (no atomics: the denominators are the same bits on every build); slot s of a tile
+// holds piece s & 7 of column s >> 3, so a column has 8 partials per strip, added in a fixed order below.
 template <typename T>
 __global__ void dense_colsum_kernel(const typename DT<T>::vec *__restrict__ Wp, int32_t R, int n_kt, int kt_per_block,
-                                    double *__restrict__ den) {
+                                    double *__restrict__ part /* [strips][n_nt * 2048] */) {
     const int nt = blockIdx.x;
     const int ktb = blockIdx.y * kt_per_block;
     const int kte = ktb + kt_per_block < n_kt ? ktb + kt_per_block : n_kt;
@@ -405,9 +407,20 @@ __global__ void dense_colsum_kernel(const typename DT<T>::vec *__restrict__ Wp, 
             for (int c = 0; c < DT<T>::EPP; ++c) sv += (double)v[c];
             s += sv;
         }
-        const int64_t r = (int64_t)nt * D_BN + (slot >> 3);
-        if (r < R) atomicAdd(&den[r], s);
+        part[((int64_t)blockIdx.y * gridDim.x + nt) * D_WSLOTS + slot] = s;
     }
+    (void)R;
+}
+
+__global__ void dense_colsum_combine_kernel(const double *__restrict__ part, int n_strips, int n_nt, int32_t R,
+                                            double *__restrict__ den) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t nt = r / D_BN, c = r % D_BN;
+    double s = 0.0;
+    for (int st = 0; st < n_strips; ++st)
+        for (int p = 0; p < 8; ++p) s += part[((int64_t)st * n_nt + nt) * D_WSLOTS + c * 8 + p];
+    den[r] = s;
 }
 
 __global__ void dense_den32_kernel(const double *__restrict__ den64, float *__restrict__ den32, int32_t R) {
@@ -453,19 +466,22 @@ __global__ void dense_synth_blocklocal_kernel(typename DT<T>::vec *__restrict__ 
     }
 }
 
-// column sums of the tile-sparse form: one block per stored tile
+// column sums of the tile-sparse form: one thread per region walks the stored tiles of its column tile in
+// order (tile_first[nt] .. tile_first[nt + 1]) -- fixed summation order, no atomics
 template <typename T>
-__global__ void dense_colsum_tiled_kernel(const typename DT<T>::vec *__restrict__ Wp, const int32_t *__restrict__ tile_nt,
+__global__ void dense_colsum_tiled_kernel(const typename DT<T>::vec *__restrict__ Wp, const int32_t *__restrict__ tile_first,
                                           int32_t R, double *__restrict__ den) {
-    const int64_t ti = blockIdx.x;
-    for (int slot = threadIdx.x; slot < D_WSLOTS; slot += blockDim.x) {
-        const typename DT<T>::vec v = Wp[ti * D_WSLOTS + slot];
-        double s = 0.0;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const int64_t nt = r / D_BN, c = r % D_BN;
+    double s = 0.0;
+    for (int64_t ti = tile_first[nt]; ti < tile_first[nt + 1]; ++ti)
+        for (int p = 0; p < 8; ++p) {
+            const typename DT<T>::vec v = Wp[ti * D_WSLOTS + c * 8 + p];
 #pragma unroll
-        for (int c = 0; c < DT<T>::EPP; ++c) s += (double)v[c];
-        const int64_t r = (int64_t)tile_nt[ti] * D_BN + (slot >> 3);
-        if (r < R && s != 0.0) atomicAdd(&den[r], s);
-    }
+            for (int e = 0; e < DT<T>::EPP; ++e) s += (double)v[e];
+        }
+    den[r] = s;
 }
 
 // plain row-major W (G x R) -> packed order (small matrices handed over by the host)
@@ -535,11 +551,17 @@ static int dense_den_to_host(wagg_dense *d) {
 template <typename T>
 static int dense_finish_den(wagg_dense *d) {
     typedef typename DT<T>::vec vec_t;
-    WAGG_HIP(hipMemset(d->den64.p, 0, sizeof(double) * (size_t)d->R));
     const int kt_per_block = 128;
-    dim3 grid((unsigned)d->n_nt, (unsigned)((d->n_kt + kt_per_block - 1) / kt_per_block));
+    const int n_strips = (d->n_kt + kt_per_block - 1) / kt_per_block;
+    dim3 grid((unsigned)d->n_nt, (unsigned)n_strips);
+    DevBuf<double> part;
+    WAGG_HIP(part.alloc((size_t)n_strips * (size_t)d->n_nt * D_WSLOTS));
     hipLaunchKernelGGL((dense_colsum_kernel<T>), grid, dim3(512), 0, nullptr,
-                       reinterpret_cast<const vec_t *>(d->W.p), d->R, d->n_kt, kt_per_block, d->den64.p);
+                       reinterpret_cast<const vec_t *>(d->W.p), d->R, d->n_kt, kt_per_block, part.p);
+    hipLaunchKernelGGL(dense_colsum_combine_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, nullptr,
+                       (const double *)part.p, n_strips, d->n_nt, d->R, d->den64.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());            // `part` is freed on return
     return dense_den_to_host(d);
 }
 
@@ -625,18 +647,24 @@ static int create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, double f
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
     std::vector<int32_t> ntv;
-    DevBuf<int32_t> dnt;
+    DevBuf<int32_t> dnt, dfirst;
     hipError_t e = dense_set_tiles(d, tiles, &ntv);
     if (e == hipSuccess) e = dnt.upload(ntv);
+    if (e == hipSuccess) {
+        std::vector<int32_t> first((size_t)n_nt + 1, 0);
+        for (size_t i = 0; i < tiles.size(); ++i) first[(size_t)ntv[i] + 1]++;
+        for (int nt = 0; nt < n_nt; ++nt) first[(size_t)nt + 1] += first[(size_t)nt];
+        e = dfirst.upload(first);
+    }
     if (e == hipSuccess) {
         hipLaunchKernelGGL((dense_synth_blocklocal_kernel<T>), dim3(256 * 16), dim3(256), 0, nullptr,
                            reinterpret_cast<vec_t *>(d->W.p), d->tile_kt.p, dnt.p, d->n_tiles, G, R, seed, (float)fill);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemset(d->den64.p, 0, sizeof(double) * (size_t)R);
-    if (e == hipSuccess && d->n_tiles > 0) {
-        hipLaunchKernelGGL((dense_colsum_tiled_kernel<T>), dim3((unsigned)d->n_tiles), dim3(512), 0, nullptr,
-                           reinterpret_cast<const vec_t *>(d->W.p), dnt.p, R, d->den64.p);
+    if (e == hipSuccess) {
+        // the slice table for one slice = first stored tile of every column tile (+ the total): [nt][0..1]
+        hipLaunchKernelGGL((dense_colsum_tiled_kernel<T>), dim3((unsigned)((R + 255) / 256)), dim3(256), 0, nullptr,
+                           reinterpret_cast<const vec_t *>(d->W.p), (const int32_t *)dfirst.p, R, d->den64.p);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { set_error("block-local synth: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }

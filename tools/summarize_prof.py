@@ -65,7 +65,9 @@ for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel<float", True), ("c2-real"
     traffic[wl] = {
         "hbm_bytes_per_launch": (2.0 if wide else 1.0) * fs * 1024 + ws * 1024,
         "fetch_size_kib_raw": fs, "write_size_kib_raw": ws,
-        "correction": WIDE if wide else GATHER,
+        "correction": (WIDE if wide else GATHER) if wl != "c5-uniform" else
+                      ("FETCH_SIZE x2 applied to the whole figure: exact for the X tiles (16-B/lane LDS-DMA), an upper bound for "
+                       "the entry lists (4-B/lane loads, uncalibrated); the bytes that must move are ~19 GB of X + 36 GB of lists"),
         "source": "profiles/%s_pmc.csv" % tag, "measured": "round %d" % int(tag.lstrip("r")),
     }
 json.dump(traffic, open(tj, "w"), indent=1)
