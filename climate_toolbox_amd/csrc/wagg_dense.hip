@@ -26,6 +26,7 @@
 //     (deterministic, no atomics).
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -96,12 +97,21 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 // tile i and tile_off[nt][ks] .. tile_off[nt][ks+1] the run of stored tiles that block (nt, ks)
 // contracts.  The k index of tile t+2 is fetched by a plain vector load at the start of tile t
 // (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
-template <typename T, int DBG = 0, bool TILED = false, int MT = D_MT>
+//
+// RM (tile-sparse only, "pack-free"): Xp is the caller's ROW-MAJOR X (row stride ldxB bytes, 16-byte aligned,
+// no NaN -> 0 pass): the LDS-DMA builds the same tile image straight from it -- lane l of 1-KiB piece q
+// fetches piece ((l & 7) ^ (l >> 4) ^ 4 (q & 1)) of row 8 q + (l >> 3), i.e. eight whole 128-byte lines per
+// instruction; rows >= T repeat row T - 1 (their results are never read).  A NaN or +-inf in X then
+// reaches the accumulators; dense_reduce_kernel notices the non-finite numerator and the launcher's gated
+// second pass (pack + the packed kernel, `gate` != 0) redoes the apply the exact way.
+template <typename T, int DBG = 0, bool TILED = false, int MT = D_MT, bool RM = false>
 __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const T *__restrict__ Xp, const T *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
     int kt_per_slice, T *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
-    const int32_t *__restrict__ tile_off = nullptr) {
+    const int32_t *__restrict__ tile_off = nullptr, int64_t ldxB = 0, int Tn = 0, const int *__restrict__ gate = nullptr) {
     static_assert(MT <= DT<T>::MT_MAX, "accumulators of MT row blocks must fit the register file");
+    static_assert(!RM || TILED, "the pack-free X source exists for the tile-sparse form only");
+    if constexpr (TILED && !RM) { if (gate != nullptr && *gate == 0) return; }     // second pass not needed
     typedef typename DT<T>::vec vec_t;
     typedef typename DT<T>::acc acc_t;
     constexpr int KS = DT<T>::EPP;                   // MFMA k-steps fed by one 16-byte fragment read
@@ -141,11 +151,23 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 
     // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
     // moves W pieces wave + 8 i (i < 4) and X pieces wave + 8 i (i < NXP, those below XPIECES)
-    const char *xsrc = reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
+    const char *xsrc = RM ? reinterpret_cast<const char *>(Xp) + (int64_t)mb * (MT * 16) * ldxB +
+                                ((((lane & 7) ^ (lane >> 4)) ^ ((wave & 1) << 2)) << 4)
+                          : reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
+    const int rm_row = lane >> 3, rm_rmax = RM ? Tn - 1 - mb * (MT * 16) : 0;
     const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * D_WTB + lane * 16;
 #define WAGG_DMA_X(q, tile, buf)                                                                  \
-    __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * XT4 + (q) * 1024),          \
-                                     (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0)
+    do {                                                                                          \
+        if constexpr (RM) {                                                                       \
+            int r_ = 8 * (q) + rm_row;                                                            \
+            r_ = r_ < rm_rmax ? r_ : rm_rmax;                                                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)r_ * ldxB + (int64_t)(tile) * D_ROWB), \
+                                             (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0); \
+        } else {                                                                                  \
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * XT4 + (q) * 1024),  \
+                                             (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0); \
+        }                                                                                         \
+    } while (0)
 #define WAGG_DMA_W(q, tile, buf)                                                                  \
     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * D_WTB + (q) * 1024),   \
                                      (lptr_t)(lds + (buf) * BUF_BYTES + XT4 + (q) * 1024), 16, 0, 0)
@@ -300,9 +322,10 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 template <typename T>
 __global__ void dense_pack_x_kernel(const T *__restrict__ X, int64_t Tn, int64_t ldx, int64_t G,
                                     int n_kt, int bm, int64_t n_slots, int aligned, typename DT<T>::vec *__restrict__ Xp,
-                                    PackXfT<T> xf, int *__restrict__ inf_flag) {
+                                    PackXfT<T> xf, int *__restrict__ inf_flag, const int *__restrict__ gate = nullptr) {
     typedef typename DT<T>::vec vec_t;
     constexpr int E = DT<T>::EPP;
+    if (gate != nullptr && *gate == 0) return;              // second pass of a pack-free apply: not needed
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int tile_slots = bm * 8;                         // bm rows x 8 pieces of 16 bytes
     bool inf_seen = false;
@@ -347,17 +370,22 @@ __host__ __device__ __forceinline__ int64_t wp_index(int64_t g, int64_t r, int n
 }
 
 // out[t, r] = sum_s slab[mb][nt][s][t_local][c] / den[r]        (aggregations.py:77-80 fused)
+// `nonfinite` (pack-free first pass): set when a numerator is NaN / +-inf; `gate` (second pass): run only if set.
 template <typename T>
 __global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
-                                    int32_t R, const T *__restrict__ den, T *__restrict__ out, int64_t ldo) {
+                                    int32_t R, const T *__restrict__ den, T *__restrict__ out, int64_t ldo,
+                                    int *__restrict__ nonfinite = nullptr, const int *__restrict__ gate = nullptr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t t = blockIdx.y;
+    if (gate != nullptr && *gate == 0) return;
     if (r >= R) return;
     const int mb = (int)(t / bm), tl = (int)(t % bm);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
     const T *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
     T s = T(0);
     for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
+    if (nonfinite != nullptr && !(fabs(s) <= std::numeric_limits<T>::max()))
+        __hip_atomic_store(nonfinite, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[t * ldo + r] = s / den[r];
 }
 
@@ -525,6 +553,7 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = d->nonfinite.alloc(1);
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, sizeof(int), hipHostMallocMapped);
     if (e == hipSuccess) { *d->inf_host = 0; e = hipHostGetDevicePointer((void **)&d->inf_dev, d->inf_host, 0); }
     if (e == hipSuccess) e = d->W.alloc((size_t)(d->w_slots() > 0 ? d->w_slots() : 1) * 4);
@@ -794,13 +823,14 @@ static int create_from_segments(const int32_t *cell_idx, const int32_t *region_c
     return WAGG_OK;
 }
 
-template <typename T, bool TILED, int MT>
-static const void *mfma_kernel_ptr() { return (const void *)dense_mfma_kernel<T, 0, TILED, MT>; }
+template <typename T, bool TILED, int MT, bool RM = false>
+static const void *mfma_kernel_ptr() { return (const void *)dense_mfma_kernel<T, 0, TILED, MT, RM>; }
 
 // the kernel instantiated for MT row blocks (fp32: 1..6, 8, 10, ..., 20, 21, 22, 23; fp64: 1..6, 8, 10, 11)
 template <typename T>
-static const void *pick_mfma_kernel(int MT, bool tiled) {
-#define WAGG_PICK(M) case M: return tiled ? mfma_kernel_ptr<T, true, M>() : mfma_kernel_ptr<T, false, M>()
+static const void *pick_mfma_kernel(int MT, bool tiled, bool rm = false) {
+#define WAGG_PICK(M) case M: return tiled ? (rm ? mfma_kernel_ptr<T, true, M, true>() : mfma_kernel_ptr<T, true, M>()) \
+                                          : mfma_kernel_ptr<T, false, M>()
     if constexpr (sizeof(T) == 4) {
         switch (MT) {
             WAGG_PICK(1); WAGG_PICK(2); WAGG_PICK(3); WAGG_PICK(4); WAGG_PICK(5); WAGG_PICK(6); WAGG_PICK(8);
@@ -864,6 +894,12 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     hipStream_t st = (hipStream_t)stream;
     const void *kern = pick_mfma_kernel<T>(MT, d->tiled);
     if (!kern) { set_error("no kernel for MT=%d", MT); return WAGG_EINVAL; }
+    // pack-free first pass (tile-sparse form, plain aggregation of 16-byte-aligned rows that hold whole k tiles):
+    // the MFMA kernel reads X where it lies; the packed pass below then runs only if a numerator came out
+    // non-finite (NaN / +-inf somewhere in the data), gated on the device so the stream never waits for the host
+    const bool rm = d->tiled && xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx;
+    const void *kern_rm = rm ? pick_mfma_kernel<T>(MT, true, true) : nullptr;
+    if (rm) WAGG_HIP(allow_dynamic_lds(kern_rm, shmem));
 #ifdef WAGG_DIAG      // ablation variants (timing only; results are wrong with bit0 or bit2): tools/dense_ablate.sh
     if constexpr (sizeof(T) == 4) {
         if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
@@ -886,22 +922,38 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     }
 #endif
     WAGG_HIP(allow_dynamic_lds(kern, shmem));
-    hipLaunchKernelGGL((dense_pack_x_kernel<T>), dim3(256 * 16), dim3(256), 0, st, X_dev, Tn, ldx, d->G, n_kt, bm, x_slots,
-                       aligned, reinterpret_cast<vec_t *>(d->xp.p), xf, d->inf_dev);
-    WAGG_HIP(hipGetLastError());
     const T *xp = reinterpret_cast<const T *>(d->xp.p), *wp = reinterpret_cast<const T *>(d->W.p);
     T *slabs = reinterpret_cast<T *>(d->slabs.p);
     int n_kt_a = n_kt, n_nt_a = n_nt, n_mb_a = n_mb, S_a = S, kps = kt_per_slice;
     const int32_t *tkt = d->tile_kt.p;
     const int32_t *toff = d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr;
-    void *args[] = {&xp, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff};
-    profile_mark(st, true);
-    WAGG_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
-    profile_mark(st, false);
+    int64_t ldxB = ldx * (int64_t)sizeof(T);
+    int Tn_a = (int)Tn;
     const T *den;
     if constexpr (sizeof(T) == 4) den = d->den32.p; else den = d->den64.p;
-    hipLaunchKernelGGL((dense_reduce_kernel<T>), dim3((unsigned)((d->R + 255) / 256), (unsigned)Tn), dim3(256), 0, st,
-                       (const T *)slabs, n_nt, S, bm, Tn, d->R, den, out_dev, ldo);
+    const dim3 rgrid((unsigned)((d->R + 255) / 256), (unsigned)Tn);
+    const int *gate = nullptr;
+    if (rm) {
+        gate = d->nonfinite.p;
+        WAGG_HIP(hipMemsetAsync(d->nonfinite.p, 0, sizeof(int), st));
+        const int *no_gate = nullptr;
+        void *args_rm[] = {&X_dev, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &no_gate};
+        profile_mark(st, true);
+        WAGG_HIP(hipLaunchKernel(kern_rm, dim3((unsigned)nblk), dim3(D_THREADS), args_rm, shmem, st));
+        profile_mark(st, false);
+        hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
+                           out_dev, ldo, d->nonfinite.p, (const int *)nullptr);
+        WAGG_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((dense_pack_x_kernel<T>), dim3(256 * 16), dim3(256), 0, st, X_dev, Tn, ldx, d->G, n_kt, bm, x_slots,
+                       aligned, reinterpret_cast<vec_t *>(d->xp.p), xf, d->inf_dev, gate);
+    WAGG_HIP(hipGetLastError());
+    void *args[] = {&xp, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &gate};
+    if (!rm) profile_mark(st, true);
+    WAGG_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
+    if (!rm) profile_mark(st, false);
+    hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
+                       out_dev, ldo, (int *)nullptr, gate);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }

@@ -78,6 +78,8 @@ struct wagg_dense {
     int ncu = 256;
     // +-inf seen in the (transformed) data of an apply in one of the MFMA forms: host-mapped word
     int *inf_host = nullptr, *inf_dev = nullptr;
+    // pack-free tile-sparse apply: "a numerator of the first pass was not finite" (device word, gates the exact second pass)
+    wagg::DevBuf<int> nonfinite;
     ~wagg_dense() { if (inf_host) (void)hipHostFree(inf_host); }
 };
 

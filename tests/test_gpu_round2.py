@@ -526,3 +526,64 @@ def test_dropin_streams_host_fields_through_the_pipeline(torch_cuda):
         "tas", "areawt", "hierid", df).tas.values
     _rel_ok(host, ref, RTOL32)
     np.testing.assert_array_equal(host, dev)
+
+
+# ---------------------------------------------------------------------------------------------
+# tile-sparse form: pack-free first pass (the MFMA kernel reads X where it lies) + gated exact second pass
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tile_sparse_pack_free_pass_and_its_exact_fallback(torch_cuda, dtype):
+    """Aligned plain applies of a tile-sparse plan skip dense_pack_x_kernel: same bits as the packed pass
+    (forced here through a 4-byte-shifted view of the same numbers), against the oracle, for ragged T
+    (clamped rows), padded row pitch, and -- through the device-gated second pass -- NaN (S6: skipped)
+    and +-inf data (noted for the caller)."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    G, R, seed = 64 * 80, 1000, 5                              # whole k tiles: the pack-free pass applies
+    W = O.blocklocal_weights_oracle(G, R, seed)
+    plan = DensePlan.synth_blocklocal(G, R, seed, dtype="float64" if dtype == np.float64 else "float32")
+    assert plan.info["tiled"] == 1
+    rng = np.random.default_rng(12)
+    rtol = RTOL32 if dtype == np.float32 else 1e-9
+
+    def shifted(Xh):
+        """the same rows at an address that is not 16-byte aligned -> the packed pass"""
+        big = torch.zeros((Xh.shape[0], G + 4), dtype=tdt, device="cuda")
+        view = big[:, 1:G + 1]
+        view.copy_(torch.from_numpy(Xh))
+        assert view.data_ptr() % 16 != 0
+        return view
+
+    for T in (400, 1, 17, 209):
+        Xh = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+        ref = O.agg_dense(Xh, W)
+        got = plan.apply(torch.from_numpy(Xh).cuda())
+        _rel_ok(got.cpu().numpy(), ref, rtol)
+        assert torch.equal(got, plan.apply(shifted(Xh)))       # pack-free == packed, bit for bit
+        assert not plan.saw_inf()
+        # padded pitch (rows 16-byte aligned, ldx > G)
+        pitched = torch.zeros((T, G + 64), dtype=tdt, device="cuda")
+        pitched[:, :G].copy_(torch.from_numpy(Xh))
+        pitched[:, G:] = float("nan")                          # never read as data of a stored cell
+        assert torch.equal(plan.apply(pitched[:, :G]), got)
+    # NaN data: the first pass trips the gate, the second pass gives the skipna result
+    T = 300
+    Xh = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+    Xh[7, 100] = np.nan
+    Xh[T - 1, G - 1] = np.nan
+    ref = O.agg_dense(Xh, W)
+    got = plan.apply(torch.from_numpy(Xh).cuda())
+    _rel_ok(got.cpu().numpy(), ref, rtol)
+    assert torch.equal(got, plan.apply(shifted(Xh)))
+    assert not plan.saw_inf()
+    # the gate is per apply: a finite field afterwards takes the first pass only and is right
+    Xf = np.nan_to_num(Xh, nan=281.0)
+    _rel_ok(plan.apply(torch.from_numpy(Xf).cuda()).cpu().numpy(), O.agg_dense(Xf, W), rtol)
+    # +-inf data: same note for the caller as the packed pass gives
+    Xh[5, 64] = np.inf
+    plan.apply(torch.from_numpy(Xh).cuda())
+    assert plan.saw_inf()
+    assert not plan.saw_inf()
+    plan.close()
