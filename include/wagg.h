@@ -256,7 +256,11 @@ int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
 /* out[t, r] = sum_g nan0(X[t,g]) * W[g,r] / den[r], fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * ksplit = 0 picks the k-slice count; otherwise a multiple of 8.  The plan owns the packed copy of
  * X and the partial-sum slabs of an apply (hence the non-const handle): applies on ONE dense plan
- * must be ordered on one stream; different plans are independent.                               */
+ * must be ordered on one stream; different plans are independent.
+ * Tile-sparse plans read X where it lies when its rows are 16-byte aligned and hold whole k tiles
+ * (ldx >= 32 ceil(G/32) floats, 16 ceil(G/16) doubles): no packed copy is written; a field with NaN
+ * or +-inf in it is noticed on the device (non-finite numerators) and redone through the packed
+ * pass on the same stream, so the result and wagg_dense_saw_inf are the same either way.          */
 int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                          float *out_dev, int64_t ldo, int ksplit, void *stream);
 /* fp64 data on an fp64 plan: out = sum_g nan0(X[t,g]) * W[g,r] / den[r] on v_mfma_f64_16x16x4_f64 */
