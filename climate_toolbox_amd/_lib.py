@@ -17,7 +17,7 @@ OUT_TR, OUT_RT = 0, 1
 
 # every symbol include/wagg.h declares (tests check that the .so exports all of them)
 EXPORTS = (
-    "wagg_version", "wagg_device_count", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
+    "wagg_version", "wagg_device_count", "wagg_shard_rows", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
     "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
     "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den", "wagg_plan_status",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
@@ -69,6 +69,7 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i32p, f64p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
     L.wagg_version.restype = C.c_int
+    L.wagg_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wagg_device_count.restype = C.c_int
     L.wagg_last_error.restype = C.c_char_p
     L.wagg_profile_enable.argtypes = [C.c_int]

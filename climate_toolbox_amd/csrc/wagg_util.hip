@@ -218,6 +218,19 @@ extern "C" int wagg_device_count(void) {
     return n;
 }
 
+// rows [start, stop) of rank `rank` when T rows are split over `world` devices: the first T mod world ranks
+// take one row more (the rule of climate_toolbox_amd/timeshard.py, for bindings in other languages)
+extern "C" int wagg_shard_rows(int64_t T, int world, int rank, int64_t *start, int64_t *stop) {
+    using namespace wagg;
+    WAGG_REQUIRE(T >= 0 && world >= 1 && rank >= 0 && rank < world, "bad shard request: T=%lld world=%d rank=%d",
+                 (long long)T, world, rank);
+    WAGG_REQUIRE(start && stop, "NULL argument");
+    const int64_t base = T / world, extra = T % world;
+    *start = rank * base + (rank < extra ? rank : extra);
+    *stop = *start + base + (rank < extra ? 1 : 0);
+    return WAGG_OK;
+}
+
 extern "C" const char *wagg_last_error(void) { return wagg::g_err; }
 
 extern "C" int wagg_gather_f32(const float *X, int64_t T, int64_t ldx, int layout,

@@ -70,6 +70,9 @@ typedef struct wagg_plan_info {
 /* ---- process / device ------------------------------------------------------------------- */
 int wagg_version(void);                 /* 10000*major + 100*minor + patch */
 int wagg_device_count(void);            /* number of visible HIP devices (0 if none), never <0  */
+/* Time-axis sharding rule of the multi-GPU form (one process per GPU; climate_toolbox_amd/timeshard.py):
+ * rank `rank` of `world` owns rows [*start, *stop) of T; the first T mod world ranks hold one row more. */
+int wagg_shard_rows(int64_t T, int world, int rank, int64_t *start, int64_t *stop);
 const char *wagg_last_error(void);      /* thread-local, never NULL                              */
 
 /* ---- in-library kernel timing (HIP events on the stream the kernel is launched on) ----------- */

@@ -50,3 +50,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.WaggError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_shard_rule_of_the_c_abi_is_the_one_timeshard_uses():
+    """wagg_shard_rows (for bindings in other languages) = climate_toolbox_amd.timeshard.shard_bounds."""
+    import ctypes as C
+    from climate_toolbox_amd import _lib
+    from climate_toolbox_amd.timeshard import shard_bounds
+    L = _lib.load()
+    for T in (0, 1, 7, 365, 10950, 18250):
+        for world in (1, 2, 3, 8):
+            want = shard_bounds(T, world)
+            for rank in range(world):
+                a, b = C.c_int64(-1), C.c_int64(-1)
+                assert L.wagg_shard_rows(T, world, rank, C.byref(a), C.byref(b)) == 0
+                assert (a.value, b.value) == want[rank]
+    a, b = C.c_int64(), C.c_int64()
+    assert L.wagg_shard_rows(10, 2, 2, C.byref(a), C.byref(b)) == -1
+    assert L.wagg_shard_rows(10, 0, 0, C.byref(a), C.byref(b)) == -1
