@@ -58,8 +58,9 @@ def parse():
     ap.add_argument("--land-frac", type=float, default=0.30, help="experiment knob for c2-real")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--diag-lib", action="store_true",
-                    help="load libwagg_diag.so (make diag): the build with the ablation knobs; timing experiments only")
+    ap.add_argument("--diag-lib", nargs="?", const="libwagg_diag.so", default=None, metavar="NAME",
+                    help="load climate_toolbox_amd/lib/NAME (default libwagg_diag.so, `make diag`) instead of libwagg.so: "
+                         "the build with the ablation knobs, or an experiment's variant; timing experiments only")
     return ap.parse_args()
 
 
@@ -196,7 +197,7 @@ def main():
 
     from climate_toolbox_amd import _lib, engine, synth
     if a.diag_lib:
-        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libwagg_diag.so")
+        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.path.basename(a.diag_lib))
     from climate_toolbox_amd.timeshard import ShardedStep, shard_bounds
 
     G, R = a.nlat * a.nlon, a.R

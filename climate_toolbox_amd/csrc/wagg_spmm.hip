@@ -36,6 +36,7 @@
 //     carry w = 0 into a trash accumulator.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "wagg_dense_int.h"
 
@@ -49,12 +50,22 @@ constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB nobody reads:
 constexpr int SP_LDS_BYTES = SP_SINK + 1024;
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
 
-#include "wagg_spmm_asm.inc"
+#ifndef WAGG_SPMM_ASM_INC          // tools/spmm_ablate.sh builds variants of the generated loop
+#define WAGG_SPMM_ASM_INC "wagg_spmm_asm.inc"
+#endif
+#include WAGG_SPMM_ASM_INC
 
 __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
     const float *__restrict__ Xp, const uint32_t *__restrict__ ent, const int32_t *__restrict__ grp_off,
     float *__restrict__ slabT, int n_tb, int n_rb, int n_chunks, int cps, int rw, int64_t Gpad,
-    int64_t Tpad, int64_t Rpad, int n_items, int n_groups) {
+    int64_t Tpad, int64_t Rpad, int n_items, int n_groups, int knob) {
+#ifdef WAGG_DIAG     // knob bit 0 (WAGG_SPMM_KNOB, diagnostic build only): no end-of-chunk barrier -- WRONG results,
+                     // timing only: the upper bound of what removing the per-chunk synchronisation could give
+#define SPMM_CHUNK_SYNC asm volatile("s_waitcnt vmcnt(0)\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 Lnb%=\n\ts_barrier\nLnb%=:" : : "s"(knob) : "memory", "scc")
+#else
+#define SPMM_CHUNK_SYNC asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+    (void)knob;
+#endif
     extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink; filled by LDS-DMA only
     const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char *)lds;   // 0: the only LDS object
     const int tid = threadIdx.x;
@@ -121,22 +132,30 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         // Chunks go in PAIRS, statement A then statement B, straight-line (an if/else between the two
         // statements makes the compiler shuffle the pinned accumulators through scratch); an odd count is
         // padded with an empty chunk (n = 0: its statement only re-issues harmless loads).
-        auto chunk_args = [&](int c, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, const char *&wsrc,
-                              int &l0, int &bufbit, int &wlim) {
-            const bool real = c < c1;
-            const int cc = real ? c : c1 - 1;
+        // The group offsets of a chunk are scalar loads (several hundred cycles).  They are ISSUED before the
+        // end-of-chunk synchronisation of the previous statement and first touched behind it (the empty asm
+        // pins that order), so their latency passes while the wave waits at the barrier anyway.
+        struct Raw { int g0, g1, gn, gw, cn, real; };
+        auto chunk_loads = [&](int c, Raw &r) {
+            r.real = c < c1;
+            const int cc = r.real ? c : c1 - 1;
             // next chunk (the last one re-loads itself: harmless), list warm-up three chunks ahead
-            const int cn = cc + 1 < c1 ? cc + 1 : cc, cw = cc + 3 < c1 ? cc + 3 : c1 - 1;
-            const int g0 = goff[(int64_t)cc * SP_WAVES], g1 = goff[(int64_t)cc * SP_WAVES + 1];
-            const int gn = goff[(int64_t)cn * SP_WAVES], gw = goff[(int64_t)cw * SP_WAVES];
-            n = real ? g1 - g0 : 0;
-            pc = reinterpret_cast<uint64_t>(ent + (int64_t)g0 * (2 * SP_GROUP));
-            pn = reinterpret_cast<uint64_t>(ent + (int64_t)gn * (2 * SP_GROUP));
-            src = xbase + (int64_t)cn * SP_BUF_BYTES;
-            wsrc = reinterpret_cast<const char *>(ent) + (int64_t)gw * 64;
+            r.cn = cc + 1 < c1 ? cc + 1 : cc;
+            const int cw = cc + 3 < c1 ? cc + 3 : c1 - 1;
+            r.g0 = goff[(int64_t)cc * SP_WAVES]; r.g1 = goff[(int64_t)cc * SP_WAVES + 1];
+            r.gn = goff[(int64_t)r.cn * SP_WAVES]; r.gw = goff[(int64_t)cw * SP_WAVES];
+        };
+        auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, const char *&wsrc,
+                              int &l0, int &bufbit, int &wlim) {
+            asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn), "+s"(r.gw));
+            n = r.real ? r.g1 - r.g0 : 0;
+            pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * (2 * SP_GROUP));
+            pn = reinterpret_cast<uint64_t>(ent + (int64_t)r.gn * (2 * SP_GROUP));
+            src = xbase + (int64_t)r.cn * SP_BUF_BYTES;
+            wsrc = reinterpret_cast<const char *>(ent) + (int64_t)r.gw * 64;
             l0 = lds0 + (par ^ 1) * SP_BUF_BYTES + wave * 4096;
             bufbit = lds0 + par * SP_BUF_BYTES;
-            wlim = n_groups - gw;
+            wlim = n_groups - r.gw;
         };
         const int sink = lds0 + SP_SINK;
 #define SPMM_CHUNK_STMT(ASM)                                                                                  \
@@ -146,17 +165,21 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
                        [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src),  \
                        [wsrc] "s"(wsrc), [wlim] "s"(wlim), [sink] "s"(sink)                                   \
                      : "memory", "scc", SPMM_CHUNK_CLOBBERS)
+        Raw ra, rb_;
+        chunk_loads(c0, ra);
         for (int c = c0; c < c1; c += 2) {
             int n, l0, bufbit, wlim;
             uint64_t pc, pn;
             const char *src, *wsrc;
-            chunk_args(c, 0, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            chunk_args(ra, 0, n, pc, pn, src, wsrc, l0, bufbit, wlim);
             SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_A);               // this chunk's list in set A, the next one's -> B
+            chunk_loads(c + 1, rb_);
             // this wave's pieces of the next chunk and the next list have landed; it is done reading this chunk
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            chunk_args(c + 1, 1, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            SPMM_CHUNK_SYNC;
+            chunk_args(rb_, 1, n, pc, pn, src, wsrc, l0, bufbit, wlim);
             SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_B);
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            chunk_loads(c + 2, ra);
+            SPMM_CHUNK_SYNC;
         }
 #undef SPMM_CHUNK_STMT
         // partial sums of this k slice: region j of the wave, 128 consecutive timesteps (two per lane) per store
@@ -424,10 +447,14 @@ int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const Pack
     WAGG_HIP(hipGetLastError());
     WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel, SP_LDS_BYTES));
     const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
+    int knob = 0;
+#ifdef WAGG_DIAG
+    if (const char *k = getenv("WAGG_SPMM_KNOB")) knob = atoi(k);
+#endif
     profile_mark(st, true);
     hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const float *)d->xp.p,
                        (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, d->slabs.p, n_tb, sp.n_rb, sp.n_chunks, cps,
-                       sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups);
+                       sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups, knob);
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)(Tpad / 64)), dim3(256), 0, st,

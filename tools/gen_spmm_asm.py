@@ -37,6 +37,9 @@ VO, LANE, SCR, LB, VMASK = 3, 12, 13, 30, 31
 ACC0 = 40
 MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
 PK = int(os.environ.get("SPMM_PK", "1"))   # 1: v_pk_fma_f32, 0: two v_fma_f32
+# ablation variants for tools/spmm_ablate.sh (timing only, results are wrong): any of nofma, nolds, noidx, now, nobfi,
+# nodma, halfdma, nolist, noent
+ABL = set(filter(None, os.environ.get("SPMM_ABL", "").split(",")))
 
 
 def lane_regs(o, with_lb):
@@ -65,24 +68,32 @@ def issue(h, which, S, T, o):
     b, base = divmod(4 * h, 64)
     for k in range(4):
         o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k, lo0 + b, base + k))
-        o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, hi0 + b, base + k))
+        if "now" not in ABL:
+            o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, hi0 + b, base + k))
     for k in range(4):
-        o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, LB))
+        if "nobfi" not in ABL:
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, LB))
     for k in range(4):
-        o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
+        if "nolds" not in ABL:
+            o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
 
 
 def fma(S, T, younger, o):
     for k in range(4):
-        o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % (S + 2 * k))
-        o.append("s_waitcnt lgkmcnt(%d)" % (3 - k + younger))
+        if "noidx" not in ABL:
+            o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % (S + 2 * k))
+        if "nolds" not in ABL:
+            o.append("s_waitcnt lgkmcnt(%d)" % (3 - k + younger))
+        if "nofma" in ABL:
+            continue
         if PK:
             o.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[0,1,0]"
                      % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, S + 2 * k, S + 2 * k + 1, ACC0, ACC0 + 1))
         else:
             o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0, T + 2 * k, S + 2 * k + 1, ACC0))
             o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0 + 1, T + 2 * k + 1, S + 2 * k + 1, ACC0 + 1))
-    o.append("s_set_gpr_idx_off")
+    if "noidx" not in ABL:
+        o.append("s_set_gpr_idx_off")
 
 
 def chunk(cur, nxt):
@@ -91,21 +102,26 @@ def chunk(cur, nxt):
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
     lane_regs(o, True)
-    load_list(o, nxt)                                          # 1. the NEXT chunk's list
+    if "nolist" not in ABL:
+        load_list(o, nxt)                                      # 1. the NEXT chunk's list
     o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))         # lane * 16: LDS-DMA of the next X tile
-    for i in range(4):
+    for i in range(2 if "halfdma" in ABL else 4):
         if i:
             o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
         o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
         o.append("s_nop 0")
-        o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
+        if "nodma" not in ABL:
+            o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
     o.append("v_min_u32 v%d, %%[wlim], v%d" % (SCR, LANE))     # L2 warm-up, one 64-byte line per lane
     o.append("v_lshlrev_b32 v%d, 6, v%d" % (SCR, SCR))
     o.append("s_mov_b32 m0, %[sink]")
     o.append("s_nop 0")
-    o.append("global_load_lds_dword v%d, %%[wsrc]" % SCR)
+    if "nolist" not in ABL:
+        o.append("global_load_lds_dword v%d, %%[wsrc]" % SCR)
     o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
     o.append("s_cbranch_scc1 8f")
+    if "noent" in ABL:
+        o.append("s_branch 8f")
     n_half = N_BLOCKS * 16
     issue(0, cur, SA, TP, o)
     for h in range(n_half):
@@ -164,11 +180,12 @@ def emit(f, name, lines):
 
 
 def main():
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "climate_toolbox_amd", "csrc",
-                        "wagg_spmm_asm.inc")
+    path = os.environ.get("SPMM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                     "climate_toolbox_amd", "csrc", "wagg_spmm_asm.inc")
     a, b, p = chunk("A", "B"), chunk("B", "A"), prologue()
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_spmm_asm.py (SPMM_PK=%d) -- do not edit; see that script for the register map.\n" % PK)
+        f.write("// GENERATED by tools/gen_spmm_asm.py (SPMM_PK=%d%s) -- do not edit; see that script for the register map.\n"
+                % (PK, " SPMM_ABL=" + ",".join(sorted(ABL)) if ABL else ""))
         emit(f, "SPMM_LOAD_LIST_ASM", p)
         emit(f, "SPMM_CHUNK_ASM_A", a)
         emit(f, "SPMM_CHUNK_ASM_B", b)
