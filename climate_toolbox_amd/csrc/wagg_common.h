@@ -131,8 +131,12 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int6
     const size_t xbytes = sizeof(T) * (size_t)(Tn * ldx), obytes = sizeof(T) * (size_t)(Tn * ldo);
     bool pin_x = false, pin_o = false;
     if (flags & WAGG_HOST_PIN) {
-        pin_x = hipHostRegister(const_cast<T *>(X_host), xbytes, hipHostRegisterDefault) == hipSuccess;
-        pin_o = hipHostRegister(out_host, obytes, hipHostRegisterDefault) == hipSuccess;
+        // Registration works on whole pages and costs ~0.1 ms per MiB.  Below 32 MiB (glibc's largest mmap threshold)
+        // an array may live in the brk heap and share its first and last page with unrelated heap objects, which would
+        // then be page-locked and GPU-mapped along with it: such buffers are staged instead (they are small anyway).
+        constexpr size_t PIN_MIN = (size_t)32 << 20;
+        pin_x = xbytes >= PIN_MIN && hipHostRegister(const_cast<T *>(X_host), xbytes, hipHostRegisterDefault) == hipSuccess;
+        pin_o = obytes >= PIN_MIN && hipHostRegister(out_host, obytes, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();            // a failed registration is not an error: the copies are staged instead
     }
     struct Guard {              // everything acquired here is released on every exit path

@@ -138,6 +138,8 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  * (host arrays of c4 / c5 size, 45-76 GB, need no device copy of the whole field).  flags:
  *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister) so that the
  *                    copies are truly asynchronous; without it pageable memory is staged by the runtime
+ *                    (arrays below 32 MiB are always staged: registration locks whole pages, and small
+ *                    arrays share theirs with other heap objects)
  *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
  * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN.  Measured on one MI355X (tools/host_path_timing.py):
  * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks,
