@@ -494,7 +494,7 @@ def test_host_streaming_forms_agree_with_the_device_apply(torch_cuda):
     with pytest.raises(_lib.WaggError):
         plan.apply_host(X, flags=64)
     # dense-family plan: blocks are whole 368-row launches
-    Gd, Rd, Td = 4096, 300, 1000
+    Gd, Rd, Td = 4096, 300, 2100                               # X: 34 MB (page-locked under HOST_PIN), out: 2.5 MB (staged)
     W = rng.uniform(0, 1, (Gd, Rd)).astype(np.float32)
     Xd = (280 + 20 * rng.standard_normal((Td, Gd))).astype(np.float32)
     dplan = DensePlan.from_host(W)
