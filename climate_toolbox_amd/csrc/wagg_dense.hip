@@ -110,8 +110,9 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     int kt_per_slice, T *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
     const int32_t *__restrict__ tile_off = nullptr, int64_t ldxB = 0, int Tn = 0, const int *__restrict__ gate = nullptr) {
     static_assert(MT <= DT<T>::MT_MAX, "accumulators of MT row blocks must fit the register file");
-    static_assert(!RM || TILED, "the pack-free X source exists for the tile-sparse form only");
-    if constexpr (TILED && !RM) { if (gate != nullptr && *gate == 0) return; }     // second pass not needed
+    // the gated second pass: every tile-sparse packed kernel, and the DBG = 256 instantiations of the full form (the
+    // plain <T, 0, false, MT> kernels stay as they are: their tile loop is sensitive to code placement)
+    if constexpr (!RM && (TILED || DBG == 256)) { if (gate != nullptr && *gate == 0) return; }
     typedef typename DT<T>::vec vec_t;
     typedef typename DT<T>::acc acc_t;
     constexpr int KS = DT<T>::EPP;                   // MFMA k-steps fed by one 16-byte fragment read
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
 
     // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
     // moves W pieces wave + 8 i (i < 4) and X pieces wave + 8 i (i < NXP, those below XPIECES)
-    const char *xsrc = RM ? reinterpret_cast<const char *>(Xp) + (int64_t)mb * (MT * 16) * ldxB +
+    const char *xsrc = RM ? reinterpret_cast<const char *>(Xp) + (int64_t)mb * (MT * 16) * ldxB + (int64_t)kt0 * D_ROWB +
                                 ((((lane & 7) ^ (lane >> 4)) ^ ((wave & 1) << 2)) << 4)
                           : reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
     const int rm_row = lane >> 3, rm_rmax = RM ? Tn - 1 - mb * (MT * 16) : 0;
@@ -825,6 +826,19 @@ static int create_from_segments(const int32_t *cell_idx, const int32_t *region_c
 
 template <typename T, bool TILED, int MT, bool RM = false>
 static const void *mfma_kernel_ptr() { return (const void *)dense_mfma_kernel<T, 0, TILED, MT, RM>; }
+// full form, pack-free: instantiated for the tall row blocks only (fp32 MT >= 20, fp64 MT >= 10), where the packing
+// pass is worth skipping; rm = first pass reading X in place, !rm = its gated packed second pass (DBG = 256)
+template <typename T>
+static const void *pick_full_rm_kernel(int MT, bool rm) {
+#define WAGG_PICK(M) case M: return rm ? (const void *)dense_mfma_kernel<T, 0, false, M, true> \
+                                       : (const void *)dense_mfma_kernel<T, 256, false, M, false>
+    if constexpr (sizeof(T) == 4) {
+        switch (MT) { WAGG_PICK(20); WAGG_PICK(21); WAGG_PICK(22); WAGG_PICK(23); default: return nullptr; }
+    } else {
+        switch (MT) { WAGG_PICK(10); WAGG_PICK(11); default: return nullptr; }
+    }
+#undef WAGG_PICK
+}
 
 // the kernel instantiated for MT row blocks (fp32: 1..6, 8, 10, ..., 20, 21, 22, 23; fp64: 1..6, 8, 10, 11)
 template <typename T>
@@ -897,10 +911,18 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     // pack-free first pass (tile-sparse form, plain aggregation of 16-byte-aligned rows that hold whole k tiles):
     // the MFMA kernel reads X where it lies; the packed pass below then runs only if a numerator came out
     // non-finite (NaN / +-inf somewhere in the data), gated on the device so the stream never waits for the host
-    const bool rm = d->tiled && xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx;
-    const void *kern_rm = rm ? pick_mfma_kernel<T>(MT, true, true) : nullptr;
+    bool rm = xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx;
+    const void *kern_rm = nullptr;
+    if (rm && d->tiled) kern_rm = pick_mfma_kernel<T>(MT, true, true);
+    else if (rm && (kern_rm = pick_full_rm_kernel<T>(MT, true)) != nullptr) kern = pick_full_rm_kernel<T>(MT, false);
+    rm = kern_rm != nullptr;
     if (rm) WAGG_HIP(allow_dynamic_lds(kern_rm, shmem));
 #ifdef WAGG_DIAG      // ablation variants (timing only; results are wrong with bit0 or bit2): tools/dense_ablate.sh
+    // WAGG_DENSE_PACKED=1 (or any WAGG_DENSE_DBG variant): always take the packed pass, for A/B runs on one GPU
+    if (getenv("WAGG_DENSE_PACKED") || (!d->tiled && getenv("WAGG_DENSE_DBG"))) {
+        rm = false; kern_rm = nullptr;
+        kern = pick_mfma_kernel<T>(MT, d->tiled);
+    }
     if constexpr (sizeof(T) == 4) {
         if (const char *dbg = (d->tiled || MT != D_MT) ? nullptr : getenv("WAGG_DENSE_DBG")) {
             switch (atoi(dbg)) {

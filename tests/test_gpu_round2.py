@@ -587,3 +587,45 @@ def test_tile_sparse_pack_free_pass_and_its_exact_fallback(torch_cuda, dtype):
     assert plan.saw_inf()
     assert not plan.saw_inf()
     plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_full_form_pack_free_pass_for_tall_row_blocks(torch_cuda, dtype):
+    """The full-matrix form takes the same pack-free first pass when the row blocks are tall (fp32: >= 20 x 16 rows,
+    fp64: >= 10 x 16): same bits as the packed pass, NaN / inf through the gated second pass; short blocks and
+    ragged grids keep the packed pass."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    rng = np.random.default_rng(21)
+    G, R = 4096, 300
+    W = rng.uniform(0.0, 1.0, (G, R)).astype(dtype)
+    plan = DensePlan.from_host(W)
+    assert plan.info["tiled"] == 0
+    rtol = RTOL32 if dtype == np.float32 else 1e-9
+    tall = (365, 700, 1369) if dtype == np.float32 else (170, 365)
+
+    def shifted(Xh):
+        big = torch.zeros((Xh.shape[0], G + 4), dtype=tdt, device="cuda")
+        view = big[:, 1:G + 1]
+        view.copy_(torch.from_numpy(Xh))
+        return view
+
+    for T in tall + (40,):
+        Xh = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+        got = plan.apply(torch.from_numpy(Xh).cuda())
+        _rel_ok(got.cpu().numpy(), O.agg_dense(Xh, W), rtol)
+        assert torch.equal(got, plan.apply(shifted(Xh)))
+    T = tall[0]
+    Xh = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+    Xh[3, 17] = np.nan
+    Xh[T - 1, G - 1] = np.nan
+    got = plan.apply(torch.from_numpy(Xh).cuda())
+    _rel_ok(got.cpu().numpy(), O.agg_dense(Xh, W), rtol)
+    assert torch.equal(got, plan.apply(shifted(Xh)))
+    assert not plan.saw_inf()
+    Xh[9, 1000] = -np.inf
+    plan.apply(torch.from_numpy(Xh).cuda())
+    assert plan.saw_inf()
+    plan.close()
