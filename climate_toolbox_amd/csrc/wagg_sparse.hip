@@ -765,25 +765,29 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             int cnt = nt - tw0;
             cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
             const float *p = X + (t0 + rbase) * ldx + cell0;
+            if constexpr (!EDD) {
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                if (VEC) R.v[i] = *reinterpret_cast<const vec4 *>(p);
-                else {
-                    const int64_t lim = G - 1 - cell0;
-                    R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
+                for (int i = 0; i < TPW; ++i) {
+                    if (VEC) R.v[i] = *reinterpret_cast<const vec4 *>(p);
+                    else {
+                        const int64_t lim = G - 1 - cell0;
+                        R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
+                    }
+                    if (i + 1 < cnt) p += ldx;
                 }
-                if (i + 1 < cnt) p += ldx;
-            }
-            if constexpr (EDD) {                                  // the second field: tasmax
+            } else {
+                // degree days: the two fields row by row (tasmin row i, tasmax row i, ...): loads retire in order, so the
+                // arithmetic of row i can start while the rows behind it are still in flight
                 const float *p2 = pv.X2 + (t0 + rbase) * ldx + cell0;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    if (VEC) R.h[i] = *reinterpret_cast<const vec4 *>(p2);
+                    if (VEC) { R.v[i] = *reinterpret_cast<const vec4 *>(p); R.h[i] = *reinterpret_cast<const vec4 *>(p2); }
                     else {
                         const int64_t lim = G - 1 - cell0;
+                        R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
                         R.h[i] = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
                     }
-                    if (i + 1 < cnt) p2 += ldx;
+                    if (i + 1 < cnt) { p += ldx; p2 += ldx; }
                 }
             }
         };
@@ -915,7 +919,9 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         auto lstage_edd = [&](Regs &R, int st) {
             const bool more = st + 1 < nst;
             for (int k = 0; k < K; ++k) {
+                stamp(-1);
                 park_edd(R, dPark, tbPark, sbuf, k);
+                stamp(2);                                         // ph2: wait for the item's rows + degree-day arithmetic + park
                 if (k + 1 == K && more) {
                     const StreamDesc dn = dq[0];
                     const int tbn = itq[0].tb;
@@ -925,7 +931,9 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
                     dPark = dn; tbPark = tbn;
                     ahead_commit(a);
                 }
+                stamp(0);                                         // ph0: issue
                 lds_only_barrier();
+                stamp(3);                                         // ph3: waiting for the consumers
                 sbuf ^= 1;
             }
         };
