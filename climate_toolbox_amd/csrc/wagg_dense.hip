@@ -914,7 +914,9 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     bool rm = xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx;
     const void *kern_rm = nullptr;
     if (rm && d->tiled) kern_rm = pick_mfma_kernel<T>(MT, true, true);
-    else if (rm && (kern_rm = pick_full_rm_kernel<T>(MT, true)) != nullptr) kern = pick_full_rm_kernel<T>(MT, false);
+    // (full form: only with two or more row blocks -- with one, A/B on one GPU shows the step unchanged: the kernel
+    // loses reading in place what the skipped packing pass saves)
+    else if (rm && n_mb >= 2 && (kern_rm = pick_full_rm_kernel<T>(MT, true)) != nullptr) kern = pick_full_rm_kernel<T>(MT, false);
     rm = kern_rm != nullptr;
     if (rm) WAGG_HIP(allow_dynamic_lds(kern_rm, shmem));
 #ifdef WAGG_DIAG      // ablation variants (timing only; results are wrong with bit0 or bit2): tools/dense_ablate.sh

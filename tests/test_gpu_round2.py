@@ -604,7 +604,7 @@ def test_full_form_pack_free_pass_for_tall_row_blocks(torch_cuda, dtype):
     plan = DensePlan.from_host(W)
     assert plan.info["tiled"] == 0
     rtol = RTOL32 if dtype == np.float32 else 1e-9
-    tall = (365, 700, 1369) if dtype == np.float32 else (170, 365)
+    tall = (700, 1369, 365) if dtype == np.float32 else (340, 500, 170)     # two or more tall row blocks; one block (365 | 170): packed
 
     def shifted(Xh):
         big = torch.zeros((Xh.shape[0], G + 4), dtype=tdt, device="cuda")
