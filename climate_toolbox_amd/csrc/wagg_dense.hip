@@ -891,9 +891,21 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     else { for (int m : mts64) if (m * 16 >= rows) { MT = m; break; } }
     const int bm = MT * 16;
     int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
-    if (d->tiled) {               // fewest slices (1, 2, 4, 8) that still give >= 4 workgroups per CU
+    if (d->tiled) {
+        // slices (1, 2, 4, 8): the count whose workgroups fill whole rounds of the CUs best, less the cost of the
+        // slabs the reduce kernel then reads (measured on c5-block, 672 items: 2 slices = 5.25 rounds: kernel 9.65 /
+        // step 9.95 ms; 4: 8.94 / 9.35; 8 = exactly 21 rounds: 8.77 / 9.43), and at least ~16 stored tiles per slice
         S = 1;
-        while (S < wagg_dense::TS && (int64_t)n_nt * n_mb * S < 1024) S *= 2;
+        double best = -1.0;
+        for (int s = 1; s <= wagg_dense::TS; s *= 2) {
+            if (s > 1 && d->n_tiles / ((int64_t)n_nt * s) < 16) break;
+            const double blocks = (double)n_nt * n_mb * s;
+            const double eff = blocks / (std::ceil(blocks / d->ncu) * d->ncu) - 0.012 * s;
+            if (eff > best + 1e-9) { best = eff; S = s; }
+        }
+#ifdef WAGG_DIAG
+        if (const char *e = getenv("WAGG_TILED_S")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) S = v; }
+#endif
     }
     const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
