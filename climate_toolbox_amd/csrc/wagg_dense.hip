@@ -375,7 +375,8 @@ __host__ __device__ __forceinline__ int64_t wp_index(int64_t g, int64_t r, int n
 template <typename T>
 __global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
                                     int32_t R, const T *__restrict__ den, T *__restrict__ out, int64_t ldo,
-                                    int *__restrict__ nonfinite = nullptr, const int *__restrict__ gate = nullptr) {
+                                    int *__restrict__ nonfinite = nullptr, const int *__restrict__ gate = nullptr,
+                                    int *__restrict__ sticky = nullptr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t t = blockIdx.y;
     if (gate != nullptr && *gate == 0) return;
@@ -385,8 +386,10 @@ __global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S
     const T *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
     T s = T(0);
     for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
-    if (nonfinite != nullptr && !(fabs(s) <= std::numeric_limits<T>::max()))
+    if (nonfinite != nullptr && !(fabs(s) <= std::numeric_limits<T>::max())) {
         __hip_atomic_store(nonfinite, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sticky != nullptr) __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     out[t * ldo + r] = s / den[r];
 }
 
@@ -555,8 +558,8 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess) e = d->nonfinite.alloc(1);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, sizeof(int), hipHostMallocMapped);
-    if (e == hipSuccess) { *d->inf_host = 0; e = hipHostGetDevicePointer((void **)&d->inf_dev, d->inf_host, 0); }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, 2 * sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) { d->inf_host[0] = d->inf_host[1] = 0; e = hipHostGetDevicePointer((void **)&d->inf_dev, d->inf_host, 0); }
     if (e == hipSuccess) e = d->W.alloc((size_t)(d->w_slots() > 0 ? d->w_slots() : 1) * 4);
     if (e == hipSuccess) e = d->den32.alloc((size_t)R);
     if (e == hipSuccess) e = d->den64.alloc((size_t)R);
@@ -923,7 +926,10 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     // pack-free first pass (tile-sparse form, plain aggregation of 16-byte-aligned rows that hold whole k tiles):
     // the MFMA kernel reads X where it lies; the packed pass below then runs only if a numerator came out
     // non-finite (NaN / +-inf somewhere in the data), gated on the device so the stream never waits for the host
-    bool rm = xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx;
+    // ... and only while no earlier pack-free pass of this plan met such data: fields with NaN in them (ocean cells of
+    // land-only variables) tend to stay that way, and for them the first pass is pure overhead.  The note is a
+    // host-mapped word written by the reduce kernel; reading it here without synchronising is a heuristic only.
+    bool rm = xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx && ((volatile int *)d->inf_host)[1] == 0;
     const void *kern_rm = nullptr;
     if (rm && d->tiled) kern_rm = pick_mfma_kernel<T>(MT, true, true);
     // (full form: only with two or more row blocks -- with one, A/B on one GPU shows the step unchanged: the kernel
@@ -978,7 +984,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
         WAGG_HIP(hipLaunchKernel(kern_rm, dim3((unsigned)nblk), dim3(D_THREADS), args_rm, shmem, st));
         profile_mark(st, false);
         hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
-                           out_dev, ldo, d->nonfinite.p, (const int *)nullptr);
+                           out_dev, ldo, d->nonfinite.p, (const int *)nullptr, d->inf_dev + 1);
         WAGG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((dense_pack_x_kernel<T>), dim3(256 * 16), dim3(256), 0, st, X_dev, Tn, ldx, d->G, n_kt, bm, x_slots,
@@ -989,7 +995,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     WAGG_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
     if (!rm) profile_mark(st, false);
     hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
-                       out_dev, ldo, (int *)nullptr, gate);
+                       out_dev, ldo, (int *)nullptr, gate, (int *)nullptr);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }

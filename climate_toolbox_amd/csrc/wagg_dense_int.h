@@ -77,6 +77,7 @@ struct wagg_dense {
     wagg::SpmmPlan sp;
     int ncu = 256;
     // +-inf seen in the (transformed) data of an apply in one of the MFMA forms: host-mapped word
+    // ([1]: a pack-free first pass met NaN / +-inf: later applies of this plan go straight to the packed pass)
     int *inf_host = nullptr, *inf_dev = nullptr;
     // pack-free tile-sparse apply: "a numerator of the first pass was not finite" (device word, gates the exact second pass)
     wagg::DevBuf<int> nonfinite;

@@ -265,7 +265,8 @@ int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
  * Tile-sparse plans read X where it lies when its rows are 16-byte aligned and hold whole k tiles
  * (ldx >= 32 ceil(G/32) floats, 16 ceil(G/16) doubles): no packed copy is written; a field with NaN
  * or +-inf in it is noticed on the device (non-finite numerators) and redone through the packed
- * pass on the same stream, so the result and wagg_dense_saw_inf are the same either way.          */
+ * pass on the same stream, so the result and wagg_dense_saw_inf are the same either way; after that
+ * the plan keeps to the packed pass.                                                              */
 int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                          float *out_dev, int64_t ldo, int ksplit, void *stream);
 /* fp64 data on an fp64 plan: out = sum_g nan0(X[t,g]) * W[g,r] / den[r] on v_mfma_f64_16x16x4_f64 */
