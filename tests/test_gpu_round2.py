@@ -629,3 +629,51 @@ def test_full_form_pack_free_pass_for_tall_row_blocks(torch_cuda, dtype):
     plan.apply(torch.from_numpy(Xh).cuda())
     assert plan.saw_inf()
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# launch-bound small cases: applies can be captured into a HIP graph and replayed
+# ---------------------------------------------------------------------------------------------
+def test_applies_are_graph_capturable_after_one_warm_up(torch_cuda):
+    """After one apply on a stream (which creates the plan's per-stream staging), the same apply enqueues
+    kernels and async memsets only: it can be captured on that stream and replayed on new data (c1-sized
+    segment table, fused tas_poly, tile-sparse plan with its gated second pass)."""
+    from climate_toolbox_amd import synth
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    torch = torch_cuda
+    lat, lon, tas, df = synth.c1_workload(T=365)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R, T = len(lat) * len(lon), len(uniq), 365
+    plan = SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    dplan = DensePlan.synth_blocklocal(64 * 80, 700, 3)
+    rng = np.random.default_rng(8)
+    X = torch.from_numpy(np.ascontiguousarray(tas.reshape(T, G))).cuda()
+    X32 = X.float()
+    Xd = torch.from_numpy((280 + 10 * rng.standard_normal((300, 64 * 80))).astype(np.float32)).cuda()
+    out = torch.empty((T, R), dtype=X.dtype, device="cuda")
+    pout = torch.empty((3, T, R), dtype=torch.float32, device="cuda")
+    dout = torch.empty((300, 700), dtype=torch.float32, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                                   # warm-up on the capture stream
+        plan.apply(X, out=out); plan.apply_poly(X32, -273.15, 3, out=pout); dplan.apply(Xd, out=dout)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        plan.apply(X, out=out); plan.apply_poly(X32, -273.15, 3, out=pout); dplan.apply(Xd, out=dout)
+    for scale in (1.0, 0.5, 3.0):
+        X.mul_(scale); X32.mul_(scale); Xd.mul_(scale)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got, gotp, gotd = out.clone(), pout.clone(), dout.clone()
+        assert torch.equal(got, plan.apply(X))
+        assert torch.equal(gotp, plan.apply_poly(X32, -273.15, 3))
+        assert torch.equal(gotd, dplan.apply(Xd))
+    Xd[5, 7] = float("nan")                                      # the gated second pass is part of the graph
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(dout, dplan.apply(Xd)) and not torch.isnan(dout).any()
+    plan.status()
+    dplan.close()
