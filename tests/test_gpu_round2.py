@@ -677,3 +677,29 @@ def test_applies_are_graph_capturable_after_one_warm_up(torch_cuda):
     assert torch.equal(dout, dplan.apply(Xd)) and not torch.isnan(dout).any()
     plan.status()
     dplan.close()
+
+
+def test_pack_free_pass_on_a_ragged_grid_inside_a_padded_pitch(torch_cuda):
+    """G is not a whole number of k tiles but the row pitch holds them: the first pass reads the pad cells of the last
+    tile (their weights are zero).  Finite pads: same bits as the packed pass; NaN pads trip the gate and the exact
+    pass gives the same result again."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    G, R, T, seed = 64 * 80 + 8, 600, 250, 9
+    W = O.blocklocal_weights_oracle(G, R, seed)
+    plan = DensePlan.synth_blocklocal(G, R, seed)
+    assert plan.info["tiled"] == 1
+    rng = np.random.default_rng(3)
+    Xh = (280 + 20 * rng.standard_normal((T, G))).astype(np.float32)
+    ref = O.agg_dense(Xh, W)
+    pitched = torch.zeros((T, G + 24), dtype=torch.float32, device="cuda")      # pitch = 161 k tiles of 32 cells
+    pitched[:, :G].copy_(torch.from_numpy(Xh))
+    got = plan.apply(pitched[:, :G])
+    _rel_ok(got.cpu().numpy(), ref, RTOL32)
+    exact = plan.apply(torch.from_numpy(Xh).cuda())             # pitch = G: not whole k tiles -> packed pass
+    assert torch.equal(got, exact)
+    pitched[:, G:] = float("nan")
+    assert torch.equal(plan.apply(pitched[:, :G]), exact)
+    assert not plan.saw_inf()
+    plan.close()
