@@ -355,6 +355,16 @@ def test_c2_dense_full_size_properties(torch_cuda):
     X365 = engine.synth_field(365, G, seed=5, base=280.0, amp=60.0)
     got365 = plan.apply(X365).cpu().numpy()
     np.testing.assert_array_equal(got365[:T], got)
+    del X365, got365
+    # configs[3] in the dense form: one rank's 1,369-row shard = four row blocks, whose first pass reads X in place
+    # (no packed copy); same bits for the shared rows, the last rows against the C oracle
+    X1369 = engine.synth_field(1369, G, seed=5, base=280.0, amp=60.0)
+    got1369 = plan.apply(X1369)
+    np.testing.assert_array_equal(got1369[:T].cpu().numpy(), got)
+    tail = X1369[1360:1369].cpu().numpy()
+    for r0 in (0, R - 16):
+        _rel_ok(got1369[1360:1369, r0:r0 + 16].cpu().numpy(), c_oracle.dense_synth(tail, 0, G, R, r0, 16, seed), RTOL32)
+    assert not plan.saw_inf()
     plan.close()
 
 
