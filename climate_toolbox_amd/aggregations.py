@@ -33,6 +33,11 @@ except Exception:  # pragma: no cover - xarray is absent from this image
 __all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data",
            "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
 
+try:  # optional: a 10 GB/s hash for the table fingerprints below (blake2b, ~1 GB/s, otherwise)
+    import xxhash as _xxhash
+except Exception:  # pragma: no cover
+    _xxhash = None
+
 _PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
 _PLAN_CACHE_MAX = 8                 # plans
 _PLAN_CACHE_MAX_FRAC = 0.5          # ... and at most this share of the device's memory (dense plans are GBs)
@@ -54,13 +59,73 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+# ----------------------------------------------------------------------------------------------
+# Per-table memo ("removes the last O(nseg) Python step").  A pipeline aggregates many
+# variables and files with ONE weights table: the label join, the label factorisation and the plan key
+# are functions of that table alone, so they are kept per table CONTENT.  The fingerprint is a hash of
+# the columns' memory -- for object columns (string labels) of the pointer table, with the hashed array
+# kept alive by the memo entry: equal pointers to live immutable objects mean equal labels, and an entry
+# can never be confused with a later table whose objects reuse freed addresses.  Any in-place edit of
+# the table changes the fingerprint and the work is redone.
+# ----------------------------------------------------------------------------------------------
+_TABLE_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()
+_TABLE_MEMO_MAX = 32
+
+
+def _raw_view(a):
+    """(array kept alive, its memory as a bytes-like object); object arrays: the pointer table."""
+    import ctypes as C
+    a = np.asarray(a)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    if a.dtype.kind == "O":
+        return a, (C.string_at(a.ctypes.data, a.nbytes) if a.nbytes else b"")
+    return a, memoryview(a.reshape(-1)).cast("B")
+
+
+def _fingerprint(*arrays, extra=""):
+    h = _xxhash.xxh3_128() if _xxhash is not None else hashlib.blake2b(digest_size=16)
+    keep = []
+    for a in arrays:
+        a, raw = _raw_view(a)
+        keep.append(a)
+        h.update(repr((a.dtype.str, a.shape)).encode())
+        h.update(raw)
+    h.update(extra.encode())
+    return h.hexdigest(), keep
+
+
+def _memo(tag, arrays, compute, extra=""):
+    key, keep = _fingerprint(*arrays, extra=extra)
+    hit = _TABLE_MEMO.get((tag, key))
+    if hit is not None:
+        _TABLE_MEMO.move_to_end((tag, key))
+        return hit[1]
+    val = compute()
+    _TABLE_MEMO[(tag, key)] = (keep, val)
+    while len(_TABLE_MEMO) > _TABLE_MEMO_MAX:
+        _TABLE_MEMO.popitem(last=False)
+    return val
+
+
+def _frozen(a):
+    a = np.asarray(a)
+    a.flags.writeable = False
+    return a
+
+
 def _resolve_cells(lat, lon, seg_lat, seg_lon, lon_major=False):
     """Exact-equality join of the segment labels to the grid labels in native code
     (``wagg_resolve_cells``; ``Dataset.sel`` without ``method=``, aggregations.py:27; S1).
-    A missing label raises KeyError, like the reference."""
+    A missing label raises KeyError, like the reference.  Memoised per (grid labels, table columns)."""
+    lat, lon, sa, so = _f64(lat), _f64(lon), _f64(seg_lat), _f64(seg_lon)
+    return _memo("cells", (lat, lon, sa, so), lambda: _frozen(_resolve_cells_impl(lat, lon, sa, so, lon_major)),
+                 extra=str(bool(lon_major)))
+
+
+def _resolve_cells_impl(lat, lon, sa, so, lon_major):
     import ctypes as C
     _lib, L = _native()
-    lat, lon, sa, so = _f64(lat), _f64(lon), _f64(seg_lat), _f64(seg_lon)
     if sa.shape != so.shape or sa.ndim != 1:
         raise ValueError("segment lat/lon columns must be 1-D and of equal length")
     cell = np.empty(len(sa), dtype=np.int32)
@@ -108,9 +173,20 @@ def _is_null_label(v):
 def _factorize_labels(labels):
     """Sorted unique labels and per-row codes, -1 for null labels (xarray groupby, :78; S3), in
     native code for integer and string labels (``wagg_factorize_i64`` / ``_bytes``); other label
-    types go through ``pandas.factorize(sort=True)``, which has the same contract."""
-    import ctypes as C
+    types go through ``pandas.factorize(sort=True)``, which has the same contract.  Memoised per label
+    column content (see _TABLE_MEMO); the codes come back read-only, the unique labels as a fresh copy."""
     labels = np.asarray(labels)
+
+    def compute():
+        uniq, codes = _factorize_labels_impl(labels)
+        return np.array(uniq, copy=True), _frozen(codes)
+
+    uniq, codes = _memo("factorize", (labels,), compute)
+    return uniq.copy(), codes
+
+
+def _factorize_labels_impl(labels):
+    import ctypes as C
     n = len(labels)
     kind = labels.dtype.kind
     if kind in "iu" and labels.dtype.itemsize <= 8 and not (kind == "u" and labels.dtype.itemsize == 8):
@@ -368,11 +444,7 @@ def _evict_plans(byte_budget, keep):
 
 
 def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
-    h = hashlib.blake2b(digest_size=16)
-    for a in (cell_idx, codes, w_eff):
-        h.update(np.ascontiguousarray(a).tobytes())
-    h.update(repr((int(G), int(R), int(row_len), bool(is_f32), layout)).encode())
-    key = h.hexdigest()
+    key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         import torch

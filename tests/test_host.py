@@ -320,3 +320,61 @@ def test_convert_lons_on_the_vectors_the_reference_tests_hold(golden_dir):
     np.testing.assert_array_equal(ds.lon.values, h["mono_expect"])
     ds = convert_lons_split(minixr.Dataset(coords={"longitude": h["split_lon"]}))
     np.testing.assert_array_equal(ds.longitude.values, h["split_expect"])
+
+
+def test_table_memo_follows_the_table_content(monkeypatch):
+    """The per-table memo of the label work: a repeated call with the same columns does no
+    O(nseg) work, any in-place edit of a column is seen (object columns are fingerprinted by their pointer
+    table with the hashed objects kept alive), and what comes back cannot poison the cache."""
+    from climate_toolbox_amd import aggregations as A
+    A._TABLE_MEMO.clear()
+    rng = np.random.default_rng(5)
+    n = 20000
+    labels = np.array(["R%05d" % k for k in rng.integers(0, 900, n)], dtype=object)
+    calls = {"n": 0}
+    real = A._factorize_labels_impl
+
+    def counting(lab):
+        calls["n"] += 1
+        return real(lab)
+
+    monkeypatch.setattr(A, "_factorize_labels_impl", counting)
+
+    def check():
+        uniq, codes = A._factorize_labels(labels)
+        ec, eu = pd.factorize(labels, sort=True)
+        np.testing.assert_array_equal(np.asarray(uniq, dtype=object), np.asarray(eu, dtype=object))
+        np.testing.assert_array_equal(codes, ec.astype(np.int32))
+        return uniq, codes
+
+    uniq, codes = check()
+    assert calls["n"] == 1
+    uniq2, codes2 = check()
+    assert calls["n"] == 1                                   # memo hit
+    assert uniq2 is not uniq and not codes2.flags.writeable
+    uniq2[0] = "poison"                                      # the caller's copy, not the cache's
+    with pytest.raises(ValueError):
+        codes2[0] = 7
+    check()
+    assert calls["n"] == 1
+    # in-place edits, including a chain of replacements in one slot (freed strings may hand their address on)
+    for k, new in enumerate(["ZZZ_%d" % i for i in range(6)]):
+        labels[17] = new
+        check()
+        assert calls["n"] == 2 + k
+    labels[17] = "R00001"
+    check()
+    # the exact-match label join: memoised per (grid, table columns), redone after an in-place edit
+    lat, lon = np.arange(-44.5, 45, 1.0), np.arange(-89.5, 90, 1.0)
+    sa, so = rng.choice(lat, n), rng.choice(lon, n)
+    c1 = A._resolve_cells(lat, lon, sa, so)
+    assert A._resolve_cells(lat, lon, sa, so) is c1 and not c1.flags.writeable
+    so[5] = lon[0] if so[5] != lon[0] else lon[1]
+    c2 = A._resolve_cells(lat, lon, sa, so)
+    assert c2 is not c1 and c2[5] % len(lon) == (0 if so[5] == lon[0] else 1)
+    sa[9] = 0.123                                            # not on the grid: KeyError, and nothing is cached
+    with pytest.raises(KeyError):
+        A._resolve_cells(lat, lon, sa, so)
+    with pytest.raises(KeyError):
+        A._resolve_cells(lat, lon, sa, so)
+    assert len(A._TABLE_MEMO) <= A._TABLE_MEMO_MAX
