@@ -1,5 +1,7 @@
+"""End-to-end time of repeated calls of the reference-named function on a DEVICE-resident field (c2-real, cached plan,
+per-table memo) and a cProfile of where the host time goes.  Run on the GPU box."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from climate_toolbox_amd import engine, minixr, synth, weighted_aggregate_grid_to_regions
 lat, lon, df = synth.realistic_segments()
