@@ -46,7 +46,7 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int SP_BUF_BYTES = SP_KC * SP_ROW;              // 65,536: one X chunk in LDS
-constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB nobody reads: destination of the list warm-up loads
+constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB behind the two buffers (kept: LDS-DMA past the last row is harmless)
 constexpr int SP_LDS_BYTES = SP_SINK + 1024;
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             // registers live ACROSS statements: nothing but scalar code may sit between two of them
             // (tools/check_spmm_codegen.py checks the compiled kernel).
             const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * (2 * SP_GROUP));
-            asm volatile(SPMM_LOAD_LIST_ASM : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32))
+            asm volatile(SPMM_LOAD_LIST_ASM : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
                          : "memory", SPMM_CHUNK_CLOBBERS);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -135,48 +135,41 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         // The group offsets of a chunk are scalar loads (several hundred cycles).  They are ISSUED before the
         // end-of-chunk synchronisation of the previous statement and first touched behind it (the empty asm
         // pins that order), so their latency passes while the wave waits at the barrier anyway.
-        struct Raw { int g0, g1, gn, gw, cn, real; };
+        struct Raw { int g0, g1, gn, cn, real; };
         auto chunk_loads = [&](int c, Raw &r) {
             r.real = c < c1;
             const int cc = r.real ? c : c1 - 1;
-            // next chunk (the last one re-loads itself: harmless), list warm-up three chunks ahead
-            r.cn = cc + 1 < c1 ? cc + 1 : cc;
-            const int cw = cc + 3 < c1 ? cc + 3 : c1 - 1;
+            r.cn = cc + 1 < c1 ? cc + 1 : cc;                     // next chunk (the last one re-loads itself: harmless)
             r.g0 = goff[(int64_t)cc * SP_WAVES]; r.g1 = goff[(int64_t)cc * SP_WAVES + 1];
-            r.gn = goff[(int64_t)r.cn * SP_WAVES]; r.gw = goff[(int64_t)cw * SP_WAVES];
+            r.gn = goff[(int64_t)r.cn * SP_WAVES];
         };
-        auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, const char *&wsrc,
-                              int &l0, int &bufbit, int &wlim) {
-            asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn), "+s"(r.gw));
+        auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, int &l0, int &bufbit) {
+            asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn));
             n = r.real ? r.g1 - r.g0 : 0;
             pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * (2 * SP_GROUP));
             pn = reinterpret_cast<uint64_t>(ent + (int64_t)r.gn * (2 * SP_GROUP));
             src = xbase + (int64_t)r.cn * SP_BUF_BYTES;
-            wsrc = reinterpret_cast<const char *>(ent) + (int64_t)r.gw * 64;
             l0 = lds0 + (par ^ 1) * SP_BUF_BYTES + wave * 4096;
             bufbit = lds0 + par * SP_BUF_BYTES;
-            wlim = n_groups - r.gw;
         };
-        const int sink = lds0 + SP_SINK;
 #define SPMM_CHUNK_STMT(ASM)                                                                                  \
         asm volatile(ASM                                                                                      \
                      : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2) \
                      : [cplo] "s"((uint32_t)pc), [cphi] "s"((uint32_t)(pc >> 32)), [nplo] "s"((uint32_t)pn),   \
-                       [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src),  \
-                       [wsrc] "s"(wsrc), [wlim] "s"(wlim), [sink] "s"(sink)                                   \
+                       [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src)   \
                      : "memory", "scc", SPMM_CHUNK_CLOBBERS)
         Raw ra, rb_;
         chunk_loads(c0, ra);
         for (int c = c0; c < c1; c += 2) {
-            int n, l0, bufbit, wlim;
+            int n, l0, bufbit;
             uint64_t pc, pn;
-            const char *src, *wsrc;
-            chunk_args(ra, 0, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            const char *src;
+            chunk_args(ra, 0, n, pc, pn, src, l0, bufbit);
             SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_A);               // this chunk's list in set A, the next one's -> B
             chunk_loads(c + 1, rb_);
             // this wave's pieces of the next chunk and the next list have landed; it is done reading this chunk
             SPMM_CHUNK_SYNC;
-            chunk_args(rb_, 1, n, pc, pn, src, wsrc, l0, bufbit, wlim);
+            chunk_args(rb_, 1, n, pc, pn, src, l0, bufbit);
             SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_B);
             chunk_loads(c + 2, ra);
             SPMM_CHUNK_SYNC;

@@ -14,14 +14,15 @@ SPMM_CHUNK_ASM_A / _B one wave, one chunk whose X tile is already in LDS, the li
                       A (B), in order:
   1. issues the loads of the NEXT chunk's list into the other set (consumed by the next statement: the
      C++ between two statements is scalar-only, which tools/check_spmm_codegen.py verifies on the
-     compiled kernel), the 4 LDS-DMA pieces of the next chunk's X tile, one L2 warm-up load for the list
-     three chunks ahead -- all retired by the `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
+     compiled kernel) and the 4 LDS-DMA pieces of the next chunk's X tile -- all retired by the
+     `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
   2. per entry: two v_readlane (entry -> SGPRs), v_bfi (LDS address), ds_read_b64 (2 x 64 timesteps of
      the cell), s_set_gpr_idx_idx + v_pk_fma_f32 (or two v_fma_f32) into the accumulator pair the entry
      names (VGPR index mode), half-group h+1's reads in flight while half-group h is accumulated;
   3. lists longer than 16 groups (never at 1 % fill) finish in a one-group-at-a-time loop.
 
-Private registers (clobbered, hard-coded): v3 entry-load lane offset; set A = v[4:5] lo, v[6:7] weights
+Private registers (clobbered, hard-coded; v3, v12, v30, v31 are set by the item prologue and live for the whole
+item): v3 entry-load lane offset; set A = v[4:5] lo, v[6:7] weights
 of blocks 0-1, set B = v[8:9], v[10:11]; v12 lane, v13 scratch; v[14:21] / v[22:29] the two LDS-read sets
 (4 register pairs each); v30 lane*8 | buffer bit; v31 0xfe00; s[36:43] / s[44:51] the two half-group
 entry sets; s68 saved M0; s[70:71] list pointer.
@@ -34,11 +35,12 @@ SA, SB = 36, 44              # SGPR half-group sets (4 entries x (lo, w))
 TP, TQ = 14, 22              # VGPR temp sets: 4 pairs each
 SETS = {"A": (4, 6), "B": (8, 10)}     # (first lo register, first weight register) of a list set
 VO, LANE, SCR, LB, VMASK = 3, 12, 13, 30, 31
+CUR_LB = LB                  # the register holding lane * 8 | buffer base for the statement being generated
 ACC0 = 40
 MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
 PK = int(os.environ.get("SPMM_PK", "1"))   # 1: v_pk_fma_f32, 0: two v_fma_f32
 # ablation variants for tools/spmm_ablate.sh (timing only, results are wrong): any of nofma, nolds, noidx, now, nobfi,
-# nodma, halfdma, nolist, noent
+# nodma, halfdma, nolist, noent; per-chunk overhead experiments (results stay right): nohoist, nonop
 ABL = set(filter(None, os.environ.get("SPMM_ABL", "").split(",")))
 
 
@@ -72,7 +74,7 @@ def issue(h, which, S, T, o):
             o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, hi0 + b, base + k))
     for k in range(4):
         if "nobfi" not in ABL:
-            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, LB))
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, CUR_LB))
     for k in range(4):
         if "nolds" not in ABL:
             o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
@@ -97,27 +99,43 @@ def fma(S, T, younger, o):
 
 
 def chunk(cur, nxt):
+    global CUR_LB
     o = []
     o.append("s_mov_b32 s68, m0")
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
-    lane_regs(o, True)
+    hoist, nonop = "nohoist" not in ABL, "nonop" in ABL
+    if hoist:
+        CUR_LB = LB                                            # v[LANE], v[VO], v[VMASK], v[LB] come from the item prologue
+    else:
+        CUR_LB = LB
+        lane_regs(o, True)
     if "nolist" not in ABL:
         load_list(o, nxt)                                      # 1. the NEXT chunk's list
-    o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))         # lane * 16: LDS-DMA of the next X tile
-    for i in range(2 if "halfdma" in ABL else 4):
-        if i:
-            o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
-        o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
-        o.append("s_nop 0")
-        if "nodma" not in ABL:
-            o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
-    o.append("v_min_u32 v%d, %%[wlim], v%d" % (SCR, LANE))     # L2 warm-up, one 64-byte line per lane
-    o.append("v_lshlrev_b32 v%d, 6, v%d" % (SCR, SCR))
-    o.append("s_mov_b32 m0, %[sink]")
-    o.append("s_nop 0")
-    if "nolist" not in ABL:
-        o.append("global_load_lds_dword v%d, %%[wsrc]" % SCR)
+    n_dma = 2 if "halfdma" in ABL else 4
+    if nonop:       # the vector instruction between the M0 write and the LDS-DMA is the wait state the pair needs
+        for i in range(n_dma):
+            o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
+            if i:
+                o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
+            else:
+                o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))     # lane * 16: LDS-DMA of the next X tile
+            if "nodma" not in ABL:
+                o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
+    else:
+        o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))     # lane * 16: LDS-DMA of the next X tile
+        for i in range(n_dma):
+            if i:
+                o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
+            o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
+            o.append("s_nop 0")
+            if "nodma" not in ABL:
+                o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
+    # (an L2 warm-up load of the list three chunks ahead used to sit here: measured 2.1 ms SLOWER on the c5 rank
+    #  shard -- profiles/r02_spmm_ablation.txt -- and removed together with its operands)
+    if hoist and cur == "B":                                   # statement B reads LDS buffer 1
+        o.append("v_add_u32 v%d, 0x10000, v%d" % (SCR, LB))
+        CUR_LB = SCR
     o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
     o.append("s_cbranch_scc1 8f")
     if "noent" in ABL:
@@ -148,7 +166,7 @@ def chunk(cur, nxt):
             o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k, lo0, 4 * hh + k))
             o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k + 1, hi0, 4 * hh + k))
         for k in range(4):
-            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TP + 2 * k, VMASK, SA + 2 * k, LB))
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TP + 2 * k, VMASK, SA + 2 * k, CUR_LB))
         for k in range(4):
             o.append("ds_read_b64 v[%d:%d], v%d" % (TP + 2 * k, TP + 2 * k + 1, TP + 2 * k))
         fma(SA, TP, 0, o)
@@ -167,7 +185,7 @@ def prologue():
     o = []
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
-    lane_regs(o, False)
+    lane_regs(o, "nohoist" not in ABL)  # lane, lane * 8 | base of LDS buffer 0 and the cell mask live for the whole item
     load_list(o, "A")
     return o
 
