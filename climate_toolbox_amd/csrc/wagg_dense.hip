@@ -923,13 +923,15 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     hipStream_t st = (hipStream_t)stream;
     const void *kern = pick_mfma_kernel<T>(MT, d->tiled);
     if (!kern) { set_error("no kernel for MT=%d", MT); return WAGG_EINVAL; }
-    // pack-free first pass (tile-sparse form, plain aggregation of 16-byte-aligned rows that hold whole k tiles):
+    // pack-free first pass (plain aggregation of 16-byte-aligned rows, grid = whole k tiles):
     // the MFMA kernel reads X where it lies; the packed pass below then runs only if a numerator came out
     // non-finite (NaN / +-inf somewhere in the data), gated on the device so the stream never waits for the host
     // ... and only while no earlier pack-free pass of this plan met such data: fields with NaN in them (ocean cells of
     // land-only variables) tend to stay that way, and for them the first pass is pure overhead.  The note is a
     // host-mapped word written by the reduce kernel; reading it here without synchronising is a heuristic only.
-    bool rm = xf.mode == 0 && aligned && (int64_t)n_kt * DT<T>::BK <= ldx && ((volatile int *)d->inf_host)[1] == 0;
+    // (G must be a whole number of k tiles: the last tile is then read from inside every row, whatever the caller's
+    // pitch and however short the buffer behind the last row is)
+    bool rm = xf.mode == 0 && aligned && d->G % DT<T>::BK == 0 && ((volatile int *)d->inf_host)[1] == 0;
     const void *kern_rm = nullptr;
     if (rm && d->tiled) kern_rm = pick_mfma_kernel<T>(MT, true, true);
     // (full form: only with two or more row blocks -- with one, A/B on one GPU shows the step unchanged: the kernel

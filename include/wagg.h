@@ -262,8 +262,8 @@ int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
  * ksplit = 0 picks the k-slice count; otherwise a multiple of 8.  The plan owns the packed copy of
  * X and the partial-sum slabs of an apply (hence the non-const handle): applies on ONE dense plan
  * must be ordered on one stream; different plans are independent.
- * Tile-sparse plans read X where it lies when its rows are 16-byte aligned and hold whole k tiles
- * (ldx >= 32 ceil(G/32) floats, 16 ceil(G/16) doubles): no packed copy is written; a field with NaN
+ * Tile-sparse plans (and full ones with two or more tall row blocks) read X where it lies when its rows
+ * are 16-byte aligned and G is a whole number of k tiles (32 floats / 16 doubles): no packed copy is written; a field with NaN
  * or +-inf in it is noticed on the device (non-finite numerators) and redone through the packed
  * pass on the same stream, so the result and wagg_dense_saw_inf are the same either way; after that
  * the plan keeps to the packed pass.                                                              */

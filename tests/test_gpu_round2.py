@@ -679,10 +679,9 @@ def test_applies_are_graph_capturable_after_one_warm_up(torch_cuda):
     dplan.close()
 
 
-def test_pack_free_pass_on_a_ragged_grid_inside_a_padded_pitch(torch_cuda):
-    """G is not a whole number of k tiles but the row pitch holds them: the first pass reads the pad cells of the last
-    tile (their weights are zero).  Finite pads: same bits as the packed pass; NaN pads trip the gate and the exact
-    pass gives the same result again."""
+def test_ragged_grid_inside_a_padded_pitch_never_reads_the_pad_cells(torch_cuda):
+    """G is not a whole number of k tiles: whatever the row pitch offers behind the G cells (here: room for the whole
+    last tile, filled with NaN) is never read -- such grids keep the packed pass."""
     from climate_toolbox_amd.engine import DensePlan
     from oracle import ref_numpy as O
     torch = torch_cuda
