@@ -116,8 +116,27 @@ void profile_mark(hipStream_t stream, bool begin);
 // the whole field.  With WAGG_HOST_PIN the caller's arrays are page-locked in place for the duration of
 // the call (hipHostRegister), which makes the copies truly asynchronous; pageable arrays are staged by
 // the runtime and overlap only partly.  apply(X_dev, rows, out_dev, stream) launches one block.
+// elements from the first element of row 0 to the last of row rows-1 (the last row of a pitched host array need
+// not be followed by its padding: never touch more than this)
+inline size_t host_span(int64_t rows, int64_t ld, int64_t cols) { return rows > 0 ? (size_t)((rows - 1) * ld + cols) : 0; }
+
+// device (rows x ld, same pitch) -> pitched host array: only the `cols` used elements of every row are written, the
+// caller's padding between rows is left alone
+template <typename T>
+inline hipError_t copy_rows_to_host(T *dst_host, const T *src_dev, int64_t rows, int64_t ld, int64_t cols, hipStream_t st,
+                                    bool async) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (ld == cols)
+        return async ? hipMemcpyAsync(dst_host, src_dev, sizeof(T) * (size_t)(rows * cols), hipMemcpyDeviceToHost, st)
+                     : hipMemcpy(dst_host, src_dev, sizeof(T) * (size_t)(rows * cols), hipMemcpyDeviceToHost);
+    return async ? hipMemcpy2DAsync(dst_host, sizeof(T) * (size_t)ld, src_dev, sizeof(T) * (size_t)ld, sizeof(T) * (size_t)cols,
+                                    (size_t)rows, hipMemcpyDeviceToHost, st)
+                 : hipMemcpy2D(dst_host, sizeof(T) * (size_t)ld, src_dev, sizeof(T) * (size_t)ld, sizeof(T) * (size_t)cols,
+                               (size_t)rows, hipMemcpyDeviceToHost);
+}
+
 template <typename T, typename ApplyFn>
-int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int64_t ldo, int64_t R, int flags,
+int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, int64_t G, T *out_host, int64_t ldo, int64_t R, int flags,
                      int64_t quantum, ApplyFn apply) {
     if (Tn == 0) return WAGG_OK;
     // ~256 MiB of X per block in whole multiples of `quantum` rows (the row count one launch handles well:
@@ -128,7 +147,7 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int6
     if (Tn >= 2 * quantum && B > (Tn + 1) / 2) B = ((Tn + 1) / 2 + quantum - 1) / quantum * quantum;
     if (B > Tn) B = Tn;
     const int64_t nb = (Tn + B - 1) / B;
-    const size_t xbytes = sizeof(T) * (size_t)(Tn * ldx), obytes = sizeof(T) * (size_t)(Tn * ldo);
+    const size_t xbytes = sizeof(T) * host_span(Tn, ldx, G), obytes = sizeof(T) * host_span(Tn, ldo, R);
     bool pin_x = false, pin_o = false;
     if (flags & WAGG_HOST_PIN) {
         // Registration works on whole pages and costs ~0.1 ms per MiB.  Below 32 MiB (glibc's largest mmap threshold)
@@ -169,17 +188,16 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int6
         WAGG_HIP(hipMalloc(&g.dx[b], sizeof(T) * (size_t)(B * ldx)));
         WAGG_HIP(hipMalloc(&g.dout[b], sizeof(T) * (size_t)(B * ldo)));
     }
-    (void)R;
     for (int64_t i = 0; i < nb; ++i) {
         const int b = (int)(i & 1);
         const int64_t r0 = i * B, rows = Tn - r0 < B ? Tn - r0 : B;
         if (i >= 2) WAGG_HIP(hipStreamWaitEvent(g.sc, g.done[b], 0));       // block i-2 no longer uses this buffer
-        WAGG_HIP(hipMemcpyAsync(g.dx[b], X_host + r0 * ldx, sizeof(T) * (size_t)(rows * ldx), hipMemcpyHostToDevice, g.sc));
+        WAGG_HIP(hipMemcpyAsync(g.dx[b], X_host + r0 * ldx, sizeof(T) * host_span(rows, ldx, G), hipMemcpyHostToDevice, g.sc));
         WAGG_HIP(hipEventRecord(g.ready[b], g.sc));
         WAGG_HIP(hipStreamWaitEvent(g.sk, g.ready[b], 0));
         const int rc = apply(static_cast<const T *>(g.dx[b]), rows, static_cast<T *>(g.dout[b]), g.sk);
         if (rc != WAGG_OK) return rc;
-        WAGG_HIP(hipMemcpyAsync(out_host + r0 * ldo, g.dout[b], sizeof(T) * (size_t)(rows * ldo), hipMemcpyDeviceToHost, g.sk));
+        WAGG_HIP(copy_rows_to_host<T>(out_host + r0 * ldo, static_cast<const T *>(g.dout[b]), rows, ldo, R, g.sk, true));
         WAGG_HIP(hipEventRecord(g.done[b], g.sk));
     }
     WAGG_HIP(hipStreamSynchronize(g.sc));

@@ -1117,14 +1117,14 @@ static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t 
         DevBuf<T> dx, dout;
         WAGG_HIP(dx.alloc((size_t)(Tn * ldx)));
         WAGG_HIP(dout.alloc((size_t)(Tn * ldo)));
-        WAGG_HIP(hipMemcpy(dx.p, X_host, sizeof(T) * (size_t)(Tn * ldx), hipMemcpyHostToDevice));
+        WAGG_HIP(hipMemcpy(dx.p, X_host, sizeof(T) * host_span(Tn, ldx, d->G), hipMemcpyHostToDevice));
         const int rc = dense_apply<T>(d, dx.p, Tn, ldx, PackXfT<T>{}, dout.p, ldo, 0, nullptr);
         if (rc != WAGG_OK) return rc;
         WAGG_HIP(hipDeviceSynchronize());
-        WAGG_HIP(hipMemcpy(out_host, dout.p, sizeof(T) * (size_t)(Tn * ldo), hipMemcpyDeviceToHost));
+        WAGG_HIP(copy_rows_to_host<T>(out_host, dout.p, Tn, ldo, d->R, nullptr, false));
         return WAGG_OK;
     }
-    return stream_host_rows<T>(X_host, Tn, ldx, out_host, ldo, d->R, flags, d->spmm ? SP_TB : DT<T>::MT_MAX * 16,
+    return stream_host_rows<T>(X_host, Tn, ldx, d->G, out_host, ldo, d->R, flags, d->spmm ? SP_TB : DT<T>::MT_MAX * 16,
                                [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
                                    return dense_apply<T>(d, xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
                                });

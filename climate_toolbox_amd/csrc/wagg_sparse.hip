@@ -1747,7 +1747,7 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     if (rc != WAGG_OK || Tn == 0) return rc;
     WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
     if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
-        rc = stream_host_rows<T>(X, Tn, ldx, out, ldo, plan->info.R, flags, 64,
+        rc = stream_host_rows<T>(X, Tn, ldx, plan->info.G, out, ldo, plan->info.R, flags, 64,
                                  [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
                                      return fn(plan, xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
                                  });
@@ -1759,13 +1759,14 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     DevBuf<T> dx, dout;
     WAGG_HIP(dx.alloc((size_t)(xrows * ldx)));
     WAGG_HIP(dout.alloc((size_t)(orows * ldo)));
-    WAGG_HIP(hipMemcpy(dx.p, X, sizeof(T) * (size_t)(xrows * ldx), hipMemcpyHostToDevice));
+    const int64_t xcols = layout == WAGG_LAYOUT_TG ? plan->info.G : Tn, ocols = out_layout == WAGG_OUT_TR ? plan->info.R : Tn;
+    WAGG_HIP(hipMemcpy(dx.p, X, sizeof(T) * host_span(xrows, ldx, xcols), hipMemcpyHostToDevice));
     WAGG_HIP(hipMemset(dout.p, 0, sizeof(T) * (size_t)(orows * ldo)));
     rc = fn(plan, dx.p, Tn, ldx, layout, dout.p, ldo, out_layout, nullptr);
     if (rc != WAGG_OK) return rc;
     WAGG_HIP(hipDeviceSynchronize());
     if (int rc2 = check_timeout(plan)) return rc2;
-    WAGG_HIP(hipMemcpy(out, dout.p, sizeof(T) * (size_t)(orows * ldo), hipMemcpyDeviceToHost));
+    WAGG_HIP(copy_rows_to_host<T>(out, dout.p, orows, ldo, ocols, nullptr, false));
     return WAGG_OK;
 }
 }  // namespace wagg

@@ -141,6 +141,8 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *                    (arrays below 32 MiB are always staged: registration locks whole pages, and small
  *                    arrays share theirs with other heap objects)
  *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
+ * Pitched arrays (ldx > G, ldo > R) are honoured: nothing behind the used cells of the last row is read and the
+ * padding between result rows is not written.
  * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN.  Measured on one MI355X (tools/host_path_timing.py):
  * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks,
  * 33 ms pageable blocks); a dense 1,369-row shard takes 602 ms whole and 523 ms in pinned blocks (the copies

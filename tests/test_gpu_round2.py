@@ -702,3 +702,67 @@ def test_ragged_grid_inside_a_padded_pitch_never_reads_the_pad_cells(torch_cuda)
     assert torch.equal(plan.apply(pitched[:, :G]), exact)
     assert not plan.saw_inf()
     plan.close()
+
+
+def _guarded(count, dtype):
+    """numpy array of `count` elements whose last byte sits right in front of a PROT_NONE page."""
+    import ctypes, mmap
+    pg = mmap.PAGESIZE
+    nbytes = count * np.dtype(dtype).itemsize
+    total = (nbytes + pg - 1) // pg * pg + pg
+    m = mmap.mmap(-1, total)
+    addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(addr + total - pg, pg, 0) == 0                      # PROT_NONE
+    return np.frombuffer(m, dtype=dtype, count=count, offset=total - pg - nbytes), m
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_host_forms_respect_the_pitch_of_host_arrays(torch_cuda, dtype):
+    """C-ABI contract of the *_host_* entry points for pitched arrays (ldx > G, ldo > R): nothing behind the last
+    row's G cells is read (the array ends at an inaccessible page), the padding between result rows is left as it
+    was -- whole-copy, staged-block and page-locked-block forms, segment-table and dense plans."""
+    import ctypes as C
+    from climate_toolbox_amd import _lib, synth
+    from climate_toolbox_amd.engine import DensePlan, SparsePlan
+    torch = torch_cuda
+    L = _lib.load()
+    sfx = "f32" if dtype == np.float32 else "f64"
+    lat, lon, df = synth.realistic_segments(64, 80, R=300, seed=2, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R, T = len(lat) * len(lon), len(uniq), 70
+    ldx, ldo = G + 96, R + 20
+    rng = np.random.default_rng(1)
+    Xc = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+    X, keep_x = _guarded((T - 1) * ldx + G, dtype)
+    X[:] = -1e30
+    for t in range(T):
+        X[t * ldx:t * ldx + G] = Xc[t]
+    splan = SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    W = rng.uniform(0, 1, (G, R)).astype(dtype)
+    dplan = DensePlan.from_host(W)
+    refs = {"sparse": splan.apply(torch.from_numpy(Xc).cuda()).cpu().numpy(),
+            "dense": dplan.apply(torch.from_numpy(Xc).cuda()).cpu().numpy()}
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    for flags in (_lib.HOST_WHOLE, 0, _lib.HOST_PIN):
+        for kind in ("sparse", "dense"):
+            out, keep_o = _guarded((T - 1) * ldo + R, dtype)
+            out[:] = 777.0
+            if kind == "sparse":
+                rc = getattr(L, "wagg_apply_host_ex_" + sfx)(splan._h, vp(X), T, ldx, 0, vp(out), ldo, 0, flags)
+            else:
+                rc = getattr(L, "wagg_dense_apply_host_" + sfx)(dplan._h, vp(X), T, ldx, vp(out), ldo, flags)
+            assert rc == 0, L.wagg_last_error()
+            rows = np.stack([out[t * ldo:t * ldo + R] for t in range(T)])
+            if kind == "sparse":
+                np.testing.assert_array_equal(rows, refs[kind])
+            else:
+                np.testing.assert_allclose(rows, refs[kind], rtol=2e-6 if dtype == np.float32 else 1e-12)
+            pads = np.concatenate([out[t * ldo + R:(t + 1) * ldo] for t in range(T - 1)])
+            assert (pads == 777.0).all()                       # the caller's padding is untouched
+            del out, rows, pads
+            keep_o.close()
+    del X
+    keep_x.close()
+    dplan.close()
