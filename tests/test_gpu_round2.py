@@ -766,3 +766,38 @@ def test_host_forms_respect_the_pitch_of_host_arrays(torch_cuda, dtype):
     del X
     keep_x.close()
     dplan.close()
+
+
+def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
+    """The drop-in's D2H copy: page-locked while the cap allows, released when the caller drops the result, same
+    numbers either way."""
+    import gc
+    from climate_toolbox_amd import aggregations as A, minixr, synth, weighted_aggregate_grid_to_regions
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(360, 720, R=3000, seed=4, string_labels=False)
+    T = 120
+    X = (280 + 10 * np.random.default_rng(0).standard_normal((T, len(lat), len(lon)))).astype(np.float32)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), torch.from_numpy(X).cuda())}, coords={"lat": lat, "lon": lon})
+    gc.collect()
+    base = A._PINNED_OUT["bytes"]
+    a = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    n = a.tas.values.nbytes
+    assert n >= 1 << 20 and A._PINNED_OUT["bytes"] == base + n
+    b = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    assert A._PINNED_OUT["bytes"] == base + 2 * n
+    np.testing.assert_array_equal(a.tas.values, b.tas.values)
+    keep = a.tas.values[3:5]                                    # a view keeps its block alive
+    del a, b
+    gc.collect()
+    assert A._PINNED_OUT["bytes"] == base + n
+    old_cap = A._PINNED_OUT_CAP
+    try:
+        A._PINNED_OUT_CAP = 0                                   # beyond the cap: pageable copy, same numbers
+        c = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+        np.testing.assert_array_equal(c.tas.values[3:5], keep)
+        assert A._PINNED_OUT["bytes"] == base + n
+    finally:
+        A._PINNED_OUT_CAP = old_cap
+    del keep
+    gc.collect()
+    assert A._PINNED_OUT["bytes"] == base

@@ -8,7 +8,7 @@ lat, lon, df = synth.realistic_segments()
 T = 365
 Xd = engine.synth_field(T, len(lat) * len(lon), seed=3, base=280.0, amp=60.0).reshape(T, len(lat), len(lon))
 ds = minixr.Dataset({"tas": (("time", "lat", "lon"), Xd)}, coords={"lat": lat, "lon": lon})
-for i in range(6):
+for i in range(12):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
     torch.cuda.synchronize()
