@@ -276,6 +276,24 @@ def main():
             pdt = (time.perf_counter() - t0) / a.steps
             res["fused_tas_poly_1to4"] = {"ms_per_step": pdt * 1e3, "value": 4 * T * Gs * Rr / pdt,
                                           "unit": "gridcell-region-timesteps/s (4 powers)"}
+            del pout
+            # fused Snyder degree days: one pass over (tasmin, tasmax) for 1 and for 3 thresholds
+            tmax = Xs + engine.synth_field(T, Gs, seed=2000 + rank, base=6.0, amp=10.0, dtype=dtype)
+            edd = {}
+            for K in (1, 3):
+                thr = [10.0, 20.0, 30.0][:K]
+                eout = torch.empty((K, T, Rr), dtype=Xs.dtype, device="cuda")
+                for _ in range(2):
+                    plan.apply_edd(Xs, tmax, thr, offset=-273.15, out=eout)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    plan.apply_edd(Xs, tmax, thr, offset=-273.15, out=eout)
+                torch.cuda.synchronize()
+                edd["K%d_ms" % K] = (time.perf_counter() - t0) / a.steps * 1e3
+                del eout
+            res["fused_snyder_edd"] = edd
+            del tmax
         return res
 
     def run_dense_family(wl):
