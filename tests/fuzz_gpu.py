@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of every C-ABI compute entry point against the oracle (GPU box).
-usage: python tools/fuzz_gpu.py [n_cases] [seed]      -- prints one line per failing case, exit 1 on any"""
+usage: python tests/fuzz_gpu.py [n_cases] [seed]      -- prints one line per failing case, exit 1 on any"""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -708,12 +708,12 @@ def test_snyder_degree_days_dropin(torch_cuda):
 
 
 def test_randomised_differential_all_entry_points(torch_cuda):
-    """tools/fuzz_gpu.py, 80 seeded cases: random grids, tables (null labels, NaN / 0 weights,
+    """tests/fuzz_gpu.py, 80 seeded cases: random grids, tables (null labels, NaN / 0 weights,
     giant regions), layouts, padded row strides, NaN / inf data -- plain, fused-power, degree-day
     and dense / tile-sparse forms against the oracle."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
-        "fuzz_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py"))
+        "fuzz_gpu", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_gpu.py"))
     fz = importlib.util.module_from_spec(spec)
     argv, sys.argv = sys.argv, ["fuzz_gpu.py"]
     try:

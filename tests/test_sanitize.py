@@ -18,6 +18,6 @@ def test_host_half_is_clean_under_asan_ubsan():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san"])
     env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hostsan_check.py")], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "hostsan_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "hostsan ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
