@@ -120,12 +120,30 @@ void profile_mark(hipStream_t stream, bool begin);
 // not be followed by its padding: never touch more than this)
 inline size_t host_span(int64_t rows, int64_t ld, int64_t cols) { return rows > 0 ? (size_t)((rows - 1) * ld + cols) : 0; }
 
+// Small host buffers (below 32 MiB) never reach an asynchronous runtime copy as they are: the runtime would page-lock
+// them on the fly and drop that pin later on its own schedule, possibly after the caller has freed the array (small
+// arrays are the ones that die right after the call).  They go through the library's own pair of page-locked staging
+// buffers instead (wagg_util.hip; blocking, ~10 GB/s -- irrelevant at these sizes).  Both return when the user memory
+// is no longer needed (h2d) / completely written (d2h).
+constexpr size_t HOST_STAGE_MAX = (size_t)32 << 20;
+hipError_t staged_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st);
+hipError_t staged_d2h_rows(void *dst_host, const void *src_dev, int64_t rows, size_t ld_bytes, size_t row_bytes, hipStream_t st);
+
+// blocking host -> device copy (small buffers through the staging pair, see above)
+inline hipError_t copy_to_device(void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes < HOST_STAGE_MAX) return staged_h2d(dst_dev, src_host, bytes, nullptr);
+    return hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice);
+}
+
 // device (rows x ld, same pitch) -> pitched host array: only the `cols` used elements of every row are written, the
 // caller's padding between rows is left alone
 template <typename T>
 inline hipError_t copy_rows_to_host(T *dst_host, const T *src_dev, int64_t rows, int64_t ld, int64_t cols, hipStream_t st,
                                     bool async) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (!async && sizeof(T) * host_span(rows, ld, cols) < HOST_STAGE_MAX)
+        return staged_d2h_rows(dst_host, src_dev, rows, sizeof(T) * (size_t)ld, sizeof(T) * (size_t)cols, st);
     if (ld == cols)
         return async ? hipMemcpyAsync(dst_host, src_dev, sizeof(T) * (size_t)(rows * cols), hipMemcpyDeviceToHost, st)
                      : hipMemcpy(dst_host, src_dev, sizeof(T) * (size_t)(rows * cols), hipMemcpyDeviceToHost);
@@ -192,12 +210,18 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, int64_t G, T *out
         const int b = (int)(i & 1);
         const int64_t r0 = i * B, rows = Tn - r0 < B ? Tn - r0 : B;
         if (i >= 2) WAGG_HIP(hipStreamWaitEvent(g.sc, g.done[b], 0));       // block i-2 no longer uses this buffer
-        WAGG_HIP(hipMemcpyAsync(g.dx[b], X_host + r0 * ldx, sizeof(T) * host_span(rows, ldx, G), hipMemcpyHostToDevice, g.sc));
+        if (!pin_x && xbytes < HOST_STAGE_MAX)
+            WAGG_HIP(staged_h2d(g.dx[b], X_host + r0 * ldx, sizeof(T) * host_span(rows, ldx, G), g.sc));
+        else
+            WAGG_HIP(hipMemcpyAsync(g.dx[b], X_host + r0 * ldx, sizeof(T) * host_span(rows, ldx, G), hipMemcpyHostToDevice, g.sc));
         WAGG_HIP(hipEventRecord(g.ready[b], g.sc));
         WAGG_HIP(hipStreamWaitEvent(g.sk, g.ready[b], 0));
         const int rc = apply(static_cast<const T *>(g.dx[b]), rows, static_cast<T *>(g.dout[b]), g.sk);
         if (rc != WAGG_OK) return rc;
-        WAGG_HIP(copy_rows_to_host<T>(out_host + r0 * ldo, static_cast<const T *>(g.dout[b]), rows, ldo, R, g.sk, true));
+        if (!pin_o && obytes < HOST_STAGE_MAX)
+            WAGG_HIP(staged_d2h_rows(out_host + r0 * ldo, g.dout[b], rows, sizeof(T) * (size_t)ldo, sizeof(T) * (size_t)R, g.sk));
+        else
+            WAGG_HIP(copy_rows_to_host<T>(out_host + r0 * ldo, static_cast<const T *>(g.dout[b]), rows, ldo, R, g.sk, true));
         WAGG_HIP(hipEventRecord(g.done[b], g.sk));
     }
     WAGG_HIP(hipStreamSynchronize(g.sc));

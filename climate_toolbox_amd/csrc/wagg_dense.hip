@@ -1117,7 +1117,7 @@ static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t 
         DevBuf<T> dx, dout;
         WAGG_HIP(dx.alloc((size_t)(Tn * ldx)));
         WAGG_HIP(dout.alloc((size_t)(Tn * ldo)));
-        WAGG_HIP(hipMemcpy(dx.p, X_host, sizeof(T) * host_span(Tn, ldx, d->G), hipMemcpyHostToDevice));
+        WAGG_HIP(copy_to_device(dx.p, X_host, sizeof(T) * host_span(Tn, ldx, d->G)));
         const int rc = dense_apply<T>(d, dx.p, Tn, ldx, PackXfT<T>{}, dout.p, ldo, 0, nullptr);
         if (rc != WAGG_OK) return rc;
         WAGG_HIP(hipDeviceSynchronize());

@@ -1760,7 +1760,7 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     WAGG_HIP(dx.alloc((size_t)(xrows * ldx)));
     WAGG_HIP(dout.alloc((size_t)(orows * ldo)));
     const int64_t xcols = layout == WAGG_LAYOUT_TG ? plan->info.G : Tn, ocols = out_layout == WAGG_OUT_TR ? plan->info.R : Tn;
-    WAGG_HIP(hipMemcpy(dx.p, X, sizeof(T) * host_span(xrows, ldx, xcols), hipMemcpyHostToDevice));
+    WAGG_HIP(copy_to_device(dx.p, X, sizeof(T) * host_span(xrows, ldx, xcols)));
     WAGG_HIP(hipMemset(dout.p, 0, sizeof(T) * (size_t)(orows * ldo)));
     rc = fn(plan, dx.p, Tn, ldx, layout, dout.p, ldo, out_layout, nullptr);
     if (rc != WAGG_OK) return rc;

@@ -138,8 +138,9 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  * (host arrays of c4 / c5 size, 45-76 GB, need no device copy of the whole field).  flags:
  *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister) so that the
  *                    copies are truly asynchronous; without it pageable memory is staged by the runtime
- *                    (arrays below 32 MiB are always staged: registration locks whole pages, and small
- *                    arrays share theirs with other heap objects)
+ *                    (arrays below 32 MiB always go through the library's own page-locked staging buffers:
+ *                    registration locks whole pages, which small arrays share with other heap objects, and
+ *                    the runtime's on-the-fly pinning of pageable memory outlives the call)
  *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
  * Pitched arrays (ldx > G, ldo > R) are honoured: nothing behind the used cells of the last row is read and the
  * padding between result rows is not written.
