@@ -96,12 +96,16 @@ def _fingerprint(*arrays, extra=""):
 
 
 def _memo(tag, arrays, compute, extra=""):
-    key, keep = _fingerprint(*arrays, extra=extra)
+    key, _ = _fingerprint(*arrays, extra=extra)
     hit = _TABLE_MEMO.get((tag, key))
     if hit is not None:
         _TABLE_MEMO.move_to_end((tag, key))
         return hit[1]
     val = compute()
+    # the entry owns COPIES of the object columns' pointer tables: they hold references to the very objects that
+    # were hashed, so none of them can be freed -- and its address handed to a different label -- while the entry
+    # lives, even if the caller's own array is edited in place later
+    keep = [np.array(a, dtype=object, copy=True) for a in arrays if np.asarray(a).dtype.kind == "O"]
     _TABLE_MEMO[(tag, key)] = (keep, val)
     while len(_TABLE_MEMO) > _TABLE_MEMO_MAX:
         _TABLE_MEMO.popitem(last=False)
