@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import functools
 import hashlib
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -41,6 +42,11 @@ except Exception:  # pragma: no cover
 _PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
 _PLAN_CACHE_MAX = 8                 # plans
 _PLAN_CACHE_MAX_FRAC = 0.5          # ... and at most this share of the device's memory (dense plans are GBs)
+# One lock for every look-up / insert / evict of the module-level caches below (_PLAN_CACHE, _TABLE_MEMO,
+# _PINNED_OUT): the drop-in may be called from several Python threads (ctypes releases the GIL inside the
+# library).  A plan handed out by _plan_for is LEASED: its own lock is held until the caller is done with it, and
+# eviction skips leased plans, so no thread can close a plan another one is applying.
+_CACHE_LOCK = threading.RLock()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -72,15 +78,36 @@ _TABLE_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()
 _TABLE_MEMO_MAX = 32
 
 
+class _Unhashable(Exception):
+    """A column whose memory does not identify its content (see _raw_view): the work is done unmemoised."""
+
+
+_POINTER_SAFE = ("string", "bytes", "empty")
+
+
 def _raw_view(a):
-    """(array kept alive, its memory as a bytes-like object); object arrays: the pointer table."""
+    """(array kept alive, its memory as a bytes-like object); object arrays: the pointer table.
+
+    The pointer table identifies the labels only while equal pointers mean equal VALUES, i.e. for immutable
+    objects: ``str`` / ``bytes`` labels and nulls (None / NaN).  Any other object column (lists, mutable
+    user objects, mixed types) raises :class:`_Unhashable` and is never memoised."""
     import ctypes as C
     a = np.asarray(a)
     if not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)
     if a.dtype.kind == "O":
+        if pd.api.types.infer_dtype(a, skipna=True) not in _POINTER_SAFE:     # C loop over the pointers
+            raise _Unhashable("object column with labels other than str / bytes / None")
         return a, (C.string_at(a.ctypes.data, a.nbytes) if a.nbytes else b"")
-    return a, memoryview(a.reshape(-1)).cast("B")
+    if a.dtype.kind in "Mm":               # datetime64 / timedelta64 refuse the buffer protocol
+        return a, memoryview(a.reshape(-1).view(np.int64)).cast("B")
+    try:
+        return a, memoryview(a.reshape(-1)).cast("B")
+    except (ValueError, TypeError):        # any other dtype without a buffer format: its bytes
+        try:
+            return a, memoryview(a.reshape(-1).view(np.uint8))
+        except (ValueError, TypeError) as e:
+            raise _Unhashable(str(e))
 
 
 def _fingerprint(*arrays, extra=""):
@@ -96,19 +123,24 @@ def _fingerprint(*arrays, extra=""):
 
 
 def _memo(tag, arrays, compute, extra=""):
-    key, _ = _fingerprint(*arrays, extra=extra)
-    hit = _TABLE_MEMO.get((tag, key))
-    if hit is not None:
-        _TABLE_MEMO.move_to_end((tag, key))
-        return hit[1]
-    val = compute()
+    try:
+        key, _ = _fingerprint(*arrays, extra=extra)
+    except _Unhashable:
+        return compute()
+    with _CACHE_LOCK:
+        hit = _TABLE_MEMO.get((tag, key))
+        if hit is not None:
+            _TABLE_MEMO.move_to_end((tag, key))
+            return hit[1]
+    val = compute()                          # outside the lock: two threads may both compute, the values are equal
     # the entry owns COPIES of the object columns' pointer tables: they hold references to the very objects that
     # were hashed, so none of them can be freed -- and its address handed to a different label -- while the entry
     # lives, even if the caller's own array is edited in place later
     keep = [np.array(a, dtype=object, copy=True) for a in arrays if np.asarray(a).dtype.kind == "O"]
-    _TABLE_MEMO[(tag, key)] = (keep, val)
-    while len(_TABLE_MEMO) > _TABLE_MEMO_MAX:
-        _TABLE_MEMO.popitem(last=False)
+    with _CACHE_LOCK:
+        _TABLE_MEMO[(tag, key)] = (keep, val)
+        while len(_TABLE_MEMO) > _TABLE_MEMO_MAX:
+            _TABLE_MEMO.popitem(last=False)
     return val
 
 
@@ -361,21 +393,26 @@ _PINNED_OUT_CAP = 512 << 20
 
 
 def _release_pinned(n):
-    _PINNED_OUT["bytes"] -= n
+    with _CACHE_LOCK:
+        _PINNED_OUT["bytes"] -= n
 
 
 def _to_host(o):
     import weakref
     import torch
     n = o.numel() * o.element_size()
-    if n >= (1 << 20) and _PINNED_OUT["bytes"] + n <= _PINNED_OUT_CAP:
+    with _CACHE_LOCK:
+        take = n >= (1 << 20) and _PINNED_OUT["bytes"] + n <= _PINNED_OUT_CAP
+        if take:
+            _PINNED_OUT["bytes"] += n
+    if take:
         try:
             host = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
         except RuntimeError:                      # no page-locked memory to be had: pageable copy
+            _release_pinned(n)
             return o.cpu().numpy()
         host.copy_(o)
         arr = host.numpy()                        # shares the block; views of `arr` keep `arr` (their base) alive
-        _PINNED_OUT["bytes"] += n
         weakref.finalize(arr, _release_pinned, n)
         return arr
     return o.cpu().numpy()
@@ -439,22 +476,33 @@ def _flatten_for_device(values, dims):
 
 
 DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins
+ENTRY_LIST_MAX_FILL = 0.10   # wagg_dense.hip SPMM_MAX_FILL: below it a scattered table is stored as entry lists
 
 
-def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes):
+def _wants_dense(n_ucells, G, layout):
     """Device-form choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
     per timestep; when regions are scattered all over the grid (e.g. <=1 % non-zeros at random
     columns: every region is a multi-chunk "giant") that is many times the grid itself and the
     dense-family forms (MFMA contraction of the stored tiles in fp32 or fp64, entry lists for very
-    sparse fp32 tables), whose cost does not depend on where a region's cells lie, are faster --
-    provided it is a (time, gridcell) problem and, in the worst case, the full W fits comfortably."""
-    if layout != "TG":
-        return False
-    return n_ucells > DENSE_SWITCH * G and _dense_bytes(G, R, is_f32) < 0.6 * free_bytes
+    sparse tables), whose cost does not depend on where a region's cells lie, are faster -- for a
+    (time, gridcell) problem."""
+    return layout == "TG" and n_ucells > DENSE_SWITCH * G
 
 
-def _dense_bytes(G, R, is_f32=True):
-    return (4 if is_f32 else 8) * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
+def _dense_bytes(G, R, is_f32=True, nseg=None):
+    """Upper bound of what a dense-family plan of this table holds in HBM.  A table filled below
+    ENTRY_LIST_MAX_FILL never becomes the full matrix: it is stored either tile-sparse (fewer than half of
+    the tiles, by the library's own rule) or as entry lists (8 B per pair in fp32, 16 B in fp64)."""
+    eb = 4 if is_f32 else 8
+    full = eb * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
+    if nseg is not None and nseg < ENTRY_LIST_MAX_FILL * float(G) * float(R):
+        return min(full, max(full // 2, 4 * eb * int(nseg)))
+    return full
+
+
+def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes, nseg=None):
+    """The form choice as one predicate (tests, tools): scattered regions AND the dense-family plan fits."""
+    return _wants_dense(n_ucells, G, layout) and _dense_bytes(G, R, is_f32, nseg=nseg) < 0.6 * free_bytes
 
 
 def _plan_bytes(plan):
@@ -463,41 +511,77 @@ def _plan_bytes(plan):
 
 def _evict_plans(byte_budget, keep):
     """Close cached plans, oldest first, until at most ``keep`` remain and they hold no more than
-    ``byte_budget`` bytes of device memory; returns the bytes released."""
+    ``byte_budget`` bytes of device memory; returns the bytes released.  Plans leased to a running call
+    (their lock is held) are passed over.  Caller holds _CACHE_LOCK."""
     freed = 0
     held = sum(_plan_bytes(p) for p in _PLAN_CACHE.values())
-    while _PLAN_CACHE and (len(_PLAN_CACHE) > keep or held > max(byte_budget, 0)):
-        _, old = _PLAN_CACHE.popitem(last=False)
-        b = _plan_bytes(old)
-        old.close()
+    for key in list(_PLAN_CACHE):
+        if not (len(_PLAN_CACHE) > keep or held > max(byte_budget, 0)):
+            break
+        old = _PLAN_CACHE[key]
+        if not old._lease.acquire(blocking=False):
+            continue                                   # in use by another thread: not ours to close
+        try:
+            del _PLAN_CACHE[key]
+            b = _plan_bytes(old)
+            old.close()
+        finally:
+            old._lease.release()
         held -= b
         freed += b
     return freed
 
 
+def _drop_plan(plan):
+    """Forget a plan that failed on the device (a poisoned plan keeps failing: its timeout word is sticky)."""
+    with _CACHE_LOCK:
+        for key, p in list(_PLAN_CACHE.items()):
+            if p is plan:
+                del _PLAN_CACHE[key]
+    plan.close()
+
+
 def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
+    """The cached plan of this table, LEASED: ``plan._lease`` is held on return and the caller releases
+    it when its device work is done (see _CACHE_LOCK)."""
     key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
-    plan = _PLAN_CACHE.get(key)
-    if plan is None:
-        import torch
+    with _CACHE_LOCK:
+        plan = _PLAN_CACHE.get(key)
+        if plan is not None:
+            _PLAN_CACHE.move_to_end(key)
+    if plan is not None:
+        plan._lease.acquire()                      # waits for a thread that is applying the same table
+        if plan._h.value:
+            return plan
+        plan._lease.release()                      # closed in the meantime (failed on the device): build anew
+    import torch
+    with _CACHE_LOCK:
         free_bytes, total_bytes = torch.cuda.mem_get_info()
-        # what the cached plans hold can be given back: evict (oldest first) before declining the
-        # dense form for lack of memory, and keep the cache under its byte budget
-        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - _dense_bytes(G, R, is_f32), keep=_PLAN_CACHE_MAX - 1)
-        # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
-        # form: go to the dense / tile-sparse form directly instead of building the sparse plan
-        # first just to read its statistics
+        # keep the cache under its plan count and byte budget (what a sparse plan adds is a few MB)
+        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes, keep=_PLAN_CACHE_MAX - 1)
+        need = _dense_bytes(G, R, is_f32, nseg=len(cell_idx))
+
+        def dense_fits():
+            # only now is the dense byte budget charged: cached plans can be given back (oldest first) before
+            # the dense form is declined for lack of memory
+            nonlocal free_bytes
+            if need >= 0.6 * free_bytes:
+                free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - need, keep=_PLAN_CACHE_MAX - 1)
+            return need < 0.6 * free_bytes
+
         dt = "float32" if is_f32 else "float64"
-        if len(cell_idx) > 4 * DENSE_SWITCH * G and _prefer_dense(float("inf"), G, R, is_f32, layout, free_bytes):
+        # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
+        # form: go to the dense-family form directly instead of building the sparse plan first just to
+        # read its statistics
+        if len(cell_idx) > 4 * DENSE_SWITCH * G and _wants_dense(float("inf"), G, layout) and dense_fits():
             plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
         else:
             plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
-            if _prefer_dense(plan.info["n_ucells"], G, R, is_f32, layout, free_bytes):
+            if _wants_dense(plan.info["n_ucells"], G, layout) and dense_fits():
                 plan.close()
                 plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
+        plan._lease.acquire()
         _PLAN_CACHE[key] = plan
-    else:
-        _PLAN_CACHE.move_to_end(key)
     return plan
 
 
@@ -627,85 +711,95 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     torch = require_gpu()
     X2, layout, _, unflatten = _flatten_for_device(values, dims)
     is_f32 = str(X2.dtype).endswith("float32")
-    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout)
-    out_layout = "TR" if layout == "TG" else "RT"
-    if (not _is_device_tensor(X2)) and layout == "TG" and powers is None and edd is None:
-        # Host-resident (time, gridcell) field, plain aggregation: the C-ABI streams it through the device
-        # in row blocks, the arrays page-locked in place for the call (wagg_apply_host_ex_* /
-        # wagg_dense_apply_host_*): the H2D of block i+1 overlaps the kernels of block i and the device
-        # never holds the whole field.  PCIe-bound for the segment-table form (49 GB/s of X, ~100x the
-        # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
-        from ._lib import HOST_PIN
-        X2c = np.ascontiguousarray(X2)
-        host_out = plan.apply_host(X2c, flags=HOST_PIN)
-        if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
+
+    def _aggregate_on_plan(plan):
+        out_layout = "TR" if layout == "TG" else "RT"
+        if (not _is_device_tensor(X2)) and layout == "TG" and powers is None and edd is None:
+            # Host-resident (time, gridcell) field, plain aggregation: the C-ABI streams it through the device
+            # in row blocks, the arrays page-locked in place for the call (wagg_apply_host_ex_* /
+            # wagg_dense_apply_host_*): the H2D of block i+1 overlaps the kernels of block i and the device
+            # never holds the whole field.  PCIe-bound for the segment-table form (49 GB/s of X, ~100x the
+            # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
+            from ._lib import HOST_PIN
+            X2c = np.ascontiguousarray(X2)
+            host_out = plan.apply_host(X2c, flags=HOST_PIN)
+            if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
+                exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
+                try:
+                    host_out = exact.apply_host(X2c, flags=HOST_PIN)
+                finally:
+                    exact.close()
+            res0 = unflatten(host_out, len(uniq))
+            rdims = _result_dims(dims, agglev)
+            coords = {}
+            for d in rdims:
+                if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+                    coords[d] = np.asarray(carried[d].values)
+            coords[agglev] = uniq
+            return res0, rdims, coords, was_xr
+        # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
+        # kernels, one D2H copy of the result
+        Xd = _to_device(X2)
+        if edd is not None:
+            # Snyder degree days: sum of coef * EDD(threshold), both fields loaded once per threshold
+            H2 = _flatten_for_device(edd[0], dims)[0]
+            if H2.shape != X2.shape or H2.dtype != X2.dtype:
+                raise ValueError("tasmin and tasmax must have the same shape and dtype")
+            Hd = _to_device(H2)
+            coefs, thr = [c for c, _ in edd[2]], [e for _, e in edd[2]]
+
+        def run(plan):
+            """The device work for one plan form; returns the list of (T, R) / (R, T) result tensors."""
+            if edd is not None:
+                if isinstance(plan, DensePlan):     # the degree days are evaluated while X is packed
+                    stack = [plan.apply_edd(Xd, Hd, e, offset=edd[1]) for e in thr]
+                else:
+                    stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
+                total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
+                for c, o in zip(coefs[1:], stack[1:]):
+                    total = total + c * o
+                return [total]
+            if powers is None:
+                return [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
+            if isinstance(plan, DensePlan):         # scattered weights: (x + offset)^p evaluated while X is packed
+                return [plan.apply_poly(Xd, offset, int(p)) for p in powers]
+            lo, hi = int(min(powers)), int(max(powers))
+            stack = plan.apply_poly(Xd, offset, hi - lo + 1, layout=layout, out_layout=out_layout, pow_first=lo)
+            return [stack[int(p) - lo] for p in powers]
+
+        outs = run(plan)
+        if isinstance(plan, DensePlan) and plan.saw_inf():
+            # +-inf in the (transformed) data: the dense forms multiply every (cell, region) pair of a
+            # stored tile, so inf * 0 would leak NaN into regions that do not own the cell.  The
+            # segment-table form confines it to the owning regions like the reference (S6): redo there.
             exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
             try:
-                host_out = exact.apply_host(X2c, flags=HOST_PIN)
+                outs = run(exact)
+                exact.status()
             finally:
                 exact.close()
-        res0 = unflatten(host_out, len(uniq))
+        res = [unflatten(_to_host(o), len(uniq)) for o in outs]
+        if isinstance(plan, SparsePlan):
+            plan.status()                                        # a device-side failure must not pass silently
         rdims = _result_dims(dims, agglev)
+
         coords = {}
         for d in rdims:
             if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
                 coords[d] = np.asarray(carried[d].values)
         coords[agglev] = uniq
-        return res0, rdims, coords, was_xr
-    # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
-    # kernels, one D2H copy of the result
-    Xd = _to_device(X2)
-    if edd is not None:
-        # Snyder degree days: sum of coef * EDD(threshold), both fields loaded once per threshold
-        H2 = _flatten_for_device(edd[0], dims)[0]
-        if H2.shape != X2.shape or H2.dtype != X2.dtype:
-            raise ValueError("tasmin and tasmax must have the same shape and dtype")
-        Hd = _to_device(H2)
-        coefs, thr = [c for c, _ in edd[2]], [e for _, e in edd[2]]
+        return (res[0] if single or edd is not None else res), rdims, coords, was_xr
 
-    def run(plan):
-        """The device work for one plan form; returns the list of (T, R) / (R, T) result tensors."""
-        if edd is not None:
-            if isinstance(plan, DensePlan):     # the degree days are evaluated while X is packed
-                stack = [plan.apply_edd(Xd, Hd, e, offset=edd[1]) for e in thr]
-            else:
-                stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
-            total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
-            for c, o in zip(coefs[1:], stack[1:]):
-                total = total + c * o
-            return [total]
-        if powers is None:
-            return [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
-        if isinstance(plan, DensePlan):         # scattered weights: (x + offset)^p evaluated while X is packed
-            return [plan.apply_poly(Xd, offset, int(p)) for p in powers]
-        lo, hi = int(min(powers)), int(max(powers))
-        stack = plan.apply_poly(Xd, offset, hi - lo + 1, layout=layout, out_layout=out_layout, pow_first=lo)
-        return [stack[int(p) - lo] for p in powers]
-
-    outs = run(plan)
-    if isinstance(plan, DensePlan) and plan.saw_inf():
-        # +-inf in the (transformed) data: the dense forms multiply every (cell, region) pair of a
-        # stored tile, so inf * 0 would leak NaN into regions that do not own the cell.  The
-        # segment-table form confines it to the owning regions like the reference (S6): redo there.
-        exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
-        try:
-            outs = run(exact)
-            exact.status()
-        finally:
-            exact.close()
-    if edd is not None:
-        single = True
-    res = [unflatten(_to_host(o), len(uniq)) for o in outs]
-    if isinstance(plan, SparsePlan):
-        plan.status()                                        # a device-side failure must not pass silently
-    rdims = _result_dims(dims, agglev)
-
-    coords = {}
-    for d in rdims:
-        if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-            coords[d] = np.asarray(carried[d].values)
-    coords[agglev] = uniq
-    return (res[0] if single else res), rdims, coords, was_xr
+    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout)
+    try:
+        return _aggregate_on_plan(plan)
+    except _engine.WaggError:
+        # a device-side failure is sticky on the plan (its timeout word): drop it from the cache so the next
+        # call on this table builds a fresh one instead of failing for the rest of the process
+        _drop_plan(plan)
+        raise
+    finally:
+        plan._lease.release()
 
 
 def _as_dataset(data_vars, rdims, coords, was_xr):

@@ -3,6 +3,7 @@ only; every number is produced by the HIP kernels in climate_toolbox_amd/csrc/."
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -64,6 +65,7 @@ class SparsePlan:
         if not (ci.shape == rc.shape == we.shape and ci.ndim == 1):
             raise ValueError("cell_idx, region_code, w_eff must be 1-D and of equal length")
         self._h = C.c_void_p()
+        self._lease = threading.Lock()       # held by whoever is applying a cached plan (aggregations._plan_for)
         self.G, self.R = int(G), int(R)
         _lib.check(L.wagg_plan_create(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32),
                                       _np_ptr(we, C.c_double), len(ci), self.G, self.R,
@@ -179,6 +181,7 @@ class DensePlan:
 
     def __init__(self, handle, G, R):
         self._h, self.G, self.R = handle, int(G), int(R)
+        self._lease = threading.Lock()
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
         self.den = den

@@ -98,8 +98,9 @@ def aggregate_time_sharded(apply_fn, X_local, rows=None, dst=0, group=None):
 class ShardedStep:
     """One benchmark / production step of a time-sharded aggregation with the reassembly of step k
     overlapped with the compute of step k + 1: results alternate between two local buffers, the
-    gather of a buffer is queued asynchronously (RCCL runs it on its own stream) and only waited
-    for when that buffer is about to be overwritten, or in ``finish()``.
+    gather of a buffer is queued asynchronously (RCCL runs it on its own stream) and waited for
+    after the NEXT step's compute, just before that step's gather is queued (both write the same
+    destination rows, so at most one gather is ever in flight), or in ``finish()``.
 
     apply_fn(out_buffer) must write this rank's (T_rank, R) block into ``out_buffer``."""
 
@@ -118,6 +119,12 @@ class ShardedStep:
             self.pending[i] = None
         self.apply_fn(self.bufs[i])
         if self.distributed:
+            # the previous step's gather writes the same rows of `gathered`: it has had this step's compute to
+            # finish in, and must be complete before the next one is queued (gloo completes asynchronous
+            # collectives on several threads in no fixed order: a late gather k could overwrite gather k + 1)
+            if self.pending[i ^ 1] is not None:
+                self.pending[i ^ 1].wait()
+                self.pending[i ^ 1] = None
             res, handle = gather_time_shards(self.bufs[i], dst=self.dst, rows=self.rows, group=self.group,
                                              out=self.gathered, async_op=True)
             if res is not None:

@@ -138,6 +138,9 @@ def test_dense_form_choice():
     assert not A._prefer_dense(1.4 * G, G, R, True, "TG", 250 * GB)        # c2-real: compact regions
     assert A._prefer_dense(240 * G, G, R, True, "TG", 250 * GB)            # c5 uniform-random columns
     assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB)       # fp64: 202 GB of W would not fit
+    # ... but a table filled to 1 % never becomes the full matrix (entry lists or fewer than half of the tiles)
+    assert A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB, nseg=int(0.01 * G * R))
+    assert not A._prefer_dense(240 * G, G, R, False, "TG", 250 * GB, nseg=int(0.2 * G * R))
     assert A._prefer_dense(240 * G, G, 4000, False, "TG", 250 * GB)        # ... a smaller fp64 problem takes the f64 MFMA form
     assert not A._prefer_dense(240 * G, G, R, True, "GT", 250 * GB)        # fixture layout stays too
     assert not A._prefer_dense(240 * G, G, R, True, "TG", 100 * GB)        # 101 GB of W must fit
@@ -378,3 +381,105 @@ def test_table_memo_follows_the_table_content(monkeypatch):
     with pytest.raises(KeyError):
         A._resolve_cells(lat, lon, sa, so)
     assert len(A._TABLE_MEMO) <= A._TABLE_MEMO_MAX
+
+
+def test_table_memo_label_types_without_a_buffer_or_a_safe_identity(monkeypatch):
+    """datetime64 / timedelta64 label columns refuse the buffer protocol: they are fingerprinted through their
+    int64 view and factorised as before.  Object columns whose elements are not str / bytes / None
+    are never fingerprinted by pointer (equal pointers to a MUTABLE object do not mean equal labels): they are
+    factorised afresh on every call."""
+    from climate_toolbox_amd import aggregations as A
+    A._TABLE_MEMO.clear()
+    days = np.array(["2001-01-03", "2000-05-01", "2001-01-03", "1999-12-31"], dtype="datetime64[D]")
+    for lab in (days, days - days[3]):
+        uniq, codes = A._factorize_labels(lab)
+        ec, eu = pd.factorize(lab, sort=True)
+        np.testing.assert_array_equal(uniq, np.asarray(eu))
+        np.testing.assert_array_equal(codes, ec.astype(np.int32))
+        n = len(A._TABLE_MEMO)
+        A._factorize_labels(lab)
+        assert len(A._TABLE_MEMO) == n                       # a hit, not a second entry
+    calls = {"n": 0}
+    real = A._factorize_labels_impl
+
+    def counting(lab):
+        calls["n"] += 1
+        return real(lab)
+
+    monkeypatch.setattr(A, "_factorize_labels_impl", counting)
+    n = len(A._TABLE_MEMO)
+    for lab in (np.array([3, "a", 2.5, "a"], dtype=object), np.array([(1, 2), (0, 1), (1, 2)] + [None], dtype=object)[:3]):
+        with pytest.raises(A._Unhashable):
+            A._raw_view(lab)
+    mixed = np.array([7, 3, 7, 5], dtype=object)             # Python ints as objects: "integer", not pointer-safe
+    for k in range(2):
+        uniq, codes = A._factorize_labels(mixed)
+        np.testing.assert_array_equal(codes, [2, 0, 2, 1])
+        assert calls["n"] == k + 1 and len(A._TABLE_MEMO) == n
+    nulls = np.array(["b", None, "a", np.nan, "b"], dtype=object)      # str + nulls stays memoised
+    A._factorize_labels(nulls)
+    A._factorize_labels(nulls)
+    assert calls["n"] == 3 and len(A._TABLE_MEMO) == n + 1
+
+
+def test_plan_cache_leases_and_eviction_budget(monkeypatch):
+    """The plan cache (host logic with stand-in plans): eviction passes over a plan that another thread has
+    leased, a sparse-form miss does not charge the dense byte budget (a 100 GB dense plan was evicted
+    for a table that then took the segment-table form), and concurrent calls on the module caches are serialised."""
+    import threading
+    from climate_toolbox_amd import aggregations as A
+
+    class FakePlan:
+        def __init__(self, nbytes):
+            self._lease, self.closed, self.info = threading.Lock(), False, {"nnz": nbytes // 16}
+
+        def close(self):
+            self.closed = True
+
+    GB = 1 << 30
+    cache = A._PLAN_CACHE
+    saved = dict(cache)
+    cache.clear()
+    try:
+        a, b, c = FakePlan(100 * GB), FakePlan(1 * GB), FakePlan(1 * GB)
+        cache["a"], cache["b"], cache["c"] = a, b, c
+        with A._CACHE_LOCK:
+            assert A._evict_plans(144 * GB, keep=7) == 0                  # under both limits: nothing goes
+            assert not (a.closed or b.closed or c.closed)
+            a._lease.acquire()                                            # "another thread is applying a"
+            freed = A._evict_plans(50 * GB, keep=7)                       # over the byte budget: a is the oldest...
+            assert not a.closed and "a" in cache                          # ... but leased: passed over
+            assert b.closed and c.closed and freed == 2 * GB              # (the others go: still over budget)
+            a._lease.release()
+            assert A._evict_plans(50 * GB, keep=7) == 100 * GB and a.closed and not cache
+        # count limit
+        ps = [FakePlan(16) for _ in range(10)]
+        for i, q in enumerate(ps):
+            cache[i] = q
+        with A._CACHE_LOCK:
+            A._evict_plans(1 << 40, keep=7)
+        assert [q.closed for q in ps] == [True] * 3 + [False] * 7
+        # _drop_plan forgets exactly the failed plan
+        A._drop_plan(ps[5])
+        assert ps[5].closed and 5 not in cache and len(cache) == 6
+    finally:
+        cache.clear()
+        cache.update(saved)
+    # the memo under threads: same answers, no exception, bounded size
+    A._TABLE_MEMO.clear()
+    labs = [np.array(["R%03d" % ((i * 7 + k) % 50) for i in range(2000)], dtype=object) for k in range(6)]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                for lab in labs[k % 3:k % 3 + 3]:
+                    uniq, codes = A._factorize_labels(lab)
+                    assert list(uniq[codes[:5]]) == list(lab[:5])
+        except Exception as e:                                            # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len(A._TABLE_MEMO) <= A._TABLE_MEMO_MAX
