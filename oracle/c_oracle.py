@@ -37,6 +37,9 @@ def lib():
         L.wagg_oracle_dense_synth2_f32.restype = C.c_int
         L.wagg_oracle_dense_synth2_f32.argtypes = [C.POINTER(C.c_float)] + [C.c_int64] * 7 + [
             C.c_uint32, C.c_double, C.c_int, f64p]
+        L.wagg_oracle_dense_synth_cols_f32.restype = C.c_int
+        L.wagg_oracle_dense_synth_cols_f32.argtypes = [C.POINTER(C.c_float)] + [C.c_int64] * 4 + [
+            C.POINTER(C.c_int64), C.c_int64, C.c_uint32, C.c_double, C.c_int, f64p]
         L.wagg_oracle_hash_u01.restype = C.c_float
         L.wagg_oracle_hash_u01.argtypes = [C.c_uint64, C.c_uint32]
         L.wagg_oracle_threads.restype = C.c_int
@@ -96,6 +99,21 @@ def dense_synth_sparse(X, g0, Gw, R_total, r0, Rw, seed, fill=1.0, blocklocal=Fa
                                            float(fill), 1 if blocklocal else 0, _p(out, C.c_double))
     if rcode != 0:
         raise RuntimeError("wagg_oracle_dense_synth2_f32 failed: %d" % rcode)
+    return out
+
+
+def dense_synth_cols(X, G, R_total, cols, seed, fill=1.0, blocklocal=False):
+    """The synthetic dense / c5 weights contracted for an arbitrary list of regions ``cols`` over all G
+    cells: (T, len(cols)) fp64.  One short window per column tile of a full-size result costs seconds."""
+    L = lib()
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    T, ldx = X.shape
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    out = np.empty((T, len(cols)), dtype=np.float64)
+    rcode = L.wagg_oracle_dense_synth_cols_f32(_p(X, C.c_float), T, ldx, G, R_total, _p(cols, C.c_int64), len(cols),
+                                               seed, float(fill), 1 if blocklocal else 0, _p(out, C.c_double))
+    if rcode != 0:
+        raise RuntimeError("wagg_oracle_dense_synth_cols_f32 failed: %d" % rcode)
     return out
 
 

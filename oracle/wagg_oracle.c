@@ -172,3 +172,50 @@ int wagg_oracle_dense_synth_f32(const float *X, int64_t T, int64_t ldx, int64_t 
     free(den);
     return 0;
 }
+
+/* The same dense-form restatement (fp32 inputs, fp64 accumulation, kept pairs only, skipna) for an
+ * ARBITRARY LIST of output columns over all G cells: out[t * ncols + j] is region cols[j].  This is what lets a
+ * parity test touch every 256-region column tile of a full-size result (one short window per tile) in seconds:
+ * each thread owns whole columns, so there is one parallel region instead of two per 64 cells. */
+int wagg_oracle_dense_synth_cols_f32(const float *X, int64_t T, int64_t ldx, int64_t G, int64_t R_total,
+                                     const int64_t *cols, int64_t ncols, uint32_t seed, double fill,
+                                     int blocklocal, double *out) {
+    const int64_t n_nt = (R_total + 255) / 256;
+    const float ffill = (float)fill;
+    int failed = 0;
+    enum { CB = 8 };                                      /* columns per work item */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c0 = 0; c0 < ncols; c0 += CB) {
+        const int64_t cn = ncols - c0 < CB ? ncols - c0 : CB;
+        double *acc = (double *)calloc((size_t)(T + 1) * CB, sizeof(double));   /* [T][CB] sums, then [CB] den */
+        if (!acc) { failed = 1; continue; }
+        double *den = acc + T * CB;
+        float w[CB];
+        for (int64_t g = 0; g < G; ++g) {
+            const int64_t owner = (97 * (g / 64)) % n_nt;
+            int any = 0;
+            for (int64_t j = 0; j < cn; ++j) {
+                const int64_t r = cols[c0 + j];
+                const uint64_t id = (uint64_t)g * (uint64_t)R_total + (uint64_t)r;
+                int keep = fill >= 1.0 || wagg_oracle_hash_u01(id, seed ^ 0x9e3779b9u) < ffill;
+                if (blocklocal && r / 256 != owner) keep = 0;
+                w[j] = keep ? wagg_oracle_hash_u01(id, seed) : 0.0f;
+                den[j] += (double)w[j];
+                any |= w[j] != 0.0f;
+            }
+            if (!any) continue;
+            for (int64_t t = 0; t < T; ++t) {
+                const float xf = X[t * ldx + g];
+                for (int64_t j = 0; j < cn; ++j) {
+                    if (w[j] == 0.0f) continue;                       /* no segment row for this pair */
+                    const double p = (double)xf * (double)w[j];
+                    if (!isnan(p)) acc[t * CB + j] += p;              /* skipna (S6) */
+                }
+            }
+        }
+        for (int64_t t = 0; t < T; ++t)
+            for (int64_t j = 0; j < cn; ++j) out[t * ncols + c0 + j] = acc[t * CB + j] / den[j];
+        free(acc);
+    }
+    return failed ? -2 : 0;
+}

@@ -327,6 +327,17 @@ def test_c2_c3_full_size_vs_oracle(torch_cuda, c2_real, wname, dtype, rtol):
     del poly
 
 
+def _tile_windows(R, width, seed):
+    """`width` consecutive regions at a random offset inside every 256-region column tile of [0, R)."""
+    rng = np.random.default_rng(seed)
+    cols = []
+    for t0 in range(0, R, 256):
+        n = min(256, R - t0)
+        off = int(rng.integers(0, max(1, n - width + 1)))
+        cols.append(t0 + off + np.arange(min(width, n)))
+    return np.concatenate(cols).astype(np.int64)
+
+
 def test_c2_dense_full_size_properties(torch_cuda):
     """configs[1] in its dense north-star form (101 GB W generated on the device).  The fp64 oracle
     cannot do 1.8e13 MACs, so: a column window against the C oracle on all 1,036,800 cells, the
@@ -343,9 +354,11 @@ def test_c2_dense_full_size_properties(torch_cuda):
     X = engine.synth_field(T, G, seed=5, base=280.0, amp=60.0)
     got = plan.apply(X).cpu().numpy()
     Xh = X.cpu().numpy()
-    for r0 in (0, 12000, R - 16):
-        ref = c_oracle.dense_synth(Xh, 0, G, R, r0, 16, seed)
-        _rel_ok(got[:, r0:r0 + 16], ref, RTOL32)
+    # one 16-column window in EVERY one of the 96 column tiles (random offset inside the tile, fixed seed; the last
+    # tile holds 58 regions), all 1,036,800 cells each: a permutation inside any tile would show
+    cols = _tile_windows(R, 16, seed=20)
+    assert len(cols) == 96 * 16 and len(set(cols // 256)) == 96
+    _rel_ok(got[:, cols], c_oracle.dense_synth_cols(Xh, G, R, cols, seed), RTOL32)
     idx = (np.arange(G, dtype=np.uint64) * np.uint64(R) + np.uint64(777))
     np.testing.assert_allclose(plan.den[777], O.hash_u01(idx, seed).astype(np.float64).sum(), rtol=1e-12)
     const = plan.apply(torch.full((2, G), 3.5, dtype=torch.float32, device="cuda")).cpu().numpy()

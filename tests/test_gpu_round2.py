@@ -10,7 +10,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from tests.test_gpu_parity import RTOL32, RTOL64, _rel_ok
+from tests.test_gpu_parity import RTOL32, RTOL64, _rel_ok, _tile_windows
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -249,9 +249,11 @@ def test_c5_full_size_rank_shard(torch_cuda, structure):
     got = plan.apply(X)
     rows = torch.from_numpy(np.r_[0:6, 1140:1146, T - 6:T]).cuda()          # first / middle / ragged last time block
     Xr = X[rows].cpu().numpy()
-    for r0 in (0, 11111, R - 16):                                           # column windows over ALL 1,036,800 cells
-        ref = c_oracle.dense_synth_sparse(Xr, 0, G, R, r0, 16, seed, fill=fill, blocklocal=not uniform)
-        _rel_ok(got[rows][:, r0:r0 + 16].cpu().numpy(), ref, RTOL32)
+    # a 16-region window in every one of the 96 column tiles (= every region block of the entry-list form / every
+    # column tile of the tile-sparse form), over ALL 1,036,800 cells
+    cols = _tile_windows(R, 16, seed=21)
+    ref = c_oracle.dense_synth_cols(Xr, G, R, cols, seed, fill=fill, blocklocal=not uniform)
+    _rel_ok(got[rows][:, torch.from_numpy(cols).cuda()].cpu().numpy(), ref, RTOL32)
     # denominators against the hashes
     r = 777
     idx = np.arange(G, dtype=np.uint64) * np.uint64(R) + np.uint64(r)
