@@ -21,9 +21,17 @@ Workloads (--workload):
 For c4/c5 the rows of a run are shard_bounds(T_total, --shards)[rank]; --shards defaults to the
 world size for c4 and to 8 for c5 (one rank's share of the 8-GPU job on a single GPU).
 
-With --gpus N (launched by torch.distributed.run, one rank per GPU) the time axis is sharded over
-the ranks and the region time series are reassembled on rank 0 with an RCCL gather that overlaps
-the next step's compute; the default workload is weak scaling (365 rows per rank).
+With --gpus N the time axis is sharded over N ranks (one process per GPU) and the region time series are
+reassembled on rank 0 with an RCCL gather that overlaps the next step's compute; the default workload is weak
+scaling (365 rows per rank).  The ranks may be started by torch.distributed.run (the driver's way: RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or by this script itself: a plain `python bench.py --gpus N` starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child BEFORE anything touches the GPU,
+relays rank 0's JSON line and returns the child's exit status (a rank whose LOCAL_RANK has no device exits
+non-zero with a one-line reason).  --dry-run rehearses exactly that plumbing on CPU (gloo, no kernels).
+
+The default N=1 run carries every BASELINE config in its line: c2-dense is the headline; "secondary" holds c1,
+c2-real, c3-real, one rank's share of c4 (1,369 rows on the c2-dense operand) and of c5 in both structures
+(2,282 rows; block-local fp32, uniform fp32 and fp64), each with its own roofline and cpu_baseline.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,7 +48,8 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk/CU
 PEAK_F64_MFMA_TFLOPS = 78.6     # half the fp32 rate
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-WORKLOADS = ["c1", "c2-dense", "c2-real", "c3-real", "c4", "c5-block", "c5-uniform", "c5-block-f64"]
+WORKLOADS = ["c1", "c2-dense", "c2-real", "c3-real", "c4", "c5-block", "c5-uniform", "c5-block-f64", "c5-uniform-f64"]
+DENSE_FAMILY = ("c2-dense", "c4", "c5-block", "c5-uniform", "c5-block-f64", "c5-uniform-f64")
 
 
 def parse():
@@ -57,11 +66,77 @@ def parse():
     ap.add_argument("--ksplit", type=int, default=0)
     ap.add_argument("--land-frac", type=float, default=0.30, help="experiment knob for c2-real")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launcher and the rank plumbing on CPU (gloo, no kernels, value 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--diag-lib", nargs="?", const="libwagg_diag.so", default=None, metavar="NAME",
                     help="load climate_toolbox_amd/lib/NAME (default libwagg_diag.so, `make diag`) instead of libwagg.so: "
                          "the build with the ablation knobs, or an experiment's variant; timing experiments only")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without torch.distributed.run in front: start the N ranks as a child job and relay
+    rank 0's line.  Nothing here touches the GPU (no torch import, no libwagg call): the children are fresh
+    processes, this one only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:                 # the ranks' stderr passes straight through
+        if ln.startswith("{"):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly without a JSON line\n")
+        rc = 1
+    return rc
+
+
+def dry_run(a, rank, local_rank, world):
+    """The rank plumbing without a GPU: gloo group, the shard rule, barrier + max-over-ranks timing, one line."""
+    import torch
+    import torch.distributed as dist
+    from climate_toolbox_amd.timeshard import ShardedStep, shard_bounds
+    if world > 1:
+        dist.init_process_group("gloo")
+    rows = [e - s0 for s0, e in shard_bounds(365 * world, world)]
+    R = 16
+    st = ShardedStep(lambda out: out.fill_(float(rank + 1)), lambda: torch.empty((rows[rank], R)), rows=rows, dst=0,
+                     distributed=world > 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        st.step()
+    got = st.finish()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ok = world == 1 or all(bool((got[sum(rows[:r]):sum(rows[:r + 1])] == r + 1).all()) for r in range(world))
+        print(json.dumps({"metric": "gridcell-region-timesteps/sec", "value": 0.0, "unit": "gridcell-region-timesteps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / max(1, a.steps) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "dry_run": True, "gather_ok": ok,
+                          "config": {"workload": "dry run: launcher + gloo gather only, no kernels", "T_job": sum(rows)}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def load_traffic(workload):
@@ -77,6 +152,10 @@ def load_traffic(workload):
         return e.get("hbm_bytes_per_launch"), "profiles/traffic.json <- %s (%s)" % (e.get("source"), e.get("measured", "round 1"))
     except Exception:
         return None, None
+
+
+# wagg_plan_info.kernel_form (when the library reports it): the dominant kernel of a segment-table apply
+PLAN_KERNEL = {}
 
 
 def sparse_algorithmic_bytes(T, G, R, nnz, b):
@@ -171,15 +250,22 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
 
 def main():
     a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)              # before anything that could initialise the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.dry_run:
+        return dry_run(a, rank, local_rank, world)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    n_dev = torch.cuda.device_count()      # (counting devices does not initialise the GPU)
+    if local_rank >= n_dev:
+        raise SystemExit("bench.py: rank %d (LOCAL_RANK %d) has no device: this box has %d GPU(s), --gpus %d"
+                         % (rank, local_rank, n_dev, a.gpus))
     torch.cuda.set_device(local_rank)
     # WAGG_BENCH_FORCE_DIST=1 exercises the RCCL init + gather code path with a single rank (rehearsal
     # on a one-GPU box); the timed step then includes the (trivial) gather exactly like N > 1 runs
@@ -202,30 +288,41 @@ def main():
 
     G, R = a.nlat * a.nlon, a.R
     scaling = "weak"
-    # rows of this rank
-    if a.workload in ("c4", "c5-block", "c5-uniform", "c5-block-f64"):
-        T_total = 10950 if a.workload == "c4" else 50 * 365
-        shards = a.shards or (world if a.workload == "c4" or world > 1 else 8)
-        bounds = shard_bounds(T_total, max(shards, world))
-        rows_all = [e - s for s, e in bounds][:world]
-        T = a.T or rows_all[rank]
-        if a.T:
-            rows_all = [a.T] * world
-        scaling = "strong" if shards == world and not a.T else "weak"
-    else:
-        T = a.T or 365
-        rows_all = [T] * world
-    T_job = sum(rows_all)
+    C5_TOTAL, C4_TOTAL = 50 * 365, 10950
 
-    def stepper(apply_fn, Rr, dtype):
-        return ShardedStep(apply_fn, lambda: torch.empty((T, Rr), dtype=dtype, device="cuda"), rows=rows_all, dst=0,
+    def rows_for(wl):
+        """(rows of this rank, rows of every rank, scaling) of a workload in this run."""
+        if wl in ("c4",) or wl.startswith("c5"):
+            T_total = C4_TOTAL if wl == "c4" else C5_TOTAL
+            shards = a.shards or (world if wl == "c4" or world > 1 else 8)
+            bounds = shard_bounds(T_total, max(shards, world))
+            rows_all = [e - s0 for s0, e in bounds][:world]
+            if a.T:
+                rows_all = [a.T] * world
+            return rows_all[rank], rows_all, ("strong" if shards == world and not a.T else "weak")
+        Tn = a.T or 365
+        return Tn, [Tn] * world, "weak"
+
+    def stepper(apply_fn, Tn, rows_all, Rr, dtype):
+        return ShardedStep(apply_fn, lambda: torch.empty((Tn, Rr), dtype=dtype, device="cuda"), rows=rows_all, dst=0,
                            distributed=use_dist)
 
-    def kernel_avg_ms(kms):
-        kms = kms[a.warmup:] if len(kms) > a.warmup else kms
+    def kernel_avg_ms(kms, warmup):
+        kms = kms[warmup:] if len(kms) > warmup else kms
         return sum(kms) / max(1, len(kms))
 
-    def run_sparse(dtype, small=False):
+    def on_traffic(roof, kavg, peak_gbs=PEAK_HBM_GBS):
+        """The same roofline priced on the bytes the counters saw move (profiles/traffic.json), next to the
+        algorithmic figure: a kernel that skips cells it does not need shows the difference here."""
+        if roof.get("traffic"):
+            roof["achieved_on_traffic"] = roof["traffic"] / kavg / 1e9
+            roof["frac_on_traffic"] = roof["achieved_on_traffic"] / peak_gbs
+        return roof
+
+    def run_sparse(dtype, small=False, steps=None, warmup=None, extras=True):
+        steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
+        T, rows_all, _ = rows_for("c1" if small else "c2-real")
+        T_job = sum(rows_all)
         if small:       # c1: the reference's 2-degree test grid, 100 block regions (SURVEY 8d)
             lat, lon, tas, df = synth.c1_workload(T=T)
             Gs, nlon = len(lat) * len(lon), len(lon)
@@ -239,10 +336,10 @@ def main():
         cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, lev)
         plan = engine.SparsePlan(cell, codes, w_eff, Gs, len(uniq), row_len=nlon)
         Rr = len(uniq)
-        st = stepper(lambda out: plan.apply(Xs, out=out), Rr, Xs.dtype)
+        st = stepper(lambda out: plan.apply(Xs, out=out), T, rows_all, Rr, Xs.dtype)
         engine.profile_enable(True)       # event records only, no synchronisation
-        dt = timed_steps(torch, dist, st.step, st.finish, a.steps, a.warmup, world)
-        kavg = kernel_avg_ms(engine.profile_read()) * 1e-3
+        dt = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
+        kavg = kernel_avg_ms(engine.profile_read(), warmup) * 1e-3
         engine.profile_enable(False)
         plan.status()
         b = 4 if dtype == "float32" else 8
@@ -250,30 +347,32 @@ def main():
         abytes = sparse_algorithmic_bytes(T, Gs, Rr, nnz, b)
         wl = "c1" if small else ("c2-real" if dtype == "float32" else "c3-real")
         traffic, tsrc = load_traffic(wl)
+        kname = PLAN_KERNEL.get(int(plan.info.get("kernel_form", -1)),
+                                "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel<double>")
         res = {
-            "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "G": Gs, "R": Rr, "nnz": int(nnz),
-            "value": T_job * Gs * Rr * a.steps / dt, "unit": "gridcell-region-timesteps/s",
-            "ms_per_step": dt / a.steps * 1e3, "nnz_timesteps_per_s": T_job * nnz * a.steps / dt,
+            "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "T_job": T_job, "G": Gs, "R": Rr, "nnz": int(nnz),
+            "value": T_job * Gs * Rr * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "nnz_timesteps_per_s": T_job * nnz * steps / dt,
             "plan": {k: int(v) for k, v in plan.info.items()},
-            "roofline": {"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel<double>",
-                         "kernel_ms_avg": kavg * 1e3, "algorithmic_bytes_per_launch": abytes},
+            "roofline": on_traffic({"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
+                                    "kernel": kname, "kernel_ms_avg": kavg * 1e3, "algorithmic_bytes_per_launch": abytes},
+                                   kavg),
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_sparse(Xs.cpu().numpy(), cell, codes, w_eff, Rr, Gs,
                                                       "the FULL workload (all %d timesteps, full segment table)" % T)
-        if dtype == "float32" and world == 1 and not small:
+        if dtype == "float32" and world == 1 and not small and extras:
             # fused tas_poly: (tas - 273.15)^p, p = 1..4, one pass over the field
             pout = torch.empty((4, T, Rr), dtype=Xs.dtype, device="cuda")
             for _ in range(2):
                 plan.apply_poly(Xs, -273.15, 4, out=pout)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(a.steps):
+            for _ in range(steps):
                 plan.apply_poly(Xs, -273.15, 4, out=pout)
             torch.cuda.synchronize()
-            pdt = (time.perf_counter() - t0) / a.steps
+            pdt = (time.perf_counter() - t0) / steps
             res["fused_tas_poly_1to4"] = {"ms_per_step": pdt * 1e3, "value": 4 * T * Gs * Rr / pdt,
                                           "unit": "gridcell-region-timesteps/s (4 powers)"}
             del pout
@@ -287,32 +386,44 @@ def main():
                     plan.apply_edd(Xs, tmax, thr, offset=-273.15, out=eout)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(a.steps):
+                for _ in range(steps):
                     plan.apply_edd(Xs, tmax, thr, offset=-273.15, out=eout)
                 torch.cuda.synchronize()
-                edd["K%d_ms" % K] = (time.perf_counter() - t0) / a.steps * 1e3
+                edd["K%d_ms" % K] = (time.perf_counter() - t0) / steps * 1e3
                 del eout
             res["fused_snyder_edd"] = edd
             del tmax
+        plan.close()
         return res
 
-    def run_dense_family(wl):
-        """c2-dense / c4 (full matrix), c5-uniform (entry lists), c5-block (tile-sparse)."""
+    cpu_dense_memo = {}
+
+    def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False):
+        """c2-dense / c4 (full matrix), c5-uniform[-f64] (entry lists), c5-block[-f64] (tile-sparse)."""
+        steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
+        T, rows_all, scal = rows_for(wl)
+        T_job = sum(rows_all)
         f64 = wl.endswith("-f64")
-        X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype="float64" if f64 else "float32")
-        if wl == "c5-uniform":
-            plan, fill, bl = engine.DensePlan.synth(G, R, seed=2, fill=0.01), 0.01, False
+        dt_name = "float64" if f64 else "float32"
+        X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype=dt_name)
+        if wl.startswith("c5-uniform"):
+            fill, bl = 0.01, False
+            plan = plan or engine.DensePlan.synth(G, R, seed=2, fill=0.01, dtype=dt_name)
         elif wl.startswith("c5-block"):
-            plan, fill, bl = engine.DensePlan.synth_blocklocal(G, R, seed=2, dtype="float64" if f64 else "float32"), 0.952, True
+            fill, bl = 0.952, True
+            plan = plan or engine.DensePlan.synth_blocklocal(G, R, seed=2, dtype=dt_name)
         else:
-            plan, fill, bl = engine.DensePlan.synth(G, R, seed=2), 1.0, False
-        st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), R, X.dtype)
+            fill, bl = 1.0, False
+            plan = plan or engine.DensePlan.synth(G, R, seed=2)
+        st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), T, rows_all, R, X.dtype)
         engine.profile_enable(True)       # event records only (no sync)
-        dt = timed_steps(torch, dist, st.step, st.finish, a.steps, a.warmup, world)
-        kavg = kernel_avg_ms(engine.profile_read()) * 1e-3
+        dt = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
+        kms = engine.profile_read()
         engine.profile_enable(False)
         form = int(plan.info["form"])
-        if wl == "c5-uniform":
+        # one apply = one dominant-kernel launch (a full-form apply of several row blocks is one launch too)
+        kavg = kernel_avg_ms(kms, warmup) * 1e-3
+        if wl.startswith("c5-uniform"):
             nnz = int(plan.info["nnz"])
         elif wl.startswith("c5-block"):
             nnz = int(round(plan.info["n_tiles"] * (16 if f64 else 32) * 256 * fill))
@@ -322,31 +433,52 @@ def main():
         traffic, tsrc = load_traffic(wl)
         kname = {0: "dense_mfma_kernel", 1: "dense_mfma_kernel<tiled>", 2: "spmm_kernel (vector ALU, entry lists)"}[form]
         if f64:
-            kname = kname.replace("dense_mfma_kernel", "dense_mfma_kernel<double>")
+            kname = kname.replace("dense_mfma_kernel", "dense_mfma_kernel<double>").replace("spmm_kernel", "spmm_kernel<double>")
+        # entry lists run on the vector ALU: fp32 FMA peak = the fp32 MFMA peak (157.3), fp64 FMA = 78.6
         peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
-        res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "G": G, "R": R, "nnz": nnz,
-               "value": T_job * G * R * a.steps / dt, "unit": "gridcell-region-timesteps/s",
-               "ms_per_step": dt / a.steps * 1e3, "plan": {k: int(v) for k, v in plan.info.items()},
-               "roofline": {"bound": "mfma", "achieved": flops / kavg / 1e12, "peak": peak,
+        res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "T_job": T_job, "G": G, "R": R, "nnz": nnz,
+               "value": T_job * G * R * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": dt / steps * 1e3, "plan": {k: int(v) for k, v in plan.info.items()}, "scaling": scal,
+               "roofline": {"bound": "mfma" if form != 2 else "valu", "achieved": flops / kavg / 1e12, "peak": peak,
                             "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / peak,
                             "traffic": traffic, "traffic_source": tsrc, "kernel": kname,
                             "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops}}
+        if wl != "c2-dense":
+            res["rows"] = ("one rank's share: %d of the job's %d rows (shard 0 of %d)"
+                           % (T, C4_TOTAL if wl == "c4" else C5_TOTAL, a.shards or 8)) if world == 1 else "rows %r" % (rows_all,)
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_dense(T, G, R, 2, fill, bl)
-        plan.close()
-        return res
+            key = (fill, bl)                                    # c4 contracts the c2-dense operand: one CPU window serves both
+            if key not in cpu_dense_memo:
+                cpu_dense_memo[key] = cpu_baseline_dense(min(T, 365), G, R, 2, fill, bl)
+            res["cpu_baseline"] = cpu_dense_memo[key]
+        del X
+        if not keep_plan:
+            plan.close()
+            plan = None
+        return res, plan
 
     secondary = []
-    if a.workload in ("c2-dense", "c4", "c5-block", "c5-uniform", "c5-block-f64"):
-        main_res = run_dense_family(a.workload)
-        if a.workload == "c2-dense" and world == 1 and not a.no_secondary:
+    sec_steps = max(1, min(a.steps, 5))
+    if a.workload in DENSE_FAMILY:
+        want_secondary = a.workload == "c2-dense" and world == 1 and not a.no_secondary
+        main_res, plan = run_dense_family(a.workload, keep_plan=want_secondary)
+        scaling = main_res.get("scaling", "weak")
+        if want_secondary:
+            # every other BASELINE config on this GPU (N = 1): c4's rank share on the SAME 101 GB operand, then the rest
+            r4, _ = run_dense_family("c4", plan=plan, steps=min(sec_steps, 3), warmup=1)
+            secondary.append(r4)
             torch.cuda.empty_cache()
-            secondary.append(run_sparse("float32"))          # c2-real: segment-table form, fp32, area weights
-            secondary.append(run_sparse("float64"))          # c3-real: fp64 data, pop weights with backup fill
+            secondary.append(run_sparse("float32", steps=sec_steps))        # c2-real: segment-table form, fp32, area weights
+            secondary.append(run_sparse("float64", steps=sec_steps))        # c3-real: fp64 data, pop weights with backup fill
+            secondary.append(run_sparse("float64", small=True, steps=sec_steps))   # c1
+            for wl in ("c5-block", "c5-block-f64", "c5-uniform", "c5-uniform-f64"):
+                torch.cuda.empty_cache()
+                secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2)[0])
     elif a.workload == "c1":
         main_res = run_sparse("float64", small=True)
     else:
         main_res = run_sparse("float32" if a.workload == "c2-real" else "float64")
+    T_job = main_res["T_job"]
 
     if rank == 0:
         wl = main_res["workload"]
@@ -356,7 +488,8 @@ def main():
                 "c3-real": "pop-weighted segment table with backup fill, f64",
                 "c5-uniform": "ensemble x time rows, ~1 % of G x R non-zero at uniformly random positions, f32",
                 "c5-block": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f32",
-                "c5-block-f64": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f64"}[wl]
+                "c5-block-f64": "ensemble x time rows, ~1 % of G x R non-zero, block-local, f64",
+                "c5-uniform-f64": "ensemble x time rows, ~1 % of G x R non-zero at uniformly random positions, f64"}[wl]
         line = {
             "metric": "gridcell-region-timesteps/sec", "value": main_res["value"],
             "unit": "gridcell-region-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -382,4 +515,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

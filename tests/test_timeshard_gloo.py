@@ -94,3 +94,27 @@ def test_time_shard_gather_gloo(world, T):
         assert p.exitcode == 0
     tag, equal, shape = q.get(timeout=5)
     assert tag == "ok" and equal and shape == (T, 9)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no torch.distributed.run in front: the parent starts the
+    ranks before anything touches a GPU, relays exactly ONE JSON line with n_gpus = N (here: the --dry-run plumbing on
+    gloo, two ranks, including the ShardedStep gather) and returns the ranks' status; on a box with fewer devices than
+    ranks every rank without a device exits non-zero with a one-line reason and so does the parent."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["config"]["T_job"] == 730
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode != 0 and p.stdout.strip() == ""
+        assert "has no device: this box has %d GPU(s), --gpus 2" % torch.cuda.device_count() in p.stderr
