@@ -624,7 +624,7 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
 }
 
 // Below this share of non-zeros a W whose tiles are (almost) all occupied goes to the entry-list form
-// (wagg_spmm.hip, fp32): it does 2*T*nnz flops on the vector ALU where the full MFMA form does 2*T*G*R at
+// (wagg_spmm.hip, fp32 and fp64): it does 2*T*nnz flops on the vector ALU where the full MFMA form does 2*T*G*R at
 // ~90 % of the matrix peak, so the break-even is well above this; 10 % keeps a safety margin.
 constexpr double SPMM_MAX_FILL = 0.10;
 
@@ -645,10 +645,10 @@ template <typename T>
 static int create_synth(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out) {
     typedef typename DT<T>::vec vec_t;
     WAGG_REQUIRE(fill > 0.0 && fill <= 1.0, "fill must be in (0, 1]");
-    if (fill < SPMM_MAX_FILL && sizeof(T) == 4) {       // scattered and sparse: entry lists instead of a matrix
-        int rc = dense_alloc<float>(G, R, out, -1, true);
+    if (fill < SPMM_MAX_FILL) {                         // scattered and sparse: entry lists instead of a matrix
+        int rc = dense_alloc<T>(G, R, out, -1, true);
         if (rc != WAGG_OK) return rc;
-        rc = spmm_build_synth(*out, seed, fill);
+        rc = spmm_build_synth<T>(*out, seed, fill);
         if (rc != WAGG_OK) { delete *out; *out = nullptr; }
         return rc;
     }
@@ -768,13 +768,13 @@ static int create_from_segments(const int32_t *cell_idx, const int32_t *region_c
     if (getenv("WAGG_DENSE_NO_TILED")) tiled = false;
 #endif
     int rc = WAGG_OK;
-    if constexpr (sizeof(T) == 4) {
+    {
         // tiles mostly occupied but few non-zeros in them (scattered weights): entry lists
         if (!tiled && (double)hc.size() < SPMM_MAX_FILL * (double)G * (double)R) {
-            rc = dense_alloc<float>(G, R, out, -1, true);
+            rc = dense_alloc<T>(G, R, out, -1, true);
             if (rc != WAGG_OK) return rc;
             wagg_dense *d = *out;
-            rc = spmm_build_from_coo(d, hc, hr, hw);
+            rc = spmm_build_from_coo<T>(d, hc, hr, hw);
             std::vector<float> den32s(den.size());
             for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
             hipError_t es = rc == WAGG_OK ? hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice) : hipSuccess;
@@ -878,9 +878,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     WAGG_REQUIRE(xf.mode != XF_EDD || xf.X2 != nullptr, "tasmax is NULL");
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
-    if constexpr (sizeof(T) == 4) {
-        if (d->spmm) return spmm_apply(d, X_dev, Tn, ldx, xf, out_dev, ldo, (hipStream_t)stream);
-    }
+    if (d->spmm) return spmm_apply<T>(d, X_dev, Tn, ldx, xf, out_dev, ldo, (hipStream_t)stream);
     const int n_nt = d->n_nt, n_kt = d->n_kt;
     // row blocks: as few as possible (<= MT_MAX x 16 rows each), evenly filled, 16 MT rows with MT from the
     // instantiated set -- fp32: T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
@@ -1058,7 +1056,7 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     WAGG_REQUIRE(d && info, "NULL argument");
     info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
     info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
-    info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 64 : d->w_slots() * 16;
+    info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 4 * (d->f64 ? wagg::SpT<double>::GW : wagg::SpT<float>::GW) : d->w_slots() * 16;
     info->form = d->spmm ? WAGG_FORM_ENTRIES : (d->tiled ? WAGG_FORM_TILES : WAGG_FORM_FULL);
     info->elem_bytes = d->f64 ? 8 : 4;
     info->nnz = d->spmm ? d->sp.nnz : -1;
@@ -1124,7 +1122,7 @@ static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t 
         WAGG_HIP(copy_rows_to_host<T>(out_host, dout.p, Tn, ldo, d->R, nullptr, false));
         return WAGG_OK;
     }
-    return stream_host_rows<T>(X_host, Tn, ldx, d->G, out_host, ldo, d->R, flags, d->spmm ? SP_TB : DT<T>::MT_MAX * 16,
+    return stream_host_rows<T>(X_host, Tn, ldx, d->G, out_host, ldo, d->R, flags, d->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16,
                                [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
                                    return dense_apply<T>(d, xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
                                });

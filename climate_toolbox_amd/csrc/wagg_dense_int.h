@@ -28,24 +28,36 @@ __device__ __forceinline__ T pack_xf(const PackXfT<T> &xf, T x, T x2, bool &inf_
 // ---- entry-list ("SpMM") form: geometry shared by the builders and the kernel -------------------
 constexpr int SP_WAVES = 16;                 // waves per workgroup (1024 threads, one workgroup per CU)
 constexpr int SP_THREADS = SP_WAVES * 64;
-constexpr int SP_NT = 2;                     // timesteps per lane
-constexpr int SP_TB = 64 * SP_NT;            // timesteps per block (one wave covers them all)
-constexpr int SP_ROW = SP_TB * 4;            // bytes of one cell's row in LDS (512)
+constexpr int SP_ROW = 512;                  // bytes of one cell's row in LDS: one time block of that cell
 constexpr int SP_KC = 128;                   // grid cells per LDS chunk (128 rows x 512 B = 64 KiB)
 constexpr int SP_ACC = 88;                   // accumulator registers per lane (v[40:127]) = 44 pairs
-constexpr int SP_RW_MAX = SP_ACC / SP_NT - 1;   // regions per wave (43); the last pair swallows the padding entries
-constexpr int SP_TRASH = SP_NT * SP_RW_MAX;  // accumulator index (register offset) of the trash pair
-constexpr int SP_GROUP = 8;                  // entries per 64-byte group, stored as [8 x lo][8 x weight]
-constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list (a wave loads 2 x 64 entries from its list start)
-// entry.lo = (cell_in_chunk << 9) | accumulator register offset (2 j for the wave's region j)
-__host__ __device__ inline unsigned sp_entry_lo(int cell_in_chunk, int j) { return (unsigned)(cell_in_chunk << 9 | SP_NT * j); }
+constexpr int SP_RW_MAX = SP_ACC / 2 - 1;    // regions per wave (43); the last pair swallows the padding entries
+constexpr int SP_TRASH = 2 * SP_RW_MAX;      // accumulator index (register offset) of the trash pair
+constexpr int SP_GROUP = 8;                  // entries per group
+constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list (a wave loads 16 groups from its list start)
+// a time block = what one wave covers: 128 fp32 timesteps (two per lane) or 64 fp64 timesteps (one per lane);
+// either way an accumulator is a register PAIR and a cell's LDS row is 512 bytes
+template <typename T> struct SpT {
+    static constexpr int TB = SP_ROW / (int)sizeof(T);            // timesteps per block: 128 / 64
+    // 32-bit words per 8-entry group: [4 x lo16 pairs][8 x weight (bits 31:0)]([8 x weight bits 63:32])
+    static constexpr int GW = 4 + 8 * (int)(sizeof(T) / 4);       // 12 / 20
+};
+// lo16 of an entry = cell_in_chunk << 9 | accumulator register offset (2 j for the wave's region j)
+__host__ __device__ inline unsigned sp_entry_lo(int cell_in_chunk, int j) { return (unsigned)(cell_in_chunk << 9 | 2 * j); }
+// word / half-word position of entry `pos` of a list that starts at group 0 (pos counts entries)
+template <typename T> __host__ __device__ inline int64_t sp_lo16_index(int64_t pos) {      // in uint16 units
+    return (pos >> 3) * (2 * SpT<T>::GW) + (pos & 7);
+}
+template <typename T> __host__ __device__ inline int64_t sp_w_index(int64_t pos) {         // in uint32 units (low word)
+    return (pos >> 3) * SpT<T>::GW + 4 + (pos & 7);
+}
 
 struct SpmmPlan {
     int rw = 0;                              // regions per wave (<= SP_RW_MAX), region r = (rb * 16 + wave) * rw + j
     int n_rb = 0;                            // region blocks of 16 * rw regions
     int n_chunks = 0;                        // ceil(G / SP_KC)
     int64_t nnz = 0, n_groups = 0;           // kept (cell, region) pairs; 8-entry groups incl. padding
-    DevBuf<uint2> ent;                       // [(n_groups + pad) * 8] entries (sp_entry_lo, weight bits), group-interleaved
+    DevBuf<uint32_t> ent;                    // [(n_groups + pad) * GW] words, see SpT<T>::GW
     DevBuf<int32_t> grp_off;                 // [n_rb * n_chunks * 16 + 1]: first group of (rb, chunk, wave)
 };
 
@@ -72,7 +84,7 @@ struct wagg_dense {
         return at;
     }
     int64_t w_slots() const { return n_tiles * (8192 / 4); }   // 16-byte slots (one tile = 256 x 32 floats)
-    // entry-list form (scattered weights, e.g. <= 1 % non-zeros at random positions): no W matrix at all
+    // entry-list form (scattered weights, e.g. <= 1 % non-zeros at random positions; fp32 or fp64): no W matrix at all
     bool spmm = false;
     wagg::SpmmPlan sp;
     int ncu = 256;
@@ -86,11 +98,11 @@ struct wagg_dense {
 
 namespace wagg {
 // wagg_spmm.hip
-int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill);
-int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
-                        const std::vector<float> &w);
-int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const PackXf &xf, float *out, int64_t ldo,
-               hipStream_t stream);
+template <typename T> int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill);
+template <typename T> int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
+                                              const std::vector<T> &w);
+template <typename T> int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out,
+                                     int64_t ldo, hipStream_t stream);
 // wagg_dense.hip
 int dense_alloc_common(wagg_dense *d);
 }  // namespace wagg

@@ -14,16 +14,19 @@
 //     zero padding fused, like the MFMA forms' pack); a chunk of 128 cells is one contiguous 64 KiB
 //     run that goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one
 //     workgroup barrier per chunk.
-//   * W is never a matrix: per (region block, chunk, wave) a list of 8-byte entries
-//     (cell_in_chunk << 8 | accumulator, weight), padded to 8-entry groups stored as [8 x lo][8 x weight].
-//     A wave loads its whole list for the chunk with coalesced vector loads up front (lane j <- entry
-//     j; the scalar cache was tried first and is latency/throughput-bound at ~870 cycles per 64-byte
-//     line: 104 ms per c5 rank shard) and broadcasts entry after entry into SGPRs with v_readlane;
-//     one entry = 2 v_readlane + v_bfi (LDS address) + ds_read_b64 (2 x 64 timesteps of the cell,
-//     conflict-free) + ONE v_pk_fma_f32 whose accumulator pair is picked by the entry itself
-//     through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[40 + M0[7:0] ...]).  The loop is
-//     generated (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc); the next chunk's list is loaded into
-//     a second register set while this chunk's entries are processed.
+//   * W is never a matrix: per (region block, chunk, wave) a list of entries (cell_in_chunk << 9 |
+//     accumulator: 16 bits; weight: 32 / 64 bits), padded to 8-entry groups stored as
+//     [4 x lo16 pairs][8 x weight]([8 x weight high words]) -- 48 bytes in fp32, 80 in fp64.
+//     A wave loads its whole list for the chunk with coalesced vector loads up front (the scalar cache
+//     was tried first and is latency/throughput-bound at ~870 cycles per 64-byte line: 104 ms per c5
+//     rank shard) and broadcasts entry after entry into SGPRs with v_readlane (one for the lo16 of TWO
+//     entries, one per weight word); one entry = 1.5 v_readlane + v_bfi (LDS address) + ds_read_b64
+//     (2 x 64 timesteps of the cell, conflict-free) + ONE v_pk_fma_f32 whose accumulator pair is picked
+//     by the entry itself through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[40 + M0[7:0] ...]).
+//     fp64 (the reference's own arithmetic type, aggregations.py:73-80): one timestep per lane, the same
+//     512-byte cell rows, 2.5 v_readlane and one v_fma_f64 per entry.  The loop is generated
+//     (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc); the next chunk's list is loaded into a second
+//     register set while this chunk's entries are processed.
 //   * bound: a wave64 vector instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU),
 //     so 4 vector instructions per entry = 16 cycles per 128 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
 //     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops; the LDS (one ds_read_b64 per
@@ -55,10 +58,13 @@ static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit
 #endif
 #include WAGG_SPMM_ASM_INC
 
+template <typename T>
 __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
-    const float *__restrict__ Xp, const uint32_t *__restrict__ ent, const int32_t *__restrict__ grp_off,
-    float *__restrict__ slabT, int n_tb, int n_rb, int n_chunks, int cps, int rw, int64_t Gpad,
+    const T *__restrict__ Xp, const uint32_t *__restrict__ ent, const int32_t *__restrict__ grp_off,
+    T *__restrict__ slabT, int n_tb, int n_rb, int n_chunks, int cps, int rw, int64_t Gpad,
     int64_t Tpad, int64_t Rpad, int n_items, int n_groups, int knob) {
+    constexpr bool F64 = sizeof(T) == 8;
+    constexpr int GW = SpT<T>::GW, TB = SpT<T>::TB;
 #ifdef WAGG_DIAG     // knob bit 0 (WAGG_SPMM_KNOB, diagnostic build only): no end-of-chunk barrier -- WRONG results,
                      // timing only: the upper bound of what removing the per-chunk synchronisation could give
 #define SPMM_CHUNK_SYNC asm volatile("s_waitcnt vmcnt(0)\n\ts_bitcmp1_b32 %0, 0\n\ts_cbranch_scc1 Lnb%=\n\ts_barrier\nLnb%=:" : : "s"(knob) : "memory", "scc")
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         for (int j = 0; j < 32; ++j) { a1[j] = 0.f; a2[j] = 0.f; if (j < 8) b0[j] = 0.f; if (j < 16) b1[j] = 0.f; }
         // cell g of this time block starts at xbase + g * 512 bytes; this wave moves bytes
         // [wave * 4096, wave * 4096 + 4096) of every 64 KiB chunk
-        const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * SP_ROW + wave * 4096;
+        const char *xbase = reinterpret_cast<const char *>(Xp) + ((int64_t)tb * Gpad) * SP_ROW + wave * 4096;      // (SP_ROW bytes per cell and time block in both types)
         const int32_t *goff = grp_off + ((int64_t)rb * n_chunks) * SP_WAVES + wave;
 
         if (c0 < c1) {
@@ -124,9 +130,13 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             // ... and its entry list -> register set A.  From here to the end of the chunk loop the list
             // registers live ACROSS statements: nothing but scalar code may sit between two of them
             // (tools/check_spmm_codegen.py checks the compiled kernel).
-            const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * (2 * SP_GROUP));
-            asm volatile(SPMM_LOAD_LIST_ASM : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
-                         : "memory", SPMM_CHUNK_CLOBBERS);
+            const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * GW);
+            if constexpr (F64)
+                asm volatile(SPMM_LOAD_LIST_ASM_F64 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
+                             : "memory", SPMM_CHUNK_CLOBBERS);
+            else
+                asm volatile(SPMM_LOAD_LIST_ASM_F32 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
+                             : "memory", SPMM_CHUNK_CLOBBERS);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         // Chunks go in PAIRS, statement A then statement B, straight-line (an if/else between the two
@@ -146,18 +156,20 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, int &l0, int &bufbit) {
             asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn));
             n = r.real ? r.g1 - r.g0 : 0;
-            pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * (2 * SP_GROUP));
-            pn = reinterpret_cast<uint64_t>(ent + (int64_t)r.gn * (2 * SP_GROUP));
+            pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * GW);
+            pn = reinterpret_cast<uint64_t>(ent + (int64_t)r.gn * GW);
             src = xbase + (int64_t)r.cn * SP_BUF_BYTES;
             l0 = lds0 + (par ^ 1) * SP_BUF_BYTES + wave * 4096;
             bufbit = lds0 + par * SP_BUF_BYTES;
         };
-#define SPMM_CHUNK_STMT(ASM)                                                                                  \
+#define SPMM_CHUNK_STMT_(ASM)                                                                                 \
         asm volatile(ASM                                                                                      \
                      : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2) \
                      : [cplo] "s"((uint32_t)pc), [cphi] "s"((uint32_t)(pc >> 32)), [nplo] "s"((uint32_t)pn),   \
                        [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src)   \
                      : "memory", "scc", SPMM_CHUNK_CLOBBERS)
+#define SPMM_CHUNK_STMT(AB)                                                                                   \
+        do { if constexpr (F64) SPMM_CHUNK_STMT_(SPMM_CHUNK_ASM_##AB##_F64); else SPMM_CHUNK_STMT_(SPMM_CHUNK_ASM_##AB##_F32); } while (0)
         Raw ra, rb_;
         chunk_loads(c0, ra);
         for (int c = c0; c < c1; c += 2) {
@@ -165,24 +177,27 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             uint64_t pc, pn;
             const char *src;
             chunk_args(ra, 0, n, pc, pn, src, l0, bufbit);
-            SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_A);               // this chunk's list in set A, the next one's -> B
+            SPMM_CHUNK_STMT(A);               // this chunk's list in set A, the next one's -> B
             chunk_loads(c + 1, rb_);
             // this wave's pieces of the next chunk and the next list have landed; it is done reading this chunk
             SPMM_CHUNK_SYNC;
             chunk_args(rb_, 1, n, pc, pn, src, l0, bufbit);
-            SPMM_CHUNK_STMT(SPMM_CHUNK_ASM_B);
+            SPMM_CHUNK_STMT(B);
             chunk_loads(c + 2, ra);
             SPMM_CHUNK_SYNC;
         }
 #undef SPMM_CHUNK_STMT
-        // partial sums of this k slice: region j of the wave, 128 consecutive timesteps (two per lane) per store
-        float *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * SP_TB + 2 * lane;
+#undef SPMM_CHUNK_STMT_
+        // partial sums of this k slice: region j of the wave, one time block per store (fp32: two timesteps per
+        // lane; fp64: the register pair is one double)
+        T *dst = slabT + (((int64_t)ks * Rpad + ((int64_t)rb * SP_WAVES + wave) * rw) * Tpad) + (int64_t)tb * TB +
+                 (F64 ? 1 : 2) * lane;
 #pragma unroll
         for (int j = 0; j < SP_RW_MAX; ++j) {
             const int q = 2 * j;
             const float lo = q < 8 ? b0[q & 7] : (q < 24 ? b1[(q - 8) & 15] : (q < 56 ? a1[(q - 24) & 31] : a2[(q - 56) & 31]));
             const float hi = q + 1 < 8 ? b0[(q + 1) & 7] : (q + 1 < 24 ? b1[(q - 7) & 15] : (q + 1 < 56 ? a1[(q - 23) & 31] : a2[(q - 55) & 31]));
-            if (j < rw) *reinterpret_cast<float2 *>(dst) = make_float2(lo, hi);
+            if (j < rw) *reinterpret_cast<float2 *>(dst) = make_float2(lo, hi);     // (fp64: the two halves of the double)
             dst += Tpad;
             asm volatile("" : "+v"(dst));            // one running pointer, not 43 hoisted offsets
         }
@@ -191,42 +206,45 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
 
 // X (T x G, row stride ldx) -> Xp[time block][cell][128 timesteps]: transform (tas_poly / snyder_edd),
 // NaN -> 0 (S6), zeros for rows >= T and cells >= G.  64 x 64 tiles through LDS: both sides coalesced.
-__global__ __launch_bounds__(256) void spmm_pack_x_kernel(const float *__restrict__ X, int64_t T, int64_t ldx, int64_t G,
-                                                          int64_t Gpad, PackXf xf, float *__restrict__ Xp) {
-    __shared__ float tile[64][65];
-    const int64_t g0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;      // blockIdx.y counts 64-timestep halves
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_pack_x_kernel(const T *__restrict__ X, int64_t Tn, int64_t ldx, int64_t G,
+                                                          int64_t Gpad, PackXfT<T> xf, T *__restrict__ Xp) {
+    constexpr int TB = SpT<T>::TB;
+    __shared__ T tile[64][65];
+    const int64_t g0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;      // blockIdx.y counts 64-timestep runs
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     bool inf_seen = false;
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
         const int64_t t = t0 + i, g = g0 + tx;
-        float v = 0.f;
-        if (t < T && g < G) {
-            const float x = X[t * ldx + g];
-            v = pack_xf<float>(xf, x, xf.mode == XF_EDD ? xf.X2[t * ldx + g] : 0.f, inf_seen);
+        T v = T(0);
+        if (t < Tn && g < G) {
+            const T x = X[t * ldx + g];
+            v = pack_xf<T>(xf, x, xf.mode == XF_EDD ? xf.X2[t * ldx + g] : T(0), inf_seen);
         }
         tile[i][tx] = v;
     }
     __syncthreads();
-    const int64_t tb = t0 / SP_TB, toff = t0 % SP_TB;
+    const int64_t tb = t0 / TB, toff = t0 % TB;
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4)
-        Xp[((tb * Gpad + g0 + i) * SP_TB) + toff + tx] = tile[tx][i];
+        Xp[((tb * Gpad + g0 + i) * TB) + toff + tx] = tile[tx][i];
 }
 
 // out[t, r] = sum_s slabT[s][r][t] / den[r]   (aggregations.py:77-80), 64 x 64 tiles through LDS
-__global__ __launch_bounds__(256) void spmm_reduce_kernel(const float *__restrict__ slabT, int S, int64_t Rpad, int64_t Tpad,
-                                                          int64_t T, int32_t R, const float *__restrict__ den,
-                                                          float *__restrict__ out, int64_t ldo) {
-    __shared__ float tile[64][65];
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(const T *__restrict__ slabT, int S, int64_t Rpad, int64_t Tpad,
+                                                          int64_t Tn, int32_t R, const T *__restrict__ den,
+                                                          T *__restrict__ out, int64_t ldo) {
+    __shared__ T tile[64][65];
     const int64_t r0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
         const int64_t r = r0 + i;
-        float s = 0.f;
+        T s = T(0);
         if (r < Rpad) {
-            const float *p = slabT + r * Tpad + t0 + tx;
+            const T *p = slabT + r * Tpad + t0 + tx;
             for (int k = 0; k < S; ++k) s += p[(int64_t)k * Rpad * Tpad];
         }
         tile[i][tx] = s;
@@ -235,18 +253,31 @@ __global__ __launch_bounds__(256) void spmm_reduce_kernel(const float *__restric
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
         const int64_t t = t0 + i, r = r0 + tx;
-        if (t < T && r < R) out[t * ldo + r] = tile[tx][i] / den[r];
+        if (t < Tn && r < R) out[t * ldo + r] = tile[tx][i] / den[r];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // builders
 // ---------------------------------------------------------------------------------------------
+// entry `pos` (counted from the start of the entry buffer, 8 per group) <- (lo16, weight)
+template <typename T>
+__host__ __device__ inline void sp_store_entry(uint32_t *ent, int64_t pos, unsigned lo16, T w) {
+    reinterpret_cast<uint16_t *>(ent)[sp_lo16_index<T>(pos)] = (uint16_t)lo16;
+    if constexpr (sizeof(T) == 4) {
+        ent[sp_w_index<T>(pos)] = __builtin_bit_cast(uint32_t, w);
+    } else {
+        const uint64_t b = __builtin_bit_cast(uint64_t, w);
+        ent[sp_w_index<T>(pos)] = (uint32_t)b;
+        ent[sp_w_index<T>(pos) + 8] = (uint32_t)(b >> 32);
+    }
+}
+
 // synthetic W[g][r] = hash_u01(g R + r, seed) where hash_u01(g R + r, seed ^ 0x9e3779b9) < fill
 // (wagg_dense_create_synth_sparse).  One workgroup per (region block, chunk), one wave per list:
 // candidates are visited cell-major, kept ones are appended in that order (ballot + prefix count),
 // so the list -- and with it every fp32 sum -- is the same on every build.
-template <bool FILL>
+template <typename T, bool FILL>
 __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32_t R, uint32_t seed, float fill, int rw,
                                                                 int n_chunks, int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ grp_off, uint32_t *__restrict__ ent) {
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32
     const int64_t bucket = ((int64_t)rb * n_chunks + c) * SP_WAVES + wave;
     const int64_t r_first = ((int64_t)rb * SP_WAVES + wave) * rw;
     const int ncand = SP_KC * rw;
-    int64_t base = FILL ? (int64_t)grp_off[bucket] * SP_GROUP : 0;
+    int64_t base = FILL ? (int64_t)grp_off[bucket] * SP_GROUP : 0;      // entry position of this list's first entry
     int kept = 0;
     for (int i0 = 0; i0 < ncand; i0 += 64) {
         const int i = i0 + lane;
@@ -270,20 +301,13 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_synth_kernel(int64_t G, int32
         const unsigned long long m = __ballot(keep);
         if (FILL && keep) {
             const int64_t pos = base + kept + __popcll(m & ((1ull << lane) - 1ull));
-            uint32_t *grp = ent + (pos >> 3) * 16 + (pos & 7);       // group = [8 x lo][8 x weight]
-            grp[0] = sp_entry_lo(gl, j);
-            grp[8] = __float_as_uint(hash_u01(id, seed));
+            sp_store_entry<T>(ent, pos, sp_entry_lo(gl, j), (T)hash_u01(id, seed));
         }
         kept += __popcll(m);
     }
     if (FILL) {                                   // pad the last group: w = 0 into the trash accumulator
         const int padded = (kept + SP_GROUP - 1) / SP_GROUP * SP_GROUP;
-        if (kept + lane < padded) {
-            const int64_t pos = base + kept + lane;
-            uint32_t *grp = ent + (pos >> 3) * 16 + (pos & 7);
-            grp[0] = (unsigned)SP_TRASH;
-            grp[8] = 0u;
-        }
+        if (kept + lane < padded) sp_store_entry<T>(ent, base + kept + lane, (unsigned)SP_TRASH, T(0));
     } else if (lane == 0) {
         counts[bucket] = kept;
     }
@@ -318,7 +342,9 @@ static void spmm_geometry(wagg_dense *d) {
 }
 
 // counts per (region block, chunk, wave) -> first 8-entry group of each list (+ total at the end)
+template <typename T>
 static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
+    constexpr int GW = SpT<T>::GW;
     SpmmPlan &sp = d->sp;
     std::vector<int32_t> off(counts.size() + 1, 0);
     int64_t groups = 0, nnz = 0;
@@ -332,12 +358,13 @@ static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
     sp.n_groups = groups;
     sp.nnz = nnz;
     WAGG_HIP(sp.grp_off.upload(off));
-    // six 64-entry blocks of padding at the end: a wave always loads five blocks from its list start
-    WAGG_HIP(sp.ent.alloc((size_t)(groups + SP_PAD_GROUPS) * SP_GROUP));
-    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * SP_GROUP, 0, sizeof(uint2) * SP_GROUP * SP_PAD_GROUPS));
+    // padding groups at the end: a wave always loads 16 groups from its list start
+    WAGG_HIP(sp.ent.alloc((size_t)(groups + SP_PAD_GROUPS) * GW));
+    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * GW, 0, sizeof(uint32_t) * GW * SP_PAD_GROUPS));
     return WAGG_OK;
 }
 
+template <typename T>
 int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
     spmm_geometry(d);
     SpmmPlan &sp = d->sp;
@@ -346,13 +373,13 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
     DevBuf<int32_t> dcounts;
     WAGG_HIP(dcounts.alloc((size_t)n_buckets));
     const dim3 grid((unsigned)((int64_t)sp.n_rb * sp.n_chunks));
-    hipLaunchKernelGGL((spmm_synth_kernel<false>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
+    hipLaunchKernelGGL((spmm_synth_kernel<T, false>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
                        sp.n_chunks, dcounts.p, (const int32_t *)nullptr, (uint32_t *)nullptr);
     WAGG_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)n_buckets);
     WAGG_HIP(hipMemcpy(counts.data(), dcounts.p, sizeof(int32_t) * counts.size(), hipMemcpyDeviceToHost));
-    if (int rc = spmm_offsets(d, counts)) return rc;
-    hipLaunchKernelGGL((spmm_synth_kernel<true>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
+    if (int rc = spmm_offsets<T>(d, counts)) return rc;
+    hipLaunchKernelGGL((spmm_synth_kernel<T, true>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
                        sp.n_chunks, (int32_t *)nullptr, (const int32_t *)sp.grp_off.p, (uint32_t *)sp.ent.p);
     WAGG_HIP(hipGetLastError());
     hipLaunchKernelGGL(spmm_synth_den_kernel, dim3((unsigned)((d->R + 3) / 4)), dim3(256), 0, nullptr, d->G, d->R, seed,
@@ -364,10 +391,14 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
     WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
     return WAGG_OK;
 }
+template int spmm_build_synth<float>(wagg_dense *, uint32_t, double);
+template int spmm_build_synth<double>(wagg_dense *, uint32_t, double);
 
 // coalesced (cell, region, weight) triples, sorted by (region, cell) -> entry lists (host side)
+template <typename T>
 int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
-                        const std::vector<float> &w) {
+                        const std::vector<T> &w) {
+    constexpr int GW = SpT<T>::GW;
     spmm_geometry(d);
     SpmmPlan &sp = d->sp;
     const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
@@ -379,15 +410,14 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
     try {
         std::vector<int32_t> counts((size_t)n_buckets, 0);
         for (size_t i = 0; i < cell.size(); ++i) counts[(size_t)bucket_of(i)]++;
-        if (int rc = spmm_offsets(d, counts)) return rc;
+        if (int rc = spmm_offsets<T>(d, counts)) return rc;
         std::vector<int32_t> off((size_t)n_buckets);
         {
             int64_t g = 0;
             for (int64_t b = 0; b < n_buckets; ++b) { off[(size_t)b] = (int32_t)g; g += (counts[(size_t)b] + SP_GROUP - 1) / SP_GROUP; }
         }
-        std::vector<uint32_t> ent((size_t)sp.n_groups * 2 * SP_GROUP, 0u);     // group = [8 x lo][8 x weight]
-        for (int64_t g = 0; g < sp.n_groups; ++g)
-            for (int k = 0; k < SP_GROUP; ++k) ent[(size_t)g * 16 + k] = (unsigned)SP_TRASH;
+        std::vector<uint32_t> ent((size_t)sp.n_groups * GW, 0u);
+        for (int64_t pos = 0; pos < sp.n_groups * SP_GROUP; ++pos) sp_store_entry<T>(ent.data(), pos, (unsigned)SP_TRASH, T(0));
         std::vector<int32_t> cur((size_t)n_buckets, 0);
         // visit the triples cell-major so that a list is ordered like the synthetic builder's
         std::vector<size_t> order(cell.size());
@@ -396,11 +426,8 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
         for (size_t i : order) {
             const int64_t b = bucket_of(i);
             const unsigned lo = sp_entry_lo(cell[i] % SP_KC, region[i] % wave_regions);
-            unsigned wb;
-            std::memcpy(&wb, &w[i], 4);
             const size_t pos = (size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++;
-            ent[(pos >> 3) * 16 + (pos & 7)] = lo;
-            ent[(pos >> 3) * 16 + 8 + (pos & 7)] = wb;
+            sp_store_entry<T>(ent.data(), (int64_t)pos, lo, w[i]);
         }
         if (!ent.empty()) WAGG_HIP(hipMemcpy(sp.ent.p, ent.data(), sizeof(uint32_t) * ent.size(), hipMemcpyHostToDevice));
     } catch (const std::bad_alloc &) {
@@ -409,12 +436,16 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
     }
     return WAGG_OK;
 }
+template int spmm_build_from_coo<float>(wagg_dense *, const std::vector<int32_t> &, const std::vector<int32_t> &, const std::vector<float> &);
+template int spmm_build_from_coo<double>(wagg_dense *, const std::vector<int32_t> &, const std::vector<int32_t> &, const std::vector<double> &);
 
-int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const PackXf &xf, float *out, int64_t ldo,
+template <typename T>
+int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out, int64_t ldo,
                hipStream_t st) {
+    constexpr int TB = SpT<T>::TB;
     const SpmmPlan &sp = d->sp;
-    const int n_tb = (int)((T + SP_TB - 1) / SP_TB);
-    const int64_t Tpad = (int64_t)n_tb * SP_TB, Gpad = (int64_t)sp.n_chunks * SP_KC;
+    const int n_tb = (int)((Tn + TB - 1) / TB);
+    const int64_t Tpad = (int64_t)n_tb * TB, Gpad = (int64_t)sp.n_chunks * SP_KC;
     const int64_t Rpad = (int64_t)sp.n_rb * SP_WAVES * sp.rw;
     // k slices: enough items for every CU to get the same number (a multiple of the CU count where
     // possible), at least ~16 chunks per slice
@@ -432,28 +463,34 @@ int spmm_apply(wagg_dense *d, const float *X, int64_t T, int64_t ldx, const Pack
     const int cps = (sp.n_chunks + S - 1) / S;
     const int64_t n_items = base_items * S;
     WAGG_REQUIRE(n_items < (int64_t)0x7fffffff, "grid too large");
-    const size_t need_x = (size_t)n_tb * (size_t)Gpad * SP_TB, need_s = (size_t)S * (size_t)Rpad * (size_t)Tpad;
+    // (the plan's buffers are sized in 4-byte units for both element types)
+    const size_t need_x = (size_t)n_tb * (size_t)Gpad * TB * (sizeof(T) / 4), need_s = (size_t)S * (size_t)Rpad * (size_t)Tpad * (sizeof(T) / 4);
     if (d->xp.n < need_x) WAGG_HIP(d->xp.alloc(need_x));
     if (d->slabs.n < need_s) WAGG_HIP(d->slabs.alloc(need_s));
-    hipLaunchKernelGGL(spmm_pack_x_kernel, dim3((unsigned)(Gpad / 64), (unsigned)(n_tb * (SP_TB / 64))), dim3(256), 0, st, X, T,
-                       ldx, d->G, Gpad, xf, d->xp.p);
+    T *xp = reinterpret_cast<T *>(d->xp.p), *slabs = reinterpret_cast<T *>(d->slabs.p);
+    hipLaunchKernelGGL((spmm_pack_x_kernel<T>), dim3((unsigned)(Gpad / 64), (unsigned)(n_tb * (TB / 64))), dim3(256), 0, st, X, Tn,
+                       ldx, d->G, Gpad, xf, xp);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel, SP_LDS_BYTES));
+    WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel<T>, SP_LDS_BYTES));
     const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
     int knob = 0;
 #ifdef WAGG_DIAG
     if (const char *k = getenv("WAGG_SPMM_KNOB")) knob = atoi(k);
 #endif
     profile_mark(st, true);
-    hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const float *)d->xp.p,
-                       (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, d->slabs.p, n_tb, sp.n_rb, sp.n_chunks, cps,
+    hipLaunchKernelGGL((spmm_kernel<T>), dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const T *)xp,
+                       (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, slabs, n_tb, sp.n_rb, sp.n_chunks, cps,
                        sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups, knob);
     profile_mark(st, false);
     WAGG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)((Rpad + 63) / 64), (unsigned)(Tpad / 64)), dim3(256), 0, st,
-                       (const float *)d->slabs.p, S, Rpad, Tpad, T, d->R, (const float *)d->den32.p, out, ldo);
+    const T *den;
+    if constexpr (sizeof(T) == 4) den = d->den32.p; else den = d->den64.p;
+    hipLaunchKernelGGL((spmm_reduce_kernel<T>), dim3((unsigned)((Rpad + 63) / 64), (unsigned)(Tpad / 64)), dim3(256), 0, st,
+                       (const T *)slabs, S, Rpad, Tpad, Tn, d->R, den, out, ldo);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }
+template int spmm_apply<float>(wagg_dense *, const float *, int64_t, int64_t, const PackXfT<float> &, float *, int64_t, hipStream_t);
+template int spmm_apply<double>(wagg_dense *, const double *, int64_t, int64_t, const PackXfT<double> &, double *, int64_t, hipStream_t);
 
 }  // namespace wagg

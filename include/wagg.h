@@ -222,7 +222,7 @@ int wagg_dense_create_synth(int64_t G, int32_t R, uint32_t seed, wagg_dense **ou
  * structure at fill = 0.01 -- no tile of W is empty, yet 99 % of every tile is.                 */
 int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 /* (fill < 10 %: built directly as entry lists, WAGG_FORM_ENTRIES -- c5 at fill = 0.01; above that the
- * full matrix is generated)                                                                        */
+ * full matrix is generated; the same holds for wagg_dense_create_synth_f64)                        */
 /* from a host row-major (G, R) fp32 matrix (small cases / tests) */
 int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
 /* from a sparse plan's coded table (weights whose regions are scattered over the grid).  The form
@@ -241,11 +241,12 @@ int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, doub
 #define WAGG_FORM_FULL 0     /* every (32-cell x 256-region) tile of W stored, fp32 MFMA contraction            */
 #define WAGG_FORM_TILES 1    /* only the non-empty tiles ("tile-sparse": block-local weights), same MFMA kernel */
 #define WAGG_FORM_ENTRIES 2  /* no matrix: per-wave (cell, region, weight) lists, vector-ALU kernel (scattered,
-                                sparse weights: <= 10 % non-zeros spread over (almost) every tile)              */
+                                sparse weights: <= 10 % non-zeros spread over (almost) every tile), fp32 or fp64 */
 /* The *_f64 constructors build the same forms with fp64 weights for fp64 data (the reference's own
  * arithmetic type, aggregations.py:73-80): tiles are (16-cell x 256-region), the contraction runs on
- * v_mfma_f64_16x16x4_f64 (wagg_dense_apply_f64).  A plan serves one element type; the entry-list form
- * is fp32 only (an fp64 table that would take it becomes a full or tile-sparse fp64 matrix).        */
+ * v_mfma_f64_16x16x4_f64 (wagg_dense_apply_f64); the entry-list form keeps 64-bit weights (80 bytes per
+ * 8 entries instead of 48) and accumulates with v_fma_f64, one timestep per lane.  A plan serves one
+ * element type.                                                                                      */
 int wagg_dense_create_synth_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32_t R, wagg_dense **out);
 int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,

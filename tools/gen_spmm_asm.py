@@ -1,176 +1,200 @@
 #!/usr/bin/env python3
 """Generates climate_toolbox_amd/csrc/wagg_spmm_asm.inc: the per-(wave, chunk) inner loop of the
-entry-list kernel (wagg_spmm.hip) as inline-asm strings.
+entry-list kernel (wagg_spmm.hip) as inline-asm strings, once for fp32 and once for fp64.
 
 Why generated: the loop is unrolled over blocks x groups x entries with static lane numbers
 (v_readlane) and a two-stage software pipeline; writing ~1,500 instructions by hand invites slips.
 
-Geometry (must match wagg_dense_int.h): a wave's 64 lanes hold NT = 2 timesteps each (a 128-timestep
-block), a chunk is KC = 128 grid cells x 512 B = 64 KiB of LDS, accumulators are register PAIRS
-v[40 + 2j : 41 + 2j] for the wave's region j (j < 44; pair 43 swallows the padding entries).
+Geometry (must match wagg_dense_int.h).  A chunk is KC = 128 grid cells x 512 B = 64 KiB of LDS; a cell's
+row holds one time block: 128 fp32 timesteps (two per lane, ds_read_b64 at lane * 8 = timesteps 2 lane,
+2 lane + 1) or 64 fp64 timesteps (one per lane).  Accumulators are register PAIRS v[40 + 2j : 41 + 2j]
+for the wave's region j (j < 44; pair 43 swallows the padding entries): two fp32 timesteps, or one double.
 
-SPMM_LOAD_LIST_ASM    (item prologue) loads the first chunk's list into register set A.
-SPMM_CHUNK_ASM_A / _B one wave, one chunk whose X tile is already in LDS, the list of THIS chunk in set
-                      A (B), in order:
+Entry lists (round 3 format).  A group of 8 entries is stored as
+    [4 x (lo16 of entry 2p | lo16 of entry 2p + 1 << 16)] [8 x weight]            fp32: 48 bytes
+    [4 x lo16 pairs] [8 x weight bits 31:0] [8 x weight bits 63:32]               fp64: 80 bytes
+with lo16 = cell_in_chunk << 9 | accumulator register offset (2 j).  One v_readlane brings the lo16 of TWO
+entries into an SGPR (the odd entry takes `s_lshr_b32 ..., 16`, a scalar instruction), so an entry costs
+1.5 v_readlane (fp64: 2.5) + v_bfi (LDS address) + ds_read_b64 + s_set_gpr_idx_idx + ONE v_pk_fma_f32 /
+v_fma_f64 whose accumulator pair the entry itself names through the VGPR index mode; one s_waitcnt per
+half-group of four entries.  (Round 2: [8 x lo32][8 x weight], two v_readlane and a wait per entry.)
+
+SPMM_LOAD_LIST_ASM_*     (item prologue) per-lane constants + the first chunk's list into register set A.
+SPMM_CHUNK_ASM_A_* / _B_*  one wave, one chunk whose X tile is already in LDS, the list of THIS chunk in
+                         set A (B), in order:
   1. issues the loads of the NEXT chunk's list into the other set (consumed by the next statement: the
      C++ between two statements is scalar-only, which tools/check_spmm_codegen.py verifies on the
-     compiled kernel) and the 4 LDS-DMA pieces of the next chunk's X tile -- all retired by the
+     compiled kernels) and the 4 LDS-DMA pieces of the next chunk's X tile -- all retired by the
      `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
-  2. per entry: two v_readlane (entry -> SGPRs), v_bfi (LDS address), ds_read_b64 (2 x 64 timesteps of
-     the cell), s_set_gpr_idx_idx + v_pk_fma_f32 (or two v_fma_f32) into the accumulator pair the entry
-     names (VGPR index mode), half-group h+1's reads in flight while half-group h is accumulated;
+  2. the entries, half-group h + 1's reads in flight while half-group h is accumulated;
   3. lists longer than 16 groups (never at 1 % fill) finish in a one-group-at-a-time loop.
 
-Private registers (clobbered, hard-coded; v3, v12, v30, v31 are set by the item prologue and live for the whole
-item): v3 entry-load lane offset; set A = v[4:5] lo, v[6:7] weights
-of blocks 0-1, set B = v[8:9], v[10:11]; v12 lane, v13 scratch; v[14:21] / v[22:29] the two LDS-read sets
-(4 register pairs each); v30 lane*8 | buffer bit; v31 0xfe00; s[36:43] / s[44:51] the two half-group
-entry sets; s68 saved M0; s[70:71] list pointer.
+Private registers (clobbered, hard-coded).  Set by the item prologue and live for the whole item: v3 lane
+offset of the lo16-pair loads, v4 lane offset of the weight loads, v15 lane, v17 lane * 8 | buffer bit, v34 the
+cell mask 0xfe00.  List set A = v5 (pairs of 128 entries), v[6:7] weights of blocks 0-1 (fp64: bits 31:0),
+v[8:9] (fp64: bits 63:32); set B = v10, v[11:12], v[13:14].  v16 scratch; v[18:25] / v[26:33] the two
+LDS-read sets (4 register pairs each).  SGPRs: two half-group sets s[36:47] / s[48:59] (fp32 uses
+(lo, weight) pairs s[36:43] / s[44:51]; fp64 lo s[36:39] + weights s[40:47], lo s[48:51] + weights
+s[52:59]); s68 saved M0; s[70:71] list pointer.
 """
 import os
 import sys
 
 N_BLOCKS = 2                 # 64-entry blocks loaded per list (16 groups); longer lists take the slow loop
-SA, SB = 36, 44              # SGPR half-group sets (4 entries x (lo, w))
-TP, TQ = 14, 22              # VGPR temp sets: 4 pairs each
-SETS = {"A": (4, 6), "B": (8, 10)}     # (first lo register, first weight register) of a list set
-VO, LANE, SCR, LB, VMASK = 3, 12, 13, 30, 31
-CUR_LB = LB                  # the register holding lane * 8 | buffer base for the statement being generated
+VPO, VWO = 3, 4              # lane offsets of the pair / weight loads
+SETS = {"A": 5, "B": 10}     # first register of a list set: +0 pairs, +1,+2 w (lo) of blocks 0,1, +3,+4 w hi (fp64)
+LANE, SCR, LB = 15, 16, 17
+TP, TQ = 18, 26              # VGPR temp sets: 4 (even-aligned) register pairs each
+VMASK = 34
 ACC0 = 40
 MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
-PK = int(os.environ.get("SPMM_PK", "1"))   # 1: v_pk_fma_f32, 0: two v_fma_f32
+V_LAST = 34
 # ablation variants for tools/spmm_ablate.sh (timing only, results are wrong): any of nofma, nolds, noidx, now, nobfi,
-# nodma, halfdma, nolist, noent; per-chunk overhead experiments (results stay right): nohoist, nonop
+# nodma, halfdma, nolist, noent
 ABL = set(filter(None, os.environ.get("SPMM_ABL", "").split(",")))
 
 
-def lane_regs(o, with_lb):
+class Geo:
+    def __init__(self, f64):
+        self.f64 = f64
+        self.sfx = "F64" if f64 else "F32"
+        self.gwb = 80 if f64 else 48            # bytes per 8-entry group
+        # SGPR half-group sets
+        if f64:
+            self.sets = {0: dict(lo=36, w=40), 1: dict(lo=48, w=52)}
+        else:
+            self.sets = {0: dict(lo=36, w=37), 1: dict(lo=44, w=45)}
+
+    def s_lo(self, s, k):
+        return self.sets[s]["lo"] + (k if self.f64 else 2 * k)
+
+    def s_w(self, s, k):
+        return self.sets[s]["w"] + 2 * k
+
+
+def lane_regs(g, o):
     o.append("v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE)
     o.append("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE))
+    # pair loads: lane l <- pair (l & 3) of group (l >> 2): 128 entries in one register
+    o.append("v_lshrrev_b32 v%d, 2, v%d" % (SCR, LANE))
+    o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
+    o.append("v_and_b32 v%d, 3, v%d" % (VPO, LANE))
+    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VPO, VPO, SCR))
+    # weight loads: lane l <- weight (l & 7) of group (l >> 3) (+ 8 groups per block)
     o.append("v_lshrrev_b32 v%d, 3, v%d" % (SCR, LANE))
-    o.append("v_and_b32 v%d, 7, v%d" % (VO, LANE))
-    o.append("v_lshlrev_b32 v%d, 6, v%d" % (SCR, SCR))
-    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VO, VO, SCR))      # (lane >> 3) * 64 + (lane & 7) * 4
-    if with_lb:
-        o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
-        o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))        # lane * 8 | buffer bit
-        o.append("v_mov_b32 v%d, 0x%x" % (VMASK, MASK))
+    o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
+    o.append("v_and_b32 v%d, 7, v%d" % (VWO, LANE))
+    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VWO, VWO, SCR))
+    o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
+    o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))            # lane * 8 | buffer bit
+    o.append("v_mov_b32 v%d, 0x%x" % (VMASK, MASK))
 
 
-def load_list(o, which):
-    lo0, hi0 = SETS[which]
+def load_list(g, o, which, ptr="s[70:71]"):
+    r0 = SETS[which]
+    o.append("global_load_dword v%d, v%d, %s" % (r0, VPO, ptr))
     for b in range(N_BLOCKS):
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (lo0 + b, VO, 512 * b))
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:%d" % (hi0 + b, VO, 512 * b + 32))
+        o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 1 + b, VWO, ptr, 8 * g.gwb * b + 16))
+        if g.f64:
+            o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 3 + b, VWO, ptr, 8 * g.gwb * b + 48))
 
 
-def issue(h, which, S, T, o):
-    """half-group h (4 entries): entry -> SGPRs, LDS address, read"""
-    lo0, hi0 = SETS[which]
-    b, base = divmod(4 * h, 64)
+def issue(g, h, which, s, T, o, cur_lb, e0=None):
+    """half-group h (entries 4h .. 4h + 3 of the loaded blocks): entries -> SGPRs, LDS addresses, reads"""
+    r0 = SETS[which]
+    e0 = 4 * h if e0 is None else e0
     for k in range(4):
-        o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k, lo0 + b, base + k))
+        e = e0 + k
+        if k % 2 == 0:
+            o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_lo(s, k), r0, e >> 1))
+        else:
+            o.append("s_lshr_b32 s%d, s%d, 16" % (g.s_lo(s, k), g.s_lo(s, k - 1)))
         if "now" not in ABL:
-            o.append("v_readlane_b32 s%d, v%d, %d" % (S + 2 * k + 1, hi0 + b, base + k))
+            b, l = divmod(e, 64)
+            if g.f64:
+                o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(s, k), r0 + 1 + b, l))
+                o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(s, k) + 1, r0 + 3 + b, l))
+            else:
+                o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(s, k), r0 + 1 + b, l))
     for k in range(4):
         if "nobfi" not in ABL:
-            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, S + 2 * k, CUR_LB))
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, g.s_lo(s, k), cur_lb))
     for k in range(4):
         if "nolds" not in ABL:
             o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
 
 
-def fma(S, T, younger, o):
+def fma(g, s, T, younger, o):
+    """accumulate a half-group; `younger` = LDS reads issued after this half-group's own four"""
+    if "nolds" not in ABL:
+        o.append("s_waitcnt lgkmcnt(%d)" % younger)
     for k in range(4):
         if "noidx" not in ABL:
-            o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % (S + 2 * k))
-        if "nolds" not in ABL:
-            o.append("s_waitcnt lgkmcnt(%d)" % (3 - k + younger))
+            o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % g.s_lo(s, k))
         if "nofma" in ABL:
             continue
-        if PK:
-            o.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[0,1,0]"
-                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, S + 2 * k, S + 2 * k + 1, ACC0, ACC0 + 1))
+        if g.f64:
+            o.append("v_fma_f64 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d]"
+                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, g.s_w(s, k), g.s_w(s, k) + 1, ACC0, ACC0 + 1))
         else:
-            o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0, T + 2 * k, S + 2 * k + 1, ACC0))
-            o.append("v_fma_f32 v%d, v%d, s%d, v%d" % (ACC0 + 1, T + 2 * k + 1, S + 2 * k + 1, ACC0 + 1))
+            o.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[0,1,0]"
+                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, g.s_lo(s, k), g.s_lo(s, k) + 1, ACC0, ACC0 + 1))
     if "noidx" not in ABL:
         o.append("s_set_gpr_idx_off")
 
 
-def chunk(cur, nxt):
-    global CUR_LB
+def chunk(g, cur, nxt):
     o = []
     o.append("s_mov_b32 s68, m0")
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
-    hoist, nonop = "nohoist" not in ABL, "nonop" in ABL
-    if hoist:
-        CUR_LB = LB                                            # v[LANE], v[VO], v[VMASK], v[LB] come from the item prologue
-    else:
-        CUR_LB = LB
-        lane_regs(o, True)
     if "nolist" not in ABL:
-        load_list(o, nxt)                                      # 1. the NEXT chunk's list
+        load_list(g, o, nxt)                                   # 1. the NEXT chunk's list
     n_dma = 2 if "halfdma" in ABL else 4
-    if nonop:       # the vector instruction between the M0 write and the LDS-DMA is the wait state the pair needs
-        for i in range(n_dma):
-            o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
-            if i:
-                o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
-            else:
-                o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))     # lane * 16: LDS-DMA of the next X tile
-            if "nodma" not in ABL:
-                o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
-    else:
-        o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))     # lane * 16: LDS-DMA of the next X tile
-        for i in range(n_dma):
-            if i:
-                o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
-            o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
-            o.append("s_nop 0")
-            if "nodma" not in ABL:
-                o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
-    # (an L2 warm-up load of the list three chunks ahead used to sit here: measured 2.1 ms SLOWER on the c5 rank
-    #  shard -- profiles/r02_spmm_ablation.txt -- and removed together with its operands)
-    if hoist and cur == "B":                                   # statement B reads LDS buffer 1
+    o.append("v_lshlrev_b32 v%d, 4, v%d" % (TP, LANE))         # lane * 16: LDS-DMA of the next X tile
+    for i in range(n_dma):
+        if i:
+            o.append("v_add_u32 v%d, 0x%x, v%d" % (TP + 1, 0x400 * i, TP))
+        o.append("s_add_u32 m0, %%[l0], 0x%x" % (0x400 * i) if i else "s_mov_b32 m0, %[l0]")
+        o.append("s_nop 0")
+        if "nodma" not in ABL:
+            o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
+    cur_lb = LB
+    if cur == "B":                                             # statement B reads LDS buffer 1
         o.append("v_add_u32 v%d, 0x10000, v%d" % (SCR, LB))
-        CUR_LB = SCR
+        cur_lb = SCR
     o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
     o.append("s_cbranch_scc1 8f")
     if "noent" in ABL:
         o.append("s_branch 8f")
     n_half = N_BLOCKS * 16
-    issue(0, cur, SA, TP, o)
+    issue(g, 0, cur, 0, TP, o, cur_lb)
     for h in range(n_half):
-        S, T = (SA, TP) if h % 2 == 0 else (SB, TQ)
-        S2, T2 = (SB, TQ) if h % 2 == 0 else (SA, TP)
+        s, T = (0, TP) if h % 2 == 0 else (1, TQ)
+        s2, T2 = (1, TQ) if h % 2 == 0 else (0, TP)
         last = h == n_half - 1
         if not last:
-            issue(h + 1, cur, S2, T2, o)
-        fma(S, T, 0 if last else 4, o)
+            issue(g, h + 1, cur, s2, T2, o, cur_lb)
+        fma(g, s, T, 0 if last else 4, o)
         if h % 2 == 1:                                         # a whole group done
             o.append("s_sub_u32 %[n], %[n], 1")
             o.append("s_cmp_eq_u32 %[n], 0")
             o.append("s_cbranch_scc1 8f")
-    # 3. overflow: one group at a time from behind the loaded blocks (uses the current set's registers)
-    lo0, hi0 = SETS[cur]
-    o.append("s_add_u32 s70, %%[cplo], %d" % (512 * N_BLOCKS))
+    # 3. overflow: one group at a time from behind the loaded blocks (reuses the current set's registers:
+    #    lanes 0-3 of the pair register, lanes 0-7 of the weight registers)
+    r0 = SETS[cur]
+    o.append("s_add_u32 s70, %%[cplo], %d" % (8 * g.gwb * N_BLOCKS))
     o.append("s_addc_u32 s71, %[cphi], 0")
     o.append("7:")
-    o.append("global_load_dword v%d, v%d, s[70:71] offset:0" % (lo0, VO))
-    o.append("global_load_dword v%d, v%d, s[70:71] offset:32" % (hi0, VO))
+    o.append("global_load_dword v%d, v%d, s[70:71]" % (r0, VPO))
+    o.append("global_load_dword v%d, v%d, s[70:71] offset:16" % (r0 + 1, VWO))
+    if g.f64:
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:48" % (r0 + 3, VWO))
     o.append("s_waitcnt vmcnt(0)")
     for hh in range(2):
-        for k in range(4):
-            o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k, lo0, 4 * hh + k))
-            o.append("v_readlane_b32 s%d, v%d, %d" % (SA + 2 * k + 1, hi0, 4 * hh + k))
-        for k in range(4):
-            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TP + 2 * k, VMASK, SA + 2 * k, CUR_LB))
-        for k in range(4):
-            o.append("ds_read_b64 v[%d:%d], v%d" % (TP + 2 * k, TP + 2 * k + 1, TP + 2 * k))
-        fma(SA, TP, 0, o)
-    o.append("s_add_u32 s70, s70, 64")
+        issue(g, hh, cur, 0, TP, o, cur_lb, e0=4 * hh)
+        fma(g, 0, TP, 0, o)
+    o.append("s_add_u32 s70, s70, %d" % g.gwb)
     o.append("s_addc_u32 s71, s71, 0")
     o.append("s_sub_u32 %[n], %[n], 1")
     o.append("s_cmp_eq_u32 %[n], 0")
@@ -181,12 +205,12 @@ def chunk(cur, nxt):
     return o
 
 
-def prologue():
+def prologue(g):
     o = []
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
-    lane_regs(o, "nohoist" not in ABL)  # lane, lane * 8 | base of LDS buffer 0 and the cell mask live for the whole item
-    load_list(o, "A")
+    lane_regs(g, o)   # lane, load offsets, lane * 8 | base of LDS buffer 0 and the cell mask live for the whole item
+    load_list(g, o, "A")
     return o
 
 
@@ -200,16 +224,18 @@ def emit(f, name, lines):
 def main():
     path = os.environ.get("SPMM_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                      "climate_toolbox_amd", "csrc", "wagg_spmm_asm.inc")
-    a, b, p = chunk("A", "B"), chunk("B", "A"), prologue()
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_spmm_asm.py (SPMM_PK=%d%s) -- do not edit; see that script for the register map.\n"
-                % (PK, " SPMM_ABL=" + ",".join(sorted(ABL)) if ABL else ""))
-        emit(f, "SPMM_LOAD_LIST_ASM", p)
-        emit(f, "SPMM_CHUNK_ASM_A", a)
-        emit(f, "SPMM_CHUNK_ASM_B", b)
-        clob = ["v%d" % i for i in range(3, 32)] + ["s%d" % i for i in range(36, 72)]
+        f.write("// GENERATED by tools/gen_spmm_asm.py%s -- do not edit; see that script for the register map.\n"
+                % (" SPMM_ABL=" + ",".join(sorted(ABL)) if ABL else ""))
+        for f64 in (False, True):
+            g = Geo(f64)
+            a, b, p = chunk(g, "A", "B"), chunk(g, "B", "A"), prologue(g)
+            emit(f, "SPMM_LOAD_LIST_ASM_" + g.sfx, p)
+            emit(f, "SPMM_CHUNK_ASM_A_" + g.sfx, a)
+            emit(f, "SPMM_CHUNK_ASM_B_" + g.sfx, b)
+            print("wrote", path, g.sfx, len(a), "instructions per chunk statement", file=sys.stderr)
+        clob = ["v%d" % i for i in range(3, V_LAST + 1)] + ["s%d" % i for i in range(36, 72)]
         f.write("#define SPMM_CHUNK_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
-    print("wrote", path, len(a), "instructions per chunk statement", file=sys.stderr)
 
 
 if __name__ == "__main__":
