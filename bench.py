@@ -290,11 +290,12 @@ def main():
     scaling = "weak"
     C5_TOTAL, C4_TOTAL = 50 * 365, 10950
 
-    def rows_for(wl):
-        """(rows of this rank, rows of every rank, scaling) of a workload in this run."""
+    def rows_for(wl, share=False):
+        """(rows of this rank, rows of every rank, scaling) of a workload in this run; ``share``: one rank's share of
+        the 8-GPU job (the secondary entries of the default N = 1 run)."""
         if wl in ("c4",) or wl.startswith("c5"):
             T_total = C4_TOTAL if wl == "c4" else C5_TOTAL
-            shards = a.shards or (world if wl == "c4" or world > 1 else 8)
+            shards = a.shards or (8 if share else (world if wl == "c4" or world > 1 else 8))
             bounds = shard_bounds(T_total, max(shards, world))
             rows_all = [e - s0 for s0, e in bounds][:world]
             if a.T:
@@ -398,10 +399,10 @@ def main():
 
     cpu_dense_memo = {}
 
-    def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False):
+    def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False, share=False):
         """c2-dense / c4 (full matrix), c5-uniform[-f64] (entry lists), c5-block[-f64] (tile-sparse)."""
         steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
-        T, rows_all, scal = rows_for(wl)
+        T, rows_all, scal = rows_for(wl, share)
         T_job = sum(rows_all)
         f64 = wl.endswith("-f64")
         dt_name = "float64" if f64 else "float32"
@@ -465,7 +466,7 @@ def main():
         scaling = main_res.get("scaling", "weak")
         if want_secondary:
             # every other BASELINE config on this GPU (N = 1): c4's rank share on the SAME 101 GB operand, then the rest
-            r4, _ = run_dense_family("c4", plan=plan, steps=min(sec_steps, 3), warmup=1)
+            r4, _ = run_dense_family("c4", plan=plan, steps=min(sec_steps, 3), warmup=1, share=True)
             secondary.append(r4)
             torch.cuda.empty_cache()
             secondary.append(run_sparse("float32", steps=sec_steps))        # c2-real: segment-table form, fp32, area weights
@@ -473,7 +474,7 @@ def main():
             secondary.append(run_sparse("float64", small=True, steps=sec_steps))   # c1
             for wl in ("c5-block", "c5-block-f64", "c5-uniform", "c5-uniform-f64"):
                 torch.cuda.empty_cache()
-                secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2)[0])
+                secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2, share=True)[0])
     elif a.workload == "c1":
         main_res = run_sparse("float64", small=True)
     else:

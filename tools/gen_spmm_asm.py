@@ -79,12 +79,12 @@ def lane_regs(g, o):
     o.append("v_lshrrev_b32 v%d, 2, v%d" % (SCR, LANE))
     o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
     o.append("v_and_b32 v%d, 3, v%d" % (VPO, LANE))
-    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VPO, VPO, SCR))
+    o.append("v_lshl_add_u32 v%d, v%d, 2, v%d" % (VPO, VPO, SCR))
     # weight loads: lane l <- weight (l & 7) of group (l >> 3) (+ 8 groups per block)
     o.append("v_lshrrev_b32 v%d, 3, v%d" % (SCR, LANE))
     o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
     o.append("v_and_b32 v%d, 7, v%d" % (VWO, LANE))
-    o.append("v_lshl_or_b32 v%d, v%d, 2, v%d" % (VWO, VWO, SCR))
+    o.append("v_lshl_add_u32 v%d, v%d, 2, v%d" % (VWO, VWO, SCR))      # (an add: 48 k and (lane & 7) * 4 share bit 4)
     o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
     o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))            # lane * 8 | buffer bit
     o.append("v_mov_b32 v%d, 0x%x" % (VMASK, MASK))
