@@ -50,13 +50,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int SP_BUF_BYTES = SP_KC * SP_ROW;              // 65,536: one X chunk in LDS
 constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB behind the two buffers (kept: LDS-DMA past the last row is harmless)
-constexpr int SP_LDS_BYTES = SP_SINK + 1024;
+// fp32: every wave keeps the WEIGHTS of its list in LDS (two buffers of 128 x 4 bytes per wave, behind the sink): they get there
+// by LDS-DMA and come back four at a time by a broadcast ds_read_b128 -- a v_readlane per weight cost more vector-ALU time
+// than the FMA it feeds (profiles/r03_spmm_ablation.txt)
+constexpr int SP_WSLOT = 512;                             // bytes per (wave, buffer): 128 weights
+constexpr int SP_LDS_BYTES = SP_SINK + 1024 + 2 * SP_WAVES * SP_WSLOT;
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
 
 #ifndef WAGG_SPMM_ASM_INC          // tools/spmm_ablate.sh builds variants of the generated loop
 #define WAGG_SPMM_ASM_INC "wagg_spmm_asm.inc"
 #endif
 #include WAGG_SPMM_ASM_INC
+static_assert(SPMM_W_LDS0 == SP_SINK + 1024, "weight slots start behind the sink (tools/gen_spmm_asm.py W_LDS0)");
 
 template <typename T>
 __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
 #define SPMM_CHUNK_SYNC asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
     (void)knob;
 #endif
-    extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink; filled by LDS-DMA only
+    extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink | [2][16][512 B] weights (fp32); LDS-DMA only
     const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char *)lds;   // 0: the only LDS object
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -131,11 +136,13 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             // registers live ACROSS statements: nothing but scalar code may sit between two of them
             // (tools/check_spmm_codegen.py checks the compiled kernel).
             const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * GW);
+            const int wbase = lds0 + SPMM_W_LDS0 + wave * SP_WSLOT;      // this wave's weight slots, buffer 0 (fp32)
             if constexpr (F64)
                 asm volatile(SPMM_LOAD_LIST_ASM_F64 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
                              : "memory", SPMM_CHUNK_CLOBBERS);
             else
-                asm volatile(SPMM_LOAD_LIST_ASM_F32 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
+                asm volatile(SPMM_LOAD_LIST_ASM_F32 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0),
+                             [wl0] "s"(wbase), [wbase] "s"(wbase)
                              : "memory", SPMM_CHUNK_CLOBBERS);
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             r.g0 = goff[(int64_t)cc * SP_WAVES]; r.g1 = goff[(int64_t)cc * SP_WAVES + 1];
             r.gn = goff[(int64_t)r.cn * SP_WAVES];
         };
-        auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, int &l0, int &bufbit) {
+        auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, int &l0, int &bufbit, int &wl0) {
+            wl0 = lds0 + SPMM_W_LDS0 + ((par ^ 1) * SP_WAVES + wave) * SP_WSLOT;      // fp32: LDS slots of the NEXT chunk's weights
             asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn));
             n = r.real ? r.g1 - r.g0 : 0;
             pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * GW);
@@ -166,22 +174,23 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
         asm volatile(ASM                                                                                      \
                      : [n] "+s"(n), "+{v[40:47]}"(b0), "+{v[48:63]}"(b1), "+{v[64:95]}"(a1), "+{v[96:127]}"(a2) \
                      : [cplo] "s"((uint32_t)pc), [cphi] "s"((uint32_t)(pc >> 32)), [nplo] "s"((uint32_t)pn),   \
-                       [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src)   \
+                       [nphi] "s"((uint32_t)(pn >> 32)), [bufbit] "s"(bufbit), [l0] "s"(l0), [src] "s"(src),  \
+                       [wl0] "s"(wl0)                                                                         \
                      : "memory", "scc", SPMM_CHUNK_CLOBBERS)
 #define SPMM_CHUNK_STMT(AB)                                                                                   \
         do { if constexpr (F64) SPMM_CHUNK_STMT_(SPMM_CHUNK_ASM_##AB##_F64); else SPMM_CHUNK_STMT_(SPMM_CHUNK_ASM_##AB##_F32); } while (0)
         Raw ra, rb_;
         chunk_loads(c0, ra);
         for (int c = c0; c < c1; c += 2) {
-            int n, l0, bufbit;
+            int n, l0, bufbit, wl0;
             uint64_t pc, pn;
             const char *src;
-            chunk_args(ra, 0, n, pc, pn, src, l0, bufbit);
+            chunk_args(ra, 0, n, pc, pn, src, l0, bufbit, wl0);
             SPMM_CHUNK_STMT(A);               // this chunk's list in set A, the next one's -> B
             chunk_loads(c + 1, rb_);
             // this wave's pieces of the next chunk and the next list have landed; it is done reading this chunk
             SPMM_CHUNK_SYNC;
-            chunk_args(rb_, 1, n, pc, pn, src, l0, bufbit);
+            chunk_args(rb_, 1, n, pc, pn, src, l0, bufbit, wl0);
             SPMM_CHUNK_STMT(B);
             chunk_loads(c + 2, ra);
             SPMM_CHUNK_SYNC;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time guard for wagg_spmm.hip: between the inline-asm statements of the chunk loop the entry-list
-registers (v[3:34], hard-coded in tools/gen_spmm_asm.py) hold loads that are still in flight, so the
-compiler-generated code between two statements of one item must not touch v[3:34] (scalar code, or
+registers (v[3:35], hard-coded in tools/gen_spmm_asm.py) hold loads that are still in flight, so the
+compiler-generated code between two statements of one item must not touch v[3:35] (scalar code, or
 vector code on other registers such as the accumulator zeroing) and the kernel must not use scratch.  Reads the device assembly of spmm_kernel (hipcc -S) and fails loudly otherwise.
 
 usage: check_spmm_codegen.py <wagg_spmm.s>"""
@@ -9,7 +9,7 @@ import re
 import sys
 
 txt = open(sys.argv[1]).read()
-V_LAST = 34          # tools/gen_spmm_asm.py: private registers v[3:V_LAST]
+V_LAST = 35          # tools/gen_spmm_asm.py: private registers v[3:V_LAST]
 kernels = re.findall(r"^(_ZN4wagg11spmm_kernel\w*):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M)
 if len(kernels) != 2:
     sys.exit("expected spmm_kernel<float> and spmm_kernel<double> in %s, found %d" % (sys.argv[1], len(kernels)))
@@ -51,5 +51,5 @@ for kname, body in kernels:
               if any(3 <= r <= V_LAST for r in regs) or not regs:
                   bad.append(l.strip())
   if bad:
-      sys.exit("vector code on v[3:34] between spmm_kernel's statements (list registers are live there):\n  " + "\n  ".join(bad[:20]))
-  print(kname + ": %d statements checked, glue code leaves v[3:34] alone, no scratch" % (last - first + 1))
+      sys.exit("vector code on v[3:35] between spmm_kernel's statements (list registers are live there):\n  " + "\n  ".join(bad[:20]))
+  print(kname + ": %d statements checked, glue code leaves v[3:35] alone, no scratch" % (last - first + 1))

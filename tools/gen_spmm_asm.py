@@ -42,13 +42,10 @@ import sys
 
 N_BLOCKS = 2                 # 64-entry blocks loaded per list (16 groups); longer lists take the slow loop
 VPO, VWO = 3, 4              # lane offsets of the pair / weight loads
-SETS = {"A": 5, "B": 10}     # first register of a list set: +0 pairs, +1,+2 w (lo) of blocks 0,1, +3,+4 w hi (fp64)
-LANE, SCR, LB = 15, 16, 17
-TP, TQ = 18, 26              # VGPR temp sets: 4 (even-aligned) register pairs each
-VMASK = 34
 ACC0 = 40
 MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
-V_LAST = 34
+V_LAST = 35
+W_LDS0 = 0x20400             # weights in LDS (fp32): behind the two X buffers and the 1 KiB sink; [2][16 waves][512 B]
 # ablation variants for tools/spmm_ablate.sh (timing only, results are wrong): any of nofma, nolds, noidx, now, nobfi,
 # nodma, halfdma, nolist, noent
 ABL = set(filter(None, os.environ.get("SPMM_ABL", "").split(",")))
@@ -59,11 +56,22 @@ class Geo:
         self.f64 = f64
         self.sfx = "F64" if f64 else "F32"
         self.gwb = 80 if f64 else 48            # bytes per 8-entry group
+        self.wlds = not f64 and "wreg" not in ABL   # fp32: the weights go to LDS by LDS-DMA and come back by broadcast reads
         # SGPR half-group sets
         if f64:
             self.sets = {0: dict(lo=36, w=40), 1: dict(lo=48, w=52)}
         else:
             self.sets = {0: dict(lo=36, w=37), 1: dict(lo=44, w=45)}
+        if self.wlds:
+            # v5 / v6 the lo16 pairs of list set A / B; v[28:31] / v[32:35] the weights of the two half-group sets
+            self.SETS = {"A": 5, "B": 6}
+            self.LANE, self.SCR, self.LB, self.VWB, self.VMASK = 7, 8, 9, 10, 11
+            self.TP, self.TQ = 12, 20
+            self.WREG = {0: 28, 1: 32}
+        else:
+            self.SETS = {"A": 5, "B": 10}       # +0 pairs, +1,+2 w (lo) of blocks 0,1, +3,+4 w hi (fp64)
+            self.LANE, self.SCR, self.LB, self.VMASK = 15, 16, 17, 34
+            self.TP, self.TQ = 18, 26
 
     def s_lo(self, s, k):
         return self.sets[s]["lo"] + (k if self.f64 else 2 * k)
@@ -73,6 +81,7 @@ class Geo:
 
 
 def lane_regs(g, o):
+    LANE, SCR, LB = g.LANE, g.SCR, g.LB
     o.append("v_mbcnt_lo_u32_b32 v%d, -1, 0" % LANE)
     o.append("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (LANE, LANE))
     # pair loads: lane l <- pair (l & 3) of group (l >> 2): 128 entries in one register
@@ -85,31 +94,46 @@ def lane_regs(g, o):
     o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
     o.append("v_and_b32 v%d, 7, v%d" % (VWO, LANE))
     o.append("v_lshl_add_u32 v%d, v%d, 2, v%d" % (VWO, VWO, SCR))      # (an add: 48 k and (lane & 7) * 4 share bit 4)
+    if g.wlds:      # the weights' 16 bytes behind the pairs go into the register: an LDS-DMA's immediate offset would
+        o.append("v_add_u32 v%d, 16, v%d" % (VWO, VWO))               # move its LDS destination as well
     o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
     o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))            # lane * 8 | buffer bit
-    o.append("v_mov_b32 v%d, 0x%x" % (VMASK, MASK))
+    o.append("v_mov_b32 v%d, 0x%x" % (g.VMASK, MASK))
+    if g.wlds:
+        o.append("v_mov_b32 v%d, %%[wbase]" % g.VWB)                # this wave's weight slots in LDS (buffer 0)
 
 
 def load_list(g, o, which, ptr="s[70:71]"):
-    r0 = SETS[which]
+    """the list at `ptr`: lo16 pairs -> set `which`; weights -> registers, or (fp32) -> this wave's LDS slots at
+    %[wl0] by LDS-DMA (lane l <- weight of entry l: the same per-lane source offsets)"""
+    r0 = g.SETS[which]
     o.append("global_load_dword v%d, v%d, %s" % (r0, VPO, ptr))
+    if g.wlds:
+        assert ptr == "s[70:71]"
+        for b in range(N_BLOCKS):
+            if b:                             # (no immediate offsets on an LDS-DMA: see lane_regs)
+                o.append("s_add_u32 s70, s70, %d" % (8 * g.gwb))
+                o.append("s_addc_u32 s71, s71, 0")
+            o.append("s_add_u32 m0, %%[wl0], 0x%x" % (256 * b) if b else "s_mov_b32 m0, %[wl0]")
+            o.append("s_nop 0")
+            o.append("global_load_lds_dword v%d, %s" % (VWO, ptr))
+        return
     for b in range(N_BLOCKS):
         o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 1 + b, VWO, ptr, 8 * g.gwb * b + 16))
         if g.f64:
             o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 3 + b, VWO, ptr, 8 * g.gwb * b + 48))
 
 
-def issue(g, h, which, s, T, o, cur_lb, e0=None):
+def issue(g, h, which, s, T, o, cur_lb, wbuf):
     """half-group h (entries 4h .. 4h + 3 of the loaded blocks): entries -> SGPRs, LDS addresses, reads"""
-    r0 = SETS[which]
-    e0 = 4 * h if e0 is None else e0
+    r0 = g.SETS[which]
     for k in range(4):
-        e = e0 + k
+        e = 4 * h + k
         if k % 2 == 0:
             o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_lo(s, k), r0, e >> 1))
         else:
             o.append("s_lshr_b32 s%d, s%d, 16" % (g.s_lo(s, k), g.s_lo(s, k - 1)))
-        if "now" not in ABL:
+        if "now" not in ABL and not g.wlds:
             b, l = divmod(e, 64)
             if g.f64:
                 o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(s, k), r0 + 1 + b, l))
@@ -118,33 +142,47 @@ def issue(g, h, which, s, T, o, cur_lb, e0=None):
                 o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(s, k), r0 + 1 + b, l))
     for k in range(4):
         if "nobfi" not in ABL:
-            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, VMASK, g.s_lo(s, k), cur_lb))
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (T + 2 * k, g.VMASK, g.s_lo(s, k), cur_lb))
     for k in range(4):
         if "nolds" not in ABL:
             o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
+    if g.wlds and "now" not in ABL:           # the four weights: one broadcast read (every lane the same address)
+        W = g.WREG[s]
+        o.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (W, W + 3, g.VWB, wbuf * 8192 + 16 * h))
 
 
-def fma(g, s, T, younger, o):
-    """accumulate a half-group; `younger` = LDS reads issued after this half-group's own four"""
-    if "nolds" not in ABL:
+def lds_ops(g):
+    """LDS instructions per half-group issue"""
+    n = 0 if "nolds" in ABL else 4
+    return n + (1 if g.wlds and "now" not in ABL else 0)
+
+
+def fma(g, s, T, younger, o, sgpr_w=False):
+    """accumulate a half-group; `younger` = LDS reads issued after this half-group's own"""
+    if lds_ops(g):
         o.append("s_waitcnt lgkmcnt(%d)" % younger)
     for k in range(4):
         if "noidx" not in ABL:
             o.append(("s_set_gpr_idx_on s%d, 0xc" if k == 0 else "s_set_gpr_idx_idx s%d") % g.s_lo(s, k))
         if "nofma" in ABL:
             continue
+        x = "v[%d:%d]" % (T + 2 * k, T + 2 * k + 1)
+        acc = "v[%d:%d]" % (ACC0, ACC0 + 1)
         if g.f64:
-            o.append("v_fma_f64 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d]"
-                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, g.s_w(s, k), g.s_w(s, k) + 1, ACC0, ACC0 + 1))
+            o.append("v_fma_f64 %s, %s, s[%d:%d], %s" % (acc, x, g.s_w(s, k), g.s_w(s, k) + 1, acc))
+        elif g.wlds and not sgpr_w:
+            W = g.WREG[s] + 2 * (k // 2)      # weights k, k + 1 sit in one aligned register pair
+            sel = "op_sel:[0,1,0]" if k % 2 else "op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+            o.append("v_pk_fma_f32 %s, %s, v[%d:%d], %s %s" % (acc, x, W, W + 1, acc, sel))
         else:
-            o.append("v_pk_fma_f32 v[%d:%d], v[%d:%d], s[%d:%d], v[%d:%d] op_sel:[0,1,0]"
-                     % (ACC0, ACC0 + 1, T + 2 * k, T + 2 * k + 1, g.s_lo(s, k), g.s_lo(s, k) + 1, ACC0, ACC0 + 1))
+            o.append("v_pk_fma_f32 %s, %s, s[%d:%d], %s op_sel:[0,1,0]" % (acc, x, g.s_lo(s, k), g.s_lo(s, k) + 1, acc))
     if "noidx" not in ABL:
         o.append("s_set_gpr_idx_off")
 
 
 def chunk(g, cur, nxt):
     o = []
+    TP, TQ, LANE, SCR, LB = g.TP, g.TQ, g.LANE, g.SCR, g.LB
     o.append("s_mov_b32 s68, m0")
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
@@ -160,40 +198,62 @@ def chunk(g, cur, nxt):
         if "nodma" not in ABL:
             o.append("global_load_lds_dwordx4 v%d, %%[src]" % (TP + 1 if i else TP))
     cur_lb = LB
-    if cur == "B":                                             # statement B reads LDS buffer 1
+    wbuf = 0
+    if cur == "B":                                             # statement B reads X buffer 1 / weight buffer 1
         o.append("v_add_u32 v%d, 0x10000, v%d" % (SCR, LB))
         cur_lb = SCR
+        wbuf = 1
     o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
     o.append("s_cbranch_scc1 8f")
     if "noent" in ABL:
         o.append("s_branch 8f")
     n_half = N_BLOCKS * 16
-    issue(g, 0, cur, 0, TP, o, cur_lb)
+    issue(g, 0, cur, 0, TP, o, cur_lb, wbuf)
     for h in range(n_half):
         s, T = (0, TP) if h % 2 == 0 else (1, TQ)
         s2, T2 = (1, TQ) if h % 2 == 0 else (0, TP)
         last = h == n_half - 1
         if not last:
-            issue(g, h + 1, cur, s2, T2, o, cur_lb)
-        fma(g, s, T, 0 if last else 4, o)
+            issue(g, h + 1, cur, s2, T2, o, cur_lb, wbuf)
+        fma(g, s, T, 0 if last else lds_ops(g), o)
         if h % 2 == 1:                                         # a whole group done
             o.append("s_sub_u32 %[n], %[n], 1")
             o.append("s_cmp_eq_u32 %[n], 0")
             o.append("s_cbranch_scc1 8f")
-    # 3. overflow: one group at a time from behind the loaded blocks (reuses the current set's registers:
-    #    lanes 0-3 of the pair register, lanes 0-7 of the weight registers)
-    r0 = SETS[cur]
+    # 3. overflow: one group at a time from behind the loaded blocks: its lo16 pairs into lanes 0-3 of the current
+    #    set's pair register, its weights into lanes 0-7 of temporaries (TQ), entries one half-group at a time
+    r0 = g.SETS[cur]
+    wr = TQ if g.wlds else r0 + 1
+    wh = TQ + 1 if g.wlds else r0 + 3
     o.append("s_add_u32 s70, %%[cplo], %d" % (8 * g.gwb * N_BLOCKS))
     o.append("s_addc_u32 s71, %[cphi], 0")
     o.append("7:")
     o.append("global_load_dword v%d, v%d, s[70:71]" % (r0, VPO))
-    o.append("global_load_dword v%d, v%d, s[70:71] offset:16" % (r0 + 1, VWO))
+    o.append("global_load_dword v%d, v%d, s[70:71]%s" % (wr, VWO, "" if g.wlds else " offset:16"))
     if g.f64:
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:48" % (r0 + 3, VWO))
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:48" % (wh, VWO))
     o.append("s_waitcnt vmcnt(0)")
     for hh in range(2):
-        issue(g, hh, cur, 0, TP, o, cur_lb, e0=4 * hh)
-        fma(g, 0, TP, 0, o)
+        for k in range(4):
+            e = 4 * hh + k
+            if k % 2 == 0:
+                o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_lo(0, k), r0, e >> 1))
+            else:
+                o.append("s_lshr_b32 s%d, s%d, 16" % (g.s_lo(0, k), g.s_lo(0, k - 1)))
+            o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(0, k), wr, e))
+            if g.f64:
+                o.append("v_readlane_b32 s%d, v%d, %d" % (g.s_w(0, k) + 1, wh, e))
+        for k in range(4):
+            o.append("v_bfi_b32 v%d, v%d, s%d, v%d" % (TP + 2 * k, g.VMASK, g.s_lo(0, k), cur_lb))
+        for k in range(4):
+            o.append("ds_read_b64 v[%d:%d], v%d" % (TP + 2 * k, TP + 2 * k + 1, TP + 2 * k))
+        o.append("s_waitcnt lgkmcnt(0)")
+        saved = set(ABL)
+        ABL.discard("nolds"); ABL.discard("nofma"); ABL.discard("noidx")
+        body = []
+        fma(g, 0, TP, 0, body, sgpr_w=True)
+        o.extend(b for b in body if not b.startswith("s_waitcnt"))
+        ABL.clear(); ABL.update(saved)
     o.append("s_add_u32 s70, s70, %d" % g.gwb)
     o.append("s_addc_u32 s71, s71, 0")
     o.append("s_sub_u32 %[n], %[n], 1")
@@ -207,10 +267,12 @@ def chunk(g, cur, nxt):
 
 def prologue(g):
     o = []
+    o.append("s_mov_b32 s68, m0")
     o.append("s_mov_b32 s70, %[nplo]")
     o.append("s_mov_b32 s71, %[nphi]")
     lane_regs(g, o)   # lane, load offsets, lane * 8 | base of LDS buffer 0 and the cell mask live for the whole item
     load_list(g, o, "A")
+    o.append("s_mov_b32 m0, s68")
     return o
 
 
@@ -236,6 +298,7 @@ def main():
             print("wrote", path, g.sfx, len(a), "instructions per chunk statement", file=sys.stderr)
         clob = ["v%d" % i for i in range(3, V_LAST + 1)] + ["s%d" % i for i in range(36, 72)]
         f.write("#define SPMM_CHUNK_CLOBBERS %s\n" % ", ".join('"%s"' % c for c in clob))
+        f.write("#define SPMM_W_LDS0 0x%x\n" % W_LDS0)
 
 
 if __name__ == "__main__":
