@@ -39,8 +39,9 @@ constexpr int SP_PAD_GROUPS = 48;            // zero groups behind the last list
 // either way an accumulator is a register PAIR and a cell's LDS row is 512 bytes
 template <typename T> struct SpT {
     static constexpr int TB = SP_ROW / (int)sizeof(T);            // timesteps per block: 128 / 64
-    // 32-bit words per 8-entry group: [4 x lo16 pairs][8 x weight (bits 31:0)]([8 x weight bits 63:32])
+    // 32-bit words per 8-entry group: [4 x lo16 pairs][8 x weight (float / double)]
     static constexpr int GW = 4 + 8 * (int)(sizeof(T) / 4);       // 12 / 20
+    static constexpr int WSLOT = 128 * (int)sizeof(T);            // bytes of a wave's weights in LDS (one buffer): 128 entries
 };
 // lo16 of an entry = cell_in_chunk << 9 | accumulator register offset (2 j for the wave's region j)
 __host__ __device__ inline unsigned sp_entry_lo(int cell_in_chunk, int j) { return (unsigned)(cell_in_chunk << 9 | 2 * j); }
@@ -48,8 +49,8 @@ __host__ __device__ inline unsigned sp_entry_lo(int cell_in_chunk, int j) { retu
 template <typename T> __host__ __device__ inline int64_t sp_lo16_index(int64_t pos) {      // in uint16 units
     return (pos >> 3) * (2 * SpT<T>::GW) + (pos & 7);
 }
-template <typename T> __host__ __device__ inline int64_t sp_w_index(int64_t pos) {         // in uint32 units (low word)
-    return (pos >> 3) * SpT<T>::GW + 4 + (pos & 7);
+template <typename T> __host__ __device__ inline int64_t sp_w_index(int64_t pos) {         // in uint32 units (first word)
+    return (pos >> 3) * SpT<T>::GW + 4 + (pos & 7) * (int)(sizeof(T) / 4);
 }
 
 struct SpmmPlan {

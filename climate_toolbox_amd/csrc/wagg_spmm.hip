@@ -49,19 +49,18 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int SP_BUF_BYTES = SP_KC * SP_ROW;              // 65,536: one X chunk in LDS
-constexpr int SP_SINK = 2 * SP_BUF_BYTES;                 // 1 KiB behind the two buffers (kept: LDS-DMA past the last row is harmless)
-// fp32: every wave keeps the WEIGHTS of its list in LDS (two buffers of 128 x 4 bytes per wave, behind the sink): they get there
-// by LDS-DMA and come back four at a time by a broadcast ds_read_b128 -- a v_readlane per weight cost more vector-ALU time
-// than the FMA it feeds (profiles/r03_spmm_ablation.txt)
-constexpr int SP_WSLOT = 512;                             // bytes per (wave, buffer): 128 weights
-constexpr int SP_LDS_BYTES = SP_SINK + 1024 + 2 * SP_WAVES * SP_WSLOT;
+// Every wave keeps the WEIGHTS of its list in LDS (two buffers of 128 weights per wave, behind the X buffers): they get
+// there by one LDS-DMA and come back four (fp64: two) at a time by broadcast ds_read_b128 -- a v_readlane per weight word
+// cost more vector-ALU time than the FMA it feeds (profiles/r03_spmm_ablation.txt).  fp64: 128 + 32 KiB = all of the LDS.
+template <typename T> constexpr int sp_lds_bytes() { return 2 * SP_BUF_BYTES + 2 * SP_WAVES * SpT<T>::WSLOT; }
+static_assert(sp_lds_bytes<double>() <= 160 * 1024, "LDS budget");
 static_assert(SP_BUF_BYTES == 0x10000, "the buffer bit of the LDS address is bit 16");
 
 #ifndef WAGG_SPMM_ASM_INC          // tools/spmm_ablate.sh builds variants of the generated loop
 #define WAGG_SPMM_ASM_INC "wagg_spmm_asm.inc"
 #endif
 #include WAGG_SPMM_ASM_INC
-static_assert(SPMM_W_LDS0 == SP_SINK + 1024, "weight slots start behind the sink (tools/gen_spmm_asm.py W_LDS0)");
+static_assert(SPMM_W_LDS0 == 2 * SP_BUF_BYTES, "weight slots start behind the X buffers (tools/gen_spmm_asm.py W_LDS0)");
 
 template <typename T>
 __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
 #define SPMM_CHUNK_SYNC asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
     (void)knob;
 #endif
-    extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | 1 KiB sink | [2][16][512 B] weights (fp32); LDS-DMA only
+    extern __shared__ __attribute__((aligned(1024))) char lds[];   // [2][64 KiB] X chunks | [2][16 waves][128 weights]; filled by LDS-DMA only
     const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) char *)lds;   // 0: the only LDS object
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,9 +135,10 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             // registers live ACROSS statements: nothing but scalar code may sit between two of them
             // (tools/check_spmm_codegen.py checks the compiled kernel).
             const uint64_t p0 = reinterpret_cast<uint64_t>(ent + (int64_t)goff[(int64_t)c0 * SP_WAVES] * GW);
-            const int wbase = lds0 + SPMM_W_LDS0 + wave * SP_WSLOT;      // this wave's weight slots, buffer 0 (fp32)
+            const int wbase = lds0 + SPMM_W_LDS0 + wave * SpT<T>::WSLOT;      // this wave's weight slots, buffer 0
             if constexpr (F64)
-                asm volatile(SPMM_LOAD_LIST_ASM_F64 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0)
+                asm volatile(SPMM_LOAD_LIST_ASM_F64 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0),
+                             [wl0] "s"(wbase), [wbase] "s"(wbase)
                              : "memory", SPMM_CHUNK_CLOBBERS);
             else
                 asm volatile(SPMM_LOAD_LIST_ASM_F32 : : [nplo] "s"((uint32_t)p0), [nphi] "s"((uint32_t)(p0 >> 32)), [bufbit] "s"(lds0),
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(SP_THREADS) void spmm_kernel(
             r.gn = goff[(int64_t)r.cn * SP_WAVES];
         };
         auto chunk_args = [&](Raw &r, int par, int &n, uint64_t &pc, uint64_t &pn, const char *&src, int &l0, int &bufbit, int &wl0) {
-            wl0 = lds0 + SPMM_W_LDS0 + ((par ^ 1) * SP_WAVES + wave) * SP_WSLOT;      // fp32: LDS slots of the NEXT chunk's weights
+            wl0 = lds0 + SPMM_W_LDS0 + ((par ^ 1) * SP_WAVES + wave) * SpT<T>::WSLOT;      // LDS slots of the NEXT chunk's weights
             asm volatile("" : "+s"(r.g0), "+s"(r.g1), "+s"(r.gn));
             n = r.real ? r.g1 - r.g0 : 0;
             pc = reinterpret_cast<uint64_t>(ent + (int64_t)r.g0 * GW);
@@ -278,7 +278,7 @@ __host__ __device__ inline void sp_store_entry(uint32_t *ent, int64_t pos, unsig
     } else {
         const uint64_t b = __builtin_bit_cast(uint64_t, w);
         ent[sp_w_index<T>(pos)] = (uint32_t)b;
-        ent[sp_w_index<T>(pos) + 8] = (uint32_t)(b >> 32);
+        ent[sp_w_index<T>(pos) + 1] = (uint32_t)(b >> 32);
     }
 }
 
@@ -480,14 +480,14 @@ int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT
     hipLaunchKernelGGL((spmm_pack_x_kernel<T>), dim3((unsigned)(Gpad / 64), (unsigned)(n_tb * (TB / 64))), dim3(256), 0, st, X, Tn,
                        ldx, d->G, Gpad, xf, xp);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel<T>, SP_LDS_BYTES));
+    WAGG_HIP(allow_dynamic_lds((const void *)spmm_kernel<T>, sp_lds_bytes<T>()));
     const int nwg = (int)(n_items < d->ncu ? n_items : d->ncu);
     int knob = 0;
 #ifdef WAGG_DIAG
     if (const char *k = getenv("WAGG_SPMM_KNOB")) knob = atoi(k);
 #endif
     profile_mark(st, true);
-    hipLaunchKernelGGL((spmm_kernel<T>), dim3((unsigned)nwg), dim3(SP_THREADS), SP_LDS_BYTES, st, (const T *)xp,
+    hipLaunchKernelGGL((spmm_kernel<T>), dim3((unsigned)nwg), dim3(SP_THREADS), sp_lds_bytes<T>(), st, (const T *)xp,
                        (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, slabs, n_tb, sp.n_rb, sp.n_chunks, cps,
                        sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups, knob);
     profile_mark(st, false);

@@ -12,7 +12,7 @@ for the wave's region j (j < 44; pair 43 swallows the padding entries): two fp32
 
 Entry lists (round 3 format).  A group of 8 entries is stored as
     [4 x (lo16 of entry 2p | lo16 of entry 2p + 1 << 16)] [8 x weight]            fp32: 48 bytes
-    [4 x lo16 pairs] [8 x weight bits 31:0] [8 x weight bits 63:32]               fp64: 80 bytes
+    [4 x lo16 pairs] [8 x weight (double)]                                        fp64: 80 bytes
 with lo16 = cell_in_chunk << 9 | accumulator register offset (2 j).  One v_readlane brings the lo16 of TWO
 entries into an SGPR (the odd entry takes `s_lshr_b32 ..., 16`, a scalar instruction), so an entry costs
 1.5 v_readlane (fp64: 2.5) + v_bfi (LDS address) + ds_read_b64 + s_set_gpr_idx_idx + ONE v_pk_fma_f32 /
@@ -45,7 +45,7 @@ VPO, VWO = 3, 4              # lane offsets of the pair / weight loads
 ACC0 = 40
 MASK = 0xfe00                # cell row bits of an entry: address = (lo & MASK) | lb
 V_LAST = 35
-W_LDS0 = 0x20400             # weights in LDS (fp32): behind the two X buffers and the 1 KiB sink; [2][16 waves][512 B]
+W_LDS0 = 0x20000             # weights in LDS, behind the two X buffers: [2 buffers][16 waves][128 weights]
 # ablation variants for tools/spmm_ablate.sh (timing only, results are wrong): any of nofma, nolds, noidx, now, nobfi,
 # nodma, halfdma, nolist, noent
 ABL = set(filter(None, os.environ.get("SPMM_ABL", "").split(",")))
@@ -56,18 +56,21 @@ class Geo:
         self.f64 = f64
         self.sfx = "F64" if f64 else "F32"
         self.gwb = 80 if f64 else 48            # bytes per 8-entry group
-        self.wlds = not f64 and "wreg" not in ABL   # fp32: the weights go to LDS by LDS-DMA and come back by broadcast reads
+        self.wlds = "wreg" not in ABL           # the weights go to LDS by LDS-DMA and come back by broadcast reads
+        self.wb = 8 if f64 else 4               # bytes per weight
+        self.wbuf_bytes = 16 * 128 * self.wb    # one weight buffer: 16 waves x 128 weights
         # SGPR half-group sets
         if f64:
             self.sets = {0: dict(lo=36, w=40), 1: dict(lo=48, w=52)}
         else:
             self.sets = {0: dict(lo=36, w=37), 1: dict(lo=44, w=45)}
         if self.wlds:
-            # v5 / v6 the lo16 pairs of list set A / B; v[28:31] / v[32:35] the weights of the two half-group sets
+            # v5 / v6 the lo16 pairs of list set A / B; fp32: v[28:31] / v[32:35] the weights of the two half-group sets;
+            # fp64: ONE set v[28:35] (four doubles), read behind the FMAs of the half-group before (see chunk)
             self.SETS = {"A": 5, "B": 6}
             self.LANE, self.SCR, self.LB, self.VWB, self.VMASK = 7, 8, 9, 10, 11
             self.TP, self.TQ = 12, 20
-            self.WREG = {0: 28, 1: 32}
+            self.WREG = {0: 28, 1: 28} if f64 else {0: 28, 1: 32}
         else:
             self.SETS = {"A": 5, "B": 10}       # +0 pairs, +1,+2 w (lo) of blocks 0,1, +3,+4 w hi (fp64)
             self.LANE, self.SCR, self.LB, self.VMASK = 15, 16, 17, 34
@@ -94,8 +97,17 @@ def lane_regs(g, o):
     o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
     o.append("v_and_b32 v%d, 7, v%d" % (VWO, LANE))
     o.append("v_lshl_add_u32 v%d, v%d, 2, v%d" % (VWO, VWO, SCR))      # (an add: 48 k and (lane & 7) * 4 share bit 4)
-    if g.wlds:      # the weights' 16 bytes behind the pairs go into the register: an LDS-DMA's immediate offset would
-        o.append("v_add_u32 v%d, 16, v%d" % (VWO, VWO))               # move its LDS destination as well
+    if g.wlds:
+        # weights by ONE LDS-DMA of 16 bytes per lane, lanes 0-31 (exec-masked): lane l <- weights 4 l .. 4 l + 3 =
+        # half (l & 1) of group (l >> 1); the 16 bytes of the pairs in front are part of the register (an LDS-DMA's
+        # immediate offset would move its LDS destination as well)
+        # (fp64: 16 bytes = 2 doubles: lane l <- quarter (l & 3) of group (l >> 2), all 64 lanes)
+        sh, m = (2, 3) if g.f64 else (1, 1)
+        o.append("v_lshrrev_b32 v%d, %d, v%d" % (SCR, sh, LANE))
+        o.append("v_mul_u32_u24 v%d, %d, v%d" % (SCR, g.gwb, SCR))
+        o.append("v_and_b32 v%d, %d, v%d" % (VWO, m, LANE))
+        o.append("v_lshl_add_u32 v%d, v%d, 4, v%d" % (VWO, VWO, SCR))
+        o.append("v_add_u32 v%d, 16, v%d" % (VWO, VWO))
     o.append("v_lshlrev_b32 v%d, 3, v%d" % (LB, LANE))
     o.append("v_or_b32 v%d, %%[bufbit], v%d" % (LB, LB))            # lane * 8 | buffer bit
     o.append("v_mov_b32 v%d, 0x%x" % (g.VMASK, MASK))
@@ -108,15 +120,17 @@ def load_list(g, o, which, ptr="s[70:71]"):
     %[wl0] by LDS-DMA (lane l <- weight of entry l: the same per-lane source offsets)"""
     r0 = g.SETS[which]
     o.append("global_load_dword v%d, v%d, %s" % (r0, VPO, ptr))
+    if g.wlds and g.f64:
+        o.append("s_mov_b32 m0, %[wl0]")
+        o.append("s_nop 0")
+        o.append("global_load_lds_dwordx4 v%d, %s" % (VWO, ptr))
+        return
     if g.wlds:
-        assert ptr == "s[70:71]"
-        for b in range(N_BLOCKS):
-            if b:                             # (no immediate offsets on an LDS-DMA: see lane_regs)
-                o.append("s_add_u32 s70, s70, %d" % (8 * g.gwb))
-                o.append("s_addc_u32 s71, s71, 0")
-            o.append("s_add_u32 m0, %%[wl0], 0x%x" % (256 * b) if b else "s_mov_b32 m0, %[wl0]")
-            o.append("s_nop 0")
-            o.append("global_load_lds_dword v%d, %s" % (VWO, ptr))
+        o.append("s_mov_b64 s[62:63], exec")
+        o.append("s_mov_b32 m0, %[wl0]")
+        o.append("s_mov_b64 exec, 0xffffffff")                 # lanes 0-31 (also the wait state behind the M0 write)
+        o.append("global_load_lds_dwordx4 v%d, %s" % (VWO, ptr))
+        o.append("s_mov_b64 exec, s[62:63]")
         return
     for b in range(N_BLOCKS):
         o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 1 + b, VWO, ptr, 8 * g.gwb * b + 16))
@@ -124,7 +138,18 @@ def load_list(g, o, which, ptr="s[70:71]"):
             o.append("global_load_dword v%d, v%d, %s offset:%d" % (r0 + 3 + b, VWO, ptr, 8 * g.gwb * b + 48))
 
 
-def issue(g, h, which, s, T, o, cur_lb, wbuf):
+def wread(g, h, s, o, wbuf):
+    """the four weights of half-group h: broadcast reads (every lane the same address)"""
+    if not g.wlds or "now" in ABL:
+        return
+    W = g.WREG[s]
+    at = wbuf * g.wbuf_bytes + 4 * g.wb * h
+    o.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (W, W + 3, g.VWB, at))
+    if g.f64:
+        o.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (W + 4, W + 7, g.VWB, at + 16))
+
+
+def issue(g, h, which, s, T, o, cur_lb, wbuf, with_w=True):
     """half-group h (entries 4h .. 4h + 3 of the loaded blocks): entries -> SGPRs, LDS addresses, reads"""
     r0 = g.SETS[which]
     for k in range(4):
@@ -146,15 +171,21 @@ def issue(g, h, which, s, T, o, cur_lb, wbuf):
     for k in range(4):
         if "nolds" not in ABL:
             o.append("ds_read_b64 v[%d:%d], v%d" % (T + 2 * k, T + 2 * k + 1, T + 2 * k))
-    if g.wlds and "now" not in ABL:           # the four weights: one broadcast read (every lane the same address)
-        W = g.WREG[s]
-        o.append("ds_read_b128 v[%d:%d], v%d offset:%d" % (W, W + 3, g.VWB, wbuf * 8192 + 16 * h))
+    if with_w:
+        wread(g, h, s, o, wbuf)
+
+
+def x_ops(g):
+    return 0 if "nolds" in ABL else 4
+
+
+def w_ops(g):
+    return ((2 if g.f64 else 1) if g.wlds and "now" not in ABL else 0)
 
 
 def lds_ops(g):
-    """LDS instructions per half-group issue"""
-    n = 0 if "nolds" in ABL else 4
-    return n + (1 if g.wlds and "now" not in ABL else 0)
+    """LDS instructions per half-group"""
+    return x_ops(g) + w_ops(g)
 
 
 def fma(g, s, T, younger, o, sgpr_w=False):
@@ -168,7 +199,10 @@ def fma(g, s, T, younger, o, sgpr_w=False):
             continue
         x = "v[%d:%d]" % (T + 2 * k, T + 2 * k + 1)
         acc = "v[%d:%d]" % (ACC0, ACC0 + 1)
-        if g.f64:
+        if g.f64 and g.wlds and not sgpr_w:
+            W = g.WREG[s] + 2 * k
+            o.append("v_fma_f64 %s, %s, v[%d:%d], %s" % (acc, x, W, W + 1, acc))
+        elif g.f64:
             o.append("v_fma_f64 %s, %s, s[%d:%d], %s" % (acc, x, g.s_w(s, k), g.s_w(s, k) + 1, acc))
         elif g.wlds and not sgpr_w:
             W = g.WREG[s] + 2 * (k // 2)      # weights k, k + 1 sit in one aligned register pair
@@ -203,22 +237,26 @@ def chunk(g, cur, nxt):
         o.append("v_add_u32 v%d, 0x10000, v%d" % (SCR, LB))
         cur_lb = SCR
         wbuf = 1
-    o.append("s_cmp_eq_u32 %[n], 0")                           # 2. the entries of THIS chunk
-    o.append("s_cbranch_scc1 8f")
+    o.append("s_sub_u32 %[n], %[n], 1")                        # 2. the entries of THIS chunk; n - 1 groups remain behind
+    o.append("s_cbranch_scc1 8f")                              #    the first (a borrow: the list is empty)
     if "noent" in ABL:
         o.append("s_branch 8f")
     n_half = N_BLOCKS * 16
+    one_wset = g.wlds and g.WREG[0] == g.WREG[1]               # (fp64) the weights of h + 1 are read behind the FMAs of h
     issue(g, 0, cur, 0, TP, o, cur_lb, wbuf)
     for h in range(n_half):
         s, T = (0, TP) if h % 2 == 0 else (1, TQ)
         s2, T2 = (1, TQ) if h % 2 == 0 else (0, TP)
         last = h == n_half - 1
         if not last:
-            issue(g, h + 1, cur, s2, T2, o, cur_lb, wbuf)
-        fma(g, s, T, 0 if last else lds_ops(g), o)
-        if h % 2 == 1:                                         # a whole group done
+            issue(g, h + 1, cur, s2, T2, o, cur_lb, wbuf, with_w=not one_wset)
+        # LDS reads in flight behind this half-group's own: the X reads of h + 1 (and its weight reads unless they
+        # come later)
+        fma(g, s, T, 0 if last else (x_ops(g) if one_wset else lds_ops(g)), o)
+        if one_wset and not last:
+            wread(g, h + 1, s2, o, wbuf)
+        if h % 2 == 1:                                         # a whole group done: was it the last one?
             o.append("s_sub_u32 %[n], %[n], 1")
-            o.append("s_cmp_eq_u32 %[n], 0")
             o.append("s_cbranch_scc1 8f")
     # 3. overflow: one group at a time from behind the loaded blocks: its lo16 pairs into lanes 0-3 of the current
     #    set's pair register, its weights into lanes 0-7 of temporaries (TQ), entries one half-group at a time
@@ -229,9 +267,15 @@ def chunk(g, cur, nxt):
     o.append("s_addc_u32 s71, %[cphi], 0")
     o.append("7:")
     o.append("global_load_dword v%d, v%d, s[70:71]" % (r0, VPO))
-    o.append("global_load_dword v%d, v%d, s[70:71]%s" % (wr, VWO, "" if g.wlds else " offset:16"))
-    if g.f64:
-        o.append("global_load_dword v%d, v%d, s[70:71] offset:48" % (wh, VWO))
+    if g.wlds:
+        o.append("v_lshlrev_b32 v%d, %d, v%d" % (TQ + 2, 3 if g.f64 else 2, LANE))   # lane e <- weight e of the group
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:16" % (wr, TQ + 2))
+        if g.f64:
+            o.append("global_load_dword v%d, v%d, s[70:71] offset:20" % (wh, TQ + 2))
+    else:
+        o.append("global_load_dword v%d, v%d, s[70:71] offset:16" % (wr, VWO))
+        if g.f64:
+            o.append("global_load_dword v%d, v%d, s[70:71] offset:48" % (wh, VWO))
     o.append("s_waitcnt vmcnt(0)")
     for hh in range(2):
         for k in range(4):
@@ -257,7 +301,6 @@ def chunk(g, cur, nxt):
     o.append("s_add_u32 s70, s70, %d" % g.gwb)
     o.append("s_addc_u32 s71, s71, 0")
     o.append("s_sub_u32 %[n], %[n], 1")
-    o.append("s_cmp_eq_u32 %[n], 0")
     o.append("s_cbranch_scc0 7b")
     o.append("8:")
     o.append("s_waitcnt lgkmcnt(0)")          # reads issued for a half-group past the end are never consumed
