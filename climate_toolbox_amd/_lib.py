@@ -32,7 +32,30 @@ EXPORTS = (
     "wagg_dense_create_synth_f64", "wagg_dense_create_host_f64", "wagg_dense_create_from_segments_f64",
     "wagg_dense_create_synth_blocklocal_f64", "wagg_dense_apply_f64", "wagg_dense_apply_poly_f64", "wagg_dense_apply_edd_f64",
     "wagg_synth_field_f32", "wagg_synth_field_f64",
+    "wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32", "wagg_dense_apply_host_multi_f64",
+    "wagg_host_block_plan", "wagg_host_stats_read",
 )
+
+
+class HostStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("calls", "blocks", "registered", "register_failed", "unregistered", "unregister_failed",
+                                         "cleanup_failed", "staged_h2d_bytes", "staged_d2h_bytes", "direct_h2d_bytes",
+                                         "direct_d2h_bytes")]
+
+
+def host_stats(reset=False):
+    """What the host-buffer paths did since the last reset (``wagg_host_stats_read``): a dict of counters."""
+    st = HostStats()
+    check(load().wagg_host_stats_read(C.byref(st), 1 if reset else 0), "wagg_host_stats_read")
+    return {k: int(getattr(st, k)) for k, _ in HostStats._fields_}
+
+
+def host_block_plan(T, row_bytes, quantum, n_devices=1):
+    """(rows per block, number of blocks) of the row-block pipeline; block i goes to device slot i % n_devices."""
+    b, n = C.c_int64(0), C.c_int64(0)
+    check(load().wagg_host_block_plan(int(T), int(row_bytes), int(quantum), int(n_devices), C.byref(b), C.byref(n)),
+          "wagg_host_block_plan")
+    return int(b.value), int(n.value)
 
 
 class DenseInfo(C.Structure):
@@ -100,6 +123,11 @@ def load():
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, C.c_int, C.c_int]
     for name in ("wagg_dense_apply_host_f32", "wagg_dense_apply_host_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int]
+    for name in ("wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32",
+                 "wagg_dense_apply_host_multi_f64"):
+        getattr(L, name).argtypes = [C.POINTER(vp), i32p, C.c_int, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int]
+    L.wagg_host_block_plan.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.wagg_host_stats_read.argtypes = [C.POINTER(HostStats), C.c_int]
     for name in ("wagg_gather_f32", "wagg_gather_f64"):
         getattr(L, name).argtypes = [vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int64, vp, C.c_int64,
                                      C.c_int, vp]

@@ -475,6 +475,37 @@ def _flatten_for_device(values, dims):
     return X2, layout, others_shape, unflatten
 
 
+# Host-resident fields stream through EVERY visible GPU of the process (one row-block pipeline per device, each on
+# its own PCIe link; SURVEY 8b `n_devices`, 8e "one process driving all devices"): None = all visible devices; a list
+# of device ordinals pins the choice (a device may be listed twice: two pipelines on one GPU).
+HOST_DEVICES = None
+_REPLICA_MAX_BYTES = 8 << 30          # plans above this (the 101 GB dense operand) are not replicated
+
+
+def _host_replicas(plan, n_rows, row_bytes):
+    """Replicas of a leased plan on the other devices of HOST_DEVICES, built once and kept with the plan; () when one
+    device serves the call (a single GPU, a field of few blocks, a plan too large to copy around)."""
+    import torch
+    devs = list(range(torch.cuda.device_count())) if HOST_DEVICES is None else [int(d) for d in HOST_DEVICES]
+    if len(devs) < 2 or _plan_bytes(plan) > _REPLICA_MAX_BYTES:
+        return ()
+    from ._lib import host_block_plan
+    if host_block_plan(n_rows, row_bytes, 64, len(devs))[1] < 2 * len(devs):
+        return ()                      # not enough blocks for every device to overlap its copies with its kernels
+    cache = plan.__dict__.setdefault("_replicas", {})
+    out = []
+    first = True
+    for slot, d in enumerate(devs):
+        if first and d == plan.device:
+            first = False              # the plan itself serves its own device once
+            continue
+        key = (slot, d)
+        if key not in cache:
+            cache[key] = plan.replica(d)
+        out.append(cache[key])
+    return tuple(out)                  # (a plan whose device is not listed still serves the first pipeline itself)
+
+
 DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins
 ENTRY_LIST_MAX_FILL = 0.10   # wagg_dense.hip SPMM_MAX_FILL: below it a scattered table is stored as entry lists
 
@@ -722,7 +753,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
             from ._lib import HOST_PIN
             X2c = np.ascontiguousarray(X2)
-            host_out = plan.apply_host(X2c, flags=HOST_PIN)
+            host_out = plan.apply_host(X2c, flags=HOST_PIN, replicas=_host_replicas(plan, X2c.shape[0], X2c.strides[0]))
             if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
                 exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
                 try:

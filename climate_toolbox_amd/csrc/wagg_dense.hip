@@ -556,6 +556,7 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     d->spmm = spmm;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
+    d->device = dev;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e == hipSuccess) e = d->nonfinite.alloc(1);
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, 2 * sizeof(int), hipHostMallocMapped);
@@ -577,7 +578,7 @@ static int dense_den_to_host(wagg_dense *d) {
                        d->den64.p, d->den32.p, d->R);
     WAGG_HIP(hipGetLastError());
     d->den_host.resize((size_t)d->R);
-    WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
+    WAGG_HIP(staged_d2h(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R));
     return WAGG_OK;
 }
 
@@ -715,7 +716,7 @@ static int create_host(const T *W_host, int64_t G, int32_t R, wagg_dense **out) 
     wagg_dense *d = *out;
     DevBuf<T> plain;
     hipError_t e = plain.alloc((size_t)(G * R));
-    if (e == hipSuccess) e = hipMemcpy(plain.p, W_host, sizeof(T) * (size_t)(G * R), hipMemcpyHostToDevice);
+    if (e == hipSuccess && copy_to_device(plain.p, W_host, sizeof(T) * (size_t)(G * R), true) != WAGG_OK) { delete d; *out = nullptr; return WAGG_EHIP; }
     if (e == hipSuccess) {
         hipLaunchKernelGGL((dense_pack_w_kernel<T>), dim3(256 * 8), dim3(256), 0, nullptr, (const T *)plain.p, G, R, d->n_kt,
                            d->w_slots(), reinterpret_cast<vec_t *>(d->W.p));
@@ -777,8 +778,8 @@ static int create_from_segments(const int32_t *cell_idx, const int32_t *region_c
             rc = spmm_build_from_coo<T>(d, hc, hr, hw);
             std::vector<float> den32s(den.size());
             for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
-            hipError_t es = rc == WAGG_OK ? hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice) : hipSuccess;
-            if (es == hipSuccess && rc == WAGG_OK) es = hipMemcpy(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), hipMemcpyHostToDevice);
+            hipError_t es = rc == WAGG_OK ? staged_h2d(d->den64.p, den.data(), sizeof(double) * den.size(), nullptr) : hipSuccess;
+            if (es == hipSuccess && rc == WAGG_OK) es = staged_h2d(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), nullptr);
             if (es != hipSuccess) { set_error("entry lists: %s", hipGetErrorString(es)); rc = WAGG_EHIP; }
             if (rc != WAGG_OK) { delete d; *out = nullptr; return rc; }
             d->den_host = den;
@@ -820,8 +821,8 @@ static int create_from_segments(const int32_t *cell_idx, const int32_t *region_c
     // denominators from the fp64 segment sums (aggregations.py:79), not from the stored matrix
     std::vector<float> den32(den.size());
     for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
-    e = hipMemcpy(d->den64.p, den.data(), sizeof(double) * den.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d->den32.p, den32.data(), sizeof(float) * den32.size(), hipMemcpyHostToDevice);
+    e = staged_h2d(d->den64.p, den.data(), sizeof(double) * den.size(), nullptr);
+    if (e == hipSuccess) e = staged_h2d(d->den32.p, den32.data(), sizeof(float) * den32.size(), nullptr);
     if (e != hipSuccess) { set_error("densify den: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
     d->den_host = den;
     return WAGG_OK;
@@ -1103,29 +1104,66 @@ extern "C" int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev,
 }
 
 namespace wagg {
+static int check_dense_device(const wagg_dense *d) {
+    int cur = 0;
+    WAGG_HIP(hipGetDevice(&cur));
+    WAGG_REQUIRE(cur == d->device, "the dense plan was created on device %d, the current device is %d", d->device, cur);
+    return WAGG_OK;
+}
+
 template <typename T>
 static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t ldx, T *out_host, int64_t ldo, int flags) {
+    clear_error();
     WAGG_REQUIRE(d != nullptr, "dense plan is NULL");
     WAGG_REQUIRE(Tn >= 0, "T < 0");
     if (Tn == 0) return WAGG_OK;
     WAGG_REQUIRE(X_host && out_host, "X/out is NULL");
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
+    if (int rc = check_dense_device(d)) return rc;
     if (flags & WAGG_HOST_WHOLE) {
         DevBuf<T> dx, dout;
         WAGG_HIP(dx.alloc((size_t)(Tn * ldx)));
         WAGG_HIP(dout.alloc((size_t)(Tn * ldo)));
-        WAGG_HIP(copy_to_device(dx.p, X_host, sizeof(T) * host_span(Tn, ldx, d->G)));
+        const bool pin = (flags & WAGG_HOST_PIN) != 0;
+        if (int rc = copy_to_device(dx.p, X_host, sizeof(T) * (size_t)((Tn - 1) * ldx + d->G), pin)) return rc;
         const int rc = dense_apply<T>(d, dx.p, Tn, ldx, PackXfT<T>{}, dout.p, ldo, 0, nullptr);
         if (rc != WAGG_OK) return rc;
         WAGG_HIP(hipDeviceSynchronize());
-        WAGG_HIP(copy_rows_to_host<T>(out_host, dout.p, Tn, ldo, d->R, nullptr, false));
-        return WAGG_OK;
+        return copy_rows_to_host(out_host, dout.p, Tn, sizeof(T) * (size_t)ldo, sizeof(T) * (size_t)d->R, pin);
     }
-    return stream_host_rows<T>(X_host, Tn, ldx, d->G, out_host, ldo, d->R, flags, d->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16,
-                               [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
+    return stream_host_rows<T>(X_host, Tn, ldx, d->G, out_host, ldo, d->R, flags, d->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16, 1, nullptr,
+                               [&](int, const T *xd, int64_t rows, T *od, hipStream_t st) {
                                    return dense_apply<T>(d, xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
-                               });
+                               },
+                               [](int, hipStream_t) {});
+}
+
+// multi-device form: one replica of the dense-family plan per device (wagg_apply_host_multi_* says how the blocks travel)
+template <typename T>
+static int dense_apply_host_multi(wagg_dense *const *plans, const int *devices, int n, const T *X_host, int64_t Tn, int64_t ldx,
+                                  T *out_host, int64_t ldo, int flags) {
+    clear_error();
+    WAGG_REQUIRE(plans && devices && n >= 1 && n <= 64, "need 1..64 plan replicas and their devices");
+    WAGG_REQUIRE((flags & ~WAGG_HOST_PIN) == 0, "unknown host flags 0x%x", flags);
+    WAGG_REQUIRE(Tn >= 0, "T < 0");
+    for (int s = 0; s < n; ++s) {
+        WAGG_REQUIRE(plans[s] != nullptr, "plan replica %d is NULL", s);
+        WAGG_REQUIRE(plans[s]->device == devices[s], "plan replica %d lives on device %d, not %d", s, plans[s]->device, devices[s]);
+        WAGG_REQUIRE(plans[s]->G == plans[0]->G && plans[s]->R == plans[0]->R && plans[s]->f64 == (sizeof(T) == 8) &&
+                     plans[s]->spmm == plans[0]->spmm, "plan replica %d has another shape, element type or form", s);
+        for (int q = 0; q < s; ++q) WAGG_REQUIRE(plans[q] != plans[s], "replicas %d and %d are the same plan (a dense-family plan owns "
+                                                 "its workspaces: one replica per pipeline)", q, s);
+    }
+    if (Tn == 0) return WAGG_OK;
+    WAGG_REQUIRE(X_host && out_host, "X/out is NULL");
+    wagg_dense *d0 = plans[0];
+    WAGG_REQUIRE(ldx >= d0->G && ldo >= d0->R, "ldx/ldo too small");
+    return stream_host_rows<T>(X_host, Tn, ldx, d0->G, out_host, ldo, d0->R, flags, d0->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16, n, devices,
+                               [&](int s, const T *xd, int64_t rows, T *od, hipStream_t st) {
+                                   return dense_apply<T>(plans[s], xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
+                               },
+                               [](int, hipStream_t) {});
 }
 }  // namespace wagg
 
@@ -1136,6 +1174,14 @@ extern "C" int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int
 extern "C" int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
                                          double *out_host, int64_t ldo, int flags) {
     return wagg::dense_apply_host<double>(d, X_host, T, ldx, out_host, ldo, flags);
+}
+extern "C" int wagg_dense_apply_host_multi_f32(wagg_dense *const *plans, const int *devices, int n_devices, const float *X_host,
+                                               int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags) {
+    return wagg::dense_apply_host_multi<float>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags);
+}
+extern "C" int wagg_dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices, int n_devices, const double *X_host,
+                                               int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags) {
+    return wagg::dense_apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags);
 }
 
 extern "C" int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw) {

@@ -1,7 +1,7 @@
 // Internal layout of a dense-family plan (wagg_dense) shared by wagg_dense.hip (full / tile-sparse
 // MFMA forms) and wagg_spmm.hip (entry-list form for scattered weights).
 #pragma once
-#include "wagg_common.h"
+#include "wagg_host.h"
 
 namespace wagg {
 
@@ -89,12 +89,13 @@ struct wagg_dense {
     bool spmm = false;
     wagg::SpmmPlan sp;
     int ncu = 256;
+    int device = 0;                    // the device the plan (W, lists, workspaces) lives on
     // +-inf seen in the (transformed) data of an apply in one of the MFMA forms: host-mapped word
     // ([1]: a pack-free first pass met NaN / +-inf: later applies of this plan go straight to the packed pass)
     int *inf_host = nullptr, *inf_dev = nullptr;
     // pack-free tile-sparse apply: "a numerator of the first pass was not finite" (device word, gates the exact second pass)
     wagg::DevBuf<int> nonfinite;
-    ~wagg_dense() { if (inf_host) (void)hipHostFree(inf_host); }
+    ~wagg_dense() { if (inf_host) wagg::note_cleanup(hipHostFree(inf_host), "hipHostFree(inf note)"); }
 };
 
 namespace wagg {

@@ -1,0 +1,365 @@
+// Host-resident data: page-locks, staging and the row-block pipeline (wagg_host.h).  Host code only.
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "wagg_host.h"
+
+namespace wagg {
+
+HostStats g_host_stats;
+
+void note_cleanup(hipError_t e, const char *what) {
+    if (e == hipSuccess) return;
+    g_host_stats.cleanup_failed++;
+    if (wagg_last_error()[0] == '\0') set_error("%s -> %s", what, hipGetErrorString(e));
+}
+
+void host_block_plan(int64_t Tn, int64_t row_bytes, int64_t quantum, int n_devices, int64_t *block_rows, int64_t *n_blocks) {
+    // ~256 MiB of X per block in whole multiples of `quantum` rows (the row count one launch handles well: 64 for the
+    // segment-table kernels, a full 368 / 176-row block for the MFMA forms, whose W is streamed once per launch), at
+    // least two blocks per device when there are that many quanta of rows (so that copies and kernels overlap)
+    if (quantum < 1) quantum = 1;
+    if (n_devices < 1) n_devices = 1;
+    if (row_bytes < 1) row_bytes = 1;
+    int64_t B = ((int64_t)256 << 20) / row_bytes;
+    B = B < quantum ? quantum : B / quantum * quantum;
+    const int64_t want = 2 * (int64_t)n_devices;
+    if (Tn >= want * quantum && B > (Tn + want - 1) / want) B = (Tn + want - 1) / want / quantum * quantum;     // (>= quantum)
+    if (B > Tn) B = Tn;
+    if (B < 1) B = 1;
+    *block_rows = B;
+    *n_blocks = Tn > 0 ? (Tn + B - 1) / B : 0;
+}
+
+// ---- page-lock of a caller array ---------------------------------------------------------------------------------
+bool HostPin::acquire(const void *p, size_t bytes, bool portable) {
+    if (ptr_ || p == nullptr || bytes < PIN_MIN) return pinned();
+    const hipError_t e = hipHostRegister(const_cast<void *>(p), bytes, portable ? hipHostRegisterPortable : hipHostRegisterDefault);
+    if (e == hipSuccess) {
+        ptr_ = const_cast<void *>(p);
+        g_host_stats.registered++;
+    } else {
+        why_ = e;                               // e.g. the range is registered already, or page-locked memory is short
+        g_host_stats.register_failed++;
+        (void)hipGetLastError();                // the refusal is handled here (staged copies): it must not taint later calls
+    }
+    return pinned();
+}
+
+hipError_t HostPin::release() {
+    if (!ptr_) return hipSuccess;
+    const hipError_t e = hipHostUnregister(ptr_);
+    ptr_ = nullptr;
+    if (e == hipSuccess) {
+        g_host_stats.unregistered++;
+    } else {
+        g_host_stats.unregister_failed++;
+        if (wagg_last_error()[0] == '\0') set_error("hipHostUnregister -> %s", hipGetErrorString(e));
+    }
+    return e;
+}
+
+// ---- the library's own page-locked staging ------------------------------------------------------------------------
+namespace {
+struct HostStage {
+    std::mutex mu;
+    char *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t init() {
+        for (int b = 0; b < 2; ++b) {
+            if (!buf[b]) { hipError_t e = hipHostMalloc((void **)&buf[b], STAGE_PIECE, hipHostMallocDefault); if (e != hipSuccess) return e; }
+            if (!ev[b]) { hipError_t e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming); if (e != hipSuccess) return e; }
+        }
+        return hipSuccess;
+    }
+};
+constexpr int MAX_DEV = 64;
+// per device and direction: a few MiB of page-locked memory, process lifetime (a copy up and a copy down of one call
+// overlap; two calls on one device take turns)
+HostStage g_up[MAX_DEV], g_down[MAX_DEV];
+
+HostStage *stage_for(HostStage *set, hipError_t *e) {
+    int dev = 0;
+    *e = hipGetDevice(&dev);
+    if (*e != hipSuccess) return nullptr;
+    if (dev < 0 || dev >= MAX_DEV) { *e = hipErrorInvalidDevice; return nullptr; }
+    return &set[dev];
+}
+}  // namespace
+
+hipError_t staged_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    hipError_t e;
+    HostStage *S = stage_for(g_up, &e);
+    if (!S) return e;
+    std::lock_guard<std::mutex> lock(S->mu);
+    if ((e = S->init()) != hipSuccess) return e;
+    size_t off = 0;
+    int n_used = 0;
+    for (int p = 0; off < bytes; ++p) {
+        const int b = p & 1;
+        const size_t n = bytes - off < STAGE_PIECE ? bytes - off : STAGE_PIECE;
+        if (p >= 2 && (e = hipEventSynchronize(S->ev[b])) != hipSuccess) return e;      // piece p-2 has left the buffer
+        std::memcpy(S->buf[b], static_cast<const char *>(src_host) + off, n);
+        if ((e = hipMemcpyAsync(static_cast<char *>(dst_dev) + off, S->buf[b], n, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(S->ev[b], st)) != hipSuccess) return e;
+        off += n;
+        n_used = p + 1 < 2 ? p + 1 : 2;
+    }
+    for (int b = 0; b < n_used; ++b)
+        if ((e = hipEventSynchronize(S->ev[b])) != hipSuccess) return e;                  // buffers free for the next caller
+    g_host_stats.staged_h2d_bytes += (int64_t)bytes;
+    return hipSuccess;
+}
+
+// the device block is (rows x ld_bytes) contiguous; of every row the first row_bytes go to the same offsets on the host
+hipError_t staged_d2h_rows(void *dst_host, const void *src_dev, int64_t rows, size_t ld_bytes, size_t row_bytes, hipStream_t st) {
+    if (rows <= 0 || row_bytes == 0) return hipSuccess;
+    hipError_t e;
+    HostStage *S = stage_for(g_down, &e);
+    if (!S) return e;
+    std::lock_guard<std::mutex> lock(S->mu);
+    if ((e = S->init()) != hipSuccess) return e;
+    const size_t bytes = (size_t)(rows - 1) * ld_bytes + row_bytes;
+    auto scatter = [&](int b, size_t off, size_t n) {         // staged bytes [off, off + n) -> the used part of each row
+        if (ld_bytes == row_bytes) { std::memcpy(static_cast<char *>(dst_host) + off, S->buf[b], n); return; }
+        for (size_t r = off / ld_bytes; r < (size_t)rows && r * ld_bytes < off + n; ++r) {
+            const size_t lo = r * ld_bytes > off ? r * ld_bytes : off;
+            const size_t hi_row = r * ld_bytes + row_bytes, hi = hi_row < off + n ? hi_row : off + n;
+            if (hi > lo) std::memcpy(static_cast<char *>(dst_host) + lo, S->buf[b] + (lo - off), hi - lo);
+        }
+    };
+    size_t off = 0, prev_off = 0, prev_n = 0;
+    int p = 0;
+    for (; off < bytes; ++p) {
+        const int b = p & 1;
+        const size_t n = bytes - off < STAGE_PIECE ? bytes - off : STAGE_PIECE;
+        if ((e = hipMemcpyAsync(S->buf[b], static_cast<const char *>(src_dev) + off, n, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(S->ev[b], st)) != hipSuccess) return e;
+        if (p >= 1) {                                          // drain the previous piece while this one flies
+            if ((e = hipEventSynchronize(S->ev[b ^ 1])) != hipSuccess) return e;
+            scatter(b ^ 1, prev_off, prev_n);
+        }
+        prev_off = off; prev_n = n;
+        off += n;
+    }
+    const int last = (p - 1) & 1;
+    if ((e = hipEventSynchronize(S->ev[last])) != hipSuccess) return e;
+    scatter(last, prev_off, prev_n);
+    g_host_stats.staged_d2h_bytes += (int64_t)((size_t)rows * row_bytes);
+    return hipSuccess;
+}
+
+int copy_to_device(void *dst_dev, const void *src_host, size_t bytes, bool pin) {
+    if (bytes == 0) return WAGG_OK;
+    HostPin lock;
+    if (pin && lock.acquire(src_host, bytes, false)) {
+        WAGG_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));       // from page-locked memory: one DMA
+        g_host_stats.direct_h2d_bytes += (int64_t)bytes;
+        WAGG_HIP(lock.release());
+        return WAGG_OK;
+    }
+    WAGG_HIP(staged_h2d(dst_dev, src_host, bytes, nullptr));
+    return WAGG_OK;
+}
+
+int copy_rows_to_host(void *dst_host, const void *src_dev, int64_t rows, size_t ld_bytes, size_t row_bytes, bool pin) {
+    if (rows <= 0 || row_bytes == 0) return WAGG_OK;
+    const size_t span = (size_t)(rows - 1) * ld_bytes + row_bytes;
+    HostPin lock;
+    if (pin && lock.acquire(dst_host, span, false)) {
+        if (ld_bytes == row_bytes) WAGG_HIP(hipMemcpy(dst_host, src_dev, span, hipMemcpyDeviceToHost));
+        else WAGG_HIP(hipMemcpy2D(dst_host, ld_bytes, src_dev, ld_bytes, row_bytes, (size_t)rows, hipMemcpyDeviceToHost));
+        g_host_stats.direct_d2h_bytes += (int64_t)((size_t)rows * row_bytes);
+        WAGG_HIP(lock.release());
+        return WAGG_OK;
+    }
+    WAGG_HIP(staged_d2h_rows(dst_host, src_dev, rows, ld_bytes, row_bytes, nullptr));
+    return WAGG_OK;
+}
+
+// ---- one device's streams, events and block buffers ---------------------------------------------------------------
+hipError_t DevicePipe::init(int dev, bool set_device, size_t x_bytes, size_t o_bytes, int nbuf) {
+    hipError_t e = hipSuccess;
+    if (set_device) { if ((e = hipSetDevice(dev)) != hipSuccess) return e; }
+    device = dev;
+    if ((e = hipStreamCreateWithFlags(&sc, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&sk, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&sd, hipStreamNonBlocking)) != hipSuccess) return e;
+    for (int b = 0; b < nbuf && b < 2; ++b) {
+        if ((e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&kdone[b], hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&ddone[b], hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipMalloc(&dx[b], x_bytes)) != hipSuccess) return e;
+        if ((e = hipMalloc(&dout[b], o_bytes)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t DevicePipe::drain() {
+    hipError_t e;
+    if (sc && (e = hipStreamSynchronize(sc)) != hipSuccess) return e;
+    if (sk && (e = hipStreamSynchronize(sk)) != hipSuccess) return e;
+    if (sd && (e = hipStreamSynchronize(sd)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+DevicePipe::~DevicePipe() {
+    // nothing may still be in flight on the buffers, whatever path led here
+    if (sc) note_cleanup(hipStreamSynchronize(sc), "hipStreamSynchronize(copy-in stream)");
+    if (sk) note_cleanup(hipStreamSynchronize(sk), "hipStreamSynchronize(kernel stream)");
+    if (sd) note_cleanup(hipStreamSynchronize(sd), "hipStreamSynchronize(copy-out stream)");
+    for (int b = 0; b < 2; ++b) {
+        if (ready[b]) note_cleanup(hipEventDestroy(ready[b]), "hipEventDestroy");
+        if (kdone[b]) note_cleanup(hipEventDestroy(kdone[b]), "hipEventDestroy");
+        if (ddone[b]) note_cleanup(hipEventDestroy(ddone[b]), "hipEventDestroy");
+        if (dx[b]) note_cleanup(hipFree(dx[b]), "hipFree(X block)");
+        if (dout[b]) note_cleanup(hipFree(dout[b]), "hipFree(result block)");
+    }
+    if (sc) note_cleanup(hipStreamDestroy(sc), "hipStreamDestroy");
+    if (sk) note_cleanup(hipStreamDestroy(sk), "hipStreamDestroy");
+    if (sd) note_cleanup(hipStreamDestroy(sd), "hipStreamDestroy");
+}
+
+// ---- the pipeline of one device: blocks slot, slot + n_dev, ... ---------------------------------------------------------
+static int run_device(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o) {
+    const int64_t my_blocks = nb > slot ? (nb - slot + a.n_dev - 1) / a.n_dev : 0;
+    if (my_blocks == 0) return WAGG_OK;
+    DevicePipe P;
+    const int dev = a.devices ? a.devices[slot] : -1;
+    int cur = 0;
+    if (!set_device) WAGG_HIP(hipGetDevice(&cur));
+    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * a.ldx_bytes), (size_t)(B * a.ldo_bytes), my_blocks >= 2 ? 2 : 1));
+    struct Releaser {                                   // per-stream plan state keyed by P.sk goes before the stream does
+        const HostRowsArgs &a; int slot; hipStream_t s;
+        ~Releaser() { if (a.release) a.release(slot, s); }
+    } rel{a, slot, P.sk};
+    auto span = [](int64_t rows, int64_t ld, int64_t row) { return (size_t)((rows - 1) * ld + row); };
+    int64_t prev_r0 = -1, prev_rows = 0;
+    int prev_b = 0;
+    auto drain_prev = [&]() -> int {                    // staged return of the previous block (blocks the host)
+        if (prev_r0 < 0) return WAGG_OK;
+        WAGG_HIP(hipStreamWaitEvent(P.sd, P.kdone[prev_b], 0));
+        WAGG_HIP(staged_d2h_rows(a.out_host + prev_r0 * a.ldo_bytes, P.dout[prev_b], prev_rows, (size_t)a.ldo_bytes, (size_t)a.orow_bytes, P.sd));
+        WAGG_HIP(hipEventRecord(P.ddone[prev_b], P.sd));
+        prev_r0 = -1;
+        return WAGG_OK;
+    };
+    int64_t j = 0;
+    for (int64_t i = slot; i < nb; i += a.n_dev, ++j) {
+        const int b = (int)(j & 1);
+        const int64_t r0 = i * B, rows = a.Tn - r0 < B ? a.Tn - r0 : B;
+        const char *src = a.X_host + r0 * a.ldx_bytes;
+        const size_t xspan = span(rows, a.ldx_bytes, a.xrow_bytes);
+        if (j >= 2) WAGG_HIP(hipStreamWaitEvent(P.sc, P.kdone[b], 0));            // the kernels of block j-2 have read dx[b]
+        if (pin_x) {
+            WAGG_HIP(hipMemcpyAsync(P.dx[b], src, xspan, hipMemcpyHostToDevice, P.sc));      // page-locked source: truly asynchronous
+            g_host_stats.direct_h2d_bytes += (int64_t)xspan;
+        } else {
+            WAGG_HIP(staged_h2d(P.dx[b], src, xspan, P.sc));
+        }
+        WAGG_HIP(hipEventRecord(P.ready[b], P.sc));
+        WAGG_HIP(hipStreamWaitEvent(P.sk, P.ready[b], 0));
+        if (j >= 2) WAGG_HIP(hipStreamWaitEvent(P.sk, P.ddone[b], 0));            // the result of block j-2 has left dout[b]
+        const int rc = a.apply(slot, P.dx[b], rows, P.dout[b], P.sk);
+        if (rc != WAGG_OK) return rc;
+        WAGG_HIP(hipEventRecord(P.kdone[b], P.sk));
+        g_host_stats.blocks++;
+        if (pin_o) {                                                               // page-locked destination: asynchronous
+            char *dst = a.out_host + r0 * a.ldo_bytes;
+            WAGG_HIP(hipStreamWaitEvent(P.sd, P.kdone[b], 0));
+            if (a.ldo_bytes == a.orow_bytes)
+                WAGG_HIP(hipMemcpyAsync(dst, P.dout[b], (size_t)(rows * a.orow_bytes), hipMemcpyDeviceToHost, P.sd));
+            else
+                WAGG_HIP(hipMemcpy2DAsync(dst, (size_t)a.ldo_bytes, P.dout[b], (size_t)a.ldo_bytes, (size_t)a.orow_bytes, (size_t)rows,
+                                          hipMemcpyDeviceToHost, P.sd));
+            WAGG_HIP(hipEventRecord(P.ddone[b], P.sd));
+            g_host_stats.direct_d2h_bytes += (int64_t)(rows * a.orow_bytes);
+        } else {
+            // the previous block's result returns through the staging pieces WHILE this block's kernels run (they are
+            // queued already); this block's own result follows in the next round (or behind the loop)
+            if (int rc2 = drain_prev()) return rc2;
+            prev_r0 = r0; prev_rows = rows; prev_b = b;
+        }
+    }
+    if (int rc2 = drain_prev()) return rc2;
+    WAGG_HIP(P.drain());
+    return WAGG_OK;
+}
+
+int stream_host_rows_any(const HostRowsArgs &a) {
+    if (a.Tn == 0) return WAGG_OK;
+    WAGG_REQUIRE(a.n_dev >= 1 && a.n_dev <= 64, "n_devices must lie in [1, 64], got %d", a.n_dev);
+    g_host_stats.calls++;
+    const int64_t fail0 = g_host_stats.cleanup_failed + g_host_stats.unregister_failed;
+    int64_t B, nb;
+    host_block_plan(a.Tn, a.ldx_bytes, a.quantum, a.n_dev, &B, &nb);
+    const size_t xbytes = (size_t)((a.Tn - 1) * a.ldx_bytes + a.xrow_bytes), obytes = (size_t)((a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
+    int rc = WAGG_OK;
+    {
+        HostPin px, po;
+        const bool want = (a.flags & WAGG_HOST_PIN) != 0;
+        const bool pin_x = want && px.acquire(a.X_host, xbytes, a.n_dev > 1);
+        const bool pin_o = want && po.acquire(a.out_host, obytes, a.n_dev > 1);
+        if (a.n_dev == 1 && a.devices == nullptr) {
+            rc = run_device(a, 0, false, B, nb, pin_x, pin_o);
+        } else {
+            // one host thread per device: each drives its own copy engines and kernels, results land straight in the
+            // caller's rows (no exchange between devices)
+            std::vector<int> rcs((size_t)a.n_dev, WAGG_OK);
+            std::vector<std::string> msgs((size_t)a.n_dev);
+            std::vector<std::thread> th;
+            int home = 0;
+            WAGG_HIP(hipGetDevice(&home));
+            for (int s = 0; s < a.n_dev; ++s)
+                th.emplace_back([&, s]() {
+                    rcs[(size_t)s] = run_device(a, s, true, B, nb, pin_x, pin_o);
+                    if (rcs[(size_t)s] != WAGG_OK) msgs[(size_t)s] = wagg_last_error();
+                });
+            for (auto &t : th) t.join();
+            for (int s = 0; s < a.n_dev && rc == WAGG_OK; ++s)
+                if (rcs[(size_t)s] != WAGG_OK) { rc = rcs[(size_t)s]; set_error("device slot %d: %s", s, msgs[(size_t)s].c_str()); }
+            (void)home;                                  // (the calling thread's current device was never changed)
+        }
+        // the page-locks go only now: every stream that touched the arrays has been drained and destroyed
+        const hipError_t ex = px.release(), eo = po.release();
+        if (rc == WAGG_OK && (ex != hipSuccess || eo != hipSuccess)) {
+            set_error("hipHostUnregister -> %s", hipGetErrorString(ex != hipSuccess ? ex : eo));
+            rc = WAGG_EHIP;
+        }
+    }
+    if (rc == WAGG_OK && g_host_stats.cleanup_failed + g_host_stats.unregister_failed != fail0) {
+        if (wagg_last_error()[0] == '\0') set_error("a HIP call failed while the host pipeline released its resources");
+        rc = WAGG_EHIP;
+    }
+    return rc;
+}
+
+}  // namespace wagg
+
+extern "C" int wagg_host_block_plan(int64_t T, int64_t row_bytes, int64_t quantum, int n_devices, int64_t *block_rows,
+                                    int64_t *n_blocks) {
+    using namespace wagg;
+    WAGG_REQUIRE(T >= 0 && row_bytes >= 1 && quantum >= 1 && n_devices >= 1, "bad block plan request");
+    WAGG_REQUIRE(block_rows && n_blocks, "NULL argument");
+    host_block_plan(T, row_bytes, quantum, n_devices, block_rows, n_blocks);
+    return WAGG_OK;
+}
+
+extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
+    using namespace wagg;
+    WAGG_REQUIRE(out != nullptr, "NULL argument");
+    HostStats &s = g_host_stats;
+    out->calls = s.calls; out->blocks = s.blocks;
+    out->registered = s.registered; out->register_failed = s.register_failed;
+    out->unregistered = s.unregistered; out->unregister_failed = s.unregister_failed;
+    out->cleanup_failed = s.cleanup_failed;
+    out->staged_h2d_bytes = s.staged_h2d_bytes; out->staged_d2h_bytes = s.staged_d2h_bytes;
+    out->direct_h2d_bytes = s.direct_h2d_bytes; out->direct_d2h_bytes = s.direct_d2h_bytes;
+    if (reset) {
+        s.calls = 0; s.blocks = 0; s.registered = 0; s.register_failed = 0; s.unregistered = 0; s.unregister_failed = 0;
+        s.cleanup_failed = 0; s.staged_h2d_bytes = 0; s.staged_d2h_bytes = 0; s.direct_h2d_bytes = 0; s.direct_d2h_bytes = 0;
+    }
+    return WAGG_OK;
+}

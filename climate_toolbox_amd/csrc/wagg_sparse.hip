@@ -28,7 +28,7 @@
 #include <numeric>
 #include <utility>
 
-#include "wagg_common.h"
+#include "wagg_host.h"
 
 namespace wagg {
 
@@ -94,8 +94,8 @@ struct wagg_plan {
         for (Staging &w : ws)
             if (w.stream == st) {
                 if (w.bytes >= bytes) return w.p;
-                (void)hipStreamSynchronize(st);              // the old buffer may still be in use on this stream
-                (void)hipFree(w.p);
+                if (hipStreamSynchronize(st) != hipSuccess) return nullptr;      // the old buffer may still be in use on this stream
+                if (hipFree(w.p) != hipSuccess) return nullptr;
                 w.p = nullptr; w.bytes = 0;
                 if (hipMalloc(&w.p, bytes) != hipSuccess) return nullptr;
                 w.bytes = bytes;
@@ -106,9 +106,20 @@ struct wagg_plan {
         ws.push_back({st, p, bytes});
         return p;
     }
+    // the stream is about to be destroyed (the host pipeline's own compute stream): its staging goes with it, so the
+    // list stays bounded and a later stream that happens to get the same handle starts clean
+    void drop_staging(hipStream_t st) const {
+        std::lock_guard<std::mutex> lock(ws_mu);
+        for (size_t i = 0; i < ws.size(); ++i)
+            if (ws[i].stream == st) {
+                if (ws[i].p) wagg::note_cleanup(hipFree(ws[i].p), "hipFree(staging)");
+                ws.erase(ws.begin() + (long)i);
+                return;
+            }
+    }
     ~wagg_plan() {
-        if (timeout_host) (void)hipHostFree(timeout_host);
-        for (Staging &w : ws) if (w.p) (void)hipFree(w.p);
+        if (timeout_host) wagg::note_cleanup(hipHostFree(timeout_host), "hipHostFree(status word)");
+        for (Staging &w : ws) if (w.p) wagg::note_cleanup(hipFree(w.p), "hipFree(staging)");
     }
 };
 
@@ -1267,8 +1278,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
                 std::vector<unsigned long long> h(8 * (size_t)nw);
                 WAGG_HIP(hipStreamSynchronize(stream));
-                WAGG_HIP(hipMemcpy(h.data(), lc_stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-                (void)hipFree(lc_stamps);
+                WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
+                WAGG_HIP(hipFree(lc_stamps));
                 double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
                 const double stg = (double)n_items;
@@ -1303,8 +1314,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         if (do_stamp) {           // diagnostic: print mean cycles per stage and phase
             std::vector<unsigned long long> h(10 * (size_t)nw);
             WAGG_HIP(hipStreamSynchronize(stream));
-            WAGG_HIP(hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-            (void)hipFree(stamps);
+            WAGG_HIP(staged_d2h(h.data(), stamps, sizeof(unsigned long long) * h.size()));
+            WAGG_HIP(hipFree(stamps));
             double sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (size_t i = 0; i < h.size(); ++i) sum[i % 10] += (double)h[i];
             const double stages = (double)n_items;
@@ -1740,17 +1751,28 @@ static int apply_poly(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     return rc;
 }
 
+// the device a plan lives on must be the current one (single-device forms) / the slot's device (multi-device form)
+static int check_plan_device(const wagg_plan *plan) {
+    int cur = 0;
+    WAGG_HIP(hipGetDevice(&cur));
+    WAGG_REQUIRE(cur == plan->device, "the plan was created on device %d, the current device is %d", plan->device, cur);
+    return WAGG_OK;
+}
+
 template <typename T, typename F>
 static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, T *out,
                       int64_t ldo, int out_layout, int flags, F fn) {
+    clear_error();
     int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
     if (rc != WAGG_OK || Tn == 0) return rc;
     WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
+    if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
-        rc = stream_host_rows<T>(X, Tn, ldx, plan->info.G, out, ldo, plan->info.R, flags, 64,
-                                 [&](const T *xd, int64_t rows, T *od, hipStream_t st) {
+        rc = stream_host_rows<T>(X, Tn, ldx, plan->info.G, out, ldo, plan->info.R, flags, 64, 1, nullptr,
+                                 [&](int, const T *xd, int64_t rows, T *od, hipStream_t st) {
                                      return fn(plan, xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
-                                 });
+                                 },
+                                 [&](int, hipStream_t st) { plan->drop_staging(st); });
         if (rc != WAGG_OK) return rc;
         return check_timeout(plan);
     }
@@ -1760,14 +1782,43 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     WAGG_HIP(dx.alloc((size_t)(xrows * ldx)));
     WAGG_HIP(dout.alloc((size_t)(orows * ldo)));
     const int64_t xcols = layout == WAGG_LAYOUT_TG ? plan->info.G : Tn, ocols = out_layout == WAGG_OUT_TR ? plan->info.R : Tn;
-    WAGG_HIP(copy_to_device(dx.p, X, sizeof(T) * host_span(xrows, ldx, xcols)));
+    const bool pin = (flags & WAGG_HOST_PIN) != 0;
+    if ((rc = copy_to_device(dx.p, X, sizeof(T) * (size_t)((xrows - 1) * ldx + xcols), pin)) != WAGG_OK) return rc;
     WAGG_HIP(hipMemset(dout.p, 0, sizeof(T) * (size_t)(orows * ldo)));
     rc = fn(plan, dx.p, Tn, ldx, layout, dout.p, ldo, out_layout, nullptr);
     if (rc != WAGG_OK) return rc;
     WAGG_HIP(hipDeviceSynchronize());
     if (int rc2 = check_timeout(plan)) return rc2;
-    WAGG_HIP(copy_rows_to_host<T>(out, dout.p, orows, ldo, ocols, nullptr, false));
-    return WAGG_OK;
+    return copy_rows_to_host(out, dout.p, orows, sizeof(T) * (size_t)ldo, sizeof(T) * (size_t)ocols, pin);
+}
+
+// Multi-device form (SURVEY 8b `n_devices`, 8e "one process driving all devices"): plan replica s lives on device
+// devices[s]; the row blocks of the host field are dealt round-robin to the devices, each device runs its own H2D /
+// kernels / D2H pipeline on its own PCIe link from its own host thread, and every block's result lands directly in
+// the caller's rows -- no exchange between devices, no collective.  The same device may appear more than once (two
+// replicas on one GPU: how the path is exercised on a one-GPU box).
+template <typename T, typename F>
+static int apply_host_multi(const wagg_plan *const *plans, const int *devices, int n, const T *X, int64_t Tn, int64_t ldx,
+                            T *out, int64_t ldo, int flags, F fn) {
+    clear_error();
+    WAGG_REQUIRE(plans && devices && n >= 1 && n <= 64, "need 1..64 plan replicas and their devices");
+    WAGG_REQUIRE((flags & ~WAGG_HOST_PIN) == 0, "unknown host flags 0x%x", flags);
+    for (int s = 0; s < n; ++s) {
+        WAGG_REQUIRE(plans[s] != nullptr, "plan replica %d is NULL", s);
+        WAGG_REQUIRE(plans[s]->device == devices[s], "plan replica %d lives on device %d, not %d", s, plans[s]->device, devices[s]);
+        WAGG_REQUIRE(plans[s]->info.G == plans[0]->info.G && plans[s]->info.R == plans[0]->info.R,
+                     "plan replica %d has another shape", s);
+        int rc = check_apply_args(plans[s], X, Tn, ldx, WAGG_LAYOUT_TG, out, ldo, WAGG_OUT_TR);
+        if (rc != WAGG_OK) return rc;
+    }
+    if (Tn == 0) return WAGG_OK;
+    int rc = stream_host_rows<T>(X, Tn, ldx, plans[0]->info.G, out, ldo, plans[0]->info.R, flags, 64, n, devices,
+                                 [&](int s, const T *xd, int64_t rows, T *od, hipStream_t st) {
+                                     return fn(plans[s], xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
+                                 },
+                                 [&](int s, hipStream_t st) { plans[s]->drop_staging(st); });
+    for (int s = 0; s < n && rc == WAGG_OK; ++s) rc = check_timeout(plans[s]);
+    return rc;
 }
 }  // namespace wagg
 
@@ -1786,6 +1837,14 @@ extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, 
 extern "C" int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                       int layout, double *out_host, int64_t ldo, int out_layout, int flags) {
     return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, wagg_apply_f64);
+}
+extern "C" int wagg_apply_host_multi_f32(const wagg_plan *const *plans, const int *devices, int n_devices, const float *X_host,
+                                         int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags) {
+    return wagg::apply_host_multi<float>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, wagg_apply_f32);
+}
+extern "C" int wagg_apply_host_multi_f64(const wagg_plan *const *plans, const int *devices, int n_devices, const double *X_host,
+                                         int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags) {
+    return wagg::apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, wagg_apply_f64);
 }
 
 extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,

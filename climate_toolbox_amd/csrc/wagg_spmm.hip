@@ -386,7 +386,8 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
                        sp.n_chunks, dcounts.p, (const int32_t *)nullptr, (uint32_t *)nullptr);
     WAGG_HIP(hipGetLastError());
     std::vector<int32_t> counts((size_t)n_buckets);
-    WAGG_HIP(hipMemcpy(counts.data(), dcounts.p, sizeof(int32_t) * counts.size(), hipMemcpyDeviceToHost));
+    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(staged_d2h(counts.data(), dcounts.p, sizeof(int32_t) * counts.size()));
     if (int rc = spmm_offsets<T>(d, counts)) return rc;
     hipLaunchKernelGGL((spmm_synth_kernel<T, true>), grid, dim3(SP_THREADS), 0, nullptr, d->G, d->R, seed, (float)fill, sp.rw,
                        sp.n_chunks, (int32_t *)nullptr, (const int32_t *)sp.grp_off.p, (uint32_t *)sp.ent.p);
@@ -397,7 +398,8 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
                        d->den32.p, d->R);
     WAGG_HIP(hipGetLastError());
     d->den_host.resize((size_t)d->R);
-    WAGG_HIP(hipMemcpy(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, hipMemcpyDeviceToHost));
+    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(staged_d2h(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R));
     return WAGG_OK;
 }
 template int spmm_build_synth<float>(wagg_dense *, uint32_t, double);
@@ -438,7 +440,7 @@ int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const s
             const size_t pos = (size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++;
             sp_store_entry<T>(ent.data(), (int64_t)pos, lo, w[i]);
         }
-        if (!ent.empty()) WAGG_HIP(hipMemcpy(sp.ent.p, ent.data(), sizeof(uint32_t) * ent.size(), hipMemcpyHostToDevice));
+        if (!ent.empty()) WAGG_HIP(staged_h2d(sp.ent.p, ent.data(), sizeof(uint32_t) * ent.size(), nullptr));
     } catch (const std::bad_alloc &) {
         set_error("host allocation failed while building the entry lists");
         return WAGG_ENOMEM;

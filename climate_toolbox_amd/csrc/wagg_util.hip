@@ -10,6 +10,8 @@ namespace wagg {
 
 static thread_local char g_err[512] = "";
 
+void clear_error() { g_err[0] = '\0'; }
+
 void set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -29,80 +31,6 @@ hipError_t allow_dynamic_lds(const void *kern, size_t bytes) {
     e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e == hipSuccess) done.emplace_back(kern, dev);
     return e;
-}
-
-// ---- page-locked staging for small host buffers (wagg_common.h) -------------------------------------------------
-namespace {
-struct HostStage {
-    static constexpr size_t PIECE = (size_t)8 << 20;
-    std::mutex mu;
-    char *buf[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipError_t init() {
-        for (int b = 0; b < 2; ++b) {
-            if (!buf[b]) { hipError_t e = hipHostMalloc((void **)&buf[b], PIECE, hipHostMallocDefault); if (e != hipSuccess) return e; }
-            if (!ev[b]) { hipError_t e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming); if (e != hipSuccess) return e; }
-        }
-        return hipSuccess;
-    }
-};
-HostStage g_stage;                       // process lifetime: a few MiB of page-locked memory, never freed
-}  // namespace
-
-hipError_t staged_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st) {
-    std::lock_guard<std::mutex> lock(g_stage.mu);
-    hipError_t e = g_stage.init();
-    if (e != hipSuccess) return e;
-    size_t off = 0;
-    int n_used = 0;
-    for (int p = 0; off < bytes; ++p) {
-        const int b = p & 1;
-        const size_t n = bytes - off < HostStage::PIECE ? bytes - off : HostStage::PIECE;
-        if (p >= 2 && (e = hipEventSynchronize(g_stage.ev[b])) != hipSuccess) return e;      // piece p-2 has left the buffer
-        std::memcpy(g_stage.buf[b], static_cast<const char *>(src_host) + off, n);
-        if ((e = hipMemcpyAsync(static_cast<char *>(dst_dev) + off, g_stage.buf[b], n, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-        if ((e = hipEventRecord(g_stage.ev[b], st)) != hipSuccess) return e;
-        off += n;
-        n_used = p + 1 < 2 ? p + 1 : 2;
-    }
-    for (int b = 0; b < n_used; ++b)
-        if ((e = hipEventSynchronize(g_stage.ev[b])) != hipSuccess) return e;                  // buffers free for the next caller
-    return hipSuccess;
-}
-
-// the device block is (rows x ld_bytes) contiguous; of every row the first row_bytes go to the same offsets on the host
-hipError_t staged_d2h_rows(void *dst_host, const void *src_dev, int64_t rows, size_t ld_bytes, size_t row_bytes, hipStream_t st) {
-    if (rows <= 0 || row_bytes == 0) return hipSuccess;
-    std::lock_guard<std::mutex> lock(g_stage.mu);
-    hipError_t e = g_stage.init();
-    if (e != hipSuccess) return e;
-    const size_t bytes = (size_t)(rows - 1) * ld_bytes + row_bytes;
-    auto scatter = [&](int b, size_t off, size_t n) {         // staged bytes [off, off + n) -> the used part of each row
-        if (ld_bytes == row_bytes) { std::memcpy(static_cast<char *>(dst_host) + off, g_stage.buf[b], n); return; }
-        for (size_t r = off / ld_bytes; r < (size_t)rows && r * ld_bytes < off + n; ++r) {
-            const size_t lo = r * ld_bytes > off ? r * ld_bytes : off;
-            const size_t hi_row = r * ld_bytes + row_bytes, hi = hi_row < off + n ? hi_row : off + n;
-            if (hi > lo) std::memcpy(static_cast<char *>(dst_host) + lo, g_stage.buf[b] + (lo - off), hi - lo);
-        }
-    };
-    size_t off = 0, prev_off = 0, prev_n = 0;
-    int p = 0;
-    for (; off < bytes; ++p) {
-        const int b = p & 1;
-        const size_t n = bytes - off < HostStage::PIECE ? bytes - off : HostStage::PIECE;
-        if ((e = hipMemcpyAsync(g_stage.buf[b], static_cast<const char *>(src_dev) + off, n, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-        if ((e = hipEventRecord(g_stage.ev[b], st)) != hipSuccess) return e;
-        if (p >= 1) {                                          // drain the previous piece while this one flies
-            if ((e = hipEventSynchronize(g_stage.ev[b ^ 1])) != hipSuccess) return e;
-            scatter(b ^ 1, prev_off, prev_n);
-        }
-        prev_off = off; prev_n = n;
-        off += n;
-    }
-    const int last = (p - 1) & 1;
-    if ((e = hipEventSynchronize(g_stage.ev[last])) != hipSuccess) return e;
-    scatter(last, prev_off, prev_n);
-    return hipSuccess;
 }
 
 struct ProfRing {
@@ -257,8 +185,7 @@ static int any_less(const T *a, const T *b, int64_t n, int *result, void *stream
     WAGG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), (hipStream_t)stream));
     hipLaunchKernelGGL((any_less_kernel<T>), dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, a, b, n, flag.p);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipMemcpyAsync(result, flag.p, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    WAGG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    WAGG_HIP(staged_d2h(result, flag.p, sizeof(int), (hipStream_t)stream));       // (blocks until the word is there)
     return WAGG_OK;
 }
 

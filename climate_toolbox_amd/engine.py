@@ -24,6 +24,30 @@ def require_gpu():
     return torch
 
 
+class _on_device:
+    """``with _on_device(d):`` -- device ``d`` is current inside (None: leave it as it is)."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        if self.device is not None:
+            import torch
+            self._ctx = torch.cuda.device(int(self.device))
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.device is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def _current_device():
+    import torch
+    return int(torch.cuda.current_device())
+
+
 def _stream_handle(stream):
     import torch
     s = stream if stream is not None else torch.cuda.current_stream()
@@ -56,9 +80,10 @@ def _check_X(X, layout):
 class SparsePlan:
     """Coded segment table -> device plan (wagg_plan_create).  Immutable after construction."""
 
-    def __init__(self, cell_idx, region_code, w_eff, G, R, row_len=0, flags=0):
+    def __init__(self, cell_idx, region_code, w_eff, G, R, row_len=0, flags=0, device=None):
         require_gpu()
         L = _lib.load()
+        self._args = (cell_idx, region_code, w_eff, G, R, row_len, flags)      # what a replica on another device is built from
         ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
         rc = np.ascontiguousarray(region_code, dtype=np.int32)
         we = np.ascontiguousarray(w_eff, dtype=np.float64)
@@ -67,9 +92,11 @@ class SparsePlan:
         self._h = C.c_void_p()
         self._lease = threading.Lock()       # held by whoever is applying a cached plan (aggregations._plan_for)
         self.G, self.R = int(G), int(R)
-        _lib.check(L.wagg_plan_create(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32),
-                                      _np_ptr(we, C.c_double), len(ci), self.G, self.R,
-                                      int(row_len), int(flags), C.byref(self._h)), "wagg_plan_create")
+        with _on_device(device):
+            self.device = _current_device()
+            _lib.check(L.wagg_plan_create(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32),
+                                          _np_ptr(we, C.c_double), len(ci), self.G, self.R,
+                                          int(row_len), int(flags), C.byref(self._h)), "wagg_plan_create")
         info = _lib.PlanInfo()
         _lib.check(L.wagg_plan_get_info(self._h, C.byref(info)), "wagg_plan_get_info")
         self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_ if k != "reserved"}
@@ -78,6 +105,8 @@ class SparsePlan:
         self.den = den
 
     def close(self):
+        for r in getattr(self, "_replicas", {}).values():
+            r.close()
         if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
             _lib._lib.wagg_plan_destroy(self._h)     # (module globals may be gone at interpreter exit)
             self._h = C.c_void_p()
@@ -155,11 +184,17 @@ class SparsePlan:
                    "wagg_apply_edd")
         return out
 
-    def apply_host(self, X, layout="TG", out_layout="TR", flags=0):
+    def replica(self, device):
+        """The same table as a plan on another device (multi-device host streaming)."""
+        return SparsePlan(*self._args, device=device)
+
+    def apply_host(self, X, layout="TG", out_layout="TR", flags=0, replicas=()):
         """Blocking host-buffer form (wagg_apply_host_ex_*): numpy in, numpy out.  (time, gridcell) data
-        is streamed through the device in row blocks (H2D of block i+1 overlapping the kernels of block
-        i); ``flags``: ``_lib.HOST_PIN`` page-locks the arrays for the call, ``_lib.HOST_WHOLE`` copies
-        the whole field at once."""
+        is streamed through the device in row blocks (H2D of block i+1, the kernels of block i and the
+        return of block i-1 at once); ``flags``: ``_lib.HOST_PIN`` page-locks the arrays for the call,
+        ``_lib.HOST_WHOLE`` copies the whole field at once.  ``replicas``: further plans of the same table
+        on other devices (``replica(d)``): the row blocks are then dealt over all of them
+        (``wagg_apply_host_multi_*``), each device on its own PCIe link."""
         X = np.ascontiguousarray(X)
         if X.dtype not in (np.float32, np.float64) or X.ndim != 2:
             raise TypeError("X must be a 2-D float32/float64 array")
@@ -167,9 +202,20 @@ class SparsePlan:
         shape = (T, self.R) if out_layout == "TR" else (self.R, T)
         out = np.empty(shape, dtype=X.dtype)
         L = _lib.load()
+        if replicas:
+            if layout != "TG" or out_layout != "TR":
+                raise ValueError("the multi-device form takes (time, gridcell) data only")
+            plans = (self,) + tuple(replicas)
+            hs = (C.c_void_p * len(plans))(*[p._h for p in plans])
+            devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
+            fn = L.wagg_apply_host_multi_f32 if X.dtype == np.float32 else L.wagg_apply_host_multi_f64
+            _lib.check(fn(hs, devs, len(plans), C.c_void_p(X.ctypes.data), T, X.shape[1], C.c_void_p(out.ctypes.data),
+                          max(1, self.R), int(flags)), "wagg_apply_host_multi")
+            return out
         fn = L.wagg_apply_host_ex_f32 if X.dtype == np.float32 else L.wagg_apply_host_ex_f64
-        _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], _LAYOUTS[layout],
-                      C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout], int(flags)), "wagg_apply_host")
+        with _on_device(self.device):
+            _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], _LAYOUTS[layout],
+                          C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout], int(flags)), "wagg_apply_host")
         return out
 
 
@@ -179,8 +225,10 @@ class DensePlan:
     sparse weights (fp32).  ``info["form"]`` says which (``_lib.FORM_*``), ``dtype`` the element type
     the plan serves ("float32" / "float64")."""
 
-    def __init__(self, handle, G, R):
+    def __init__(self, handle, G, R, device=None, recipe=None):
         self._h, self.G, self.R = handle, int(G), int(R)
+        self.device = _current_device() if device is None else int(device)
+        self._recipe = recipe                # (constructor, args, kwargs): what a replica on another device is built from
         self._lease = threading.Lock()
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
@@ -195,44 +243,50 @@ class DensePlan:
         return str(dtype).endswith("float64") or dtype is np.float64
 
     @classmethod
-    def synth_blocklocal(cls, G, R, seed, fill=0.952, dtype="float32"):
+    def synth_blocklocal(cls, G, R, seed, fill=0.952, dtype="float32", device=None):
         """c5's block-local weights, generated on the device in tile-sparse form."""
         require_gpu()
         h = C.c_void_p()
         L = _lib.load()
         fn = L.wagg_dense_create_synth_blocklocal_f64 if cls._is64(dtype) else L.wagg_dense_create_synth_blocklocal
-        _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth_blocklocal")
-        return cls(h, G, R)
+        with _on_device(device):
+            dev = _current_device()
+            _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth_blocklocal")
+        return cls(h, G, R, dev, (cls.synth_blocklocal, (G, R, seed), dict(fill=fill, dtype=dtype)))
 
     @classmethod
-    def synth(cls, G, R, seed, fill=1.0, dtype="float32"):
+    def synth(cls, G, R, seed, fill=1.0, dtype="float32", device=None):
         """W[g, r] = hash_u01(g R + r, seed); with fill < 1 only that fraction of the entries, at
         uniformly random positions (c5's uniform-random structure at fill = 0.01: entry lists)."""
         require_gpu()
         h = C.c_void_p()
         L = _lib.load()
         fn = L.wagg_dense_create_synth_f64 if cls._is64(dtype) else L.wagg_dense_create_synth_sparse
-        _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth")
-        return cls(h, G, R)
+        with _on_device(device):
+            dev = _current_device()
+            _lib.check(fn(int(G), int(R), int(seed), float(fill), C.byref(h)), "wagg_dense_create_synth")
+        return cls(h, G, R, dev, (cls.synth, (G, R, seed), dict(fill=fill, dtype=dtype)))
 
     @classmethod
-    def from_host(cls, W):
+    def from_host(cls, W, device=None):
         """From a host (G, R) matrix; a float64 array makes an fp64 plan, anything else fp32."""
         require_gpu()
         W = np.asarray(W)
         h = C.c_void_p()
-        if W.dtype == np.float64:
-            W = np.ascontiguousarray(W)
-            _lib.check(_lib.load().wagg_dense_create_host_f64(_np_ptr(W, C.c_double), W.shape[0], W.shape[1], C.byref(h)),
-                       "wagg_dense_create_host_f64")
-        else:
-            W = np.ascontiguousarray(W, dtype=np.float32)
-            _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1], C.byref(h)),
-                       "wagg_dense_create_host")
-        return cls(h, W.shape[0], W.shape[1])
+        with _on_device(device):
+            dev = _current_device()
+            if W.dtype == np.float64:
+                W = np.ascontiguousarray(W)
+                _lib.check(_lib.load().wagg_dense_create_host_f64(_np_ptr(W, C.c_double), W.shape[0], W.shape[1], C.byref(h)),
+                           "wagg_dense_create_host_f64")
+            else:
+                W = np.ascontiguousarray(W, dtype=np.float32)
+                _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1], C.byref(h)),
+                           "wagg_dense_create_host")
+        return cls(h, W.shape[0], W.shape[1], dev, (cls.from_host, (W,), {}))
 
     @classmethod
-    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32"):
+    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32", device=None):
         require_gpu()
         ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
         rc = np.ascontiguousarray(region_code, dtype=np.int32)
@@ -240,11 +294,21 @@ class DensePlan:
         h = C.c_void_p()
         L = _lib.load()
         fn = L.wagg_dense_create_from_segments_f64 if cls._is64(dtype) else L.wagg_dense_create_from_segments
-        _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
-                      int(R), C.byref(h)), "wagg_dense_create_from_segments")
-        return cls(h, G, R)
+        with _on_device(device):
+            dev = _current_device()
+            _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
+                          int(R), C.byref(h)), "wagg_dense_create_from_segments")
+        return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype)))
+
+    def replica(self, device):
+        """The same weights as a plan of its own on ``device`` (multi-device host streaming; a dense-family plan
+        owns its workspaces, so every pipeline needs its own replica -- also two on one device)."""
+        fn, args, kw = self._recipe
+        return fn(*args, device=device, **kw)
 
     def close(self):
+        for r in getattr(self, "_replicas", {}).values():
+            r.close()
         if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
             _lib._lib.wagg_dense_destroy(self._h)
             self._h = C.c_void_p()
@@ -298,17 +362,26 @@ class DensePlan:
             "wagg_dense_apply_edd")
         return out
 
-    def apply_host(self, X, flags=0):
+    def apply_host(self, X, flags=0, replicas=()):
         """Host-resident (time, gridcell) array through the plan in row blocks (``wagg_dense_apply_host_*``):
-        numpy in, numpy out; flags as for :meth:`SparsePlan.apply_host`."""
+        numpy in, numpy out; flags and ``replicas`` as for :meth:`SparsePlan.apply_host`."""
         want = np.float64 if self.dtype == "float64" else np.float32
         X = np.ascontiguousarray(X)
         if X.dtype != want or X.ndim != 2 or X.shape[1] != self.G:
             raise TypeError("X must be a (T, %d) %s array" % (self.G, self.dtype))
         out = np.empty((X.shape[0], self.R), dtype=want)
-        _lib.check(self._fn("wagg_dense_apply_host")(self._h, C.c_void_p(X.ctypes.data), X.shape[0], X.shape[1],
-                                                     C.c_void_p(out.ctypes.data), max(1, self.R), int(flags)),
-                   "wagg_dense_apply_host")
+        if replicas:
+            plans = (self,) + tuple(replicas)
+            hs = (C.c_void_p * len(plans))(*[p._h for p in plans])
+            devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
+            _lib.check(self._fn("wagg_dense_apply_host_multi")(hs, devs, len(plans), C.c_void_p(X.ctypes.data), X.shape[0],
+                                                               X.shape[1], C.c_void_p(out.ctypes.data), max(1, self.R),
+                                                               int(flags)), "wagg_dense_apply_host_multi")
+            return out
+        with _on_device(self.device):
+            _lib.check(self._fn("wagg_dense_apply_host")(self._h, C.c_void_p(X.ctypes.data), X.shape[0], X.shape[1],
+                                                         C.c_void_p(out.ctypes.data), max(1, self.R), int(flags)),
+                       "wagg_dense_apply_host")
         return out
 
     def saw_inf(self, stream=None):

@@ -133,21 +133,24 @@ int wagg_apply_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t
 int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
                    double *out_dev, int64_t ldo, int out_layout, void *stream);
 /* Blocking forms on host buffers.  (time, gridcell) data with a (time, region) result is
- * streamed through the device in row blocks of ~256 MiB: the H2D copy of block i+1 overlaps the kernels
- * of block i on a second stream, results return block by block, the device holds two blocks at a time
- * (host arrays of c4 / c5 size, 45-76 GB, need no device copy of the whole field).  flags:
- *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister) so that the
- *                    copies are truly asynchronous; without it pageable memory is staged by the runtime
- *                    (arrays below 32 MiB always go through the library's own page-locked staging buffers:
- *                    registration locks whole pages, which small arrays share with other heap objects, and
- *                    the runtime's on-the-fly pinning of pageable memory outlives the call)
+ * streamed through the device in row blocks of ~256 MiB: the H2D copy of block i+1, the kernels of block i
+ * and the return of block i-1's result run on three streams at once, and the device holds two blocks at a
+ * time (host arrays of c4 / c5 size, 45-76 GB, need no device copy of the whole field).  flags:
+ *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister / hipHostUnregister,
+ *                    both statuses checked) so that the copy engines read and write them directly
  *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
+ * What is not page-locked -- arrays below 32 MiB (registration locks whole pages, which a small heap array
+ * shares with unrelated objects), arrays whose registration the runtime refuses, and everything without
+ * WAGG_HOST_PIN -- passes through the library's own page-locked staging pieces by CPU copy.  A pageable caller
+ * pointer is never handed to a runtime copy: the runtime would page-lock the range on the fly and keep that
+ * pin, keyed by address, beyond the call.  Every HIP status on this path is checked; failures
+ * while resources are released are counted (wagg_host_stats) and fail the call.
  * Pitched arrays (ldx > G, ldo > R) are honoured: nothing behind the used cells of the last row is read and the
- * padding between result rows is not written.
+ * padding between result rows is not written.  The plan must live on the current device.
  * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN.  Measured on one MI355X (tools/host_path_timing.py):
- * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks,
- * 33 ms pageable blocks); a dense 1,369-row shard takes 602 ms whole and 523 ms in pinned blocks (the copies
- * hide behind the 490 ms of MFMA work; pageable blocks 601 ms: staged copies do not overlap).           */
+ * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks);
+ * a dense 1,369-row shard takes 602 ms whole and 523 ms in pinned blocks (the copies hide behind the 490 ms of
+ * MFMA work).                                                                                         */
 #define WAGG_HOST_PIN 1
 #define WAGG_HOST_WHOLE 2
 int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
@@ -158,6 +161,27 @@ int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T
                            int layout, float *out_host, int64_t ldo, int out_layout, int flags);
 int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                            int layout, double *out_host, int64_t ldo, int out_layout, int flags);
+/* Multi-device form of the above (SURVEY 8b `n_devices`, 8e "one process driving all devices"): plans[s] is a
+ * replica of the same table created while device devices[s] was current.  The row blocks of the host field are
+ * dealt round-robin to the n_devices pipelines (block i -> slot i mod n_devices, wagg_host_block_plan gives the
+ * block size), each driven by its own host thread over its own PCIe link; every block's result lands directly in
+ * the caller's rows, so there is no exchange between devices and no collective.  (time, gridcell) data and
+ * (time, region) results only; flags: 0 or WAGG_HOST_PIN.  The same device may be listed more than once.       */
+int wagg_apply_host_multi_f32(const wagg_plan *const *plans, const int *devices, int n_devices, const float *X_host,
+                              int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags);
+int wagg_apply_host_multi_f64(const wagg_plan *const *plans, const int *devices, int n_devices, const double *X_host,
+                              int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags);
+/* rows per block and number of blocks of a host field of T rows of row_bytes (= ldx * element size) bytes when a launch
+ * handles `quantum` rows well (64: segment-table kernels; 368 / 176: fp32 / fp64 MFMA forms; 128 / 64: entry lists) */
+int wagg_host_block_plan(int64_t T, int64_t row_bytes, int64_t quantum, int n_devices, int64_t *block_rows, int64_t *n_blocks);
+/* what the host paths did since the last reset (process-wide counters): page-locks taken / refused / released /
+ * whose release failed, HIP failures met while releasing resources, bytes moved through the staging pieces and
+ * directly from / to page-locked caller memory                                                                      */
+typedef struct wagg_host_stats {
+    int64_t calls, blocks, registered, register_failed, unregistered, unregister_failed, cleanup_failed;
+    int64_t staged_h2d_bytes, staged_d2h_bytes, direct_h2d_bytes, direct_d2h_bytes;
+} wagg_host_stats;
+int wagg_host_stats_read(wagg_host_stats *out, int reset);
 
 /* ---- fused grid-level transform ---------------------------------------------- */
 /* Replaces  tas_poly  (climate_toolbox/transformations/transformations.py:160-208, the arithmetic
@@ -294,6 +318,12 @@ int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int
                               float *out_host, int64_t ldo, int flags);
 int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
                               double *out_host, int64_t ldo, int flags);
+/* ... and over several devices, one replica of the plan per device (as wagg_apply_host_multi_*; a dense-family plan
+ * owns its workspaces, so every slot needs a replica of its own)                                                      */
+int wagg_dense_apply_host_multi_f32(wagg_dense *const *plans, const int *devices, int n_devices, const float *X_host,
+                                    int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags);
+int wagg_dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices, int n_devices, const double *X_host,
+                                    int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags);
 /* The MFMA forms multiply every (cell, region) pair of a stored tile, so +-inf in the (transformed)
  * data turns the zero weights of regions that do not own the cell into NaN, where the reference and
  * the segment-table form confine it to the owning regions (S6).  The pack stage notes such data:

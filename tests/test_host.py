@@ -132,6 +132,33 @@ def test_synth_workloads_are_wellformed():
     assert per_cell.max() <= 3 and per_cell.min() >= 1
 
 
+def test_host_block_plan_covers_the_rows_and_deals_blocks_round_robin():
+    """The row-block pipeline's block plan (wagg_host_block_plan; no GPU needed): whole quanta per block, ~256 MiB of
+    X, every row in exactly one block, at least two blocks per device when there are that many quanta, and block i on
+    device slot i mod n -- the map the multi-device form (wagg_apply_host_multi_*) deals by."""
+    from climate_toolbox_amd import _lib
+    for T, row_bytes, q, n in [(700, 259200 * 4, 64, 1), (700, 259200 * 4, 64, 2), (18250, 1036800 * 4, 64, 8),
+                               (10950, 1036800 * 4, 368, 8), (5, 4000, 64, 3), (0, 4000, 64, 2), (129, 8, 64, 4),
+                               (2282, 1036800 * 8, 64, 1), (1000, 100, 176, 2)]:
+        B, nb = _lib.host_block_plan(T, row_bytes, q, n)
+        if T == 0:
+            assert nb == 0
+            continue
+        assert nb == -(-T // B) and 1 <= B <= T
+        assert B % q == 0 or B == T or B < q                       # whole quanta (a field shorter than one is one block)
+        assert B * row_bytes <= max(256 << 20, q * row_bytes) or B <= q
+        if T >= 2 * n * q:
+            assert nb >= 2 * n                                     # copies and kernels of every device can overlap
+        rows_of = [0] * n
+        for i in range(nb):
+            rows_of[i % n] += min(B, T - i * B)
+        assert sum(rows_of) == T
+        if nb >= n:
+            assert max(rows_of) - min(rows_of) <= 2 * B           # round-robin keeps the devices within two blocks
+    with pytest.raises(_lib.WaggError):
+        _lib.host_block_plan(10, 0, 64, 1)
+
+
 def test_dense_form_choice():
     """Structure-driven choice between the gather form and the dense MFMA form (host logic only)."""
     G, R, GB = 1036800, 24378, 1 << 30
