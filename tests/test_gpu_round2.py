@@ -608,12 +608,13 @@ def test_host_path_checks_every_status_and_spreads_over_devices(torch_cuda):
     dplan = DensePlan.from_host(W)
     refd = dplan.apply_host(Xd, flags=_lib.HOST_PIN)
     drep = dplan.replica(0)
-    np.testing.assert_array_equal(dplan.apply_host(Xd, flags=_lib.HOST_PIN, replicas=[drep]), refd)
+    # (another block size means another k split inside the dense-family kernels: same numbers to rounding)
+    np.testing.assert_allclose(dplan.apply_host(Xd, flags=_lib.HOST_PIN, replicas=[drep]), refd, rtol=2e-6)
     with pytest.raises(_lib.WaggError, match="same plan"):
         dplan.apply_host(Xd, replicas=[dplan])
     sp = DensePlan.synth(Gd, Rd, 3, fill=0.03, dtype="float64")             # entry lists, fp64
     Xs = Xd.astype(np.float64)
-    np.testing.assert_array_equal(sp.apply_host(Xs, flags=0, replicas=[sp.replica(0)]), sp.apply_host(Xs, flags=0))
+    np.testing.assert_allclose(sp.apply_host(Xs, flags=0, replicas=[sp.replica(0)]), sp.apply_host(Xs, flags=0), rtol=1e-12)
 
 
 def test_dropin_spreads_host_fields_over_the_listed_devices(torch_cuda):
