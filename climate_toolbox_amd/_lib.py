@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
 
 EKEY = -6
-PLAN_NO_LC, PLAN_NO_STREAM = 1, 2
+PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA = 1, 2, 4, 8
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
 HOST_PIN, HOST_WHOLE = 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
@@ -71,8 +71,8 @@ class WaggError(RuntimeError):
 class PlanInfo(C.Structure):
     _fields_ = [("nseg_in", C.c_int64), ("nnz", C.c_int64), ("n_groups", C.c_int64),
                 ("n_chunks", C.c_int64), ("n_ucells", C.c_int64), ("n_giant", C.c_int64),
-                ("n_empty", C.c_int64), ("G", C.c_int64), ("R", C.c_int32), ("reserved", C.c_int32),
-                ("n_lines128", C.c_int64), ("n_sectors64", C.c_int64)]
+                ("n_empty", C.c_int64), ("G", C.c_int64), ("R", C.c_int32), ("lines", C.c_int32),
+                ("n_lines128", C.c_int64), ("n_sectors64", C.c_int64), ("n_partial_rows", C.c_int64)]
 
 
 _lib = None

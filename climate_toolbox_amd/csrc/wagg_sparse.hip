@@ -69,6 +69,10 @@ struct SparsePlanDev {
     DevBuf<float> ent_den32;
     DevBuf<double> ent_den64;
     int g0_normal = 0, c0_normal = 0;
+    // whole-line plan: an entry is a (chunk, region) PARTIAL sum, ent_region its row in the partial buffer;
+    // region r is the sum of rows part_rows[part_begin[r] .. part_begin[r + 1]) divided by den[r]
+    DevBuf<int32_t> part_begin, part_rows;
+    int64_t n_part = 0;
 };
 
 }  // namespace wagg
@@ -649,7 +653,11 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
 //     themselves through a monotonic LDS counter (bounded spin).
 // Chunks whose data contain +-inf fall back to the exact per-segment VALU reduction.
 // ---------------------------------------------------------------------------------------------
-constexpr int LC_LW = 8, LC_CW = 4, LC_THREADS = (LC_LW + LC_CW) * 64;
+constexpr int LC_LW = 8, LC_CW = 4, LC_THREADS = (LC_LW + LC_CW) * 64;      // the MFMA-consumer form: 8 loader + 4 consumer waves
+// vector-ALU consumers: 8 + 8 waves for the plain aggregation (114 registers: four waves per SIMD fit); the fused powers
+// and degree days keep 8 + 4 (their loaders need the 168 registers of three waves per SIMD)
+constexpr int lc_cw(int npow, bool edd, bool mfma) { return (!mfma && npow == 1 && !edd) ? 8 : 4; }
+constexpr int lc_threads(int npow, bool edd, bool mfma) { return (LC_LW + lc_cw(npow, edd, mfma)) * 64; }
 constexpr int LC_TB = 64;
 constexpr int LC_AROW = UC + 4;                 // Aw row stride (elements)
 constexpr int LC_ENT = RG_MAX + 1;              // entries per chunk
@@ -676,8 +684,15 @@ struct LcLds {
 // and keep them in registers; one stage per threshold: they park snyder_edd1(tasmin + xoff, tasmax + xoff,
 // thr[k]) (transformations.py:64-87) into the image buffer and the consumers reduce it into output plane
 // k, so the two fields are read from HBM once for up to four thresholds.
-template <bool VEC, int NPOW = 1, bool EDD = false>
-__global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
+// MFMA_CONS = false (round 3, the default): the consumer waves reduce an item on the VECTOR ALU instead -- every wave
+// takes every fourth region entry and walks its segments with lane = timestep: v_readlane broadcasts (cell, weight),
+// one LDS read and one FMA per segment, eight reads in flight.  A chunk has ~155 segments: ~1.3k cycles per item and
+// wave, where the dense-tile MFMA pass costs 8.5k (scatter the weights, 64 MFMAs per wave over a tile that is 6 % full,
+// un-scatter, three consumer barriers -- profiles/r02_edd_stamps.txt) and needs a second pass for more than 16
+// regions (39 % of the whole-line chunks).  It multiplies real (cell, region) pairs only, so +-inf data needs no
+// separate exact path, and the consumer waves never wait for each other (no bounded spin, no timeout).
+template <bool VEC, int NPOW = 1, bool EDD = false, bool MFMA_CONS = false>
+__global__ __launch_bounds__(lc_threads(NPOW, EDD, MFMA_CONS), lc_cw(NPOW, EDD, MFMA_CONS) == 8 ? 4 : 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
                                                                   int64_t Ttot, int64_t ldx, int64_t G,
                                                                   float *__restrict__ out, int64_t ldo,
                                                                   int n_norm, long long n_items,
@@ -960,8 +975,107 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
         }
         lds_only_barrier();                                       // consumers finish the last item
         if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
+    } else if constexpr (!MFMA_CONS) {
+        // ==================== consumer waves, vector ALU: lane = timestep, wave cw takes entries cw, cw + 8, ... ====================
+        constexpr int CWV = lc_cw(NPOW, EDD, false);              // consumer waves of this variant
+        const int cw = wave - LC_LW;
+        const int nstages = nst * (EDD ? pv.n_thr : 1);
+        for (int st = 0; st < nstages; ++st) {
+            stamp(-1);
+            lds_only_barrier();                                   // stage st has been parked
+            stamp(3);                                             // consumer ph3: waiting for the loaders
+            const int buf = st & 1;
+            const int64_t plane_off = EDD ? (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 4]) * out_pstride : 0;
+            const float *im = img + buf * LC_TB * UROW + lane * UROW;       // this lane's timestep row of the image
+            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
+            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LC_TB;
+            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
+            const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
+            const bool odd = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);   // +-inf (or a value too large to raise) somewhere
+            if (knob & 1) continue;                               // (diagnostic build: consumers idle)
+            // the entries of this wave; ODD (decided once per item, so the segment loop is branch-free): the general form in
+            // which a NaN product counts 0 (S6: inf x 0-weight, overflow of a power)
+            // Results leave in batches of four entries: the quotients go through a per-wave LDS scratch (the space of the
+            // MFMA consumers' weight tile) so that ONE 16-byte-per-lane store covers four entries' 64 timesteps (lane =
+            // (entry of the batch, four consecutive timesteps)).  A consumer's stores queue behind the loaders' row loads
+            // in the CU's memory pipeline: with one dword store per entry the consumers spent most of an item waiting to
+            // issue them (7.7k of 10.4k cycles, profiles/r03_lc_stamps.txt).
+            float *scr = aw + cw * (NPOW * 4 * 64);            // (8 x 1 KiB or 4 x NPOW KiB: inside the 16.6 KB tile)
+            auto walk = [&](auto odd_tag) {
+                constexpr bool ODD = decltype(odd_tag)::value;
+                for (int eb = cw; eb < ne; eb += 4 * CWV) {
+#pragma unroll 1
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int e = eb + kb * CWV;
+                    if (e >= ne) break;
+                    const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e]);
+                    const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e + 1]);
+                    float acc[NPOW];
+#pragma unroll
+                    for (int pp = 0; pp < NPOW; ++pp) acc[pp] = 0.f;
+                    for (int base = (knob & 256) ? s1 : s0; base < s1; base += 64) {     // (knob 256, diagnostic build: no segment walk)
+                        // lane j holds segment base + j (padding lanes: cell 0, weight 0: they add exactly 0 to finite data)
+                        const int n = s1 - base < 64 ? s1 - base : 64;
+                        const int k = base + (lane < n ? lane : 0);
+                        int ul = sm_u[buf * LC_SEGS + k] & 0xff;
+                        float wl = sm_w[buf * LC_SEGS + k];
+                        if (lane >= n) { ul = 0; wl = 0.f; }
+                        for (int j0 = 0; j0 < n; j0 += 8) {
+                            float xv[8], wv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {         // 8 independent LDS reads in flight
+                                const int u = __builtin_amdgcn_readlane(ul, j0 + j);
+                                wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
+                                xv[j] = im[u];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                float yp = xv[j];
+                                if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) yp *= xv[j];   // first power of this pass
+#pragma unroll
+                                for (int pp = 0; pp < NPOW; ++pp) {
+                                    if (pp > 0) yp *= xv[j];                                   // y^(pp+1), transformations.py:188
+                                    if constexpr (ODD) {
+                                        const float p = yp * wv[j];
+                                        acc[pp] += (p == p) ? p : 0.f;
+                                    } else {
+                                        acc[pp] = __builtin_fmaf(yp, wv[j], acc[pp]);          // aggregations.py:78
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    const float den = sm_ed[buf * LC_ENT + e];
+#pragma unroll
+                    for (int pp = 0; pp < NPOW; ++pp) scr[(pp * 4 + kb) * 64 + lane] = acc[pp] / den;   // :77-80
+                }
+                // (LDS operations of one wave execute in order: the reads below see the writes above)
+                const int kq = lane >> 4, piece = lane & 15;
+                const int e = eb + kq * CWV, tl = 4 * piece;
+                if (e < ne && tl < nt && !(knob & 128)) {         // (knob 128, diagnostic build: no result stores)
+                    float *op = out + plane_off + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+#pragma unroll
+                    for (int pp = 0; pp < NPOW; ++pp) {
+                        const vec4 qv = *reinterpret_cast<const vec4 *>(&scr[(pp * 4 + kq) * 64 + tl]);
+                        float *o2 = op + (int64_t)pp * out_pstride;
+                        if (out_vec && tl + 3 < nt) {
+                            *reinterpret_cast<vec4 *>(o2) = qv;
+                        } else {
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) o2[rg] = qv[rg];
+                        }
+                    }
+                }
+                }
+            };
+            if (odd) walk(std::true_type{}); else walk(std::false_type{});
+            stamp(1);                                             // ph1: the item's entries
+        }
+        lds_only_barrier();                                       // matches the loaders' final barrier
+        if (stamps && tid == LC_LW * 64) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
     } else {
-        // =============================== consumer waves ===============================
+        // =============================== consumer waves, matrix cores ===============================
         const int cw = wave - LC_LW;                              // 0..3: owns timesteps 16cw .. 16cw+15
         const int ctid = tid - LC_LW * 64;                        // 0..255
         const int lr = lane & 15, kq = lane >> 4;
@@ -1151,6 +1265,47 @@ __global__ __launch_bounds__(256) void transpose_rt_to_tr_kernel(const T *__rest
     }
 }
 
+// Whole-line plans: out[t][r] = (sum of region r's partial rows)[t] / den[r] (aggregations.py:77-80), the same padded
+// 64 x 64 LDS tile transpose for (time, region) results; regions without any row give 0 / den (S7).
+template <typename T, bool TR>
+__global__ __launch_bounds__(256) void combine_parts_kernel(const T *__restrict__ P, int64_t ldp, const int32_t *__restrict__ part_begin,
+                                                            const int32_t *__restrict__ part_rows, const T *__restrict__ den,
+                                                            int64_t R, int64_t Ttot, T *__restrict__ out, int64_t ldo) {
+    constexpr int V = 16 / sizeof(T);
+    typedef T vecv __attribute__((ext_vector_type(V)));
+    __shared__ T tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
+    constexpr int TQ = 64 / V;
+    const int tq = threadIdx.x % TQ, ry = threadIdx.x / TQ;
+#pragma unroll 1
+    for (int i = ry; i < 64; i += 256 / TQ) {
+        const int64_t r = r0 + i;
+        if (r < R) {
+            vecv s;
+#pragma unroll
+            for (int c = 0; c < V; ++c) s[c] = T(0);
+            for (int32_t k = part_begin[r]; k < part_begin[r + 1]; ++k)       // fixed order: bitwise reproducible
+                s += *reinterpret_cast<const vecv *>(P + (int64_t)part_rows[k] * ldp + t0 + V * tq);
+            const T d = den[r];
+            if (TR) {
+#pragma unroll
+                for (int c = 0; c < V; ++c) tile[V * tq + c][i] = s[c] / d;
+            } else {
+#pragma unroll
+                for (int c = 0; c < V; ++c) { const int64_t t = t0 + V * tq + c; if (t < Ttot) out[r * ldo + t] = s[c] / d; }
+            }
+        }
+    }
+    if (!TR) return;
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        const int64_t t = t0 + ty + i, r = r0 + tx;
+        if (r < R && t < Ttot) out[t * ldo + r] = tile[ty + i][tx];
+    }
+}
+
 // regions without any kept segment: 0 / den (NaN when den == 0, S7)
 template <typename T>
 __global__ void fill_empty_kernel(const int32_t *__restrict__ regions, int n_empty,
@@ -1224,6 +1379,9 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     pv.seg_u = d.seg_u.p;
     if constexpr (sizeof(T) == 4) { pv.seg_w = d.seg_w32.p; pv.den = d.den32.p; pv.ent_den = d.ent_den32.p; }
     else { pv.seg_w = d.seg_w64.p; pv.den = d.den64.p; pv.ent_den = d.ent_den64.p; }
+    // whole-line plan: an entry's "region" is its partial row and nothing is divided before the rows are combined
+    // (ent_den holds one 1.0 per entry = per partial row)
+    if (d.n_part > 0) pv.den = pv.ent_den;
     pv.n_groups = (int)plan->info.n_groups;
     if (Ttot == 0) return WAGG_OK;
     const int64_t n_tb = (Ttot + TB - 1) / TB;
@@ -1233,15 +1391,19 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     int64_t ldws = 0;
     T *kout = out;
     int64_t kldo = ldo;
-    const bool via_ws = out_layout == WAGG_OUT_TR && plan->info.n_groups > 0;
+    // whole-line plans: the kernels write PARTIAL rows (one per (chunk, region) entry) into the workspace whatever the
+    // output layout; combine_parts_kernel sums a region's rows, divides and (for (T x R)) transposes
+    const bool lines = d.n_part > 0;
+    const bool via_ws = (out_layout == WAGG_OUT_TR || lines) && plan->info.n_groups > 0;
+    const int64_t ws_rows = lines ? d.n_part : (int64_t)plan->info.R;
     int64_t kpstride = pstride;
     if (via_ws) {
         ldws = (Ttot + 63) / 64 * 64;
-        ws = static_cast<T *>(plan->staging(stream, sizeof(T) * (size_t)(ldws * plan->info.R) * (size_t)nplanes));
-        if (!ws) { set_error("staging buffer of %.1f MB: allocation failed", (double)(sizeof(T) * ldws * plan->info.R * nplanes) * 1e-6); return WAGG_ENOMEM; }
+        ws = static_cast<T *>(plan->staging(stream, sizeof(T) * (size_t)(ldws * ws_rows) * (size_t)nplanes));
+        if (!ws) { set_error("staging buffer of %.1f MB: allocation failed", (double)(sizeof(T) * ldws * ws_rows * nplanes) * 1e-6); return WAGG_ENOMEM; }
         kout = ws;
         kldo = ldws;
-        kpstride = ldws * (int64_t)plan->info.R;
+        kpstride = ldws * ws_rows;
     }
     pv.chunk_desc = d.chunk_desc.p; pv.g0_normal = d.g0_normal; pv.c0_normal = d.c0_normal;
     // aligned fast path: 16-byte aligned rows
@@ -1264,13 +1426,20 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
             if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
             if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
+            if (plan->flags & WAGG_PLAN_LC_MFMA) {                // the dense-tile MFMA consumers of rounds 1-2
+                kern = vec ? sparse_lc_kernel<true, 1, false, true> : sparse_lc_kernel<false, 1, false, true>;
+                if (edd) kern = vec ? sparse_lc_kernel<true, 1, true, true> : sparse_lc_kernel<false, 1, true, true>;
+                if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2, false, true> : sparse_lc_kernel<false, 2, false, true>;
+                if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3, false, true> : sparse_lc_kernel<false, 3, false, true>;
+                if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4, false, true> : sparse_lc_kernel<false, 4, false, true>;
+            }
             // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
             const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)(xpow + nfuse - 1)) : 0.f;
             WAGG_HIP(allow_dynamic_lds((const void *)kern, LcLds::total));
             unsigned long long *lc_stamps = nullptr;
             if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
+            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3((unsigned)((plan->flags & WAGG_PLAN_LC_MFMA) ? LC_THREADS : lc_threads(nfuse, edd, false))), LcLds::total, stream, pv, X, Ttot, ldx,
                                plan->info.G, kout, kldo, n_norm, n_items, plan->timeout_dev, lc_stamps,
                                diag_env("WAGG_LC_KNOB"), kpstride, ylim);
             profile_mark(stream, false);
@@ -1353,6 +1522,21 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     }
     }
     for (int pz = 0; pz < nplanes; ++pz) {    // per plane: transpose, regions without any kept row
+    if (via_ws && lines) {
+        dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
+        const T *den;
+        if constexpr (sizeof(T) == 4) den = d.den32.p; else den = d.den64.p;
+        if (out_layout == WAGG_OUT_TR)
+            hipLaunchKernelGGL((combine_parts_kernel<T, true>), tg, dim3(256), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
+                               (const int32_t *)d.part_begin.p, (const int32_t *)d.part_rows.p, den, (int64_t)plan->info.R, Ttot,
+                               out + (int64_t)pz * pstride, ldo);
+        else
+            hipLaunchKernelGGL((combine_parts_kernel<T, false>), tg, dim3(256), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
+                               (const int32_t *)d.part_begin.p, (const int32_t *)d.part_rows.p, den, (int64_t)plan->info.R, Ttot,
+                               out + (int64_t)pz * pstride, ldo);
+        WAGG_HIP(hipGetLastError());
+        continue;                             // (regions without rows came out as 0 / den there)
+    }
     if (via_ws) {
         dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
         hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws + (int64_t)pz * kpstride, ldws,
@@ -1396,7 +1580,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
     using namespace wagg;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
-    WAGG_REQUIRE((flags & ~(WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) == 0, "unknown plan flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LINES | WAGG_PLAN_LC_MFMA)) == 0, "unknown plan flags 0x%x", flags);
     WAGG_REQUIRE(nseg >= 0 && G > 0 && R >= 0, "bad sizes nseg=%lld G=%lld R=%d", (long long)nseg,
                  (long long)G, R);
     WAGG_REQUIRE(G < (int64_t)0x7fffffff, "G must fit int32");
@@ -1435,11 +1619,115 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         std::vector<int64_t> rbeg((size_t)R + 1, 0);
         for (const Seg &s : segs) rbeg[(size_t)s.region + 1]++;
         for (int32_t r = 0; r < R; ++r) rbeg[(size_t)r + 1] += rbeg[(size_t)r];
+        std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
+        std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
+        std::vector<double> seg_w;
+        std::vector<int32_t> part_begin, part_rows;                        // whole-line plan only
+        std::vector<int32_t> empty;
+        int64_t n_giant = 0;
+        int band_rows = 8;
+        seg_u.reserve((size_t)nnz); seg_w.reserve((size_t)nnz);
+
+        // ---- whole-line plan (round 3) --------------------------------------------------------------------------------
+        // A chunk = up to 8 whole 32-cell LINES (128 bytes of a fp32 row, 256 of a fp64 row) of ONE column strip: the
+        // land lines of the strip in row order, eight at a time (ocean rows in between are skipped).  Every line belongs
+        // to exactly one chunk and is fetched whole: 8 line requests per timestep and chunk where the region-shaped
+        // chunks below need ~23 (their quads straddle lines, and border lines are fetched by both neighbours), at
+        // ~1.4x the bytes (the ocean cells of a coastal line come along).  The price: a region cut by a strip or by a
+        // group of eight lines becomes several (chunk, region) ENTRIES, each a partial sum with a row of its own in the
+        // partial buffer; combine_parts_kernel adds them up (1.6 rows per region on the 0.25-degree impact regions).
+        // Taken when the grid's row length is known (whole rows of whole quads) and the table is compact enough.
+        constexpr int LINE = 32, LPC = UC / LINE;                          // cells per line, lines per chunk (8)
+        bool lines_plan = !(flags & WAGG_PLAN_NO_LINES) && row_len < G && G % row_len == 0 && row_len % 4 == 0 && nnz > 0;
+        if (lines_plan) {
+            struct LSeg { int64_t line; int32_t region, col; double w; };
+            std::vector<LSeg> ls((size_t)nnz);
+            for (int64_t i = 0; i < nnz; ++i) {
+                const int64_t row = segs[(size_t)i].cell / row_len, col = segs[(size_t)i].cell % row_len;
+                ls[(size_t)i] = {(col / LINE) * (G / row_len) + row, segs[(size_t)i].region, (int32_t)(col % LINE), segs[(size_t)i].w};
+            }
+            // (strip-major line key: strip * n_rows + row)
+            std::sort(ls.begin(), ls.end(), [](const LSeg &a, const LSeg &b) {
+                if (a.line != b.line) return a.line < b.line;
+                if (a.region != b.region) return a.region < b.region;
+                return a.col < b.col;
+            });
+            const int64_t n_rows = G / row_len;
+            std::vector<std::vector<int32_t>> parts((size_t)R);
+            std::vector<int32_t> region_mark((size_t)R, -1);
+            struct CSeg { int32_t region, ulocal; double w; };
+            std::vector<CSeg> cs;
+            size_t i = 0;
+            int64_t n_part = 0;
+            while (i < ls.size() && lines_plan) {
+                // one chunk: lines of this strip while it holds < LPC lines, <= SEG_MAX segments, <= RG_MAX regions
+                const int64_t strip = ls[i].line / n_rows;
+                const int32_t chunk_id = (int32_t)(chunk_u_begin.size() - 1);
+                int n_lines = 0, n_regions = 0;
+                cs.clear();
+                while (i < ls.size() && ls[i].line / n_rows == strip && n_lines < LPC) {
+                    size_t j = i;                                          // the segments of the next line
+                    int fresh = 0;
+                    while (j < ls.size() && ls[j].line == ls[i].line) {
+                        if (region_mark[(size_t)ls[j].region] != chunk_id) { region_mark[(size_t)ls[j].region] = chunk_id; ++fresh; }
+                        ++j;
+                    }
+                    if (n_lines > 0 && ((int64_t)cs.size() + (int64_t)(j - i) > SEG_MAX || n_regions + fresh > RG_MAX)) {
+                        for (size_t k = i; k < j; ++k) region_mark[(size_t)ls[k].region] = -1;   // (marks of the line not taken)
+                        for (const CSeg &c : cs) region_mark[(size_t)c.region] = chunk_id;
+                        break;
+                    }
+                    if ((int64_t)(j - i) > SEG_MAX || fresh > RG_MAX) { lines_plan = false; break; }   // one line alone is too much
+                    n_regions += fresh;
+                    const int64_t row = ls[i].line % n_rows;
+                    for (int q = 0; q < LINE / 4; ++q) {                   // the line's quads; those behind the row end repeat its last
+                        int64_t c0 = strip * LINE + 4 * q;
+                        if (c0 + 4 > row_len) c0 = row_len - 4;
+                        ucell.push_back((int32_t)(row * row_len + c0));
+                    }
+                    for (size_t k = i; k < j; ++k) cs.push_back({ls[k].region, n_lines * LINE + ls[k].col, ls[k].w});
+                    ++n_lines;
+                    i = j;
+                }
+                if (!lines_plan) break;
+                chunk_u_begin.push_back((int32_t)ucell.size());
+                std::sort(cs.begin(), cs.end(), [](const CSeg &a, const CSeg &b) {
+                    return a.region != b.region ? a.region < b.region : a.ulocal < b.ulocal; });
+                for (size_t k = 0; k < cs.size();) {
+                    size_t m2 = k;
+                    while (m2 < cs.size() && cs[m2].region == cs[k].region) {
+                        seg_u.push_back(cs[m2].ulocal); seg_w.push_back(cs[m2].w);
+                        ++m2;
+                    }
+                    parts[(size_t)cs[k].region].push_back((int32_t)n_part);
+                    ent_region.push_back((int32_t)n_part++);              // the entry's row in the partial buffer
+                    ent_seg_begin.push_back((int32_t)seg_u.size());
+                    k = m2;
+                }
+                chunk_e_begin.push_back((int32_t)ent_region.size());
+                grp_giant.push_back(0);
+                grp_chunk_begin.push_back((int32_t)(chunk_u_begin.size() - 1));
+            }
+            // scattered regions (a c5-like table) would need more partial rows than the table has regions many times
+            // over: such tables keep the region-shaped chunks (and usually take a dense-family form anyway)
+            if (lines_plan && n_part > 4 * (int64_t)R + 1024) lines_plan = false;
+            if (lines_plan) {
+                part_begin.assign((size_t)R + 1, 0);
+                for (int32_t r = 0; r < R; ++r) {
+                    part_begin[(size_t)r + 1] = part_begin[(size_t)r] + (int32_t)parts[(size_t)r].size();
+                    part_rows.insert(part_rows.end(), parts[(size_t)r].begin(), parts[(size_t)r].end());
+                    if (parts[(size_t)r].empty()) empty.push_back(r);
+                }
+            } else {                                                        // start over with the region-shaped chunks
+                grp_chunk_begin.assign(1, 0); grp_giant.clear(); chunk_u_begin.assign(1, 0); chunk_e_begin.assign(1, 0);
+                ucell.clear(); ent_region.clear(); ent_seg_begin.assign(1, 0); seg_u.clear(); seg_w.clear();
+            }
+        }
+        if (!lines_plan) {
         // regions are ordered along latitude bands of `band_rows` grid rows (column-major inside a
         // band): a chunk then covers ~band_rows rows x a run of columns
-        int band_rows = 8;
         if (const int v = diag_env("WAGG_BAND_ROWS")) { if (v >= 1 && v <= 1024) band_rows = v; }
-        std::vector<int32_t> order, empty;
+        std::vector<int32_t> order;
         std::vector<double> key_col((size_t)R, 0.0);
         std::vector<int64_t> key_band((size_t)R, 0);
         for (int32_t r = 0; r < R; ++r) {
@@ -1480,7 +1768,6 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             if (!cur.regions.empty()) { groups.push_back(std::move(cur)); cur = Group(); }
             ++cur_id;
         };
-        int64_t n_giant = 0;
         for (int32_t r : order) {
             const int64_t b = rbeg[(size_t)r], e = rbeg[(size_t)r + 1];
             const int64_t nq_r = quads_of(r);
@@ -1518,10 +1805,6 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         });
 
         // flatten
-        std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
-        std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
-        std::vector<double> seg_w;
-        seg_u.reserve((size_t)nnz); seg_w.reserve((size_t)nnz);
         std::vector<int32_t> &pos = stamp;  // reuse as quad -> local index scratch
         std::vector<int32_t> quads;
         for (const Group &gr : groups) {
@@ -1588,6 +1871,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
             grp_chunk_begin.push_back((int32_t)(chunk_u_begin.size() - 1));
         }
+        }   // region-shaped chunks
 
         // bit 15 of a segment's local cell index marks the LAST segment of its region entry
         // (local indices are < 256); entries without segments cannot exist (every entry has >= 1)
@@ -1621,13 +1905,15 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             dd[7] = (int32_t)(uint32_t)(packed >> 32);
         }
         int g0_normal = 0;
-        while (g0_normal < (int)groups.size() && groups[(size_t)g0_normal].giant) ++g0_normal;
+        while (g0_normal < (int)grp_giant.size() && grp_giant[(size_t)g0_normal]) ++g0_normal;
         const int c0_normal = grp_chunk_begin[(size_t)g0_normal];
 
         wagg_plan *plan = new wagg_plan();
         plan->den_host = den;
         plan->info.nseg_in = nseg; plan->info.nnz = nnz;
-        plan->info.n_groups = (int64_t)groups.size();
+        plan->info.n_groups = (int64_t)grp_giant.size();
+        plan->info.lines = lines_plan ? 1 : 0;
+        plan->info.n_partial_rows = (int64_t)part_rows.size();
         plan->info.n_chunks = (int64_t)chunk_u_begin.size() - 1;
         plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
         plan->info.n_giant = n_giant;
@@ -1644,10 +1930,10 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         }
 #ifdef WAGG_DIAG
         if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
-            fprintf(stderr, "[wagg plan] band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld\n",
-                    band_rows, (long long)plan->info.n_chunks, (long long)plan->info.n_groups, (long long)n_giant,
+            fprintf(stderr, "[wagg plan] lines=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
+                    (int)lines_plan, band_rows, (long long)plan->info.n_chunks, (long long)plan->info.n_groups, (long long)n_giant,
                     (long long)plan->info.n_ucells, (long long)plan->info.n_lines128, (long long)plan->info.n_sectors64,
-                    (long long)nnz);
+                    (long long)nnz, (long long)part_rows.size());
 #endif
         std::vector<float> seg_w32(seg_w.size()), den32(den.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
@@ -1670,12 +1956,13 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         {
             std::vector<double> ed64(ent_region.size() + 1, 1.0);   // +1: the clamped ent_seg_begin twin
             std::vector<float> ed32(ent_region.size() + 1, 1.0f);
-            for (size_t e = 0; e < ent_region.size(); ++e) {
+            for (size_t e = 0; e < ent_region.size() && !lines_plan; ++e) {       // (partial rows are divided when combined)
                 ed64[e] = den[(size_t)ent_region[e]];
                 ed32[e] = den32[(size_t)ent_region[e]];
             }
             up(d.ent_den64, ed64); up(d.ent_den32, ed32);
         }
+        if (lines_plan) { up(d.part_begin, part_begin); up(d.part_rows, part_rows); d.n_part = (int64_t)part_rows.size(); }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));

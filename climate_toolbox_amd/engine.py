@@ -99,7 +99,7 @@ class SparsePlan:
                                           int(row_len), int(flags), C.byref(self._h)), "wagg_plan_create")
         info = _lib.PlanInfo()
         _lib.check(L.wagg_plan_get_info(self._h, C.byref(info)), "wagg_plan_get_info")
-        self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_ if k != "reserved"}
+        self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_}
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(L.wagg_plan_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_plan_get_den")
         self.den = den

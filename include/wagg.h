@@ -62,9 +62,10 @@ typedef struct wagg_plan_info {
     int64_t n_empty;     /* regions with no kept segment (result 0/den)                          */
     int64_t G;
     int32_t R;
-    int32_t reserved;
+    int32_t lines;       /* 1: whole-line plan (chunks of eight 32-cell lines, partial rows + combine); 0: region-shaped chunks */
     int64_t n_lines128;  /* sum over chunks of distinct 128-byte lines (32 fp32 cells) their quads touch */
     int64_t n_sectors64; /* ... of distinct 64-byte sectors */
+    int64_t n_partial_rows; /* whole-line plan: (chunk, region) partial sums = rows of the partial buffer; else 0 */
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */
@@ -106,12 +107,16 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
 /* cell_idx[i]    flat grid cell of segment row i  = ilat*nlon + ilon            (0 <= . < G)
  * region_code[i] rank of the row's label among the sorted unique labels, -1 = null label (S3)
  * w_eff[i]       fp64 weight after the per-row backup fill of :73; NaN rows leave both sums
- * row_len        cells per grid row (nlon); only a locality hint for grouping, 0 = unknown
+ * row_len        cells per grid row (nlon), 0 = unknown.  Known (and a whole number of 4-cell quads, G a whole number of
+ *                rows), compact tables get the whole-line plan: chunks of eight whole 128-byte lines of one 32-cell
+ *                column strip, every line fetched exactly once; regions cut by chunk borders are summed from partial rows
  * flags          0, or WAGG_PLAN_* bits that pin the kernel form for this plan (tests, ablations);
  *                resolved here, once -- the library reads no environment variable
  * Host pointers; copied.  Duplicate (cell, region) rows add (S5).                              */
 #define WAGG_PLAN_NO_LC 1     /* fp32 (time, gridcell) data: persistent VALU kernel instead of the loader/consumer MFMA kernel */
 #define WAGG_PLAN_NO_STREAM 2 /* every group through the chunk-walking kernel */
+#define WAGG_PLAN_NO_LINES 4  /* region-shaped chunks (rounds 1-2) even where the whole-line plan applies */
+#define WAGG_PLAN_LC_MFMA 8   /* loader/consumer kernel: dense-tile MFMA consumers (rounds 1-2) instead of the vector-ALU ones */
 int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
                      int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
                      wagg_plan **out);

@@ -79,6 +79,21 @@ for nseg, giant in ((0, 0), (1, 0), (40000, 0), (30000, 3)):
     assert rcode in (0, -1, -2, -3, -4), (rcode, L.wagg_last_error())
     if rcode == 0:
         L.wagg_dense_destroy(h2)
+# compact regions on a grid whose rows are not a whole number of 32-cell lines: the whole-line plan (chunks of eight
+# lines per column strip, partial rows) and, with WAGG_PLAN_NO_LINES = 4, the region-shaped chunks
+nlat, nlon = 61, 100
+cells = np.flatnonzero(rng.random(nlat * nlon) < 0.6).astype(np.int32)
+reg = ((cells // nlon) // 5 * 20 + (cells % nlon) // 5).astype(np.int32)
+dup = rng.integers(0, len(cells), 700)
+ci = np.concatenate([cells, cells[dup]]); rc = np.concatenate([reg, (reg[dup] + 1) % (reg.max() + 1)])
+ww = rng.uniform(0.1, 1, len(ci))
+for fl in (0, 4):
+    h = C.c_void_p()
+    rcode = L.wagg_plan_create(p(ci, C.c_int32), p(rc, C.c_int32), p(ww, C.c_double), C.c_int64(len(ci)), C.c_int64(nlat * nlon),
+                               C.c_int32(int(reg.max()) + 1), C.c_int64(nlon), fl, C.byref(h))
+    assert rcode in (0, -2, -4), (rcode, L.wagg_last_error())
+    if rcode == 0:
+        L.wagg_plan_destroy(h)
 # out-of-range rows are rejected, not read past
 ci = np.array([G], np.int32); rc = np.array([0], np.int32); ww = np.array([1.0])
 h = C.c_void_p()

@@ -523,8 +523,9 @@ def test_standardized_raw_0_360_file_matches_reference_order_of_operations(torch
         _rel_ok(out.tas.values, ref, RTOL32 if tas.dtype == np.float32 else RTOL64)
 
 
+@pytest.mark.parametrize("lines", [True, False])
 @pytest.mark.parametrize("dtype,layout", [(np.float32, "TG"), (np.float64, "TG"), (np.float32, "GT"), (np.float64, "GT")])
-def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layout):
+def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layout, lines):
     """(tas - 273.15) ** p for p = 1..4 fused into the aggregation's loads
     (wagg_apply_poly_*) equals the reference order of operations: transform the grid
     (transformations.py:188), then aggregate (aggregations.py:78-80)."""
@@ -544,8 +545,10 @@ def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layo
     X = (288.15 + 8 * rng.standard_normal((T, G))).astype(dtype)   # ~15 +- 8 degrees C
     X[3, cell[:40]] = np.nan                                      # NaN data: skipped products (S6)
     X[5, cell[100]], X[6, cell[101]], X[7, cell[102]] = 1e12, np.inf, -np.inf   # overflow at p=4 / exact path
-    plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon)
-    assert plan.info["n_giant"] >= 1
+    # (whole-line plan: the scattered region is ~200 partial rows; region-shaped chunks: a multi-chunk "giant" group)
+    from climate_toolbox_amd import _lib
+    plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon, flags=0 if lines else _lib.PLAN_NO_LINES)
+    assert plan.info["lines"] == int(lines) and (plan.info["n_giant"] >= 1) == (not lines)
     Xd = torch.from_numpy(X if layout == "TG" else np.ascontiguousarray(X.T)).cuda()
     got = plan.apply_poly(Xd, -273.15, 4, layout=layout).cpu().numpy()
     assert got.shape == (4, T, Rn)

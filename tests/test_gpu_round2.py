@@ -313,7 +313,8 @@ def test_mfma_forms_pack_stage_transforms_and_inf_note(torch_cuda):
 # kernel-form flags and the device-failure status
 # ---------------------------------------------------------------------------------------------
 def test_plan_flags_pin_the_kernel_form(torch_cuda):
-    """WAGG_PLAN_NO_LC / NO_STREAM (wagg_plan_create flags): the three fp32 kernels agree."""
+    """WAGG_PLAN_* (wagg_plan_create flags): the fp32 kernels (loader/consumer with vector-ALU or dense-tile MFMA
+    consumers, persistent stream kernel, chunk-walking kernel) and both chunk shapes agree."""
     from climate_toolbox_amd import _lib, synth
     from climate_toolbox_amd.engine import SparsePlan
     torch = torch_cuda
@@ -322,14 +323,65 @@ def test_plan_flags_pin_the_kernel_form(torch_cuda):
     G = len(lat) * len(lon)
     X = torch.from_numpy((280 + np.random.default_rng(1).standard_normal((130, G))).astype(np.float32)).cuda()
     outs = []
-    for flags in (0, _lib.PLAN_NO_LC, _lib.PLAN_NO_STREAM):
+    NL = _lib.PLAN_NO_LINES
+    for flags in (0, _lib.PLAN_LC_MFMA, _lib.PLAN_NO_LC, _lib.PLAN_NO_STREAM, NL, NL | _lib.PLAN_LC_MFMA, NL | _lib.PLAN_NO_LC,
+                  NL | _lib.PLAN_NO_STREAM):
         plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=flags)
         outs.append(plan.apply(X).cpu().numpy())
         plan.status()
-    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-6)
-    np.testing.assert_allclose(outs[2], outs[0], rtol=2e-6)
+    for o in outs[1:]:
+        np.testing.assert_allclose(o, outs[0], rtol=3e-6)
     with pytest.raises(_lib.WaggError):
         SparsePlan(cell, code, w, G, len(uniq), flags=64)
+
+
+@pytest.mark.parametrize("nlat,nlon", [(96, 192), (61, 100), (40, 36)])
+def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda, nlat, nlon):
+    """the whole-line plan (chunks of eight 32-cell lines of one column strip, (chunk, region) partial
+    rows, combine kernel) is what a compact table on a grid of known row length gets; WAGG_PLAN_NO_LINES keeps the
+    region-shaped chunks.  Both against the fp64 oracle and each other: fp32 and fp64, (time, gridcell) and (gridcell,
+    time) data, both result layouts, ragged T, fused powers and degree days, NaN data, rows whose length is not a
+    whole number of lines, a split cell, a null label, a region without rows."""
+    from climate_toolbox_amd import _lib, synth
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(nlat, nlon, R=max(20, nlat * nlon // 70), seed=4, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "popwt", "hierid")
+    cell, code, w = cell.copy(), code.copy(), w.copy()
+    code[5] = -1                                                # a null label (S3)
+    R = len(uniq) + 1                                           # ... and a last region nobody maps to
+    G = nlat * nlon
+    rng = np.random.default_rng(2)
+    for dtype, rtol in ((np.float32, RTOL32), (np.float64, RTOL64)):
+        X = (280 + 15 * rng.standard_normal((135, G))).astype(dtype)
+        X[7, cell[11]] = np.nan
+        ref = O.agg_coded(X, cell, code, w, R)
+        Xd = torch.from_numpy(X).cuda()
+        XT = torch.from_numpy(np.ascontiguousarray(X[:50].T)).cuda()
+        got = {}
+        for flags in (0, _lib.PLAN_NO_LINES):
+            plan = SparsePlan(cell, code, w, G, R, row_len=nlon, flags=flags)
+            assert plan.info["lines"] == (1 if flags == 0 else 0)
+            if flags == 0:
+                assert plan.info["n_giant"] == 0 and plan.info["n_partial_rows"] >= len(uniq) - 1
+                assert plan.info["n_lines128"] * 8 == plan.info["n_ucells"] // 4 or nlon % 32     # every quad of a line, each line once
+            g = plan.apply(Xd).cpu().numpy()
+            _rel_ok(g, ref, rtol)
+            np.testing.assert_array_equal(plan.apply(Xd, out_layout="RT").cpu().numpy(), g.T)
+            gt = plan.apply(XT, layout="GT", out_layout="RT").cpu().numpy()
+            _rel_ok(gt, ref[:50].T, rtol)
+            np.testing.assert_allclose(plan.apply(XT, layout="GT", out_layout="TR").cpu().numpy(), gt.T, rtol=1e-12 if dtype == np.float64 else 1e-6)
+            pol = plan.apply_poly(Xd, -273.15, 3).cpu().numpy()
+            _rel_ok(pol[1], O.agg_coded(O.tas_poly_values(X, 2), cell, code, w, R), rtol)
+            Xhi = X + dtype(5.0)
+            edd = O.snyder_edd_values(X + dtype(-273.15), Xhi + dtype(-273.15), 9.0)
+            e2 = plan.apply_edd(Xd, torch.from_numpy(Xhi).cuda(), [9.0, 11.0], offset=-273.15).cpu().numpy()
+            _rel_ok(e2[0], O.agg_coded(edd, cell, code, w, R), rtol, scale=0.05)
+            plan.status()
+            got[flags] = g
+        np.testing.assert_allclose(got[0], got[_lib.PLAN_NO_LINES], rtol=1e-5 if dtype == np.float32 else 1e-12, equal_nan=True)
+        assert np.isnan(got[0][:, R - 1]).all()                 # 0 / 0 for the region without rows (S7)
 
 
 def test_consumer_barrier_timeout_surfaces_as_an_error(torch_cuda):
@@ -347,7 +399,7 @@ from climate_toolbox_amd.engine import SparsePlan
 lat, lon, df = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=False)
 cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
 G = len(lat) * len(lon)
-plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon))
+plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=_lib.PLAN_LC_MFMA)   # the consumers that have a barrier
 X = torch.ones((1920, G), dtype=torch.float32, device="cuda")
 plan.apply(X)
 try:
