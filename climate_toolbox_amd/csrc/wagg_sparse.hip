@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <utility>
@@ -73,6 +74,7 @@ struct SparsePlanDev {
     // region r is the sum of rows part_rows[part_begin[r] .. part_begin[r + 1]) divided by den[r]
     DevBuf<int32_t> part_begin, part_rows;
     int64_t n_part = 0;
+    int64_t n_groups = 0, n_empty = 0;          // groups of this chunking; regions without any kept row
 };
 
 }  // namespace wagg
@@ -80,7 +82,9 @@ struct SparsePlanDev {
 struct wagg_plan {
     wagg_plan_info info{};
     std::vector<double> den_host;
-    wagg::SparsePlanDev d;
+    wagg::SparsePlanDev d;        // region-shaped chunks: every kernel, every layout and data type
+    wagg::SparsePlanDev dl;       // whole-line chunks (has_lines): the fp32 (time, gridcell) loader/consumer kernel, which is
+    bool has_lines = false;       // bound by line requests; the other kernels pay for the extra bytes of whole lines
     int device = 0;
     int ncu = 256;                 // compute units of `device` (read once, at plan creation)
     int flags = 0;                 // WAGG_PLAN_* kernel-form switches, fixed at plan creation
@@ -1353,11 +1357,14 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // nfuse > 1: powers xpow .. xpow + nfuse - 1 of (x + xoff) in one pass over X (fused tas_poly);
     // the i-th goes to out + i * pstride.  Only the loader/consumer kernel fuses; everything else (fp64,
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
-    const auto &d = plan->d;
+    // the whole-line chunking serves the loader/consumer kernel (fp32, (time, gridcell) data); everything else the
+    // region-shaped chunks
+    const bool use_lines = plan->has_lines && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG;
+    const auto &d = use_lines ? plan->dl : plan->d;
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
         const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
-                           (int)plan->info.n_groups - d.g0_normal > 0 && Ttot > 0;
+                           (int)d.n_groups - d.g0_normal > 0 && Ttot > 0;
         if (!lc_ok || nfuse > 4) {
             for (int i = 0; i < nfuse; ++i) {
                 const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
@@ -1382,7 +1389,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // whole-line plan: an entry's "region" is its partial row and nothing is divided before the rows are combined
     // (ent_den holds one 1.0 per entry = per partial row)
     if (d.n_part > 0) pv.den = pv.ent_den;
-    pv.n_groups = (int)plan->info.n_groups;
+    pv.n_groups = (int)d.n_groups;
     if (Ttot == 0) return WAGG_OK;
     const int64_t n_tb = (Ttot + TB - 1) / TB;
     // (T x R) results: gather kernel writes region-major into a stream-ordered workspace, then
@@ -1394,7 +1401,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // whole-line plans: the kernels write PARTIAL rows (one per (chunk, region) entry) into the workspace whatever the
     // output layout; combine_parts_kernel sums a region's rows, divides and (for (T x R)) transposes
     const bool lines = d.n_part > 0;
-    const bool via_ws = (out_layout == WAGG_OUT_TR || lines) && plan->info.n_groups > 0;
+    const bool via_ws = (out_layout == WAGG_OUT_TR || lines) && d.n_groups > 0;
     const int64_t ws_rows = lines ? d.n_part : (int64_t)plan->info.R;
     int64_t kpstride = pstride;
     if (via_ws) {
@@ -1413,7 +1420,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // chunk-walking kernel
     const bool edd = xpow == XF_EDD;
     const bool stream_path = layout == WAGG_LAYOUT_TG && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
-    const int n_norm = (int)plan->info.n_groups - d.g0_normal;
+    const int n_norm = (int)d.n_groups - d.g0_normal;
     bool lc_done = false;
     if constexpr (sizeof(T) == 4) {
         if (stream_path && n_norm > 0 && !(plan->flags & WAGG_PLAN_NO_LC)) {
@@ -1543,12 +1550,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                            (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
         WAGG_HIP(hipGetLastError());
     }
-    if (plan->info.n_empty > 0) {
-        const int64_t n = plan->info.n_empty * Ttot;
+    if (d.n_empty > 0) {
+        const int64_t n = d.n_empty * Ttot;
         const T *den;
         if constexpr (sizeof(T) == 4) den = d.den32.p; else den = d.den64.p;
         hipLaunchKernelGGL((fill_empty_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                           stream, d.empty_regions.p, (int)plan->info.n_empty, den, Ttot, out + (int64_t)pz * pstride, ldo,
+                           stream, d.empty_regions.p, (int)d.n_empty, den, Ttot, out + (int64_t)pz * pstride, ldo,
                            out_layout);
         WAGG_HIP(hipGetLastError());
     }
@@ -1619,6 +1626,23 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         std::vector<int64_t> rbeg((size_t)R + 1, 0);
         for (const Seg &s : segs) rbeg[(size_t)s.region + 1]++;
         for (int32_t r = 0; r < R; ++r) rbeg[(size_t)r + 1] += rbeg[(size_t)r];
+        wagg_plan *plan = new wagg_plan();
+        std::unique_ptr<wagg_plan> plan_guard(plan);
+        plan->den_host = den;
+        plan->info.nseg_in = nseg; plan->info.nnz = nnz;
+        plan->info.G = G; plan->info.R = R;
+        plan->flags = flags;
+        std::vector<float> den32(den.size());
+        for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
+        hipError_t he = hipGetDevice(&plan->device);
+        if (he == hipSuccess) he = hipDeviceGetAttribute(&plan->ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
+        if (he == hipSuccess) he = hipHostMalloc((void **)&plan->timeout_host, sizeof(int), hipHostMallocMapped);
+        if (he == hipSuccess) {
+            *plan->timeout_host = 0;
+            he = hipHostGetDevicePointer((void **)&plan->timeout_dev, plan->timeout_host, 0);
+        }
+        // one chunking of the table -> device arrays `d`; returns false when the whole-line chunking does not apply
+        auto build = [&](bool want_lines, SparsePlanDev &d) -> bool {
         std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
         std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
         std::vector<double> seg_w;
@@ -1638,7 +1662,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         // partial buffer; combine_parts_kernel adds them up (1.6 rows per region on the 0.25-degree impact regions).
         // Taken when the grid's row length is known (whole rows of whole quads) and the table is compact enough.
         constexpr int LINE = 32, LPC = UC / LINE;                          // cells per line, lines per chunk (8)
-        bool lines_plan = !(flags & WAGG_PLAN_NO_LINES) && row_len < G && G % row_len == 0 && row_len % 4 == 0 && nnz > 0;
+        bool lines_plan = want_lines;
         if (lines_plan) {
             struct LSeg { int64_t line; int32_t region, col; double w; };
             std::vector<LSeg> ls((size_t)nnz);
@@ -1908,45 +1932,39 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         while (g0_normal < (int)grp_giant.size() && grp_giant[(size_t)g0_normal]) ++g0_normal;
         const int c0_normal = grp_chunk_begin[(size_t)g0_normal];
 
-        wagg_plan *plan = new wagg_plan();
-        plan->den_host = den;
-        plan->info.nseg_in = nseg; plan->info.nnz = nnz;
-        plan->info.n_groups = (int64_t)grp_giant.size();
-        plan->info.lines = lines_plan ? 1 : 0;
-        plan->info.n_partial_rows = (int64_t)part_rows.size();
-        plan->info.n_chunks = (int64_t)chunk_u_begin.size() - 1;
-        plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
-        plan->info.n_giant = n_giant;
-        plan->info.n_empty = (int64_t)empty.size();
-        plan->info.G = G; plan->info.R = R;
+        if (lines_plan != want_lines) return false;
+        if (!want_lines) {
+            plan->info.n_groups = (int64_t)grp_giant.size();
+            plan->info.n_chunks = (int64_t)chunk_u_begin.size() - 1;
+            plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
+            plan->info.n_giant = n_giant;
+            plan->info.n_empty = (int64_t)empty.size();
+        } else {
+            plan->info.lines = 1;
+            plan->info.n_partial_rows = (int64_t)part_rows.size();
+            plan->info.lines_chunks = (int64_t)chunk_u_begin.size() - 1;
+            plan->info.lines_ucells = (int64_t)ucell.size() * 4;
+        }
+        int64_t l128s = 0, s64s = 0;
         for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c) {      // locality statistics of the gather
             int32_t l128 = -1, s64 = -1;
             std::vector<int32_t> qs(ucell.begin() + chunk_u_begin[c], ucell.begin() + chunk_u_begin[c + 1]);
             std::sort(qs.begin(), qs.end());
             for (int32_t q : qs) {
-                if ((q >> 5) != l128) { l128 = q >> 5; ++plan->info.n_lines128; }
-                if ((q >> 4) != s64) { s64 = q >> 4; ++plan->info.n_sectors64; }
+                if ((q >> 5) != l128) { l128 = q >> 5; ++l128s; }
+                if ((q >> 4) != s64) { s64 = q >> 4; ++s64s; }
             }
         }
+        if (!want_lines) { plan->info.n_lines128 = l128s; plan->info.n_sectors64 = s64s; }
+        else plan->info.lines_lines128 = l128s;
 #ifdef WAGG_DIAG
         if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
             fprintf(stderr, "[wagg plan] lines=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
-                    (int)lines_plan, band_rows, (long long)plan->info.n_chunks, (long long)plan->info.n_groups, (long long)n_giant,
-                    (long long)plan->info.n_ucells, (long long)plan->info.n_lines128, (long long)plan->info.n_sectors64,
-                    (long long)nnz, (long long)part_rows.size());
+                    (int)lines_plan, band_rows, (long long)chunk_u_begin.size() - 1, (long long)grp_giant.size(), (long long)n_giant,
+                    (long long)ucell.size() * 4, (long long)l128s, (long long)s64s, (long long)nnz, (long long)part_rows.size());
 #endif
-        std::vector<float> seg_w32(seg_w.size()), den32(den.size());
+        std::vector<float> seg_w32(seg_w.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
-        for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
-        plan->flags = flags;
-        auto &d = plan->d;
-        hipError_t he = hipGetDevice(&plan->device);
-        if (he == hipSuccess) he = hipDeviceGetAttribute(&plan->ncu, hipDeviceAttributeMultiprocessorCount, plan->device);
-        if (he == hipSuccess) he = hipHostMalloc((void **)&plan->timeout_host, sizeof(int), hipHostMallocMapped);
-        if (he == hipSuccess) {
-            *plan->timeout_host = 0;
-            he = hipHostGetDevicePointer((void **)&plan->timeout_dev, plan->timeout_host, 0);
-        }
         auto up = [&](auto &buf, const auto &h) { if (he == hipSuccess) he = buf.upload(h); };
         up(d.grp_chunk_begin, grp_chunk_begin); up(d.grp_giant, grp_giant);
         up(d.chunk_u_begin, chunk_u_begin); up(d.chunk_e_begin, chunk_e_begin);
@@ -1964,11 +1982,21 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         }
         if (lines_plan) { up(d.part_begin, part_begin); up(d.part_rows, part_rows); d.n_part = (int64_t)part_rows.size(); }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
+        d.n_groups = (int64_t)grp_giant.size(); d.n_empty = (int64_t)empty.size();
+        return true;
+        };   // build
+
+        build(false, plan->d);
+        // the whole-line chunking as well, for the kernel that is bound by line requests; its extra bytes (ocean cells of
+        // coastal lines) cost the other kernels more than the aligned lines save them (c3, fp64: 0.47 -> 0.52 ms)
+        if (!(flags & (WAGG_PLAN_NO_LINES | WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) && row_len < G && G % row_len == 0 &&
+            row_len % 4 == 0 && nnz > 0 && he == hipSuccess)
+            plan->has_lines = build(true, plan->dl);
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));
-            delete plan;
-            return WAGG_EHIP;
+            return WAGG_EHIP;                                         // (plan_guard deletes the plan)
         }
+        plan_guard.release();
         *out = plan;
         return WAGG_OK;
     } catch (const std::bad_alloc &) {

@@ -62,10 +62,14 @@ typedef struct wagg_plan_info {
     int64_t n_empty;     /* regions with no kept segment (result 0/den)                          */
     int64_t G;
     int32_t R;
-    int32_t lines;       /* 1: whole-line plan (chunks of eight 32-cell lines, partial rows + combine); 0: region-shaped chunks */
+    int32_t lines;       /* 1: the plan also holds the whole-line chunking (used by the fp32 (time, gridcell) loader/consumer kernel) */
     int64_t n_lines128;  /* sum over chunks of distinct 128-byte lines (32 fp32 cells) their quads touch */
     int64_t n_sectors64; /* ... of distinct 64-byte sectors */
-    int64_t n_partial_rows; /* whole-line plan: (chunk, region) partial sums = rows of the partial buffer; else 0 */
+    /* whole-line chunking (lines == 1, else 0): chunks of eight whole 32-cell lines of one column strip */
+    int64_t n_partial_rows; /* (chunk, region) partial sums = rows of the partial buffer that combine_parts_kernel adds up */
+    int64_t lines_chunks;   /* its chunks                                                                               */
+    int64_t lines_ucells;   /* cells it fetches per timestep (every line whole, each exactly once)                      */
+    int64_t lines_lines128; /* distinct 128-byte lines per timestep (= lines_ucells / 32 on grids of whole lines)       */
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */
@@ -108,8 +112,10 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
  * region_code[i] rank of the row's label among the sorted unique labels, -1 = null label (S3)
  * w_eff[i]       fp64 weight after the per-row backup fill of :73; NaN rows leave both sums
  * row_len        cells per grid row (nlon), 0 = unknown.  Known (and a whole number of 4-cell quads, G a whole number of
- *                rows), compact tables get the whole-line plan: chunks of eight whole 128-byte lines of one 32-cell
- *                column strip, every line fetched exactly once; regions cut by chunk borders are summed from partial rows
+ *                rows), compact tables get a second, whole-line chunking next to the region-shaped one: chunks of eight
+ *                whole 128-byte lines of one 32-cell column strip, every line fetched exactly once, regions cut by chunk
+ *                borders summed from partial rows -- what fp32 (time, gridcell) applies use (their kernel is bound by
+ *                line requests); everything else keeps the region-shaped chunks (fewer bytes)
  * flags          0, or WAGG_PLAN_* bits that pin the kernel form for this plan (tests, ablations);
  *                resolved here, once -- the library reads no environment variable
  * Host pointers; copied.  Duplicate (cell, region) rows add (S5).                              */

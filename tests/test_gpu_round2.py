@@ -337,9 +337,10 @@ def test_plan_flags_pin_the_kernel_form(torch_cuda):
 
 @pytest.mark.parametrize("nlat,nlon", [(96, 192), (61, 100), (40, 36)])
 def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda, nlat, nlon):
-    """the whole-line plan (chunks of eight 32-cell lines of one column strip, (chunk, region) partial
-    rows, combine kernel) is what a compact table on a grid of known row length gets; WAGG_PLAN_NO_LINES keeps the
-    region-shaped chunks.  Both against the fp64 oracle and each other: fp32 and fp64, (time, gridcell) and (gridcell,
+    """the whole-line chunking (chunks of eight 32-cell lines of one column strip, (chunk, region)
+    partial rows, combine kernel) is what fp32 (time, gridcell) applies of a compact table on a grid of known row length
+    use; every other apply, and every apply under WAGG_PLAN_NO_LINES, uses the region-shaped chunks.  Both against the
+    fp64 oracle and each other: fp32 and fp64, (time, gridcell) and (gridcell,
     time) data, both result layouts, ragged T, fused powers and degree days, NaN data, rows whose length is not a
     whole number of lines, a split cell, a null label, a region without rows."""
     from climate_toolbox_amd import _lib, synth
@@ -364,8 +365,8 @@ def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda,
             plan = SparsePlan(cell, code, w, G, R, row_len=nlon, flags=flags)
             assert plan.info["lines"] == (1 if flags == 0 else 0)
             if flags == 0:
-                assert plan.info["n_giant"] == 0 and plan.info["n_partial_rows"] >= len(uniq) - 1
-                assert plan.info["n_lines128"] * 8 == plan.info["n_ucells"] // 4 or nlon % 32     # every quad of a line, each line once
+                assert plan.info["n_partial_rows"] >= len(uniq) - 1 and plan.info["lines_chunks"] > 0
+                assert plan.info["lines_lines128"] * 8 == plan.info["lines_ucells"] // 4 or nlon % 32    # every quad of a line, each line once
             g = plan.apply(Xd).cpu().numpy()
             _rel_ok(g, ref, rtol)
             np.testing.assert_array_equal(plan.apply(Xd, out_layout="RT").cpu().numpy(), g.T)
