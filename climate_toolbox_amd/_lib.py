@@ -34,6 +34,7 @@ EXPORTS = (
     "wagg_synth_field_f32", "wagg_synth_field_f64",
     "wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32", "wagg_dense_apply_host_multi_f64",
     "wagg_host_block_plan", "wagg_host_stats_read",
+    "wagg_combine_planes_f32", "wagg_combine_planes_f64", "wagg_take_axis", "wagg_relayout_f32", "wagg_relayout_f64",
 )
 
 
@@ -127,6 +128,11 @@ def load():
     for name in ("wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32",
                  "wagg_dense_apply_host_multi_f64"):
         getattr(L, name).argtypes = [C.POINTER(vp), i32p, C.c_int, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int]
+    for name in ("wagg_combine_planes_f32", "wagg_combine_planes_f64"):
+        getattr(L, name).argtypes = [vp, C.c_int, C.c_int64, f64p, C.c_int64, vp, vp]
+    L.wagg_take_axis.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, vp, C.c_int64, vp, vp]
+    for name in ("wagg_relayout_f32", "wagg_relayout_f64"):
+        getattr(L, name).argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]
     L.wagg_host_block_plan.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wagg_host_stats_read.argtypes = [C.POINTER(HostStats), C.c_int]
     for name in ("wagg_gather_f32", "wagg_gather_f64"):

@@ -439,8 +439,11 @@ def _flatten_for_device(values, dims):
     if on_dev:
         import torch
         if values.dtype not in (torch.float32, torch.float64):
-            values = values.double()
-        contig, transpose = (lambda a: a.contiguous()), (lambda a, order: a.permute(*order))
+            raise TypeError("a device-resident variable must be float32 or float64 (got %s): the library moves device data "
+                            "with its own kernels only" % (values.dtype,))
+        # the re-layout of a device field runs in the library's own kernel (wagg_relayout_*), not in a torch one
+        contig = lambda a: a if a.is_contiguous() else _engine.relayout(a)
+        transpose = lambda a, order: _engine.relayout(a, order)
     else:
         values = np.asarray(values)
         if values.dtype not in (np.float32, np.float64):
@@ -782,14 +785,15 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
         def run(plan):
             """The device work for one plan form; returns the list of (T, R) / (R, T) result tensors."""
             if edd is not None:
-                if isinstance(plan, DensePlan):     # the degree days are evaluated while X is packed
-                    stack = [plan.apply_edd(Xd, Hd, e, offset=edd[1]) for e in thr]
+                if isinstance(plan, DensePlan):     # the degree days are evaluated while X is packed, one threshold per apply
+                    stack = torch.empty((len(thr), Xd.shape[0], plan.R), dtype=Xd.dtype, device=Xd.device)
+                    for k, e in enumerate(thr):
+                        plan.apply_edd(Xd, Hd, e, offset=edd[1], out=stack[k])
                 else:
                     stack = plan.apply_edd(Xd, Hd, thr, offset=edd[1], layout=layout, out_layout=out_layout)
-                total = coefs[0] * stack[0] if coefs[0] != 1.0 else stack[0]
-                for c, o in zip(coefs[1:], stack[1:]):
-                    total = total + c * o
-                return [total]
+                if len(coefs) == 1 and coefs[0] == 1.0:
+                    return [stack[0]]
+                return [_engine.combine_planes(stack, coefs)]     # wagg_combine_planes_*: sum_k coef_k * EDD_k (gdd, :138-140)
             if powers is None:
                 return [plan.apply(Xd) if isinstance(plan, DensePlan) else plan.apply(Xd, layout=layout, out_layout=out_layout)]
             if isinstance(plan, DensePlan):         # scattered weights: (x + offset)^p evaluated while X is packed

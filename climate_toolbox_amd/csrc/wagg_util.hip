@@ -150,6 +150,45 @@ __global__ void any_less_kernel(const T *__restrict__ a, const T *__restrict__ b
     if (__ballot(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// out[i] = sum_k coef[k] * planes[k * pstride + i]   (snyder_gdd = EDD(lo) - EDD(hi): the aggregation is linear, so the
+// degree days of several thresholds are combined AFTER they were aggregated; transformations.py:138-140)
+template <typename T>
+__global__ void combine_planes_kernel(const T *__restrict__ planes, int64_t pstride, EddTerms<T> tm, int64_t n, T *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T s = tm.coef[0] * planes[i];
+        for (int k = 1; k < tm.n; ++k) s += tm.coef[k] * planes[(int64_t)k * pstride + i];
+        out[i] = s;
+    }
+}
+
+// dst[o][i][:] = src[o][idx[i]][:] -- "take along an axis" of a contiguous array seen as (outer, n_src, inner bytes):
+// the leap-day removal along time (utils.py:60-74) and the lon re-ordering (utils.py:33-40) of device-resident fields.
+// One thread per 16-byte (or 4-byte) piece of the destination.
+template <typename V>
+__global__ void take_axis_kernel(const V *__restrict__ src, int64_t n_src, int64_t inner, const int64_t *__restrict__ idx,
+                                 int64_t n_idx, int64_t total, V *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const int64_t c = p % inner, oi = p / inner;
+        const int64_t i = oi % n_idx, o = oi / n_idx;
+        dst[p] = src[(o * n_src + idx[i]) * inner + c];
+    }
+}
+
+// dst (contiguous, shape `shape`) <- src with arbitrary element strides: the one transpose a (lat, time, lon)-ordered
+// device field needs before it is a (time, gridcell) matrix.  Up to 6 dims; the last destination dim on the lanes.
+struct RelayoutDims { int nd; int64_t shape[6], sstride[6]; };
+template <typename T>
+__global__ void relayout_kernel(const T *__restrict__ src, RelayoutDims d, int64_t total, T *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        int64_t rem = p, off = 0;
+        for (int k = d.nd - 1; k >= 0; --k) { off += (rem % d.shape[k]) * d.sstride[k]; rem /= d.shape[k]; }
+        dst[p] = src[off];
+    }
+}
+
 template <typename T>
 static int transform_poly(const T *X, int64_t n, double offset, int power, T *out, void *stream) {
     WAGG_REQUIRE(n >= 0 && power >= 1 && power <= 16, "bad arguments (n=%lld, power=%d)", (long long)n, power);
@@ -205,6 +244,78 @@ extern "C" int wagg_transform_edd_f64(const double *tasmin, const double *tasmax
                                       const double *coefs, const double *thresholds, int n_terms, double *out, void *stream) {
     return wagg::transform_edd<double>(tasmin, tasmax, n, offset, coefs, thresholds, n_terms, out, stream);
 }
+namespace wagg {
+template <typename T>
+static int combine_planes(const T *planes, int n_planes, int64_t pstride, const double *coefs, int64_t n, T *out, void *stream) {
+    WAGG_REQUIRE(n >= 0 && n_planes >= 1 && n_planes <= XF_MAX_TERMS && coefs, "bad arguments (n=%lld, planes=%d)", (long long)n, n_planes);
+    if (n == 0) return WAGG_OK;
+    WAGG_REQUIRE(planes && out && (n_planes == 1 || pstride >= n), "NULL pointer or overlapping planes");
+    EddTerms<T> tm;
+    tm.n = n_planes;
+    for (int k = 0; k < XF_MAX_TERMS; ++k) { tm.coef[k] = (T)(k < n_planes ? coefs[k] : 0.0); tm.thr[k] = T(0); }
+    hipLaunchKernelGGL((combine_planes_kernel<T>), dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, planes, pstride, tm, n, out);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+
+static int take_axis(const void *src, int64_t outer, int64_t n_src, int64_t inner_bytes, const int64_t *idx_dev, int64_t n_idx,
+                     void *dst, void *stream) {
+    WAGG_REQUIRE(outer >= 0 && n_src >= 0 && inner_bytes >= 0 && n_idx >= 0, "negative size");
+    const int64_t bytes = outer * n_idx * inner_bytes;
+    if (bytes == 0) return WAGG_OK;
+    WAGG_REQUIRE(src && dst && idx_dev && inner_bytes % 4 == 0, "NULL pointer, or rows that are not whole 4-byte words");
+    typedef int v4 __attribute__((ext_vector_type(4)));
+    const bool wide = inner_bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (wide)
+        hipLaunchKernelGGL((take_axis_kernel<v4>), dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const v4 *)src, n_src,
+                           inner_bytes / 16, idx_dev, n_idx, bytes / 16, (v4 *)dst);
+    else
+        hipLaunchKernelGGL((take_axis_kernel<int>), dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const int *)src, n_src,
+                           inner_bytes / 4, idx_dev, n_idx, bytes / 4, (int *)dst);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+
+template <typename T>
+static int relayout(const T *src, int nd, const int64_t *shape, const int64_t *sstride, T *dst, void *stream) {
+    WAGG_REQUIRE(nd >= 1 && nd <= 6 && shape && sstride, "1..6 dimensions");
+    RelayoutDims d;
+    d.nd = nd;
+    int64_t total = 1;
+    for (int k = 0; k < 6; ++k) {
+        d.shape[k] = k < nd ? shape[k] : 1; d.sstride[k] = k < nd ? sstride[k] : 0;
+        WAGG_REQUIRE(d.shape[k] >= 0 && d.sstride[k] >= 0, "negative extent or stride");
+        total *= d.shape[k];
+    }
+    if (total == 0) return WAGG_OK;
+    WAGG_REQUIRE(src && dst, "NULL pointer");
+    hipLaunchKernelGGL((relayout_kernel<T>), dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, src, d, total, dst);
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
+}  // namespace wagg
+
+extern "C" int wagg_combine_planes_f32(const float *planes_dev, int n_planes, int64_t plane_stride, const double *coefs,
+                                       int64_t n, float *out_dev, void *stream) {
+    return wagg::combine_planes<float>(planes_dev, n_planes, plane_stride, coefs, n, out_dev, stream);
+}
+extern "C" int wagg_combine_planes_f64(const double *planes_dev, int n_planes, int64_t plane_stride, const double *coefs,
+                                       int64_t n, double *out_dev, void *stream) {
+    return wagg::combine_planes<double>(planes_dev, n_planes, plane_stride, coefs, n, out_dev, stream);
+}
+extern "C" int wagg_take_axis(const void *src_dev, int64_t outer, int64_t n_src, int64_t inner_bytes, const int64_t *idx_dev,
+                              int64_t n_idx, void *dst_dev, void *stream) {
+    return wagg::take_axis(src_dev, outer, n_src, inner_bytes, idx_dev, n_idx, dst_dev, stream);
+}
+extern "C" int wagg_relayout_f32(const float *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, float *dst_dev,
+                                 void *stream) {
+    return wagg::relayout<float>(src_dev, ndim, shape, src_strides, dst_dev, stream);
+}
+extern "C" int wagg_relayout_f64(const double *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, double *dst_dev,
+                                 void *stream) {
+    return wagg::relayout<double>(src_dev, ndim, shape, src_strides, dst_dev, stream);
+}
+
 extern "C" int wagg_any_less_f32(const float *a, const float *b, int64_t n, int *result, void *stream) {
     return wagg::any_less<float>(a, b, n, result, stream);
 }

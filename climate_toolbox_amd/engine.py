@@ -414,7 +414,7 @@ def _flat_dev(t):
     import torch
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.float64)):
         raise TypeError("expected a float32/float64 CUDA tensor")
-    return t if t.is_contiguous() else t.contiguous()
+    return t if t.is_contiguous() else relayout(t)
 
 
 def transform_poly(X, offset, power, stream=None):
@@ -445,6 +445,66 @@ def transform_edd(tasmin, tasmax, offset, terms, stream=None):
     _lib.check(fn(C.c_void_p(lo.data_ptr()), C.c_void_p(hi.data_ptr()), lo.numel(), float(offset),
                   _np_ptr(coefs, C.c_double), _np_ptr(thr, C.c_double), len(coefs), C.c_void_p(out.data_ptr()),
                   _stream_handle(stream)), "wagg_transform_edd")
+    return out
+
+
+def combine_planes(stack, coefs, stream=None):
+    """sum_k coefs[k] * stack[k] on the device (``wagg_combine_planes_*``): how the aggregated degree days of several
+    thresholds become snyder_gdd (transformations.py:138-140).  ``stack``: contiguous (K, ...) CUDA tensor, K <= 8."""
+    import torch
+    if not (isinstance(stack, torch.Tensor) and stack.is_cuda and stack.is_contiguous() and stack.dtype in (torch.float32, torch.float64)):
+        raise TypeError("stack must be a contiguous float32/float64 CUDA tensor")
+    cf = np.ascontiguousarray(coefs, dtype=np.float64)
+    if len(cf) != stack.shape[0]:
+        raise ValueError("one coefficient per plane")
+    out = torch.empty(stack.shape[1:], dtype=stack.dtype, device=stack.device)
+    L = _lib.load()
+    fn = L.wagg_combine_planes_f32 if stack.dtype == torch.float32 else L.wagg_combine_planes_f64
+    n = out.numel()
+    _lib.check(fn(C.c_void_p(stack.data_ptr()), len(cf), n, _np_ptr(cf, C.c_double), n, C.c_void_p(out.data_ptr()),
+                  _stream_handle(stream)), "wagg_combine_planes")
+    return out
+
+
+def take_axis(t, axis, index, stream=None):
+    """``t`` with only the positions ``index`` (host integers) kept / re-ordered along ``axis`` (``wagg_take_axis``):
+    the leap-day drop and the lon re-ordering of a device-resident field, without a torch kernel."""
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError("expected a CUDA tensor")
+    t = relayout(t) if not t.is_contiguous() else t
+    idx = np.ascontiguousarray(index, dtype=np.int64)
+    if len(idx) and (idx.min() < 0 or idx.max() >= t.shape[axis]):
+        raise IndexError("index out of range")
+    outer = int(np.prod(t.shape[:axis], dtype=np.int64))
+    inner_bytes = int(np.prod(t.shape[axis + 1:], dtype=np.int64)) * t.element_size()
+    if inner_bytes % 4:
+        raise TypeError("rows of whole 4-byte words only (dtype %s)" % t.dtype)
+    out = torch.empty(tuple(t.shape[:axis]) + (len(idx),) + tuple(t.shape[axis + 1:]), dtype=t.dtype, device=t.device)
+    idx_dev = torch.from_numpy(idx).to(t.device)
+    _lib.check(_lib.load().wagg_take_axis(C.c_void_p(t.data_ptr()), outer, int(t.shape[axis]), inner_bytes,
+                                          C.c_void_p(idx_dev.data_ptr()), len(idx), C.c_void_p(out.data_ptr()),
+                                          _stream_handle(stream)), "wagg_take_axis")
+    return out
+
+
+def relayout(t, order=None, stream=None):
+    """A contiguous copy of ``t`` (float32/float64 CUDA tensor, any strides), its dims in ``order`` if given
+    (``wagg_relayout_*``): what ``permute(order).contiguous()`` would do, in the library's own kernel."""
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype in (torch.float32, torch.float64)):
+        raise TypeError("device-resident fields must be float32 or float64 CUDA tensors, got %s" % getattr(t, "dtype", type(t)))
+    order = list(range(t.dim())) if order is None else [int(i) for i in order]
+    if t.dim() > 6 or t.dim() < 1:
+        raise ValueError("1..6 dimensions")
+    shape = [int(t.shape[i]) for i in order]
+    strides = [int(t.stride(i)) for i in order]
+    out = torch.empty(shape, dtype=t.dtype, device=t.device)
+    sh = (C.c_int64 * len(shape))(*shape)
+    st = (C.c_int64 * len(shape))(*strides)
+    L = _lib.load()
+    fn = L.wagg_relayout_f32 if t.dtype == torch.float32 else L.wagg_relayout_f64
+    _lib.check(fn(C.c_void_p(t.data_ptr()), len(shape), sh, st, C.c_void_p(out.data_ptr()), _stream_handle(stream)), "wagg_relayout")
     return out
 
 

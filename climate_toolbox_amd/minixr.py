@@ -115,8 +115,8 @@ class LazyArray(DataArray):
             return buf
         ax = self.dims.index("lon")
         if _is_tensor(buf):
-            import torch
-            return buf.index_select(ax, torch.from_numpy(self._lon_perm).to(buf.device))
+            from . import engine
+            return engine.take_axis(buf, ax, self._lon_perm)          # wagg_take_axis
         return np.take(np.asarray(buf), self._lon_perm, axis=ax)
 
     @property

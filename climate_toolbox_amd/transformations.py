@@ -68,9 +68,9 @@ def remove_leap_days(ds):
 
 
 def _compress(buf, keep, axis):
-    if type(buf).__module__.startswith("torch"):          # device-resident buffer
-        import torch
-        return buf.index_select(axis, torch.from_numpy(np.flatnonzero(keep)).to(buf.device))
+    if type(buf).__module__.startswith("torch"):          # device-resident buffer: wagg_take_axis
+        from . import engine
+        return engine.take_axis(buf, axis, np.flatnonzero(keep))
     return np.compress(keep, np.asarray(buf), axis=axis)
 
 

@@ -236,6 +236,21 @@ int wagg_transform_edd_f32(const float *tasmin_dev, const float *tasmax_dev, int
                            const double *coefs, const double *thresholds, int n_terms, float *out_dev, void *stream);
 int wagg_transform_edd_f64(const double *tasmin_dev, const double *tasmax_dev, int64_t n, double offset,
                            const double *coefs, const double *thresholds, int n_terms, double *out_dev, void *stream);
+/* out[i] = sum_k coefs[k] * planes[k * plane_stride + i], n_planes <= 8: several aggregated planes combined into one
+ * (snyder_gdd = EDD(threshold_low) - EDD(threshold_high), transformations.py:138-140, after the aggregation: it is linear) */
+int wagg_combine_planes_f32(const float *planes_dev, int n_planes, int64_t plane_stride, const double *coefs, int64_t n,
+                            float *out_dev, void *stream);
+int wagg_combine_planes_f64(const double *planes_dev, int n_planes, int64_t plane_stride, const double *coefs, int64_t n,
+                            double *out_dev, void *stream);
+/* Data movement of device-resident fields in front of the path.  wagg_take_axis: dst[o][i][:] = src[o][idx[i]][:] for a
+ * contiguous array seen as (outer, n_src, inner_bytes) -- the 29-February drop along time (utils.py:60-74) and the lon
+ * re-ordering (utils.py:33-40); idx_dev is an int64 device array, inner_bytes a multiple of 4.  wagg_relayout_*: dst
+ * (contiguous, shape[0..ndim)) <- src with element strides src_strides (any permutation of up to 6 dims: the transpose of a
+ * field whose lat/lon axes are not adjacent).                                                                            */
+int wagg_take_axis(const void *src_dev, int64_t outer, int64_t n_src, int64_t inner_bytes, const int64_t *idx_dev,
+                   int64_t n_idx, void *dst_dev, void *stream);
+int wagg_relayout_f32(const float *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, float *dst_dev, void *stream);
+int wagg_relayout_f64(const double *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, double *dst_dev, void *stream);
 int wagg_any_less_f32(const float *a_dev, const float *b_dev, int64_t n, int *result, void *stream);
 int wagg_any_less_f64(const double *a_dev, const double *b_dev, int64_t n, int *result, void *stream);
 

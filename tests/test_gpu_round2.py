@@ -700,6 +700,94 @@ def test_dropin_spreads_host_fields_over_the_listed_devices(torch_cuda):
     assert st["register_failed"] == st["unregister_failed"] == st["cleanup_failed"] == 0
 
 
+def test_library_owns_the_data_movement_of_device_fields(torch_cuda):
+    """what used to be torch kernels on product branches is the library's own code --
+    wagg_combine_planes_* (gdd = EDD(lo) - EDD(hi) of aggregated planes), wagg_take_axis (leap-day drop, lon re-ordering
+    of device fields), wagg_relayout_* (the transpose of a field whose lat/lon axes are not adjacent) -- each against
+    NumPy, then the drop-in on device-resident (lat, time, lon) fields with a leap day and a 0..360 lon axis against the
+    same call on host arrays."""
+    from climate_toolbox_amd import engine, minixr, standardize_climate_data, snyder_gdd, weighted_aggregate_grid_to_regions, synth
+    from climate_toolbox_amd.transformations import remove_leap_days
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    for dt in (np.float32, np.float64):
+        a = rng.standard_normal((3, 40, 7, 12)).astype(dt)
+        ad = torch.from_numpy(a).cuda()
+        np.testing.assert_array_equal(engine.combine_planes(ad, [1.0, -1.0, 0.5]).cpu().numpy(), (a[0] - a[1]) + dt(0.5) * a[2])
+        for axis, idx in ((1, np.r_[0:10, 11:40]), (3, rng.permutation(12)), (0, [2, 0])):
+            np.testing.assert_array_equal(engine.take_axis(ad, axis, idx).cpu().numpy(), np.take(a, idx, axis=axis))
+        for order in ((1, 0, 2, 3), (3, 1, 0, 2), (0, 1, 2, 3)):
+            np.testing.assert_array_equal(engine.relayout(ad, order).cpu().numpy(), np.ascontiguousarray(np.transpose(a, order)))
+        np.testing.assert_array_equal(engine.relayout(ad[:, ::2, :, 1:9]).cpu().numpy(), a[:, ::2, :, 1:9])
+    with pytest.raises(TypeError):
+        engine.relayout(torch.zeros((4, 4), dtype=torch.int32, device="cuda"))
+    # the drop-in on device-resident fields: (lat, time, lon) order, 0..360 longitudes, a 29 February in the time axis
+    nlat, nlon = 48, 96
+    lat = np.arange(nlat) * 1.0 - 23.5
+    lon360 = np.arange(nlon) * 3.75
+    time = pd.date_range("2004-02-20", periods=20).values
+    lat_s, lon_s, df = synth.realistic_segments(nlat, nlon, R=60, seed=3, string_labels=False,
+                                                lat=lat, lon=np.sort((lon360 + 180) % 360 - 180))
+    tmin = (280 + 8 * rng.standard_normal((nlat, len(time), nlon))).astype(np.float32)
+    tmax = tmin + rng.uniform(0, 9, tmin.shape).astype(np.float32)
+    outs = []
+    for wrap in (lambda v: v, lambda v: torch.from_numpy(v).cuda()):
+        ds = minixr.Dataset({"tasmin": (("lat", "time", "lon"), wrap(tmin)), "tasmax": (("lat", "time", "lon"), wrap(tmax))},
+                            coords={"lat": lat, "time": time, "lon": lon360})
+        ds = remove_leap_days(standardize_climate_data(ds))
+        ds["gdd"] = snyder_gdd(ds["tasmin"], ds["tasmax"], 283.15, 303.15)
+        outs.append(weighted_aggregate_grid_to_regions(ds, "gdd", "areawt", "hierid", df).gdd.values)
+    assert outs[0].shape[1] == 19                                              # (region, time) with the leap day gone
+    np.testing.assert_allclose(outs[1], outs[0], rtol=2e-5, atol=1e-6)
+
+
+def test_dropin_from_two_threads_shares_the_caches_safely(torch_cuda):
+    """the module-level caches are locked and a plan handed out is leased.  Two Python threads call
+    the reference-named function at once -- the same table (they serialise on the plan's lease), two different tables
+    (they run concurrently), with a cache of ONE plan so that every miss tries to evict the other thread's plan while it
+    is being applied -- and every result equals the single-threaded one."""
+    import threading
+    from climate_toolbox_amd import aggregations as A, minixr, synth
+    lat, lon, dfa = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=True)
+    _, _, dfb = synth.realistic_segments(96, 192, R=200, seed=9, string_labels=True)
+    rng = np.random.default_rng(21)
+    T = 90
+    fields = [(280 + 10 * rng.standard_normal((T, len(lat), len(lon)))).astype(dt) for dt in (np.float32, np.float64)]
+    jobs = [(f, df, wt) for f in fields for df, wt in ((dfa, "areawt"), (dfb, "popwt"), (dfa, "popwt"))]
+
+    def run(job):
+        f, df, wt = job
+        ds = minixr.Dataset({"tas": (("time", "lat", "lon"), f)}, coords={"time": np.arange(T), "lat": lat, "lon": lon})
+        return A.weighted_aggregate_grid_to_regions(ds, "tas", wt, "hierid", df).tas.values
+
+    A._PLAN_CACHE.clear()
+    expect = [run(j) for j in jobs]
+    saved = A._PLAN_CACHE_MAX
+    errs, got = [], {}
+
+    def worker(k):
+        try:
+            for rep in range(6):
+                for i in (range(len(jobs)) if k == 0 else reversed(range(len(jobs)))):
+                    got[(k, rep, i)] = run(jobs[i])
+        except Exception as e:                                            # pragma: no cover
+            errs.append(repr(e))
+
+    try:
+        A._PLAN_CACHE_MAX = 1
+        A._PLAN_CACHE.clear()
+        ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    finally:
+        A._PLAN_CACHE_MAX = saved
+    assert not errs, errs
+    assert len(got) == 2 * 6 * len(jobs)
+    for (k, rep, i), v in got.items():
+        np.testing.assert_array_equal(v, expect[i])
+    assert len(A._PLAN_CACHE) <= 2                                        # (a leased plan may outlive the limit by one)
+
+
 def test_dropin_streams_host_fields_through_the_pipeline(torch_cuda):
     """A plain aggregation of a NumPy-backed (time, lat, lon) variable goes through the row-block
     pipeline (no whole-field device copy) and matches the oracle; a device-resident variable and a lazily
