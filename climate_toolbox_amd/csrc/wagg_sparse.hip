@@ -1359,7 +1359,10 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // (G,T) data, giant groups) runs once per power with the transform applied on load.
     // the whole-line chunking serves the loader/consumer kernel (fp32, (time, gridcell) data); everything else the
     // region-shaped chunks
-    const bool use_lines = plan->has_lines && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG;
+    // (the fused powers and degree days keep the round-2 configuration -- region-shaped chunks, dense-tile MFMA consumers,
+    // which reduce four planes in one pass: measured with whole lines + vector-ALU consumers they were slower, 0.55 vs
+    // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
+    const bool use_lines = plan->has_lines && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && nfuse == 1 && xpow != XF_EDD;
     const auto &d = use_lines ? plan->dl : plan->d;
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
@@ -1428,12 +1431,11 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             const int ncu = plan->ncu;
             const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
             const long long nw = n_items < ncu ? n_items : ncu;
+            // plain aggregation: vector-ALU consumers (8 + 8 waves); fused powers / degree days (and WAGG_PLAN_LC_MFMA): the
+            // dense-tile MFMA consumers (8 + 4 waves)
+            const bool mfma_cons = (plan->flags & WAGG_PLAN_LC_MFMA) || edd || nfuse > 1;
             auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
-            if (edd) kern = vec ? sparse_lc_kernel<true, 1, true> : sparse_lc_kernel<false, 1, true>;
-            if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
-            if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
-            if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
-            if (plan->flags & WAGG_PLAN_LC_MFMA) {                // the dense-tile MFMA consumers of rounds 1-2
+            if (mfma_cons) {
                 kern = vec ? sparse_lc_kernel<true, 1, false, true> : sparse_lc_kernel<false, 1, false, true>;
                 if (edd) kern = vec ? sparse_lc_kernel<true, 1, true, true> : sparse_lc_kernel<false, 1, true, true>;
                 if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2, false, true> : sparse_lc_kernel<false, 2, false, true>;
@@ -1446,7 +1448,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             unsigned long long *lc_stamps = nullptr;
             if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3((unsigned)((plan->flags & WAGG_PLAN_LC_MFMA) ? LC_THREADS : lc_threads(nfuse, edd, false))), LcLds::total, stream, pv, X, Ttot, ldx,
+            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3((unsigned)(mfma_cons ? LC_THREADS : lc_threads(1, false, false))), LcLds::total, stream, pv, X, Ttot, ldx,
                                plan->info.G, kout, kldo, n_norm, n_items, plan->timeout_dev, lc_stamps,
                                diag_env("WAGG_LC_KNOB"), kpstride, ylim);
             profile_mark(stream, false);

@@ -53,23 +53,34 @@ def mean(kernel_sub, counter):
 
 tj = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
-WIDE = ("FETCH_SIZE x2 (gfx950 tallies the 128-B requests of a 16-B/lane contiguous stream at 64 B; for the dense kernel "
-        "the raw value is below the bytes of W that must be read), WRITE_SIZE exact")
+WIDE = ("FETCH_SIZE x2 (gfx950 tallies the 128-B requests of a 16-B/lane contiguous stream at 64 B: MI355X_MICROARCH.md, HBM), "
+        "WRITE_SIZE exact")
 GATHER = ("FETCH_SIZE x1: calibrated on the segment-table gather in round 1 with every grid cell referenced (land_frac=1.0): "
           "raw 1.567 GB vs 1.514 GB of X, TCC_EA0_RDREQ x 64 B = 1.567 GB; WRITE_SIZE exact")
-for wl, ksub, wide in (("c2-dense", "dense_mfma_kernel<float", True), ("c2-real", "sparse_lc_kernel<true, 1, false>", False),
-                       ("c3-real", "sparse_stream_kernel<double", False), ("c5-uniform", "spmm_kernel", True)):
+LINES = ("whole-line chunks: every load instruction reads eight whole 128-B lines, i.e. the wide coalesced case: FETCH_SIZE x2 if "
+         "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T, in the bench line's plan), x1 if it matches "
+         "them: see `calibration`; WRITE_SIZE exact")
+for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
+                       ("c2-real", "sparse_lc_kernel<true, 1, false, false>", "lines"), ("c3-real", "sparse_stream_kernel<double", "gather"),
+                       ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
+                       ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
     if fs is None or ws is None:
         continue
-    traffic[wl] = {
-        "hbm_bytes_per_launch": (2.0 if wide else 1.0) * fs * 1024 + ws * 1024,
-        "fetch_size_kib_raw": fs, "write_size_kib_raw": ws,
-        "correction": (WIDE if wide else GATHER) if wl != "c5-uniform" else
-                      ("FETCH_SIZE x2 applied to the whole figure: exact for the X tiles (16-B/lane LDS-DMA), an upper bound for "
-                       "the entry lists (4-B/lane loads, uncalibrated); the bytes that must move are ~19 GB of X + 36 GB of lists"),
-        "source": "profiles/%s_pmc.csv" % tag, "measured": "round %d" % int(tag.lstrip("r")),
-    }
+    factor = 1.0 if mode == "gather" else 2.0
+    entry = {"fetch_size_kib_raw": fs, "write_size_kib_raw": ws, "source": "profiles/%s_pmc.csv" % tag,
+             "measured": "round %d" % int(tag.lstrip("r"))}
+    if mode == "lines":
+        # known bytes of the whole-line gather: 20,607 lines x 128 B x 365 rows for c2-real (bench line: plan.lines_ucells)
+        known = float(os.environ.get("LINES_BYTES", "0")) or None
+        if known:
+            factor = 2.0 if fs * 1024 < 0.75 * known else 1.0
+            entry["calibration"] = {"lines_bytes": known, "raw_over_lines": fs * 1024 / known, "factor": factor}
+    entry["hbm_bytes_per_launch"] = factor * fs * 1024 + ws * 1024
+    entry["correction"] = {"wide": WIDE, "gather": GATHER, "lines": LINES}[mode] if not wl.startswith("c5-uniform") else (
+        "FETCH_SIZE x2 applied to the whole figure: exact for the X tiles and the weight lists (16-B/lane LDS-DMA), an upper bound for "
+        "the lo16 pair lists (4-B/lane loads, uncalibrated)")
+    traffic[wl] = entry
 json.dump(traffic, open(tj, "w"), indent=1)
 print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read()[:1500])
 print(json.dumps(traffic, indent=1))
