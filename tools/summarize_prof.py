@@ -45,10 +45,51 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
 
 
 def mean(kernel_sub, counter):
+    """mean counter value per launch of the kernel.  c1 and c3-real run the SAME instantiation
+    (sparse_stream_kernel<double>): "<name>#big" / "<name>#small" select the launches above / below half of the
+    largest value (c3: 1M cells, c1: 16,200)."""
+    pick = None
+    if "#" in kernel_sub:
+        kernel_sub, pick = kernel_sub.split("#")
     for (k, c), v in agg.items():
         if kernel_sub in k and c == counter:
-            return sum(v) / len(v)
+            if pick:
+                top = max(v)
+                v = [x for x in v if (x >= 0.5 * top) == (pick == "big")]
+            return sum(v) / len(v) if v else None
     return None
+
+
+# per workload: the dominant kernel's launches and mean duration from the kernel trace (the --stats table averages c1
+# and c3-real together: one kernel instantiation serves both)
+tr = os.path.join(src, "trace", "bench_kernel_trace.csv")
+if os.path.exists(tr):
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr)):
+        dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+    rows = []
+    for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share)", "dense_mfma_kernel<float, 0, false, 22, true"),
+                     ("c2-real", "sparse_lc_kernel<true, 1, false, false>"), ("c3-real", "sparse_stream_kernel<double#big"),
+                     ("c1", "sparse_stream_kernel<double#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
+                     ("c5-block-f64", "dense_mfma_kernel<double, 0, true"), ("c5-uniform", "spmm_kernel<float>"),
+                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lc_kernel<true, 4, false, true>"),
+                     ("c2-real fused snyder_edd (K = 1 and K = 3 launches)", "sparse_lc_kernel<true, 1, true, true>"),
+                     ("c2-real combine + transpose", "combine_parts_kernel<float, true>")):
+        pick = None
+        if "#" in ksub:
+            ksub, pick = ksub.split("#")
+        for k, v in dur.items():
+            if ksub in k:
+                if pick:
+                    top = max(v)
+                    v = [x for x in v if (x >= 0.5 * top) == (pick == "big")]
+                if v:
+                    rows.append((wl, k.replace("void wagg::", ""), len(v), sum(v) / len(v), min(v), max(v)))
+    with open(os.path.join(dst, tag + "_kernel_by_workload.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["workload", "dominant kernel", "launches", "avg_ms", "min_ms", "max_ms"])
+        for r in rows:
+            w.writerow([r[0], r[1], r[2]] + ["%.4f" % x for x in r[3:]])
 
 
 tj = os.path.join(dst, "traffic.json")
@@ -61,13 +102,13 @@ LINES = ("whole-line chunks: every load instruction reads eight whole 128-B line
          "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T, in the bench line's plan), x1 if it matches "
          "them: see `calibration`; WRITE_SIZE exact")
 for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
-                       ("c2-real", "sparse_lc_kernel<true, 1, false, false>", "lines"), ("c3-real", "sparse_stream_kernel<double", "gather"),
+                       ("c2-real", "sparse_lc_kernel<true, 1, false, false>", "lines"), ("c3-real", "sparse_stream_kernel<double#big", "gather64"),
                        ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
     if fs is None or ws is None:
         continue
-    factor = 1.0 if mode == "gather" else 2.0
+    factor = 1.0 if mode == "gather" else 2.0      # gather64: see below
     entry = {"fetch_size_kib_raw": fs, "write_size_kib_raw": ws, "source": "profiles/%s_pmc.csv" % tag,
              "measured": "round %d" % int(tag.lstrip("r"))}
     if mode == "lines":
@@ -77,7 +118,13 @@ for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wi
             factor = 2.0 if fs * 1024 < 0.75 * known else 1.0
             entry["calibration"] = {"lines_bytes": known, "raw_over_lines": fs * 1024 / known, "factor": factor}
     entry["hbm_bytes_per_launch"] = factor * fs * 1024 + ws * 1024
-    entry["correction"] = {"wide": WIDE, "gather": GATHER, "lines": LINES}[mode] if not wl.startswith("c5-uniform") else (
+    if mode == "gather64":
+        # fp64 quads are 32 bytes per lane (two 16-byte loads): the raw figure is below the bytes of the quads the plan lists
+        # (n_ucells x 8 B x T = 1.36 GB for c3-real), so the x1 calibration of the fp32 gather does not carry over; x2 is
+        # reported as an upper bound
+        entry["needed_bytes"] = float(os.environ.get("C3_QUAD_BYTES", "0")) or None
+    entry["correction"] = {"wide": WIDE, "gather": GATHER, "lines": LINES, "gather64": "FETCH_SIZE x2 (an upper bound: 32 bytes per lane "
+                           "as two 16-byte loads; uncalibrated), WRITE_SIZE exact"}[mode] if not wl.startswith("c5-uniform") else (
         "FETCH_SIZE x2 applied to the whole figure: exact for the X tiles and the weight lists (16-B/lane LDS-DMA), an upper bound for "
         "the lo16 pair lists (4-B/lane loads, uncalibrated)")
     traffic[wl] = entry
