@@ -349,7 +349,7 @@ def main():
         wl = "c1" if small else ("c2-real" if dtype == "float32" else "c3-real")
         traffic, tsrc = load_traffic(wl)
         kname = PLAN_KERNEL.get(int(plan.info.get("kernel_form", -1)),
-                                "sparse_lc_kernel" if b == 4 else "sparse_stream_kernel<double>")
+                                "sparse_lcv_kernel<float>" if b == 4 else "sparse_lcv_kernel<double>")
         res = {
             "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "T_job": T_job, "G": Gs, "R": Rr, "nnz": int(nnz),
             "value": T_job * Gs * Rr * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,

@@ -74,7 +74,8 @@ class PlanInfo(C.Structure):
                 ("n_chunks", C.c_int64), ("n_ucells", C.c_int64), ("n_giant", C.c_int64),
                 ("n_empty", C.c_int64), ("G", C.c_int64), ("R", C.c_int32), ("lines", C.c_int32),
                 ("n_lines128", C.c_int64), ("n_sectors64", C.c_int64), ("n_partial_rows", C.c_int64),
-                ("lines_chunks", C.c_int64), ("lines_ucells", C.c_int64), ("lines_lines128", C.c_int64)]
+                ("lines_chunks", C.c_int64), ("lines_ucells", C.c_int64), ("lines_lines128", C.c_int64),
+                ("n_partial_rows64", C.c_int64), ("lines64_chunks", C.c_int64), ("lines64_ucells", C.c_int64)]
 
 
 _lib = None

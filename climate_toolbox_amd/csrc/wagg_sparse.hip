@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -46,7 +47,10 @@ static inline constexpr bool diag_set(const char *) { return false; }
 
 constexpr int UC = 256;      // cell slots per LDS chunk == workgroup size
 constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of a wave)
-constexpr int UROW = UC + 4; // LDS row stride in elements (t-major image, 16-byte aligned rows)
+constexpr int UROW = UC + 4; // LDS row stride in elements (t-major image, 16-byte aligned rows): fp32, 260 dwords = 4 (mod 64)
+// the same for a type: fp64 rows of UC + 2 doubles are 516 dwords = 4 (mod 64) as well (UC + 4 doubles = 8 (mod 64) made a
+// lane = timestep column read 4-way conflicted: VERDICT r2 item 5); still 16-byte aligned for the vector stores
+template <typename T> constexpr int urow() { return sizeof(T) == 8 ? UC + 2 : UC + 4; }
 constexpr int RG_MAX = 127;  // regions per group
 constexpr int SEG_MAX = 512; // segments per chunk staged in LDS
 constexpr int SEG_LAST = 0x8000;   // flag bit in a segment's local cell index: last segment of its entry
@@ -71,8 +75,8 @@ struct SparsePlanDev {
     DevBuf<double> ent_den64;
     int g0_normal = 0, c0_normal = 0;
     // whole-line plan: an entry is a (chunk, region) PARTIAL sum, ent_region its row in the partial buffer;
-    // region r is the sum of rows part_rows[part_begin[r] .. part_begin[r + 1]) divided by den[r]
-    DevBuf<int32_t> part_begin, part_rows;
+    // region r is the sum of rows part_begin[r] .. part_begin[r + 1] - 1 of the partial buffer, divided by den[r]
+    DevBuf<int32_t> part_begin;
     int64_t n_part = 0;
     int64_t n_groups = 0, n_empty = 0;          // groups of this chunking; regions without any kept row
 };
@@ -83,8 +87,10 @@ struct wagg_plan {
     wagg_plan_info info{};
     std::vector<double> den_host;
     wagg::SparsePlanDev d;        // region-shaped chunks: every kernel, every layout and data type
-    wagg::SparsePlanDev dl;       // whole-line chunks (has_lines): the fp32 (time, gridcell) loader/consumer kernel, which is
-    bool has_lines = false;       // bound by line requests; the other kernels pay for the extra bytes of whole lines
+    wagg::SparsePlanDev dl;       // whole-line chunks (has_lines): 8 lines x 32 cells, the fp32 (time, gridcell) loader/consumer
+    bool has_lines = false;       // kernel, which is bound by line requests
+    wagg::SparsePlanDev dl64;     // the same for fp64 data: 8 lines x 16 cells (a line = 128 bytes of a row in both)
+    bool has_lines64 = false;
     int device = 0;
     int ncu = 256;                 // compute units of `device` (read once, at plan creation)
     int flags = 0;                 // WAGG_PLAN_* kernel-form switches, fixed at plan creation
@@ -160,7 +166,7 @@ template <typename T> struct PlanView {
 // f32/TB=64: 75.8 KB, f64/TB=32: 78.9 KB  ->  two workgroups per CU (160 KB).
 template <typename T, int TB> struct SparseLds {
     static constexpr size_t xs = 0;
-    static constexpr size_t red = xs + sizeof(T) * TB * UROW;
+    static constexpr size_t red = xs + sizeof(T) * TB * urow<T>();
     static constexpr size_t seg_w = red + sizeof(T) * NWAVE * TB;
     static constexpr size_t ent_den = seg_w + sizeof(T) * SEG_MAX;
     static constexpr size_t ent_r = ent_den + sizeof(T) * (RG_MAX + 1);
@@ -281,13 +287,13 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
 #pragma unroll
                                 for (int cc = 0; cc < 4; ++cc) val[cc] = snyder_edd1<T>(v[i][cc], hi[i][cc], pv.edd_thr[k]);
                             }
-                            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = val;
+                            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * urow<T>() + 4 * lane]) = val;
                         }
                     } else {
                         vec4 sum = vec4{T(0), T(0), T(0), T(0)};
 #pragma unroll
                         for (int i = 0; i < TPW; ++i) sum += v[i];
-                        *reinterpret_cast<vec4 *>(&xs[tw0 * UROW + 4 * lane]) = sum;
+                        *reinterpret_cast<vec4 *>(&xs[tw0 * urow<T>() + 4 * lane]) = sum;
                     }
                 }
             } else {
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                         else if (pv.xpow == XF_EDD)
                             xv = snyder_edd1<T>(xv + pv.xoff, (lane_live ? pv.X2[cell * ldx + t0 + lane] : T(0)) + pv.xoff,
                                                 pv.edd_thr[k]);
-                        xs[lane * UROW + u] = xv;
+                        xs[lane * urow<T>() + u] = xv;
                     }
                 }
             }
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                     for (int sgi = s0; sgi < s1; ++sgi) {
                         const int u = sm_u[sgi] & SEG_UMASK;
                         const T w = sm_w[sgi];
-                        const T p = xs[lane * UROW + u] * w;        // aggregations.py:78 product
+                        const T p = xs[lane * urow<T>() + u] * w;        // aggregations.py:78 product
                         acc += (p == p) ? p : T(0);                 // skipna: NaN product counts 0 (S6)
                     }
                 }
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * UROW + 4 * lane]) = v[i];
+            *reinterpret_cast<vec4 *>(&xs[(tw0 + i) * urow<T>() + 4 * lane]) = v[i];
             const vec4 z = v[i] - v[i];                         // 0 for finite values, NaN for NaN / inf
             odd |= !(z[0] == T(0) && z[1] == T(0) && z[2] == T(0) && z[3] == T(0));
         }
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
                             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), j0 + j);
                             wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
                         }
-                        xv[j] = xs[lane * UROW + (uf[j] & SEG_UMASK)];
+                        xv[j] = xs[lane * urow<T>() + (uf[j] & SEG_UMASK)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -658,10 +664,6 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
 // Chunks whose data contain +-inf fall back to the exact per-segment VALU reduction.
 // ---------------------------------------------------------------------------------------------
 constexpr int LC_LW = 8, LC_CW = 4, LC_THREADS = (LC_LW + LC_CW) * 64;      // the MFMA-consumer form: 8 loader + 4 consumer waves
-// vector-ALU consumers: 8 + 8 waves for the plain aggregation (114 registers: four waves per SIMD fit); the fused powers
-// and degree days keep 8 + 4 (their loaders need the 168 registers of three waves per SIMD)
-constexpr int lc_cw(int npow, bool edd, bool mfma) { return (!mfma && npow == 1 && !edd) ? 8 : 4; }
-constexpr int lc_threads(int npow, bool edd, bool mfma) { return (LC_LW + lc_cw(npow, edd, mfma)) * 64; }
 constexpr int LC_TB = 64;
 constexpr int LC_AROW = UC + 4;                 // Aw row stride (elements)
 constexpr int LC_ENT = RG_MAX + 1;              // entries per chunk
@@ -688,15 +690,10 @@ struct LcLds {
 // and keep them in registers; one stage per threshold: they park snyder_edd1(tasmin + xoff, tasmax + xoff,
 // thr[k]) (transformations.py:64-87) into the image buffer and the consumers reduce it into output plane
 // k, so the two fields are read from HBM once for up to four thresholds.
-// MFMA_CONS = false (round 3, the default): the consumer waves reduce an item on the VECTOR ALU instead -- every wave
-// takes every fourth region entry and walks its segments with lane = timestep: v_readlane broadcasts (cell, weight),
-// one LDS read and one FMA per segment, eight reads in flight.  A chunk has ~155 segments: ~1.3k cycles per item and
-// wave, where the dense-tile MFMA pass costs 8.5k (scatter the weights, 64 MFMAs per wave over a tile that is 6 % full,
-// un-scatter, three consumer barriers -- profiles/r02_edd_stamps.txt) and needs a second pass for more than 16
-// regions (39 % of the whole-line chunks).  It multiplies real (cell, region) pairs only, so +-inf data needs no
-// separate exact path, and the consumer waves never wait for each other (no bounded spin, no timeout).
-template <bool VEC, int NPOW = 1, bool EDD = false, bool MFMA_CONS = false>
-__global__ __launch_bounds__(lc_threads(NPOW, EDD, MFMA_CONS), lc_cw(NPOW, EDD, MFMA_CONS) == 8 ? 4 : 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
+// Round 3: the plain aggregation left this kernel for sparse_lcv_kernel (vector-ALU consumers, below); what runs here
+// are the fused powers, the degree days, and plans created with WAGG_PLAN_LC_MFMA.
+template <bool VEC, int NPOW = 1, bool EDD = false>
+__global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
                                                                   int64_t Ttot, int64_t ldx, int64_t G,
                                                                   float *__restrict__ out, int64_t ldo,
                                                                   int n_norm, long long n_items,
@@ -979,105 +976,6 @@ __global__ __launch_bounds__(lc_threads(NPOW, EDD, MFMA_CONS), lc_cw(NPOW, EDD, 
         }
         lds_only_barrier();                                       // consumers finish the last item
         if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
-    } else if constexpr (!MFMA_CONS) {
-        // ==================== consumer waves, vector ALU: lane = timestep, wave cw takes entries cw, cw + 8, ... ====================
-        constexpr int CWV = lc_cw(NPOW, EDD, false);              // consumer waves of this variant
-        const int cw = wave - LC_LW;
-        const int nstages = nst * (EDD ? pv.n_thr : 1);
-        for (int st = 0; st < nstages; ++st) {
-            stamp(-1);
-            lds_only_barrier();                                   // stage st has been parked
-            stamp(3);                                             // consumer ph3: waiting for the loaders
-            const int buf = st & 1;
-            const int64_t plane_off = EDD ? (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 4]) * out_pstride : 0;
-            const float *im = img + buf * LC_TB * UROW + lane * UROW;       // this lane's timestep row of the image
-            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
-            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LC_TB;
-            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
-            const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
-            const bool odd = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);   // +-inf (or a value too large to raise) somewhere
-            if (knob & 1) continue;                               // (diagnostic build: consumers idle)
-            // the entries of this wave; ODD (decided once per item, so the segment loop is branch-free): the general form in
-            // which a NaN product counts 0 (S6: inf x 0-weight, overflow of a power)
-            // Results leave in batches of four entries: the quotients go through a per-wave LDS scratch (the space of the
-            // MFMA consumers' weight tile) so that ONE 16-byte-per-lane store covers four entries' 64 timesteps (lane =
-            // (entry of the batch, four consecutive timesteps)).  A consumer's stores queue behind the loaders' row loads
-            // in the CU's memory pipeline: with one dword store per entry the consumers spent most of an item waiting to
-            // issue them (7.7k of 10.4k cycles, profiles/r03_lc_stamps.txt).
-            float *scr = aw + cw * (NPOW * 4 * 64);            // (8 x 1 KiB or 4 x NPOW KiB: inside the 16.6 KB tile)
-            auto walk = [&](auto odd_tag) {
-                constexpr bool ODD = decltype(odd_tag)::value;
-                for (int eb = cw; eb < ne; eb += 4 * CWV) {
-#pragma unroll 1
-                for (int kb = 0; kb < 4; ++kb) {
-                    const int e = eb + kb * CWV;
-                    if (e >= ne) break;
-                    const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e]);
-                    const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e + 1]);
-                    float acc[NPOW];
-#pragma unroll
-                    for (int pp = 0; pp < NPOW; ++pp) acc[pp] = 0.f;
-                    for (int base = (knob & 256) ? s1 : s0; base < s1; base += 64) {     // (knob 256, diagnostic build: no segment walk)
-                        // lane j holds segment base + j (padding lanes: cell 0, weight 0: they add exactly 0 to finite data)
-                        const int n = s1 - base < 64 ? s1 - base : 64;
-                        const int k = base + (lane < n ? lane : 0);
-                        int ul = sm_u[buf * LC_SEGS + k] & 0xff;
-                        float wl = sm_w[buf * LC_SEGS + k];
-                        if (lane >= n) { ul = 0; wl = 0.f; }
-                        for (int j0 = 0; j0 < n; j0 += 8) {
-                            float xv[8], wv[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {         // 8 independent LDS reads in flight
-                                const int u = __builtin_amdgcn_readlane(ul, j0 + j);
-                                wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
-                                xv[j] = im[u];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                float yp = xv[j];
-                                if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) yp *= xv[j];   // first power of this pass
-#pragma unroll
-                                for (int pp = 0; pp < NPOW; ++pp) {
-                                    if (pp > 0) yp *= xv[j];                                   // y^(pp+1), transformations.py:188
-                                    if constexpr (ODD) {
-                                        const float p = yp * wv[j];
-                                        acc[pp] += (p == p) ? p : 0.f;
-                                    } else {
-                                        acc[pp] = __builtin_fmaf(yp, wv[j], acc[pp]);          // aggregations.py:78
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    const float den = sm_ed[buf * LC_ENT + e];
-#pragma unroll
-                    for (int pp = 0; pp < NPOW; ++pp) scr[(pp * 4 + kb) * 64 + lane] = acc[pp] / den;   // :77-80
-                }
-                // (LDS operations of one wave execute in order: the reads below see the writes above)
-                const int kq = lane >> 4, piece = lane & 15;
-                const int e = eb + kq * CWV, tl = 4 * piece;
-                if (e < ne && tl < nt && !(knob & 128)) {         // (knob 128, diagnostic build: no result stores)
-                    float *op = out + plane_off + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
-#pragma unroll
-                    for (int pp = 0; pp < NPOW; ++pp) {
-                        const vec4 qv = *reinterpret_cast<const vec4 *>(&scr[(pp * 4 + kq) * 64 + tl]);
-                        float *o2 = op + (int64_t)pp * out_pstride;
-                        if (out_vec && tl + 3 < nt) {
-                            *reinterpret_cast<vec4 *>(o2) = qv;
-                        } else {
-#pragma unroll
-                            for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) o2[rg] = qv[rg];
-                        }
-                    }
-                }
-                }
-            };
-            if (odd) walk(std::true_type{}); else walk(std::false_type{});
-            stamp(1);                                             // ph1: the item's entries
-        }
-        lds_only_barrier();                                       // matches the loaders' final barrier
-        if (stamps && tid == LC_LW * 64) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
     } else {
         // =============================== consumer waves, matrix cores ===============================
         const int cw = wave - LC_LW;                              // 0..3: owns timesteps 16cw .. 16cw+15
@@ -1236,6 +1134,330 @@ __global__ __launch_bounds__(lc_threads(NPOW, EDD, MFMA_CONS), lc_cw(NPOW, EDD, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Loader/consumer form with VECTOR-ALU consumers (round 3): the plain aggregation of (time, gridcell) data over the
+// whole-line chunking, fp32 AND fp64.  One 1024-thread workgroup per CU, persistent over items (chunk, 64 timesteps):
+//   * 8 LOADER waves stream the next item into registers -- 64 rows x 1024 bytes: lane l fetches 16 bytes of a row, eight
+//     lanes one whole 128-byte line -- and park it in the other half of a double-buffered LDS image (NaN -> 0 on the
+//     way, S6; a flag notes +-inf);
+//   * 8 CONSUMER waves reduce the current item: wave c takes the chunk's region entries c, c + 8, ... and walks their
+//     segments with lane = timestep: v_readlane broadcasts (cell, weight), one LDS read and one FMA per segment, eight
+//     reads in flight; results leave through a per-wave LDS scratch as 16-byte stores (one store per 4 / 2 entries).
+//     Only real (cell, region) pairs are multiplied, so +-inf data needs no separate exact path, and the consumer waves
+//     never wait for each other.
+// The image is SWIZZLED so that both sides are bank-conflict free: element (t, u) of row t lives at u ^ t -- the
+// loaders' 16-byte pieces stay whole and a row's 64 pieces still fill its 1024 bytes (the XOR moves a piece inside the
+// row and permutes the 4 / 2 elements inside it, the latter at compile time: the row is a loop constant), and the
+// consumers' lanes, reading one cell u of 64 consecutive timesteps, hit 64 different banks (32 bank pairs per half-wave
+// in fp64).  Rounds 1-2
+// read a padded image (row stride 260): 4-way conflicts, 51 % of the LDS cycles of the fp64 kernel (profiles/r02_pmc.csv).
+// ---------------------------------------------------------------------------------------------
+constexpr int LV_LW = 8, LV_CW = 8, LV_THREADS = (LV_LW + LV_CW) * 64, LV_TB = 64;
+constexpr int LV_ROWB = 1024;                   // bytes of an image row: 256 floats / 128 doubles = the cells of a chunk
+template <typename T> struct LvLds {
+    static constexpr size_t img = 0;                                            // [2][64][1024 B]
+    static constexpr size_t scr = img + 2 * (size_t)LV_TB * LV_ROWB;            // [8 consumer waves][1 KiB] result scratch
+    static constexpr size_t seg_w = scr + LV_CW * 1024;                         // [2][LC_SEGS] T
+    static constexpr size_t seg_u = seg_w + 2 * sizeof(T) * LC_SEGS;            // [2][LC_SEGS] i32 (packed)
+    static constexpr size_t ent_r = seg_u + 2 * sizeof(int32_t) * LC_SEGS;      // [2][LC_ENT] i32
+    static constexpr size_t ent_d = ent_r + 2 * sizeof(int32_t) * LC_ENT;       // [2][LC_ENT] T
+    static constexpr size_t ent_s = ent_d + 2 * sizeof(T) * LC_ENT;             // [2][LC_ENT + 2] u16
+    static constexpr size_t hdr = (ent_s + 2 * sizeof(uint16_t) * (LC_ENT + 2) + 15) / 16 * 16;   // [2][16] i32
+    static constexpr size_t total = hdr + 2 * 16 * sizeof(int32_t);
+    static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot,
+                                                                int64_t ldx, int64_t G, T *__restrict__ out, int64_t ldo,
+                                                                int n_norm, long long n_items,
+                                                                unsigned long long *__restrict__ stamps_arg, int knob_arg) {
+#ifdef WAGG_DIAG
+    const int knob = knob_arg;                       // ablation switches / phase stamps: diagnostic build only
+    unsigned long long *const stamps = stamps_arg;
+#else
+    constexpr int knob = 0;
+    constexpr unsigned long long *stamps = nullptr;
+    (void)knob_arg; (void)stamps_arg;
+#endif
+    constexpr int E = 16 / (int)sizeof(T);           // elements per 16-byte piece: 4 / 2
+    constexpr int LPQ = 4 / E;                       // lanes per 4-cell quad of the plan: 1 / 2
+    typedef T vecE __attribute__((ext_vector_type(E)));
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    using L = LvLds<T>;
+    char *img = smem_raw + L::img;
+    T *sm_w = reinterpret_cast<T *>(smem_raw + L::seg_w);
+    int32_t *sm_u = reinterpret_cast<int32_t *>(smem_raw + L::seg_u);
+    int32_t *sm_er = reinterpret_cast<int32_t *>(smem_raw + L::ent_r);
+    T *sm_ed = reinterpret_cast<T *>(smem_raw + L::ent_d);
+    uint16_t *sm_es = reinterpret_cast<uint16_t *>(smem_raw + L::ent_s);
+    int32_t *hdr = reinterpret_cast<int32_t *>(smem_raw + L::hdr);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave < LV_LW;
+    const bool out_vec = (ldo % E == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // XCD-contiguous ids (speed only)
+    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
+    const long long NW = NWu;
+    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
+    if (w0 >= n_items) return;
+    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
+    const int nst = (int)((n_items - 1 - w0) / NW) + 1;
+    struct Item { int g, tb; };
+    auto advance = [&](Item a) {
+        Item b{a.g + dg, a.tb + dtb};
+        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
+        return b;
+    };
+    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int i) {
+        if (stamps) {
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            if (i >= 0) ph[i] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+
+    if (loader) {
+        // =============================== loader waves ===============================
+        constexpr int TPW = LV_TB / LV_LW;                       // 8 rows per wave
+        const int tw0 = wave * TPW;
+        auto load_desc = [&](Item a, StreamDesc &d) {
+            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
+            const int4v x = *reinterpret_cast<const int4v *>(p);
+            const int4v y = *reinterpret_cast<const int4v *>(p + 4);
+            d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
+        };
+        // first cell of this lane's 16 bytes: quad lane / LPQ of the chunk (clamped), half lane % LPQ of it
+        auto load_cell = [&](const StreamDesc &d) {
+            const int q = lane / LPQ;
+            return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (lane % LPQ) * E;
+        };
+        struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; };
+        static_assert(LC_SEGS <= LV_LW * 64, "one metadata element per loader thread");
+        auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
+            // small metadata loads first, the rows last (vmcnt retires in order)
+            {
+                const int k = tid < d.ns ? tid : d.ns - 1;
+                R.mu = pv.seg_u[d.sb + k];
+                R.mw = pv.seg_w[d.sb + k];
+                R.er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+                R.ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
+                R.es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];
+            }
+            const int64_t t0 = (int64_t)tb * LV_TB;
+            const int nt = (int)((Ttot - t0) < LV_TB ? (Ttot - t0) : LV_TB);
+            const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
+            int cnt = nt - tw0;
+            cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
+            const T *p = X + (t0 + rbase) * ldx + cell0;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(p);
+                else {
+                    const int64_t lim = G - 1 - cell0;
+#pragma unroll
+                    for (int c = 0; c < E; ++c) R.v[i][c] = p[lim < c ? lim : c];
+                }
+                if (i + 1 < cnt) p += ldx;
+            }
+        };
+        auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
+            char *im = img + (size_t)buf * LV_TB * LV_ROWB;
+            bool odd = false;
+            if (pv.xpow > 0) {                                    // (x + xoff)^xpow on the way in (transformations.py:188)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int c = 0; c < E; ++c) R.v[i][c] = xform1<T>(R.v[i][c], pv.xoff, pv.xpow);
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int c = 0; c < E; ++c) {                     // one v_cmp_class per element: sNaN | qNaN | -inf | +inf
+                    if constexpr (sizeof(T) == 4) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);
+                    else odd |= __builtin_amdgcn_class(R.v[i][c], 0x207);
+                }
+            bool inf_any = false;
+            if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
+                bool inf_seen = false;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int c = 0; c < E; ++c) {
+                        const T x = R.v[i][c];
+                        inf_seen |= __builtin_isinf(x);                            // the consumers then take the general form
+                        R.v[i][c] = (x == x) ? x : T(0);                           // NaN data counts 0 (S6)
+                    }
+                inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
+            }
+            if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;            // every wave, every item: no reset needed
+            // row t = tw0 + i: piece `lane` goes to piece lane ^ (t / E), its elements permuted by t % E = i % E
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int m = tw0 + i;
+                vecE v;
+#pragma unroll
+                for (int c = 0; c < E; ++c) v[c ^ (i % E)] = R.v[i][c];
+                *reinterpret_cast<vecE *>(im + (size_t)(tw0 + i) * LV_ROWB + 16 * (lane ^ (m / E))) = v;
+            }
+            if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
+            if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
+            if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
+            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; }
+        };
+        // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
+        Item itq[3];
+        StreamDesc dq[3];
+        int cellq[2];
+        itq[0] = Item{(int)(w0 % n_norm), (int)(w0 / n_norm)};
+        itq[1] = nst > 1 ? advance(itq[0]) : itq[0];
+        itq[2] = nst > 2 ? advance(itq[1]) : itq[1];
+        load_desc(itq[0], dq[0]); load_desc(itq[1], dq[1]); load_desc(itq[2], dq[2]);
+        cellq[0] = load_cell(dq[0]);
+        cellq[1] = load_cell(dq[1]);
+        Regs RA, RB;
+        issue(RA, dq[0], cellq[0], itq[0].tb);
+        StreamDesc dPark = dq[0];
+        int tbPark = itq[0].tb;
+        struct Ahead { Item nx; StreamDesc dn; int cn; };
+        auto ahead_load = [&](Ahead &a) {
+            a.nx = advance(itq[2]);
+            if (a.nx.tb * (long long)n_norm + a.nx.g >= n_items) a.nx = itq[2];
+            load_desc(a.nx, a.dn);
+            a.cn = load_cell(dq[2]);
+        };
+        auto ahead_commit = [&](const Ahead &a) {
+            itq[0] = itq[1]; itq[1] = itq[2]; itq[2] = a.nx;
+            dq[0] = dq[1]; dq[1] = dq[2]; dq[2] = a.dn;
+            cellq[0] = cellq[1]; cellq[1] = a.cn;
+        };
+        { Ahead a; ahead_load(a); ahead_commit(a); }              // queue now describes items 1, 2, 3
+        int sbuf = 0;
+        auto lstage = [&](Regs &Rcur, Regs &Rnext, int st) {
+            const StreamDesc dn = dq[0];
+            const int tbn = itq[0].tb;
+            const bool more = st + 1 < nst;
+            Ahead a;
+            stamp(-1);
+            if (more) { ahead_load(a); issue(Rnext, dn, cellq[0], tbn); }
+            stamp(0);                                             // loader ph0: issue (blocked at VMEM)
+            park(Rcur, dPark, tbPark, sbuf);
+            stamp(2);                                             // ph2: wait for item st + park
+            if (more) { dPark = dn; tbPark = tbn; ahead_commit(a); }
+            stamp(1);
+            lds_only_barrier();                                   // stage st is in buffer sbuf
+            stamp(3);                                             // ph3: waiting for the consumers
+            sbuf ^= 1;
+        };
+        for (int st = 0; st < nst; st += 2) {
+            lstage(RA, RB, st);
+            if (st + 1 < nst) lstage(RB, RA, st + 1);
+        }
+        lds_only_barrier();                                       // consumers finish the last item
+        if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
+    } else {
+        // ==================== consumer waves: lane = timestep, wave cw takes entries cw, cw + 8, ... ====================
+        const int cw = wave - LV_LW;
+        constexpr int EPB = E;                                    // entries per result batch = per 16-byte-per-lane store
+        constexpr int LPE = 64 / E;                               // lanes per entry of that store
+        T *scr = reinterpret_cast<T *>(smem_raw + L::scr + cw * 1024);
+        // this lane's image row, with the swizzle folded in: element u sits at rowoff ^ (u * sizeof(T))
+        // (LDS addresses as plain integers: the low half of a generic pointer into LDS is its LDS address; the image starts
+        // at a multiple of its row size -- at 0 in fact, the kernel has no static LDS -- so the XOR stays inside the row)
+        typedef const T __attribute__((address_space(3))) *lds_cptr;
+        const unsigned img0 = (unsigned)reinterpret_cast<uintptr_t>(img);
+        if (img0 & (LV_ROWB - 1)) __builtin_trap();
+        const unsigned rowoff = img0 + ((unsigned)lane * LV_ROWB | ((unsigned)lane * (unsigned)sizeof(T)));
+        for (int st = 0; st < nst; ++st) {
+            stamp(-1);
+            lds_only_barrier();                                   // stage st has been parked
+            stamp(3);                                             // consumer ph3: waiting for the loaders
+            const int buf = st & 1;
+            const unsigned rb = rowoff + (unsigned)buf * (LV_TB * LV_ROWB);         // (the XOR below only touches bits 0..9)
+            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
+            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LV_TB;
+            const int nt = (int)((Ttot - t0) < LV_TB ? (Ttot - t0) : LV_TB);
+            const int fl = lane < LV_LW ? hdr[buf * 16 + 8 + lane] : 0;
+            const bool odd = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);   // +-inf somewhere in the item
+            if (knob & 1) continue;                               // (diagnostic build: consumers idle)
+            // ODD (decided once per item, so the segment loop is branch-free): the general form in which a NaN product
+            // counts 0 (S6: +-inf data times a zero weight)
+            auto walk = [&](auto odd_tag) {
+                constexpr bool ODD = decltype(odd_tag)::value;
+                for (int eb = cw; eb < ne; eb += EPB * LV_CW) {
+#pragma unroll 1
+                    for (int kb = 0; kb < EPB; ++kb) {
+                        const int e = eb + kb * LV_CW;
+                        if (e >= ne) break;
+                        const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e]);
+                        const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e + 1]);
+                        T acc = T(0);
+                        for (int base = (knob & 256) ? s1 : s0; base < s1; base += 64) {
+                            // lane j holds segment base + j (padding lanes: cell 0, weight 0: they add exactly 0 to finite data)
+                            const int n = s1 - base < 64 ? s1 - base : 64;
+                            const int k = base + (lane < n ? lane : 0);
+                            int ul = (sm_u[buf * LC_SEGS + k] & 0xff) * (int)sizeof(T);     // byte offset of the cell in a row
+                            T wl = sm_w[buf * LC_SEGS + k];
+                            if (lane >= n) { ul = 0; wl = T(0); }
+                            for (int j0 = 0; j0 < n; j0 += 8) {
+                                T xv[8], wv[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {     // 8 independent LDS reads in flight
+                                    const unsigned u = (unsigned)__builtin_amdgcn_readlane(ul, j0 + j);
+                                    if constexpr (sizeof(T) == 4) {
+                                        wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
+                                    } else {
+                                        const long long wb = __builtin_bit_cast(long long, wl);
+                                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(wb & 0xffffffffll), j0 + j);
+                                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), j0 + j);
+                                        wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+                                    }
+                                    xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    if constexpr (ODD) {
+                                        const T p = xv[j] * wv[j];
+                                        acc += (p == p) ? p : T(0);
+                                    } else {
+                                        if constexpr (sizeof(T) == 4) acc = __builtin_fmaf(xv[j], wv[j], acc);   // aggregations.py:78
+                                        else acc = __builtin_fma(xv[j], wv[j], acc);
+                                    }
+                                }
+                            }
+                        }
+                        scr[kb * 64 + lane] = acc / sm_ed[buf * LC_ENT + e];                       // :77-80
+                    }
+                    // (LDS operations of one wave execute in order: the reads below see the writes above)
+                    const int kq = lane / LPE, piece = lane % LPE;
+                    const int e = eb + kq * LV_CW, tl = E * piece;
+                    if (e < ne && tl < nt && !(knob & 128)) {
+                        T *op = out + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+                        const vecE qv = *reinterpret_cast<const vecE *>(&scr[kq * 64 + tl]);
+                        if (out_vec && tl + E - 1 < nt) {
+                            *reinterpret_cast<vecE *>(op) = qv;
+                        } else {
+#pragma unroll
+                            for (int rg = 0; rg < E; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                        }
+                    }
+                }
+            };
+            if (odd) walk(std::true_type{}); else walk(std::false_type{});
+            stamp(1);                                             // ph1: the item's entries
+        }
+        lds_only_barrier();                                       // matches the loaders' final barrier
+        if (stamps && tid == LV_LW * 64) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
+    }
+}
+
 // (R x T) -> (T x R) through a padded 64x64 LDS tile: both sides coalesced.  The gather kernel
 // stores region-major (lane = timestep: 256 contiguous bytes per region) because a (T x R) store
 // from it would scatter single dwords over R-strided lines (7x write amplification measured).
@@ -1270,26 +1492,36 @@ __global__ __launch_bounds__(256) void transpose_rt_to_tr_kernel(const T *__rest
 }
 
 // Whole-line plans: out[t][r] = (sum of region r's partial rows)[t] / den[r] (aggregations.py:77-80), the same padded
-// 64 x 64 LDS tile transpose for (time, region) results; regions without any row give 0 / den (S7).
+// 64 x 64 LDS tile transpose for (time, region) results; regions without any row give 0 / den (S7).  Region r's rows are
+// rows part_begin[r] .. part_begin[r + 1] - 1 of the buffer (the builder numbers them region-major), added in that order
+// (bitwise reproducible), four loads in flight.
+constexpr int CB_THREADS = 1024;
 template <typename T, bool TR>
-__global__ __launch_bounds__(256) void combine_parts_kernel(const T *__restrict__ P, int64_t ldp, const int32_t *__restrict__ part_begin,
-                                                            const int32_t *__restrict__ part_rows, const T *__restrict__ den,
-                                                            int64_t R, int64_t Ttot, T *__restrict__ out, int64_t ldo) {
+__global__ __launch_bounds__(CB_THREADS) void combine_parts_kernel(const T *__restrict__ P, int64_t ldp, const int32_t *__restrict__ part_begin,
+                                                                   const T *__restrict__ den, int64_t R, int64_t Ttot,
+                                                                   T *__restrict__ out, int64_t ldo) {
     constexpr int V = 16 / sizeof(T);
     typedef T vecv __attribute__((ext_vector_type(V)));
     __shared__ T tile[64][65];
     const int64_t r0 = (int64_t)blockIdx.x * 64, t0 = (int64_t)blockIdx.y * 64;
     constexpr int TQ = 64 / V;
     const int tq = threadIdx.x % TQ, ry = threadIdx.x / TQ;
-#pragma unroll 1
-    for (int i = ry; i < 64; i += 256 / TQ) {
+#pragma unroll
+    for (int i = ry; i < 64; i += CB_THREADS / TQ) {
         const int64_t r = r0 + i;
         if (r < R) {
             vecv s;
 #pragma unroll
             for (int c = 0; c < V; ++c) s[c] = T(0);
-            for (int32_t k = part_begin[r]; k < part_begin[r + 1]; ++k)       // fixed order: bitwise reproducible
-                s += *reinterpret_cast<const vecv *>(P + (int64_t)part_rows[k] * ldp + t0 + V * tq);
+            const int32_t kb = part_begin[r], ke = part_begin[r + 1];
+            const T *p = P + t0 + V * tq;
+            for (int32_t k = kb; k < ke; k += 4) {
+                vecv v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const vecv *>(p + (int64_t)(k + q < ke ? k + q : ke - 1) * ldp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (k + q < ke) s += v[q];
+            }
             const T d = den[r];
             if (TR) {
 #pragma unroll
@@ -1304,7 +1536,7 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(const T *__restrict_
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 64; i += 4) {
+    for (int i = 0; i < 64; i += CB_THREADS / 64) {
         const int64_t t = t0 + ty + i, r = r0 + tx;
         if (r < R && t < Ttot) out[t * ldo + r] = tile[ty + i][tx];
     }
@@ -1362,8 +1594,9 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // (the fused powers and degree days keep the round-2 configuration -- region-shaped chunks, dense-tile MFMA consumers,
     // which reduce four planes in one pass: measured with whole lines + vector-ALU consumers they were slower, 0.55 vs
     // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
-    const bool use_lines = plan->has_lines && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && nfuse == 1 && xpow != XF_EDD;
-    const auto &d = use_lines ? plan->dl : plan->d;
+    const bool use_lines = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG && nfuse == 1 &&
+                           xpow != XF_EDD;
+    const auto &d = use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d;
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
         const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
@@ -1425,30 +1658,55 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const bool stream_path = layout == WAGG_LAYOUT_TG && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
     const int n_norm = (int)d.n_groups - d.g0_normal;
     bool lc_done = false;
+    // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
+    // whole-line chunking only (a region-shaped chunk of 64 quads is 2 KiB of a fp64 row: twice the image row)
+    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && !edd && nfuse == 1 &&
+        (sizeof(T) == 4 || lines)) {
+        const int ncu = plan->ncu;
+        const long long n_items = (long long)n_norm * ((Ttot + LV_TB - 1) / LV_TB);
+        const long long nw = n_items < ncu ? n_items : ncu;
+        auto kern = vec ? sparse_lcv_kernel<T, true> : sparse_lcv_kernel<T, false>;
+        WAGG_HIP(allow_dynamic_lds((const void *)kern, LvLds<T>::total));
+        unsigned long long *lc_stamps = nullptr;
+        if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
+        profile_mark(stream, true);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LV_THREADS), LvLds<T>::total, stream, pv, X, Ttot, ldx,
+                           plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"));
+        profile_mark(stream, false);
+        WAGG_HIP(hipGetLastError());
+        if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
+            std::vector<unsigned long long> h(8 * (size_t)nw);
+            WAGG_HIP(hipStreamSynchronize(stream));
+            WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
+            WAGG_HIP(hipFree(lc_stamps));
+            double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
+            const double stg = (double)n_items;
+            fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
+                    n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
+        }
+        pv.n_groups = d.g0_normal;
+        lc_done = true;
+    }
     if constexpr (sizeof(T) == 4) {
-        if (stream_path && n_norm > 0 && !(plan->flags & WAGG_PLAN_NO_LC)) {
-            // loader/consumer MFMA kernel over the single-chunk groups; one workgroup per CU
+        if (stream_path && n_norm > 0 && !lc_done && !(plan->flags & WAGG_PLAN_NO_LC)) {
+            // loader/consumer kernel with dense-tile MFMA consumers (8 + 4 waves) over the single-chunk groups: the fused powers,
+            // the degree days and plans with WAGG_PLAN_LC_MFMA; one workgroup per CU
             const int ncu = plan->ncu;
             const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
             const long long nw = n_items < ncu ? n_items : ncu;
-            // plain aggregation: vector-ALU consumers (8 + 8 waves); fused powers / degree days (and WAGG_PLAN_LC_MFMA): the
-            // dense-tile MFMA consumers (8 + 4 waves)
-            const bool mfma_cons = (plan->flags & WAGG_PLAN_LC_MFMA) || edd || nfuse > 1;
             auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
-            if (mfma_cons) {
-                kern = vec ? sparse_lc_kernel<true, 1, false, true> : sparse_lc_kernel<false, 1, false, true>;
-                if (edd) kern = vec ? sparse_lc_kernel<true, 1, true, true> : sparse_lc_kernel<false, 1, true, true>;
-                if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2, false, true> : sparse_lc_kernel<false, 2, false, true>;
-                if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3, false, true> : sparse_lc_kernel<false, 3, false, true>;
-                if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4, false, true> : sparse_lc_kernel<false, 4, false, true>;
-            }
+            if (edd) kern = vec ? sparse_lc_kernel<true, 1, true> : sparse_lc_kernel<false, 1, true>;
+            if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
+            if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
+            if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
             // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
             const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)(xpow + nfuse - 1)) : 0.f;
             WAGG_HIP(allow_dynamic_lds((const void *)kern, LcLds::total));
             unsigned long long *lc_stamps = nullptr;
             if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
             profile_mark(stream, true);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3((unsigned)(mfma_cons ? LC_THREADS : lc_threads(1, false, false))), LcLds::total, stream, pv, X, Ttot, ldx,
+            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
                                plan->info.G, kout, kldo, n_norm, n_items, plan->timeout_dev, lc_stamps,
                                diag_env("WAGG_LC_KNOB"), kpstride, ylim);
             profile_mark(stream, false);
@@ -1536,13 +1794,11 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         const T *den;
         if constexpr (sizeof(T) == 4) den = d.den32.p; else den = d.den64.p;
         if (out_layout == WAGG_OUT_TR)
-            hipLaunchKernelGGL((combine_parts_kernel<T, true>), tg, dim3(256), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
-                               (const int32_t *)d.part_begin.p, (const int32_t *)d.part_rows.p, den, (int64_t)plan->info.R, Ttot,
-                               out + (int64_t)pz * pstride, ldo);
+            hipLaunchKernelGGL((combine_parts_kernel<T, true>), tg, dim3(CB_THREADS), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
+                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
         else
-            hipLaunchKernelGGL((combine_parts_kernel<T, false>), tg, dim3(256), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
-                               (const int32_t *)d.part_begin.p, (const int32_t *)d.part_rows.p, den, (int64_t)plan->info.R, Ttot,
-                               out + (int64_t)pz * pstride, ldo);
+            hipLaunchKernelGGL((combine_parts_kernel<T, false>), tg, dim3(CB_THREADS), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
+                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
         WAGG_HIP(hipGetLastError());
         continue;                             // (regions without rows came out as 0 / den there)
     }
@@ -1644,11 +1900,14 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             he = hipHostGetDevicePointer((void **)&plan->timeout_dev, plan->timeout_host, 0);
         }
         // one chunking of the table -> device arrays `d`; returns false when the whole-line chunking does not apply
-        auto build = [&](bool want_lines, SparsePlanDev &d) -> bool {
+        // (line_cells: 0 = region-shaped chunks; 32 / 16 = whole lines of that many cells, 128 bytes of a fp32 / fp64 row)
+        auto build = [&](int line_cells, SparsePlanDev &d) -> bool {
+        const bool want_lines = line_cells > 0;
         std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
         std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
         std::vector<double> seg_w;
-        std::vector<int32_t> part_begin, part_rows;                        // whole-line plan only
+        std::vector<int32_t> part_begin;                                   // whole-line plan only
+        int64_t n_part_rows = 0;
         std::vector<int32_t> empty;
         int64_t n_giant = 0;
         int band_rows = 8;
@@ -1663,7 +1922,8 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         // group of eight lines becomes several (chunk, region) ENTRIES, each a partial sum with a row of its own in the
         // partial buffer; combine_parts_kernel adds them up (1.6 rows per region on the 0.25-degree impact regions).
         // Taken when the grid's row length is known (whole rows of whole quads) and the table is compact enough.
-        constexpr int LINE = 32, LPC = UC / LINE;                          // cells per line, lines per chunk (8)
+        const int LINE = want_lines ? line_cells : 32;                     // cells per line
+        constexpr int LPC = 8;                                             // lines per chunk
         bool lines_plan = want_lines;
         if (lines_plan) {
             struct LSeg { int64_t line; int32_t region, col; double w; };
@@ -1682,15 +1942,18 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             std::vector<std::vector<int32_t>> parts((size_t)R);
             std::vector<int32_t> region_mark((size_t)R, -1);
             struct CSeg { int32_t region, ulocal; double w; };
-            std::vector<CSeg> cs;
+            // pass 1: form the chunks strip by strip
+            struct LChunk { int64_t key; std::vector<int32_t> quads; std::vector<CSeg> cs; };
+            std::vector<LChunk> chunks;
+            const int64_t n_strips = (row_len + LINE - 1) / LINE;
             size_t i = 0;
-            int64_t n_part = 0;
             while (i < ls.size() && lines_plan) {
                 // one chunk: lines of this strip while it holds < LPC lines, <= SEG_MAX segments, <= RG_MAX regions
                 const int64_t strip = ls[i].line / n_rows;
-                const int32_t chunk_id = (int32_t)(chunk_u_begin.size() - 1);
+                const int32_t chunk_id = (int32_t)chunks.size();
                 int n_lines = 0, n_regions = 0;
-                cs.clear();
+                LChunk ch;
+                ch.key = ((ls[i].line % n_rows) / LPC) * n_strips + strip;       // band of LPC grid rows, then strip
                 while (i < ls.size() && ls[i].line / n_rows == strip && n_lines < LPC) {
                     size_t j = i;                                          // the segments of the next line
                     int fresh = 0;
@@ -1698,9 +1961,9 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                         if (region_mark[(size_t)ls[j].region] != chunk_id) { region_mark[(size_t)ls[j].region] = chunk_id; ++fresh; }
                         ++j;
                     }
-                    if (n_lines > 0 && ((int64_t)cs.size() + (int64_t)(j - i) > SEG_MAX || n_regions + fresh > RG_MAX)) {
+                    if (n_lines > 0 && ((int64_t)ch.cs.size() + (int64_t)(j - i) > SEG_MAX || n_regions + fresh > RG_MAX)) {
                         for (size_t k = i; k < j; ++k) region_mark[(size_t)ls[k].region] = -1;   // (marks of the line not taken)
-                        for (const CSeg &c : cs) region_mark[(size_t)c.region] = chunk_id;
+                        for (const CSeg &c : ch.cs) region_mark[(size_t)c.region] = chunk_id;
                         break;
                     }
                     if ((int64_t)(j - i) > SEG_MAX || fresh > RG_MAX) { lines_plan = false; break; }   // one line alone is too much
@@ -1709,16 +1972,29 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                     for (int q = 0; q < LINE / 4; ++q) {                   // the line's quads; those behind the row end repeat its last
                         int64_t c0 = strip * LINE + 4 * q;
                         if (c0 + 4 > row_len) c0 = row_len - 4;
-                        ucell.push_back((int32_t)(row * row_len + c0));
+                        ch.quads.push_back((int32_t)(row * row_len + c0));
                     }
-                    for (size_t k = i; k < j; ++k) cs.push_back({ls[k].region, n_lines * LINE + ls[k].col, ls[k].w});
+                    for (size_t k = i; k < j; ++k) ch.cs.push_back({ls[k].region, n_lines * LINE + ls[k].col, ls[k].w});
                     ++n_lines;
                     i = j;
                 }
                 if (!lines_plan) break;
-                chunk_u_begin.push_back((int32_t)ucell.size());
-                std::sort(cs.begin(), cs.end(), [](const CSeg &a, const CSeg &b) {
+                std::sort(ch.cs.begin(), ch.cs.end(), [](const CSeg &a, const CSeg &b) {
                     return a.region != b.region ? a.region < b.region : a.ulocal < b.ulocal; });
+                chunks.push_back(std::move(ch));
+            }
+            // pass 2: flatten, in the order formed (strip-major: down one column strip, then the next).  Measured against
+            // band-major order (all strips of eight grid rows, then the next eight rows: neighbouring lines of the same
+            // DRAM pages in flight together) on c2-real / c3-real: 0.236 / 0.331 ms strip-major, 0.237 / 0.352 ms
+            // band-major (gpurun r3r) -- the diagnostic build keeps the switch
+            if (diag_env("WAGG_LINES_ORDER") == 2)
+                std::stable_sort(chunks.begin(), chunks.end(), [](const LChunk &a, const LChunk &b) { return a.key < b.key; });
+            int64_t n_part = 0;
+            for (const LChunk &ch : chunks) {
+                if (!lines_plan) break;
+                ucell.insert(ucell.end(), ch.quads.begin(), ch.quads.end());
+                chunk_u_begin.push_back((int32_t)ucell.size());
+                const std::vector<CSeg> &cs = ch.cs;
                 for (size_t k = 0; k < cs.size();) {
                     size_t m2 = k;
                     while (m2 < cs.size() && cs[m2].region == cs[k].region) {
@@ -1738,12 +2014,18 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             // over: such tables keep the region-shaped chunks (and usually take a dense-family form anyway)
             if (lines_plan && n_part > 4 * (int64_t)R + 1024) lines_plan = false;
             if (lines_plan) {
+                // partial rows are numbered region-major: region r owns rows part_begin[r] .. part_begin[r + 1] - 1 of the
+                // partial buffer, in chunk order, so the combine kernel streams the buffer front to back
                 part_begin.assign((size_t)R + 1, 0);
+                std::vector<int32_t> new_id((size_t)n_part, 0);
                 for (int32_t r = 0; r < R; ++r) {
                     part_begin[(size_t)r + 1] = part_begin[(size_t)r] + (int32_t)parts[(size_t)r].size();
-                    part_rows.insert(part_rows.end(), parts[(size_t)r].begin(), parts[(size_t)r].end());
+                    for (size_t j = 0; j < parts[(size_t)r].size(); ++j)
+                        new_id[(size_t)parts[(size_t)r][j]] = part_begin[(size_t)r] + (int32_t)j;
                     if (parts[(size_t)r].empty()) empty.push_back(r);
                 }
+                for (int32_t &e : ent_region) e = new_id[(size_t)e];
+                n_part_rows = n_part;
             } else {                                                        // start over with the region-shaped chunks
                 grp_chunk_begin.assign(1, 0); grp_giant.clear(); chunk_u_begin.assign(1, 0); chunk_e_begin.assign(1, 0);
                 ucell.clear(); ent_region.clear(); ent_seg_begin.assign(1, 0); seg_u.clear(); seg_w.clear();
@@ -1941,11 +2223,16 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
             plan->info.n_giant = n_giant;
             plan->info.n_empty = (int64_t)empty.size();
-        } else {
-            plan->info.lines = 1;
-            plan->info.n_partial_rows = (int64_t)part_rows.size();
+        } else if (line_cells == 32) {
+            plan->info.lines |= 1;
+            plan->info.n_partial_rows = n_part_rows;
             plan->info.lines_chunks = (int64_t)chunk_u_begin.size() - 1;
             plan->info.lines_ucells = (int64_t)ucell.size() * 4;
+        } else {
+            plan->info.lines |= 2;
+            plan->info.n_partial_rows64 = n_part_rows;
+            plan->info.lines64_chunks = (int64_t)chunk_u_begin.size() - 1;
+            plan->info.lines64_ucells = (int64_t)ucell.size() * 4;
         }
         int64_t l128s = 0, s64s = 0;
         for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c) {      // locality statistics of the gather
@@ -1958,12 +2245,12 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
         }
         if (!want_lines) { plan->info.n_lines128 = l128s; plan->info.n_sectors64 = s64s; }
-        else plan->info.lines_lines128 = l128s;
+        else if (line_cells == 32) plan->info.lines_lines128 = l128s;
 #ifdef WAGG_DIAG
         if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
-            fprintf(stderr, "[wagg plan] lines=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
-                    (int)lines_plan, band_rows, (long long)chunk_u_begin.size() - 1, (long long)grp_giant.size(), (long long)n_giant,
-                    (long long)ucell.size() * 4, (long long)l128s, (long long)s64s, (long long)nnz, (long long)part_rows.size());
+            fprintf(stderr, "[wagg plan] line_cells=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
+                    lines_plan ? line_cells : 0, band_rows, (long long)chunk_u_begin.size() - 1, (long long)grp_giant.size(), (long long)n_giant,
+                    (long long)ucell.size() * 4, (long long)l128s, (long long)s64s, (long long)nnz, (long long)n_part_rows);
 #endif
         std::vector<float> seg_w32(seg_w.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
@@ -1982,18 +2269,20 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
             up(d.ent_den64, ed64); up(d.ent_den32, ed32);
         }
-        if (lines_plan) { up(d.part_begin, part_begin); up(d.part_rows, part_rows); d.n_part = (int64_t)part_rows.size(); }
+        if (lines_plan) { up(d.part_begin, part_begin); d.n_part = n_part_rows; }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         d.n_groups = (int64_t)grp_giant.size(); d.n_empty = (int64_t)empty.size();
         return true;
         };   // build
 
-        build(false, plan->d);
+        build(0, plan->d);
         // the whole-line chunking as well, for the kernel that is bound by line requests; its extra bytes (ocean cells of
         // coastal lines) cost the other kernels more than the aligned lines save them (c3, fp64: 0.47 -> 0.52 ms)
         if (!(flags & (WAGG_PLAN_NO_LINES | WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) && row_len < G && G % row_len == 0 &&
-            row_len % 4 == 0 && nnz > 0 && he == hipSuccess)
-            plan->has_lines = build(true, plan->dl);
+            row_len % 4 == 0 && nnz > 0 && he == hipSuccess) {
+            plan->has_lines = build(32, plan->dl);
+            if (he == hipSuccess) plan->has_lines64 = build(16, plan->dl64);
+        }
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));
             return WAGG_EHIP;                                         // (plan_guard deletes the plan)

@@ -62,14 +62,18 @@ typedef struct wagg_plan_info {
     int64_t n_empty;     /* regions with no kept segment (result 0/den)                          */
     int64_t G;
     int32_t R;
-    int32_t lines;       /* 1: the plan also holds the whole-line chunking (used by the fp32 (time, gridcell) loader/consumer kernel) */
+    int32_t lines;       /* bit 0: the plan also holds the whole-line chunking for fp32 (time, gridcell) data (lines of 32 cells);
+                            bit 1: the one for fp64 data (lines of 16 cells).  Both serve the loader/consumer kernel.             */
     int64_t n_lines128;  /* sum over chunks of distinct 128-byte lines (32 fp32 cells) their quads touch */
     int64_t n_sectors64; /* ... of distinct 64-byte sectors */
-    /* whole-line chunking (lines == 1, else 0): chunks of eight whole 32-cell lines of one column strip */
+    /* whole-line chunkings (else 0): chunks of eight whole 128-byte lines (32 fp32 / 16 fp64 cells) of one column strip */
     int64_t n_partial_rows; /* (chunk, region) partial sums = rows of the partial buffer that combine_parts_kernel adds up */
     int64_t lines_chunks;   /* its chunks                                                                               */
     int64_t lines_ucells;   /* cells it fetches per timestep (every line whole, each exactly once)                      */
     int64_t lines_lines128; /* distinct 128-byte lines per timestep (= lines_ucells / 32 on grids of whole lines)       */
+    int64_t n_partial_rows64; /* the same three for the fp64 chunking (16-cell lines)                                   */
+    int64_t lines64_chunks;
+    int64_t lines64_ucells;
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */

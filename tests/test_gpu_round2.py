@@ -338,8 +338,8 @@ def test_plan_flags_pin_the_kernel_form(torch_cuda):
 @pytest.mark.parametrize("nlat,nlon", [(96, 192), (61, 100), (40, 36)])
 def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda, nlat, nlon):
     """the whole-line chunking (chunks of eight 32-cell lines of one column strip, (chunk, region)
-    partial rows, combine kernel) is what fp32 (time, gridcell) applies of a compact table on a grid of known row length
-    use; every other apply, and every apply under WAGG_PLAN_NO_LINES, uses the region-shaped chunks.  Both against the
+    partial rows, combine kernel; 16-cell lines for fp64) is what plain (time, gridcell) applies of a compact table on a
+    grid of known row length use; every other apply, and every apply under WAGG_PLAN_NO_LINES, uses the region-shaped chunks.  Both against the
     fp64 oracle and each other: fp32 and fp64, (time, gridcell) and (gridcell,
     time) data, both result layouts, ragged T, fused powers and degree days, NaN data, rows whose length is not a
     whole number of lines, a split cell, a null label, a region without rows."""
@@ -357,18 +357,24 @@ def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda,
     for dtype, rtol in ((np.float32, RTOL32), (np.float64, RTOL64)):
         X = (280 + 15 * rng.standard_normal((135, G))).astype(dtype)
         X[7, cell[11]] = np.nan
+        Xi = X.copy()
+        Xi[9, cell[20]], Xi[70, cell[31]] = np.inf, -np.inf         # +-inf data: the consumers' general form (S6)
+        refi = O.agg_coded(Xi, cell, code, w, R)
         ref = O.agg_coded(X, cell, code, w, R)
         Xd = torch.from_numpy(X).cuda()
         XT = torch.from_numpy(np.ascontiguousarray(X[:50].T)).cuda()
         got = {}
         for flags in (0, _lib.PLAN_NO_LINES):
             plan = SparsePlan(cell, code, w, G, R, row_len=nlon, flags=flags)
-            assert plan.info["lines"] == (1 if flags == 0 else 0)
+            assert plan.info["lines"] == (3 if flags == 0 else 0)       # the fp32 and the fp64 whole-line chunking, or neither
             if flags == 0:
                 assert plan.info["n_partial_rows"] >= len(uniq) - 1 and plan.info["lines_chunks"] > 0
+                assert plan.info["n_partial_rows64"] >= plan.info["n_partial_rows"] and plan.info["lines64_chunks"] >= plan.info["lines_chunks"]
+                assert plan.info["lines64_ucells"] <= plan.info["lines_ucells"]    # 16-cell lines carry fewer ocean cells along
                 assert plan.info["lines_lines128"] * 8 == plan.info["lines_ucells"] // 4 or nlon % 32    # every quad of a line, each line once
             g = plan.apply(Xd).cpu().numpy()
             _rel_ok(g, ref, rtol)
+            _rel_ok(plan.apply(torch.from_numpy(Xi).cuda()).cpu().numpy(), refi, rtol)
             np.testing.assert_array_equal(plan.apply(Xd, out_layout="RT").cpu().numpy(), g.T)
             gt = plan.apply(XT, layout="GT", out_layout="RT").cpu().numpy()
             _rel_ok(gt, ref[:50].T, rtol)
