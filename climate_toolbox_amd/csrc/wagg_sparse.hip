@@ -1154,10 +1154,13 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 // ---------------------------------------------------------------------------------------------
 constexpr int LV_LW = 8, LV_CW = 8, LV_THREADS = (LV_LW + LV_CW) * 64, LV_TB = 64;
 constexpr int LV_ROWB = 1024;                   // bytes of an image row: 256 floats / 128 doubles = the cells of a chunk
-template <typename T> struct LvLds {
+template <typename T, int NPOW = 1> struct LvLds {
+    static constexpr int E = 16 / (int)sizeof(T);                               // elements of a 16-byte piece
+    static constexpr int scr_rows = NPOW > E ? NPOW : E;                        // result rows (entry, power) of one batch
+    static constexpr size_t scr_wave = (size_t)scr_rows * 64 * sizeof(T);       // 1 KiB (2 KiB: fp64 with 3 or 4 powers)
     static constexpr size_t img = 0;                                            // [2][64][1024 B]
-    static constexpr size_t scr = img + 2 * (size_t)LV_TB * LV_ROWB;            // [8 consumer waves][1 KiB] result scratch
-    static constexpr size_t seg_w = scr + LV_CW * 1024;                         // [2][LC_SEGS] T
+    static constexpr size_t scr = img + 2 * (size_t)LV_TB * LV_ROWB;            // [8 consumer waves][scr_wave] result scratch
+    static constexpr size_t seg_w = scr + LV_CW * scr_wave;                     // [2][LC_SEGS] T
     static constexpr size_t seg_u = seg_w + 2 * sizeof(T) * LC_SEGS;            // [2][LC_SEGS] i32 (packed)
     static constexpr size_t ent_r = seg_u + 2 * sizeof(int32_t) * LC_SEGS;      // [2][LC_ENT] i32
     static constexpr size_t ent_d = ent_r + 2 * sizeof(int32_t) * LC_ENT;       // [2][LC_ENT] T
@@ -1167,11 +1170,19 @@ template <typename T> struct LvLds {
     static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
 };
 
-template <typename T, bool VEC>
+// NPOW > 1 (fused tas_poly): the loaders park y = x + pv.xoff; the consumers raise every value they read to
+// the powers pv.xpow .. pv.xpow + NPOW - 1 and keep NPOW sums per entry, so X is read once for NPOW powers; power i goes
+// to out + i * out_pstride.  fp32 consumers take the segments two at a time through the packed instructions (v_pk_mul_f32 /
+// v_pk_fma_f32: two partial sums per power, added at the end).  Only real (cell, region) pairs are multiplied, so a power
+// that overflows gives +-inf as it does in the reference (transformations.py:188 then aggregations.py:78); what needs
+// the general form is a NaN PRODUCT (inf times a zero weight), hence the loaders also flag |y| >= ylim, the largest
+// value whose highest power is finite.
+template <typename T, bool VEC, int NPOW = 1>
 __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot,
                                                                 int64_t ldx, int64_t G, T *__restrict__ out, int64_t ldo,
                                                                 int n_norm, long long n_items,
-                                                                unsigned long long *__restrict__ stamps_arg, int knob_arg) {
+                                                                unsigned long long *__restrict__ stamps_arg, int knob_arg,
+                                                                int64_t out_pstride = 0, T ylim = T(0)) {
 #ifdef WAGG_DIAG
     const int knob = knob_arg;                       // ablation switches / phase stamps: diagnostic build only
     unsigned long long *const stamps = stamps_arg;
@@ -1185,7 +1196,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     typedef T vecE __attribute__((ext_vector_type(E)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    using L = LvLds<T>;
+    using L = LvLds<T, NPOW>;
     char *img = smem_raw + L::img;
     T *sm_w = reinterpret_cast<T *>(smem_raw + L::seg_w);
     int32_t *sm_u = reinterpret_cast<int32_t *>(smem_raw + L::seg_u);
@@ -1198,7 +1209,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave < LV_LW;
-    const bool out_vec = (ldo % E == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const bool out_vec = (ldo % E == 0) && (out_pstride % E == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     // XCD-contiguous ids (speed only)
     const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
@@ -1231,7 +1242,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
             const int4v x = *reinterpret_cast<const int4v *>(p);
             const int4v y = *reinterpret_cast<const int4v *>(p + 4);
-            d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
+            // (wave-uniform: into scalar registers, the descriptors of three items are live at any time)
+            d.u0 = __builtin_amdgcn_readfirstlane(x[0]); d.nq = __builtin_amdgcn_readfirstlane(x[1]);
+            d.e0 = __builtin_amdgcn_readfirstlane(x[2]); d.ne = __builtin_amdgcn_readfirstlane(x[3]);
+            d.sb = __builtin_amdgcn_readfirstlane(y[0]); d.ns = __builtin_amdgcn_readfirstlane(y[1]); d.split = 0;
         };
         // first cell of this lane's 16 bytes: quad lane / LPQ of the chunk (clamped), half lane % LPQ of it
         auto load_cell = [&](const StreamDesc &d) {
@@ -1270,7 +1284,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
             char *im = img + (size_t)buf * LV_TB * LV_ROWB;
             bool odd = false;
-            if (pv.xpow > 0) {                                    // (x + xoff)^xpow on the way in (transformations.py:188)
+            if (NPOW > 1) {                                       // the consumers raise y = x + xoff to the powers
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) R.v[i] = R.v[i] + pv.xoff;
+            } else if (pv.xpow > 0) {                             // (x + xoff)^xpow on the way in (transformations.py:188)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -1279,8 +1296,9 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
-                for (int c = 0; c < E; ++c) {                     // one v_cmp_class per element: sNaN | qNaN | -inf | +inf
-                    if constexpr (sizeof(T) == 4) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);
+                for (int c = 0; c < E; ++c) {
+                    if (NPOW > 1) odd |= !(__builtin_fabs(R.v[i][c]) < ylim);             // NaN, +-inf, or a power overflows
+                    else if constexpr (sizeof(T) == 4) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN | qNaN | -inf | +inf
                     else odd |= __builtin_amdgcn_class(R.v[i][c], 0x207);
                 }
             bool inf_any = false;
@@ -1291,7 +1309,8 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
 #pragma unroll
                     for (int c = 0; c < E; ++c) {
                         const T x = R.v[i][c];
-                        inf_seen |= __builtin_isinf(x);                            // the consumers then take the general form
+                        if (NPOW > 1) inf_seen |= __builtin_fabs(x) >= ylim;       // the consumers then take the general form
+                        else inf_seen |= __builtin_isinf(x);
                         R.v[i][c] = (x == x) ? x : T(0);                           // NaN data counts 0 (S6)
                     }
                 inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
@@ -1364,16 +1383,19 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     } else {
         // ==================== consumer waves: lane = timestep, wave cw takes entries cw, cw + 8, ... ====================
         const int cw = wave - LV_LW;
-        constexpr int EPB = E;                                    // entries per result batch = per 16-byte-per-lane store
-        constexpr int LPE = 64 / E;                               // lanes per entry of that store
-        T *scr = reinterpret_cast<T *>(smem_raw + L::scr + cw * 1024);
-        // this lane's image row, with the swizzle folded in: element u sits at rowoff ^ (u * sizeof(T))
+        constexpr int EPB = E / NPOW > 0 ? E / NPOW : 1;          // entries per result batch
+        constexpr int ROWS = EPB * NPOW;                          // its rows (entry, power): E per 16-byte-per-lane store
+        constexpr int LPE = 64 / E;                               // lanes per row of that store
+        T *scr = reinterpret_cast<T *>(smem_raw + L::scr + cw * L::scr_wave);
         // (LDS addresses as plain integers: the low half of a generic pointer into LDS is its LDS address; the image starts
         // at a multiple of its row size -- at 0 in fact, the kernel has no static LDS -- so the XOR stays inside the row)
         typedef const T __attribute__((address_space(3))) *lds_cptr;
         const unsigned img0 = (unsigned)reinterpret_cast<uintptr_t>(img);
         if (img0 & (LV_ROWB - 1)) __builtin_trap();
+        // this lane's image row, with the swizzle folded in: element u sits at rowoff ^ (u * sizeof(T))
         const unsigned rowoff = img0 + ((unsigned)lane * LV_ROWB | ((unsigned)lane * (unsigned)sizeof(T)));
+        typedef T pair2 __attribute__((ext_vector_type(2)));
+        constexpr bool PK = NPOW > 1 && sizeof(T) == 4;           // fp32 powers: two segments per packed instruction
         for (int st = 0; st < nst; ++st) {
             stamp(-1);
             lds_only_barrier();                                   // stage st has been parked
@@ -1384,7 +1406,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LV_TB;
             const int nt = (int)((Ttot - t0) < LV_TB ? (Ttot - t0) : LV_TB);
             const int fl = lane < LV_LW ? hdr[buf * 16 + 8 + lane] : 0;
-            const bool odd = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);   // +-inf somewhere in the item
+            const bool odd = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);   // +-inf (or an overflowing power) in the item
             if (knob & 1) continue;                               // (diagnostic build: consumers idle)
             // ODD (decided once per item, so the segment loop is branch-free): the general form in which a NaN product
             // counts 0 (S6: +-inf data times a zero weight)
@@ -1397,7 +1419,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                         if (e >= ne) break;
                         const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e]);
                         const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e + 1]);
-                        T acc = T(0);
+                        T acc[NPOW];
+                        pair2 acc2[NPOW];
+#pragma unroll
+                        for (int pw = 0; pw < NPOW; ++pw) { acc[pw] = T(0); acc2[pw] = pair2{T(0), T(0)}; }
                         for (int base = (knob & 256) ? s1 : s0; base < s1; base += 64) {
                             // lane j holds segment base + j (padding lanes: cell 0, weight 0: they add exactly 0 to finite data)
                             const int n = s1 - base < 64 ? s1 - base : 64;
@@ -1421,31 +1446,61 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                     xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (PK && !ODD) {
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) {
-                                    if constexpr (ODD) {
-                                        const T p = xv[j] * wv[j];
-                                        acc += (p == p) ? p : T(0);
-                                    } else {
-                                        if constexpr (sizeof(T) == 4) acc = __builtin_fmaf(xv[j], wv[j], acc);   // aggregations.py:78
-                                        else acc = __builtin_fma(xv[j], wv[j], acc);
+                                    for (int j = 0; j < 8; j += 2) {
+                                        const pair2 y = pair2{xv[j], xv[j + 1]}, w2 = pair2{wv[j], wv[j + 1]};
+                                        pair2 yp = y;
+                                        for (int i = 1; i < pv.xpow; ++i) yp *= y;                       // first power of this pass
+#pragma unroll
+                                        for (int pw = 0; pw < NPOW; ++pw) {
+                                            if (pw) yp *= y;
+                                            acc2[pw] = __builtin_elementwise_fma(yp, w2, acc2[pw]);
+                                        }
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) {
+                                        T yp = xv[j];
+                                        if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) yp *= xv[j];     // first power of this pass
+#pragma unroll
+                                        for (int pw = 0; pw < NPOW; ++pw) {
+                                            if (pw) yp *= xv[j];
+                                            if constexpr (ODD) {
+                                                const T p = yp * wv[j];
+                                                acc[pw] += (p == p) ? p : T(0);
+                                            } else if constexpr (sizeof(T) == 4) {
+                                                acc[pw] = __builtin_fmaf(yp, wv[j], acc[pw]);           // aggregations.py:78
+                                            } else {
+                                                acc[pw] = __builtin_fma(yp, wv[j], acc[pw]);
+                                            }
+                                        }
                                     }
                                 }
                             }
                         }
-                        scr[kb * 64 + lane] = acc / sm_ed[buf * LC_ENT + e];                       // :77-80
+                        const T dn = sm_ed[buf * LC_ENT + e];
+#pragma unroll
+                        for (int pw = 0; pw < NPOW; ++pw) {
+                            if constexpr (PK && !ODD) acc[pw] = acc2[pw][0] + acc2[pw][1];
+                            scr[(kb * NPOW + pw) * 64 + lane] = acc[pw] / dn;                    // :77-80
+                        }
                     }
                     // (LDS operations of one wave execute in order: the reads below see the writes above)
-                    const int kq = lane / LPE, piece = lane % LPE;
-                    const int e = eb + kq * LV_CW, tl = E * piece;
-                    if (e < ne && tl < nt && !(knob & 128)) {
-                        T *op = out + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
-                        const vecE qv = *reinterpret_cast<const vecE *>(&scr[kq * 64 + tl]);
-                        if (out_vec && tl + E - 1 < nt) {
-                            *reinterpret_cast<vecE *>(op) = qv;
-                        } else {
 #pragma unroll
-                            for (int rg = 0; rg < E; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                    for (int pass = 0; pass < (ROWS + E - 1) / E; ++pass) {
+                        const int row = pass * E + lane / LPE, piece = lane % LPE;
+                        const int kq = row / NPOW, pw = row % NPOW;
+                        const int e = eb + kq * LV_CW, tl = E * piece;
+                        if (row < ROWS && e < ne && tl < nt && !(knob & 128)) {
+                            T *op = out + (int64_t)pw * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
+                            const vecE qv = *reinterpret_cast<const vecE *>(&scr[row * 64 + tl]);
+                            if (out_vec && tl + E - 1 < nt) {
+                                *reinterpret_cast<vecE *>(op) = qv;
+                            } else {
+#pragma unroll
+                                for (int rg = 0; rg < E; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
+                            }
                         }
                     }
                 }
@@ -1594,13 +1649,15 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // (the fused powers and degree days keep the round-2 configuration -- region-shaped chunks, dense-tile MFMA consumers,
     // which reduce four planes in one pass: measured with whole lines + vector-ALU consumers they were slower, 0.55 vs
     // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
-    const bool use_lines = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG && nfuse == 1 &&
-                           xpow != XF_EDD;
+    const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
+    const bool use_lines = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG && xpow != XF_EDD &&
+                           (nfuse == 1 || (nfuse <= 4 && !lcv_off));
     const auto &d = use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d;
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
-        const bool lc_ok = sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
-                           (int)d.n_groups - d.g0_normal > 0 && Ttot > 0;
+        // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
+        const bool lc_ok = layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
+                           (int)d.n_groups - d.g0_normal > 0 && Ttot > 0 && (sizeof(T) == 4 || (use_lines && !lcv_off));
         if (!lc_ok || nfuse > 4) {
             for (int i = 0; i < nfuse; ++i) {
                 const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
@@ -1660,18 +1717,24 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
     // whole-line chunking only (a region-shaped chunk of 64 quads is 2 KiB of a fp64 row: twice the image row)
-    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && !edd && nfuse == 1 &&
+    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && !edd && nfuse <= 4 &&
         (sizeof(T) == 4 || lines)) {
         const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * ((Ttot + LV_TB - 1) / LV_TB);
         const long long nw = n_items < ncu ? n_items : ncu;
         auto kern = vec ? sparse_lcv_kernel<T, true> : sparse_lcv_kernel<T, false>;
-        WAGG_HIP(allow_dynamic_lds((const void *)kern, LvLds<T>::total));
+        size_t lds_bytes = LvLds<T>::total;
+        if (nfuse == 2) { kern = vec ? sparse_lcv_kernel<T, true, 2> : sparse_lcv_kernel<T, false, 2>; lds_bytes = LvLds<T, 2>::total; }
+        if (nfuse == 3) { kern = vec ? sparse_lcv_kernel<T, true, 3> : sparse_lcv_kernel<T, false, 3>; lds_bytes = LvLds<T, 3>::total; }
+        if (nfuse == 4) { kern = vec ? sparse_lcv_kernel<T, true, 4> : sparse_lcv_kernel<T, false, 4>; lds_bytes = LvLds<T, 4>::total; }
+        // |y| below this can be raised to the highest power of the pass inside T
+        const T ylim = nfuse > 1 ? (T)std::pow((double)std::numeric_limits<T>::max() / 1024.0, 1.0 / (double)(xpow + nfuse - 1)) : T(0);
+        WAGG_HIP(allow_dynamic_lds((const void *)kern, lds_bytes));
         unsigned long long *lc_stamps = nullptr;
         if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
         profile_mark(stream, true);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LV_THREADS), LvLds<T>::total, stream, pv, X, Ttot, ldx,
-                           plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LV_THREADS), lds_bytes, stream, pv, X, Ttot, ldx,
+                           plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
         profile_mark(stream, false);
         WAGG_HIP(hipGetLastError());
         if (lc_stamps) {          // diagnostic: mean cycles per stage and phase

@@ -46,7 +46,7 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
 
 def mean(kernel_sub, counter):
     """mean counter value per launch of the kernel.  c1 and c3-real run the SAME instantiation
-    (sparse_stream_kernel<double>): "<name>#big" / "<name>#small" select the launches above / below half of the
+    (sparse_lcv_kernel<double, true, 1>): "<name>#big" / "<name>#small" select the launches above / below half of the
     largest value (c3: 1M cells, c1: 16,200)."""
     pick = None
     if "#" in kernel_sub:
@@ -69,12 +69,13 @@ if os.path.exists(tr):
         dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     rows = []
     for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share)", "dense_mfma_kernel<float, 0, false, 22, true"),
-                     ("c2-real", "sparse_lc_kernel<true, 1, false, false>"), ("c3-real", "sparse_stream_kernel<double#big"),
-                     ("c1", "sparse_stream_kernel<double#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
+                     ("c2-real", "sparse_lcv_kernel<float, true, 1>"), ("c3-real", "sparse_lcv_kernel<double, true, 1>#big"),
+                     ("c1", "sparse_lcv_kernel<double, true, 1>#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
                      ("c5-block-f64", "dense_mfma_kernel<double, 0, true"), ("c5-uniform", "spmm_kernel<float>"),
-                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lc_kernel<true, 4, false, true>"),
-                     ("c2-real fused snyder_edd (K = 1 and K = 3 launches)", "sparse_lc_kernel<true, 1, true, true>"),
-                     ("c2-real combine + transpose", "combine_parts_kernel<float, true>")):
+                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4>"),
+                     ("c2-real fused snyder_edd (K = 1 and K = 3 launches)", "sparse_lc_kernel<true, 1, true>"),
+                     ("c2-real combine + transpose", "combine_parts_kernel<float, true>"),
+                     ("c3-real combine + transpose (and c1's)", "combine_parts_kernel<double, true>")):
         pick = None
         if "#" in ksub:
             ksub, pick = ksub.split("#")
@@ -99,10 +100,10 @@ WIDE = ("FETCH_SIZE x2 (gfx950 tallies the 128-B requests of a 16-B/lane contigu
 GATHER = ("FETCH_SIZE x1: calibrated on the segment-table gather in round 1 with every grid cell referenced (land_frac=1.0): "
           "raw 1.567 GB vs 1.514 GB of X, TCC_EA0_RDREQ x 64 B = 1.567 GB; WRITE_SIZE exact")
 LINES = ("whole-line chunks: every load instruction reads eight whole 128-B lines, i.e. the wide coalesced case: FETCH_SIZE x2 if "
-         "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T, in the bench line's plan), x1 if it matches "
-         "them: see `calibration`; WRITE_SIZE exact")
+         "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T for fp32, lines64_ucells x 8 B x T for fp64, in "
+         "the bench line's plan), x1 if it matches them: see `calibration`; WRITE_SIZE exact")
 for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
-                       ("c2-real", "sparse_lc_kernel<true, 1, false, false>", "lines"), ("c3-real", "sparse_stream_kernel<double#big", "gather64"),
+                       ("c2-real", "sparse_lcv_kernel<float, true, 1>", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1>#big", "lines64"),
                        ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
@@ -111,20 +112,15 @@ for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wi
     factor = 1.0 if mode == "gather" else 2.0      # gather64: see below
     entry = {"fetch_size_kib_raw": fs, "write_size_kib_raw": ws, "source": "profiles/%s_pmc.csv" % tag,
              "measured": "round %d" % int(tag.lstrip("r"))}
-    if mode == "lines":
-        # known bytes of the whole-line gather: 20,607 lines x 128 B x 365 rows for c2-real (bench line: plan.lines_ucells)
-        known = float(os.environ.get("LINES_BYTES", "0")) or None
+    if mode in ("lines", "lines64"):
+        # known bytes of the whole-line gather: 20,607 lines x 128 B x 365 rows for c2-real (bench line: plan.lines_ucells),
+        # 30,527 x 128 B x 365 for c3-real (plan.lines64_ucells)
+        known = float(os.environ.get("LINES_BYTES" if mode == "lines" else "LINES64_BYTES", "0")) or None
         if known:
             factor = 2.0 if fs * 1024 < 0.75 * known else 1.0
             entry["calibration"] = {"lines_bytes": known, "raw_over_lines": fs * 1024 / known, "factor": factor}
     entry["hbm_bytes_per_launch"] = factor * fs * 1024 + ws * 1024
-    if mode == "gather64":
-        # fp64 quads are 32 bytes per lane (two 16-byte loads): the raw figure is below the bytes of the quads the plan lists
-        # (n_ucells x 8 B x T = 1.36 GB for c3-real), so the x1 calibration of the fp32 gather does not carry over; x2 is
-        # reported as an upper bound
-        entry["needed_bytes"] = float(os.environ.get("C3_QUAD_BYTES", "0")) or None
-    entry["correction"] = {"wide": WIDE, "gather": GATHER, "lines": LINES, "gather64": "FETCH_SIZE x2 (an upper bound: 32 bytes per lane "
-                           "as two 16-byte loads; uncalibrated), WRITE_SIZE exact"}[mode] if not wl.startswith("c5-uniform") else (
+    entry["correction"] = {"wide": WIDE, "gather": GATHER, "lines": LINES, "lines64": LINES}[mode] if not wl.startswith("c5-uniform") else (
         "FETCH_SIZE x2 applied to the whole figure: exact for the X tiles and the weight lists (16-B/lane LDS-DMA), an upper bound for "
         "the lo16 pair lists (4-B/lane loads, uncalibrated)")
     traffic[wl] = entry
