@@ -1964,7 +1964,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         }
         // one chunking of the table -> device arrays `d`; returns false when the whole-line chunking does not apply
         // (line_cells: 0 = region-shaped chunks; 32 / 16 = whole lines of that many cells, 128 bytes of a fp32 / fp64 row)
-        auto build = [&](int line_cells, SparsePlanDev &d) -> bool {
+        auto build = [&](int line_cells, int lines_per_chunk, bool for_f64, SparsePlanDev &d) -> bool {
         const bool want_lines = line_cells > 0;
         std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
         std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
@@ -1986,7 +1986,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         // partial buffer; combine_parts_kernel adds them up (1.6 rows per region on the 0.25-degree impact regions).
         // Taken when the grid's row length is known (whole rows of whole quads) and the table is compact enough.
         const int LINE = want_lines ? line_cells : 32;                     // cells per line
-        constexpr int LPC = 8;                                             // lines per chunk
+        const int LPC = lines_per_chunk;                                   // lines per chunk
         bool lines_plan = want_lines;
         if (lines_plan) {
             struct LSeg { int64_t line; int32_t region, col; double w; };
@@ -2286,7 +2286,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
             plan->info.n_giant = n_giant;
             plan->info.n_empty = (int64_t)empty.size();
-        } else if (line_cells == 32) {
+        } else if (!for_f64) {
             plan->info.lines |= 1;
             plan->info.n_partial_rows = n_part_rows;
             plan->info.lines_chunks = (int64_t)chunk_u_begin.size() - 1;
@@ -2308,7 +2308,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
         }
         if (!want_lines) { plan->info.n_lines128 = l128s; plan->info.n_sectors64 = s64s; }
-        else if (line_cells == 32) plan->info.lines_lines128 = l128s;
+        else if (!for_f64) plan->info.lines_lines128 = l128s;
 #ifdef WAGG_DIAG
         if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
             fprintf(stderr, "[wagg plan] line_cells=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
@@ -2338,13 +2338,22 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         return true;
         };   // build
 
-        build(0, plan->d);
+        build(0, 0, false, plan->d);
         // the whole-line chunking as well, for the kernel that is bound by line requests; its extra bytes (ocean cells of
         // coastal lines) cost the other kernels more than the aligned lines save them (c3, fp64: 0.47 -> 0.52 ms)
         if (!(flags & (WAGG_PLAN_NO_LINES | WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) && row_len < G && G % row_len == 0 &&
             row_len % 4 == 0 && nnz > 0 && he == hipSuccess) {
-            plan->has_lines = build(32, plan->dl);
-            if (he == hipSuccess) plan->has_lines64 = build(16, plan->dl64);
+            // (diagnostic build: WAGG_LINE_MULT = 2, 4, 8 makes the lines that many times longer and the chunk that many
+            // times flatter -- 8 lines x 128 bytes by default, 1 x 1 KiB at the other end)
+            int mult = diag_env("WAGG_LINE_MULT");
+            if (mult != 2 && mult != 4 && mult != 8) mult = 1;
+            if (diag_env("WAGG_LINE_MULT") == 16) {                      // ... and 16: half lines (64 bytes), 16 per chunk
+                plan->has_lines = build(16, 16, false, plan->dl);
+                if (he == hipSuccess) plan->has_lines64 = build(8, 16, true, plan->dl64);
+            } else {
+            plan->has_lines = build(32 * mult, 8 / mult, false, plan->dl);
+            if (he == hipSuccess) plan->has_lines64 = build(16 * mult, 8 / mult, true, plan->dl64);
+            }
         }
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));
