@@ -14,28 +14,39 @@ Entry lists (round 3 format).  A group of 8 entries is stored as
     [4 x (lo16 of entry 2p | lo16 of entry 2p + 1 << 16)] [8 x weight]            fp32: 48 bytes
     [4 x lo16 pairs] [8 x weight (double)]                                        fp64: 80 bytes
 with lo16 = cell_in_chunk << 9 | accumulator register offset (2 j).  One v_readlane brings the lo16 of TWO
-entries into an SGPR (the odd entry takes `s_lshr_b32 ..., 16`, a scalar instruction), so an entry costs
-1.5 v_readlane (fp64: 2.5) + v_bfi (LDS address) + ds_read_b64 + s_set_gpr_idx_idx + ONE v_pk_fma_f32 /
-v_fma_f64 whose accumulator pair the entry itself names through the VGPR index mode; one s_waitcnt per
-half-group of four entries.  (Round 2: [8 x lo32][8 x weight], two v_readlane and a wait per entry.)
+entries into an SGPR (the odd entry takes `s_lshr_b32 ..., 16`, a scalar instruction).  The WEIGHTS of a list never
+pass through SGPRs: the 16 groups a wave loads per chunk go to the wave's own LDS slots by LDS-DMA (one
+global_load_lds_dwordx4: fp32 lanes 0-31, 16 bytes = four weights each; fp64 all lanes, two doubles each) together
+with the next chunk's X tile, and come back as BROADCAST reads (every lane the same address, conflict-free): one
+ds_read_b128 per half-group of four entries in fp32 (two in fp64).  So an entry costs
+    0.5 v_readlane + v_bfi (LDS address of its cell) + ds_read_b64 (X) + 0.25 ds_read_b128 (weights; fp64 0.5)
+    + s_set_gpr_idx_idx + ONE v_pk_fma_f32 (weight = half of a VGPR pair picked by op_sel) / v_fma_f64
+whose accumulator pair the entry itself names through the VGPR index mode; one s_waitcnt per half-group.
+(Round 2: [8 x lo32][8 x weight], weights through v_readlane: two v_readlane and a wait per entry, 53.2 ms on
+c5-uniform; this format 46.4 ms -- profiles/r03_spmm_ablation_a.txt / _b.txt.)  `SPMM_ABL=wreg` generates the
+intermediate form with the weights in registers + v_readlane (ablation only).
 
-SPMM_LOAD_LIST_ASM_*     (item prologue) per-lane constants + the first chunk's list into register set A.
+SPMM_LOAD_LIST_ASM_*     (item prologue) per-lane constants + the first chunk's list (lo16 pairs -> set A, weights ->
+                         LDS weight buffer 0).
 SPMM_CHUNK_ASM_A_* / _B_*  one wave, one chunk whose X tile is already in LDS, the list of THIS chunk in
-                         set A (B), in order:
-  1. issues the loads of the NEXT chunk's list into the other set (consumed by the next statement: the
-     C++ between two statements is scalar-only, which tools/check_spmm_codegen.py verifies on the
-     compiled kernels) and the 4 LDS-DMA pieces of the next chunk's X tile -- all retired by the
-     `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
-  2. the entries, half-group h + 1's reads in flight while half-group h is accumulated;
-  3. lists longer than 16 groups (never at 1 % fill) finish in a one-group-at-a-time loop.
+                         set A (B) / weight buffer 0 (1), in order:
+  1. issues the loads of the NEXT chunk's list (pairs into the other set, weights into the other weight buffer;
+     consumed by the next statement: the C++ between two statements is scalar-only, which
+     tools/check_spmm_codegen.py verifies on the compiled kernels) and the 4 LDS-DMA pieces of the next chunk's X
+     tile -- all retired by the `s_waitcnt vmcnt(0)` + barrier that ends the chunk;
+  2. the entries, half-group h + 1's reads in flight while half-group h is accumulated (fp64 has ONE weight register
+     set: the weights of h + 1 are read behind the FMAs of h);
+  3. lists longer than 16 groups (never at 1 % fill; a 9.5 % table has them) finish in a one-group-at-a-time loop
+     with the weights through v_readlane.
 
-Private registers (clobbered, hard-coded).  Set by the item prologue and live for the whole item: v3 lane
-offset of the lo16-pair loads, v4 lane offset of the weight loads, v15 lane, v17 lane * 8 | buffer bit, v34 the
-cell mask 0xfe00.  List set A = v5 (pairs of 128 entries), v[6:7] weights of blocks 0-1 (fp64: bits 31:0),
-v[8:9] (fp64: bits 63:32); set B = v10, v[11:12], v[13:14].  v16 scratch; v[18:25] / v[26:33] the two
-LDS-read sets (4 register pairs each).  SGPRs: two half-group sets s[36:47] / s[48:59] (fp32 uses
-(lo, weight) pairs s[36:43] / s[44:51]; fp64 lo s[36:39] + weights s[40:47], lo s[48:51] + weights
-s[52:59]); s68 saved M0; s[70:71] list pointer.
+LDS: [2 x 64 KiB X tiles][2 buffers x 16 waves x 128 weights] (SPMM_W_LDS0 = 0x20000; 144 KiB fp32, 160 KiB fp64).
+
+Private registers (clobbered, hard-coded; class Geo holds the map).  Set by the item prologue and live for the whole
+item: v3 lane offset of the lo16-pair loads, v4 lane offset of the weight DMA, v7 lane, v9 lane * 8 | buffer bit, v10
+this wave's weight slots in LDS, v11 the cell mask 0xfe00.  v5 / v6 the lo16 pairs of list set A / B (128 entries
+each); v8 scratch; v[12:19] / v[20:27] the two X read sets (4 register pairs each); v[28:31] / v[32:35] the weights of
+the two half-group sets (fp64: one set v[28:35]).  SGPRs: lo16 of the two half-group sets s36.. / s44.. (fp64 s36.. /
+s48..); s[62:63] saved exec; s68 saved M0; s[70:71] list pointer.
 """
 import os
 import sys
