@@ -318,6 +318,10 @@ def main():
         if roof.get("traffic"):
             roof["achieved_on_traffic"] = roof["traffic"] / kavg / 1e9
             roof["frac_on_traffic"] = roof["achieved_on_traffic"] / peak_gbs
+            if roof["traffic"] < roof.get("algorithmic_bytes_per_launch", 0):
+                roof["note"] = ("`achieved`/`frac` price SURVEY 8d's algorithmic bytes (all of X once); this kernel reads only "
+                                "the 128-byte lines that hold referenced cells, so the fraction on those bytes can exceed 1: "
+                                "`frac_on_traffic` is the one that says how close to the HBM the kernel runs")
         return roof
 
     def run_sparse(dtype, small=False, steps=None, warmup=None, extras=True):
