@@ -123,10 +123,11 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
  * flags          0, or WAGG_PLAN_* bits that pin the kernel form for this plan (tests, ablations);
  *                resolved here, once -- the library reads no environment variable
  * Host pointers; copied.  Duplicate (cell, region) rows add (S5).                              */
-#define WAGG_PLAN_NO_LC 1     /* fp32 (time, gridcell) data: persistent VALU kernel instead of the loader/consumer MFMA kernel */
+#define WAGG_PLAN_NO_LC 1     /* (time, gridcell) data: the persistent one-role kernel instead of the loader/consumer kernels */
 #define WAGG_PLAN_NO_STREAM 2 /* every group through the chunk-walking kernel */
-#define WAGG_PLAN_NO_LINES 4  /* region-shaped chunks (rounds 1-2) even where the whole-line plan applies */
-#define WAGG_PLAN_LC_MFMA 8   /* loader/consumer kernel: dense-tile MFMA consumers (rounds 1-2) instead of the vector-ALU ones */
+#define WAGG_PLAN_NO_LINES 4  /* region-shaped chunks only (rounds 1-2) even where the whole-line chunkings apply */
+#define WAGG_PLAN_LC_MFMA 8   /* fp32 loader/consumer kernel with dense-tile MFMA consumers (rounds 1-2) instead of the vector-ALU
+                                 consumers of sparse_lcv_kernel; fp64 then takes the one-role kernel */
 int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
                      int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
                      wagg_plan **out);
@@ -204,8 +205,8 @@ int wagg_host_stats_read(wagg_host_stats *out, int reset);
  * p = pow_first .. pow_first + n_pow - 1 in ONE call:
  *   out_p[t, r] = sum_i (X[t, cell_i] + offset)^p * w_eff[i] / den[r].
  * The transform is evaluated in the data type while X is loaded (NaN stays NaN and is skipped
- * like any NaN product, S6), so the transformed grids are never written to memory; fp32
- * (time, gridcell) data is read from HBM once per four consecutive powers.  The i-th
+ * like any NaN product, S6), so the transformed grids are never written to memory;
+ * (time, gridcell) data, fp32 and fp64, is read from HBM once per four consecutive powers.  The i-th
  * power is stored at out_dev + i * out_pstride (elements) with leading dimension ldo.  Powers must
  * lie in [1, 16]. */
 int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
