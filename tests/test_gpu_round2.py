@@ -375,6 +375,12 @@ def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda,
             g = plan.apply(Xd).cpu().numpy()
             _rel_ok(g, ref, rtol)
             _rel_ok(plan.apply(torch.from_numpy(Xi).cuda()).cpu().numpy(), refi, rtol)
+            # rows that are not 16-byte aligned (a view into a wider buffer): the element-wise loads, same arithmetic
+            wide = torch.zeros((X.shape[0], G + 3), dtype=Xd.dtype, device="cuda")
+            wide[:, 1:G + 1] = Xd
+            np.testing.assert_array_equal(plan.apply(wide[:, 1:G + 1]).cpu().numpy(), g)
+            np.testing.assert_array_equal(plan.apply_poly(wide[:, 1:G + 1], -273.15, 3).cpu().numpy(),
+                                          plan.apply_poly(Xd, -273.15, 3).cpu().numpy())
             np.testing.assert_array_equal(plan.apply(Xd, out_layout="RT").cpu().numpy(), g.T)
             gt = plan.apply(XT, layout="GT", out_layout="RT").cpu().numpy()
             _rel_ok(gt, ref[:50].T, rtol)
