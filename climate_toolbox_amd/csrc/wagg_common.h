@@ -64,30 +64,35 @@ template <typename T> __device__ __forceinline__ T snyder_edd1(T tmin, T tmax, T
     return ((M - e) * (pi / T(2) - theta) + w * c) / pi;
 }
 
-// fp32: the same function with the slow parts replaced -- v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the IEEE
-// division and square-root sequences, and arcsin by Abramowitz & Stegun 4.4.46,
-//   asin|z| = pi/2 - sqrt(1 - |z|) (a0 + a1 |z| + ... + a7 |z|^7),  |error| <= 2e-8,
-// all three cases evaluated and selected (no divergent branches): ~35 vector instructions instead of ~100.
-// The degree days differ from the libm evaluation by ~1e-7 relative (tolerance of the fp32 path: 1e-4);
-// NaN / inf behave as in the generic form (a NaN tasmin gives NaN, a NaN tasmax below the threshold 0).
-template <> __device__ __forceinline__ float snyder_edd1<float>(float tmin, float tmax, float e) {
+// fp32: the same function in a cheaper form.  With z = (e - M) / w in (-1, 1), theta = asin z and d = M - e = -z w the
+// band value is  w (sqrt(1 - z^2) - z acos z) / pi =: w f(z),  f(-z) = f(z) + z,  and on [0, 1]
+//   f(x) = (1 - x)^(3/2) P(x),  P smooth between 1/pi (x = 0) and 2 sqrt(2) / (3 pi) (x = 1):
+// a degree-6 minimax fit of P (|error| <= 5e-9, tools/fit_edd_poly.py) leaves ONE v_sqrt_f32, v_rcp_f32 and ~15 vector
+// instructions per value (round 2: Abramowitz & Stegun 4.4.46 for the arcsine, two square roots, ~27).  With |z| clamped to 1
+// the expression  w s t P(|z|) + max(d, 0)  (t = 1 - |z|, s = sqrt t) also gives the two outer cases by itself for finite
+// data: M - e where tasmin >= e (z <= -1) and 0 where tasmax <= e (z >= 1); w = 0 is covered by the clamp (v_min returns
+// the number when z is 0 * inf).  snyder_edd1_finite is that expression alone; snyder_edd1<float> adds the reference's two
+// selections, which also decide what a NaN in either field gives (a NaN tasmin NaN, a NaN tasmax below the threshold 0).
+// The degree days differ from the fp64 libm evaluation by <= 2e-6 absolute (tolerance of the fp32 path: 1e-4 relative).
+__device__ __forceinline__ float snyder_edd1_finite(float tmin, float tmax, float e) {
     const float M = 0.5f * (tmax + tmin), w = 0.5f * (tmax - tmin);
     const float d = M - e;
-    const float z = -d * __builtin_amdgcn_rcpf(w);                     // (e - M) / w, strictly inside (-1, 1) in the band
-    const float az = __builtin_fabsf(z);
-    float p = -0.0012624911f;
-    p = __builtin_fmaf(p, az, 0.0066700901f);
-    p = __builtin_fmaf(p, az, -0.0170881256f);
-    p = __builtin_fmaf(p, az, 0.0308918810f);
-    p = __builtin_fmaf(p, az, -0.0501743046f);
-    p = __builtin_fmaf(p, az, 0.0889789874f);
-    p = __builtin_fmaf(p, az, -0.2145988016f);
-    p = __builtin_fmaf(p, az, 1.5707963050f);
-    const float acos_az = __builtin_amdgcn_sqrtf(__builtin_fmaxf(1.0f - az, 0.0f)) * p;   // pi/2 - asin|z|
-    const float pi = 3.14159265358979323846f;
-    const float quarter = z >= 0.0f ? acos_az : pi - acos_az;         // pi/2 - theta
-    const float c = __builtin_amdgcn_sqrtf(__builtin_fmaxf((1.0f - z) * (1.0f + z), 0.0f));   // cos(theta)
-    const float inner = (d * quarter + w * c) * (1.0f / pi);
+    const float z = -d * __builtin_amdgcn_rcpf(w);                     // (e - M) / w
+    const float az = __builtin_fminf(__builtin_fabsf(z), 1.0f);
+    const float t = 1.0f - az;
+    float p = 7.577220821985975e-05f;
+    p = __builtin_fmaf(p, az, -0.0003951705584768206f);
+    p = __builtin_fmaf(p, az, 0.0010792884277179837f);
+    p = __builtin_fmaf(p, az, -0.002406827174127102f);
+    p = __builtin_fmaf(p, az, 0.005977150052785873f);
+    p = __builtin_fmaf(p, az, -0.022534651681780815f);
+    p = __builtin_fmaf(p, az, 0.31830987334251404f);
+    const float q = __builtin_amdgcn_sqrtf(t) * t;                     // (1 - |z|)^(3/2)
+    return __builtin_fmaf(w, q * p, __builtin_fmaxf(d, 0.0f));
+}
+template <> __device__ __forceinline__ float snyder_edd1<float>(float tmin, float tmax, float e) {
+    const float d = 0.5f * (tmax + tmin) - e;
+    const float inner = snyder_edd1_finite(tmin, tmax, e);
     return !(tmin < e) ? d : (!(tmax > e) ? 0.0f : inner);
 }
 

@@ -1140,8 +1140,8 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 //   * 8 LOADER waves stream the next item into registers -- 64 rows x 1024 bytes: lane l fetches 16 bytes of a row, eight
 //     lanes one whole 128-byte line -- and park it in the other half of a double-buffered LDS image (NaN -> 0 on the
 //     way, S6; a flag notes +-inf);
-//   * 8 CONSUMER waves reduce the current item: wave c takes the chunk's region entries c, c + 8, ... and walks their
-//     segments with lane = timestep: v_readlane broadcasts (cell, weight), one LDS read and one FMA per segment, eight
+//   * 8 CONSUMER waves reduce the current item: each takes the chunk's next entry from a shared LDS counter (the plan
+//     lists a chunk's entries longest first) and walks their segments with lane = timestep: v_readlane broadcasts (cell, weight), one LDS read and one FMA per segment, eight
 //     reads in flight; results leave through a per-wave LDS scratch as 16-byte stores (one store per 4 / 2 entries).
 //     Only real (cell, region) pairs are multiplied, so +-inf data needs no separate exact path, and the consumer waves
 //     never wait for each other.
@@ -1177,7 +1177,13 @@ template <typename T, int NPOW = 1> struct LvLds {
 // that overflows gives +-inf as it does in the reference (transformations.py:188 then aggregations.py:78); what needs
 // the general form is a NaN PRODUCT (inf times a zero weight), hence the loaders also flag |y| >= ylim, the largest
 // value whose highest power is finite.
-template <typename T, bool VEC, int NPOW = 1>
+// EDD (fused Snyder degree days, fp32; NPOW = number of thresholds of the pass, <= 4): the chunks are the
+// 128-cell ones (eight 64-byte pieces per field and timestep), an image row holds tasmin of the chunk in its first 512
+// bytes and tasmax in the second (lanes 0-31 / 32-63 of the loaders fetch one field each, both shifted by pv.xoff), and
+// the CONSUMERS evaluate snyder_edd1(tasmin, tasmax, thr[k]) for every (segment, timestep) and threshold -- so the
+// arithmetic (about 35 vector instructions per value) runs on eight waves beside the gather instead of on the waves
+// that issue it (rounds 1-2: one stage per threshold on the loader waves of sparse_lc_kernel, 0.29 ms per threshold).
+template <typename T, bool VEC, int NPOW = 1, bool EDD = false>
 __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot,
                                                                 int64_t ldx, int64_t G, T *__restrict__ out, int64_t ldo,
                                                                 int n_norm, long long n_items,
@@ -1193,6 +1199,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
 #endif
     constexpr int E = 16 / (int)sizeof(T);           // elements per 16-byte piece: 4 / 2
     constexpr int LPQ = 4 / E;                       // lanes per 4-cell quad of the plan: 1 / 2
+    static_assert(!EDD || sizeof(T) == 4, "degree days: fp32 (a row holds both fields of a 128-cell chunk)");
     typedef T vecE __attribute__((ext_vector_type(E)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1248,10 +1255,12 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             d.sb = __builtin_amdgcn_readfirstlane(y[0]); d.ns = __builtin_amdgcn_readfirstlane(y[1]); d.split = 0;
         };
         // first cell of this lane's 16 bytes: quad lane / LPQ of the chunk (clamped), half lane % LPQ of it
+        // (degree days: lanes 0-31 fetch the chunk's 32 quads of tasmin, lanes 32-63 the same quads of tasmax)
         auto load_cell = [&](const StreamDesc &d) {
-            const int q = lane / LPQ;
-            return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (lane % LPQ) * E;
+            const int q = EDD ? (lane & 31) : lane / LPQ;
+            return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (EDD ? 0 : (lane % LPQ) * E);
         };
+        const T *const Xl = EDD && lane >= 32 ? pv.X2 : X;        // this lane's field
         struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; };
         static_assert(LC_SEGS <= LV_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
             int cnt = nt - tw0;
             cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
-            const T *p = X + (t0 + rbase) * ldx + cell0;
+            const T *p = Xl + (t0 + rbase) * ldx + cell0;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(p);
@@ -1284,7 +1293,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
             char *im = img + (size_t)buf * LV_TB * LV_ROWB;
             bool odd = false;
-            if (NPOW > 1) {                                       // the consumers raise y = x + xoff to the powers
+            if (EDD) {                                            // both fields shifted (transformations.py:64-66)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) R.v[i] = R.v[i] + pv.xoff;
+            } else if (NPOW > 1) {                                // the consumers raise y = x + xoff to the powers
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) R.v[i] = R.v[i] + pv.xoff;
             } else if (pv.xpow > 0) {                             // (x + xoff)^xpow on the way in (transformations.py:188)
@@ -1297,19 +1309,23 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             for (int i = 0; i < TPW; ++i)
 #pragma unroll
                 for (int c = 0; c < E; ++c) {
-                    if (NPOW > 1) odd |= !(__builtin_fabs(R.v[i][c]) < ylim);             // NaN, +-inf, or a power overflows
+                    if (NPOW > 1 && !EDD) odd |= !(__builtin_fabs(R.v[i][c]) < ylim);     // NaN, +-inf, or a power overflows
                     else if constexpr (sizeof(T) == 4) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN | qNaN | -inf | +inf
                     else odd |= __builtin_amdgcn_class(R.v[i][c], 0x207);
                 }
             bool inf_any = false;
-            if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
+            if (EDD) {
+                // a NaN in either field must reach the formula (NaN tasmin -> NaN, skipped; NaN tasmax below the threshold -> 0:
+                // the two nested xr.where of transformations.py:74-87), so nothing is replaced here: the item takes the general form
+                inf_any = __builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull);
+            } else if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
                 bool inf_seen = false;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
 #pragma unroll
                     for (int c = 0; c < E; ++c) {
                         const T x = R.v[i][c];
-                        if (NPOW > 1) inf_seen |= __builtin_fabs(x) >= ylim;       // the consumers then take the general form
+                        if (NPOW > 1 && !EDD) inf_seen |= __builtin_fabs(x) >= ylim;   // the consumers then take the general form
                         else inf_seen |= __builtin_isinf(x);
                         R.v[i][c] = (x == x) ? x : T(0);                           // NaN data counts 0 (S6)
                     }
@@ -1328,7 +1344,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
             if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
             if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
-            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; }
+            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 2] = 0; hdr[buf * 16 + 3] = tb; }
         };
         // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
         Item itq[3];
@@ -1381,7 +1397,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         lds_only_barrier();                                       // consumers finish the last item
         if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
     } else {
-        // ==================== consumer waves: lane = timestep, wave cw takes entries cw, cw + 8, ... ====================
+        // ==================== consumer waves: lane = timestep, entries from the item's shared counter ====================
         const int cw = wave - LV_LW;
         constexpr int EPB = E / NPOW > 0 ? E / NPOW : 1;          // entries per result batch
         constexpr int ROWS = EPB * NPOW;                          // its rows (entry, power): E per 16-byte-per-lane store
@@ -1395,7 +1411,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         // this lane's image row, with the swizzle folded in: element u sits at rowoff ^ (u * sizeof(T))
         const unsigned rowoff = img0 + ((unsigned)lane * LV_ROWB | ((unsigned)lane * (unsigned)sizeof(T)));
         typedef T pair2 __attribute__((ext_vector_type(2)));
-        constexpr bool PK = NPOW > 1 && sizeof(T) == 4;           // fp32 powers: two segments per packed instruction
+        constexpr bool PK = NPOW > 1 && sizeof(T) == 4 && !EDD;   // fp32 powers: two segments per packed instruction
         for (int st = 0; st < nst; ++st) {
             stamp(-1);
             lds_only_barrier();                                   // stage st has been parked
@@ -1412,11 +1428,20 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             // counts 0 (S6: +-inf data times a zero weight)
             auto walk = [&](auto odd_tag) {
                 constexpr bool ODD = decltype(odd_tag)::value;
-                for (int eb = cw; eb < ne; eb += EPB * LV_CW) {
+                for (bool more = true; more;) {
+                    // entries come one at a time from the item's shared counter (the waves' shares differ in length: a
+                    // static deal left the first wave idle a third of the degree-day stage); EPB of them share a store
+                    int es[EPB];
+#pragma unroll
+                    for (int kb = 0; kb < EPB; ++kb) es[kb] = ne;
 #pragma unroll 1
                     for (int kb = 0; kb < EPB; ++kb) {
-                        const int e = eb + kb * LV_CW;
-                        if (e >= ne) break;
+                        int e = 0;
+                        if (lane == 0) e = __hip_atomic_fetch_add(&hdr[buf * 16 + 2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        e = __builtin_amdgcn_readfirstlane(e);
+                        if (e >= ne) { more = false; break; }
+#pragma unroll
+                        for (int q = 0; q < EPB; ++q) if (q == kb) es[q] = e;       // (static indices: es stays in scalar registers)
                         const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e]);
                         const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[buf * (LC_ENT + 2) + e + 1]);
                         T acc[NPOW];
@@ -1431,7 +1456,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                             T wl = sm_w[buf * LC_SEGS + k];
                             if (lane >= n) { ul = 0; wl = T(0); }
                             for (int j0 = 0; j0 < n; j0 += 8) {
-                                T xv[8], wv[8];
+                                T xv[8], wv[8], xh[EDD ? 8 : 1];
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {     // 8 independent LDS reads in flight
                                     const unsigned u = (unsigned)__builtin_amdgcn_readlane(ul, j0 + j);
@@ -1444,6 +1469,9 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                         wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
                                     }
                                     xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
+                                    // (degree days: tasmax of the same cell sits 512 bytes further on -- the XOR never reaches
+                                    // bit 9: cells < 128, timesteps < 64 -- so the two reads fuse into one ds_read2_b32)
+                                    if constexpr (EDD) xh[j] = *(lds_cptr)(uintptr_t)((rb ^ u) + 512);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 if constexpr (PK && !ODD) {
@@ -1456,6 +1484,21 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                         for (int pw = 0; pw < NPOW; ++pw) {
                                             if (pw) yp *= y;
                                             acc2[pw] = __builtin_elementwise_fma(yp, w2, acc2[pw]);
+                                        }
+                                    }
+                                } else if constexpr (EDD) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                                        for (int pw = 0; pw < NPOW; ++pw) {                            // one plane per threshold
+                                            // transformations.py:64-87 (finite fields: the expression that needs no selection)
+                                            const T ev = ODD ? snyder_edd1<T>(xv[j], xh[j], pv.edd_thr[pw]) : snyder_edd1_finite(xv[j], xh[j], pv.edd_thr[pw]);
+                                            if constexpr (ODD) {
+                                                const T p = ev * wv[j];
+                                                acc[pw] += (p == p) ? p : T(0);
+                                            } else {
+                                                acc[pw] = __builtin_fmaf(ev, wv[j], acc[pw]);
+                                            }
                                         }
                                     }
                                 } else {
@@ -1487,11 +1530,13 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                         }
                     }
                     // (LDS operations of one wave execute in order: the reads below see the writes above)
-#pragma unroll
                     for (int pass = 0; pass < (ROWS + E - 1) / E; ++pass) {
                         const int row = pass * E + lane / LPE, piece = lane % LPE;
                         const int kq = row / NPOW, pw = row % NPOW;
-                        const int e = eb + kq * LV_CW, tl = E * piece;
+                        int e = ne;
+#pragma unroll
+                        for (int q = 0; q < EPB; ++q) if (q == kq) e = es[q];
+                        const int tl = E * piece;
                         if (row < ROWS && e < ne && tl < nt && !(knob & 128)) {
                             T *op = out + (int64_t)pw * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
                             const vecE qv = *reinterpret_cast<const vecE *>(&scr[row * 64 + tl]);
@@ -1650,9 +1695,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // which reduce four planes in one pass: measured with whole lines + vector-ALU consumers they were slower, 0.55 vs
     // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
     const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
-    const bool use_lines = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG && xpow != XF_EDD &&
-                           (nfuse == 1 || (nfuse <= 4 && !lcv_off));
-    const auto &d = use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d;
+    // degree days in sparse_lcv_kernel: fp32 (time, gridcell) fields on the 128-cell chunking (the fp64 one: 64-byte pieces)
+    const bool edd_lcv = xpow == XF_EDD && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && plan->has_lines64 && !lcv_off &&
+                         n_thr >= 1 && n_thr <= 4;
+    const bool use_lines = edd_lcv || ((sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG &&
+                                       xpow != XF_EDD && (nfuse == 1 || (nfuse <= 4 && !lcv_off)));
+    const auto &d = use_lines ? (sizeof(T) == 4 && !edd_lcv ? plan->dl : plan->dl64) : plan->d;
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
         // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
@@ -1717,7 +1765,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
     // whole-line chunking only (a region-shaped chunk of 64 quads is 2 KiB of a fp64 row: twice the image row)
-    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && !edd && nfuse <= 4 &&
+    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && (!edd || edd_lcv) && nfuse <= 4 &&
         (sizeof(T) == 4 || lines)) {
         const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * ((Ttot + LV_TB - 1) / LV_TB);
@@ -1727,6 +1775,16 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         if (nfuse == 2) { kern = vec ? sparse_lcv_kernel<T, true, 2> : sparse_lcv_kernel<T, false, 2>; lds_bytes = LvLds<T, 2>::total; }
         if (nfuse == 3) { kern = vec ? sparse_lcv_kernel<T, true, 3> : sparse_lcv_kernel<T, false, 3>; lds_bytes = LvLds<T, 3>::total; }
         if (nfuse == 4) { kern = vec ? sparse_lcv_kernel<T, true, 4> : sparse_lcv_kernel<T, false, 4>; lds_bytes = LvLds<T, 4>::total; }
+        if constexpr (sizeof(T) == 4) {
+            if (edd_lcv) {
+                const int kt = pv.n_thr;
+                kern = vec ? sparse_lcv_kernel<T, true, 1, true> : sparse_lcv_kernel<T, false, 1, true>;
+                if (kt == 2) kern = vec ? sparse_lcv_kernel<T, true, 2, true> : sparse_lcv_kernel<T, false, 2, true>;
+                if (kt == 3) kern = vec ? sparse_lcv_kernel<T, true, 3, true> : sparse_lcv_kernel<T, false, 3, true>;
+                if (kt == 4) kern = vec ? sparse_lcv_kernel<T, true, 4, true> : sparse_lcv_kernel<T, false, 4, true>;
+                lds_bytes = LvLds<T, 4>::total;                  // (the same for 1..4 planes of fp32)
+            }
+        }
         // |y| below this can be raised to the highest power of the pass inside T
         const T ylim = nfuse > 1 ? (T)std::pow((double)std::numeric_limits<T>::max() / 1024.0, 1.0 / (double)(xpow + nfuse - 1)) : T(0);
         WAGG_HIP(allow_dynamic_lds((const void *)kern, lds_bytes));
@@ -2058,16 +2116,22 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                 ucell.insert(ucell.end(), ch.quads.begin(), ch.quads.end());
                 chunk_u_begin.push_back((int32_t)ucell.size());
                 const std::vector<CSeg> &cs = ch.cs;
+                // the chunk's entries, longest first: the consumer waves of sparse_lcv_kernel take them from a shared
+                // counter, so the long ones start early and the short ones fill the end (longest-processing-time order)
+                std::vector<std::pair<size_t, size_t>> runs;
                 for (size_t k = 0; k < cs.size();) {
                     size_t m2 = k;
-                    while (m2 < cs.size() && cs[m2].region == cs[k].region) {
-                        seg_u.push_back(cs[m2].ulocal); seg_w.push_back(cs[m2].w);
-                        ++m2;
-                    }
-                    parts[(size_t)cs[k].region].push_back((int32_t)n_part);
+                    while (m2 < cs.size() && cs[m2].region == cs[k].region) ++m2;
+                    runs.push_back({k, m2});
+                    k = m2;
+                }
+                std::stable_sort(runs.begin(), runs.end(), [](const std::pair<size_t, size_t> &a, const std::pair<size_t, size_t> &b) {
+                    return a.second - a.first > b.second - b.first; });
+                for (const auto &run : runs) {
+                    for (size_t m2 = run.first; m2 < run.second; ++m2) { seg_u.push_back(cs[m2].ulocal); seg_w.push_back(cs[m2].w); }
+                    parts[(size_t)cs[run.first].region].push_back((int32_t)n_part);
                     ent_region.push_back((int32_t)n_part++);              // the entry's row in the partial buffer
                     ent_seg_begin.push_back((int32_t)seg_u.size());
-                    k = m2;
                 }
                 chunk_e_begin.push_back((int32_t)ent_region.size());
                 grp_giant.push_back(0);
