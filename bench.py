@@ -473,9 +473,11 @@ def main():
             r4, _ = run_dense_family("c4", plan=plan, steps=min(sec_steps, 3), warmup=1, share=True)
             secondary.append(r4)
             torch.cuda.empty_cache()
-            secondary.append(run_sparse("float32", steps=sec_steps))        # c2-real: segment-table form, fp32, area weights
-            secondary.append(run_sparse("float64", steps=sec_steps))        # c3-real: fp64 data, pop weights with backup fill
-            secondary.append(run_sparse("float64", small=True, steps=sec_steps))   # c1
+            # the segment-table steps take 0.04-0.4 ms: 100 of them after 10 warm-up (five would time 2 ms of a cold start)
+            seg_steps = max(sec_steps, 100)
+            secondary.append(run_sparse("float32", steps=seg_steps, warmup=10))        # c2-real: segment-table form, fp32, area weights
+            secondary.append(run_sparse("float64", steps=seg_steps, warmup=10))        # c3-real: fp64 data, pop weights with backup fill
+            secondary.append(run_sparse("float64", small=True, steps=seg_steps, warmup=10))   # c1
             for wl in ("c5-block", "c5-block-f64", "c5-uniform", "c5-uniform-f64"):
                 torch.cuda.empty_cache()
                 secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2, share=True)[0])
