@@ -1135,22 +1135,23 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Loader/consumer form with VECTOR-ALU consumers (round 3): the plain aggregation of (time, gridcell) data over the
-// whole-line chunking, fp32 AND fp64.  One 1024-thread workgroup per CU, persistent over items (chunk, 64 timesteps):
-//   * 8 LOADER waves stream the next item into registers -- 64 rows x 1024 bytes: lane l fetches 16 bytes of a row, eight
-//     lanes one whole 128-byte line -- and park it in the other half of a double-buffered LDS image (NaN -> 0 on the
-//     way, S6; a flag notes +-inf);
+// Loader/consumer form with VECTOR-ALU consumers (round 3): (time, gridcell) data, fp32 AND fp64 -- the plain aggregation,
+// the fused powers and (fp32) the fused degree days.  One 1024-thread workgroup per CU, persistent over items
+// (chunk, 64 timesteps); an item is 64 rows x 1 KiB of the whole-line chunking of the data type:
+//   * 8 LOADER waves stream the next item into registers -- lane l fetches 16 bytes of a row, eight lanes one whole
+//     128-byte line -- and park it in the other half of a double-buffered LDS image (NaN -> 0 on the way, S6; a flag
+//     notes +-inf);
 //   * 8 CONSUMER waves reduce the current item: each takes the chunk's next entry from a shared LDS counter (the plan
-//     lists a chunk's entries longest first) and walks their segments with lane = timestep: v_readlane broadcasts (cell, weight), one LDS read and one FMA per segment, eight
-//     reads in flight; results leave through a per-wave LDS scratch as 16-byte stores (one store per 4 / 2 entries).
-//     Only real (cell, region) pairs are multiplied, so +-inf data needs no separate exact path, and the consumer waves
-//     never wait for each other.
+//     lists a chunk's entries longest first) and walks its segments with lane = timestep: v_readlane broadcasts
+//     (cell, weight), one LDS read and one FMA per segment, eight reads in flight; results leave through a per-wave LDS
+//     scratch as 16-byte stores (one store per 4 / 2 entries).  Only real (cell, region) pairs are multiplied, so
+//     +-inf data needs no separate exact path, and the consumer waves never wait for each other.
 // The image is SWIZZLED so that both sides are bank-conflict free: element (t, u) of row t lives at u ^ t -- the
 // loaders' 16-byte pieces stay whole and a row's 64 pieces still fill its 1024 bytes (the XOR moves a piece inside the
 // row and permutes the 4 / 2 elements inside it, the latter at compile time: the row is a loop constant), and the
 // consumers' lanes, reading one cell u of 64 consecutive timesteps, hit 64 different banks (32 bank pairs per half-wave
-// in fp64).  Rounds 1-2
-// read a padded image (row stride 260): 4-way conflicts, 51 % of the LDS cycles of the fp64 kernel (profiles/r02_pmc.csv).
+// in fp64).  Rounds 1-2 read a padded image (row stride 260): 4-way conflicts, 51 % of the LDS cycles of the fp64 kernel
+// (profiles/r02_pmc.csv); this one 0.03 % (profiles/r03_pmc.csv).
 // ---------------------------------------------------------------------------------------------
 constexpr int LV_LW = 8, LV_CW = 8, LV_THREADS = (LV_LW + LV_CW) * 64, LV_TB = 64;
 constexpr int LV_ROWB = 1024;                   // bytes of an image row: 256 floats / 128 doubles = the cells of a chunk
@@ -1181,8 +1182,9 @@ template <typename T, int NPOW = 1> struct LvLds {
 // 128-cell ones (eight 64-byte pieces per field and timestep), an image row holds tasmin of the chunk in its first 512
 // bytes and tasmax in the second (lanes 0-31 / 32-63 of the loaders fetch one field each, both shifted by pv.xoff), and
 // the CONSUMERS evaluate snyder_edd1(tasmin, tasmax, thr[k]) for every (segment, timestep) and threshold -- so the
-// arithmetic (about 35 vector instructions per value) runs on eight waves beside the gather instead of on the waves
-// that issue it (rounds 1-2: one stage per threshold on the loader waves of sparse_lc_kernel, 0.29 ms per threshold).
+// arithmetic (about 15 vector instructions per value, wagg_common.h::snyder_edd1_finite) runs on eight waves beside the
+// gather instead of on the waves that issue it (rounds 1-2: one stage per threshold on the loader waves of
+// sparse_lc_kernel, 0.29 ms per threshold; now 0.07).
 template <typename T, bool VEC, int NPOW = 1, bool EDD = false>
 __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot,
                                                                 int64_t ldx, int64_t G, T *__restrict__ out, int64_t ldo,
