@@ -1601,7 +1601,9 @@ constexpr int CB_THREADS = 1024;
 template <typename T, bool TR>
 __global__ __launch_bounds__(CB_THREADS) void combine_parts_kernel(const T *__restrict__ P, int64_t ldp, const int32_t *__restrict__ part_begin,
                                                                    const T *__restrict__ den, int64_t R, int64_t Ttot,
-                                                                   T *__restrict__ out, int64_t ldo) {
+                                                                   T *__restrict__ out, int64_t ldo, int64_t p_pstride, int64_t out_pstride) {
+    P += (int64_t)blockIdx.z * p_pstride;              // one plane (power / threshold) per blockIdx.z
+    out += (int64_t)blockIdx.z * out_pstride;
     constexpr int V = 16 / sizeof(T);
     typedef T vecv __attribute__((ext_vector_type(V)));
     __shared__ T tile[64][65];
@@ -1911,20 +1913,20 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         WAGG_HIP(hipGetLastError());
     }
     }
-    for (int pz = 0; pz < nplanes; ++pz) {    // per plane: transpose, regions without any kept row
-    if (via_ws && lines) {
-        dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
+    if (via_ws && lines) {                    // all planes in one launch (regions without rows come out as 0 / den there)
+        dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64), (unsigned)nplanes);
         const T *den;
         if constexpr (sizeof(T) == 4) den = d.den32.p; else den = d.den64.p;
         if (out_layout == WAGG_OUT_TR)
-            hipLaunchKernelGGL((combine_parts_kernel<T, true>), tg, dim3(CB_THREADS), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
-                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
+            hipLaunchKernelGGL((combine_parts_kernel<T, true>), tg, dim3(CB_THREADS), 0, stream, (const T *)ws, ldws,
+                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out, ldo, kpstride, pstride);
         else
-            hipLaunchKernelGGL((combine_parts_kernel<T, false>), tg, dim3(CB_THREADS), 0, stream, (const T *)(ws + (int64_t)pz * kpstride), ldws,
-                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out + (int64_t)pz * pstride, ldo);
+            hipLaunchKernelGGL((combine_parts_kernel<T, false>), tg, dim3(CB_THREADS), 0, stream, (const T *)ws, ldws,
+                               (const int32_t *)d.part_begin.p, den, (int64_t)plan->info.R, Ttot, out, ldo, kpstride, pstride);
         WAGG_HIP(hipGetLastError());
-        continue;                             // (regions without rows came out as 0 / den there)
+        return WAGG_OK;
     }
+    for (int pz = 0; pz < nplanes; ++pz) {    // per plane: transpose, regions without any kept row
     if (via_ws) {
         dim3 tg((unsigned)((plan->info.R + 63) / 64), (unsigned)((Ttot + 63) / 64));
         hipLaunchKernelGGL((transpose_rt_to_tr_kernel<T>), tg, dim3(256), 0, stream, ws + (int64_t)pz * kpstride, ldws,
