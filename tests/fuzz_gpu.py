@@ -40,6 +40,19 @@ def one_case(i, rng):
     nseg = int(rng.integers(0, min(4 * G, 400000) + 2))
     cell = rng.integers(0, G, nseg).astype(np.int32)
     code = rng.integers(-1 if rng.random() < 0.3 else 0, R, nseg).astype(np.int32)     # some null labels
+    if rng.random() < 0.5:
+        # a COMPACT table (regions = blocks of the grid with holes, a few split cells): what the whole-line chunkings
+        # are built for -- a scattered table above is declined by them (too many partial rows)
+        bh, bw = int(rng.integers(1, 9)), int(rng.integers(1, 17))
+        keep = np.flatnonzero(rng.random(G) < rng.uniform(0.3, 1.0))
+        nbw = (nlon + bw - 1) // bw
+        reg = ((keep // nlon) // bh) * nbw + (keep % nlon) // bw
+        R = int(reg.max()) + 1 + int(rng.integers(0, 3)) if len(keep) else R           # (sometimes a region nobody maps to)
+        extra = rng.choice(keep, min(len(keep), 40)) if len(keep) else keep
+        cell = np.concatenate([keep, extra]).astype(np.int32)
+        code = np.concatenate([reg, rng.integers(0, R, len(extra))]).astype(np.int32)
+        if rng.random() < 0.3 and len(code):
+            code[rng.integers(0, len(code), 3)] = -1
     if rng.random() < 0.4 and G > 700:                                                # a giant region
         n = int(rng.integers(300, min(G, 3000)))
         cell = np.concatenate([cell, rng.choice(G, n, replace=False).astype(np.int32)])
