@@ -1185,7 +1185,7 @@ template <typename T, int NPOW = 1> struct LvLds {
 // arithmetic (about 15 vector instructions per value, wagg_common.h::snyder_edd1_finite) runs on eight waves beside the
 // gather instead of on the waves that issue it (rounds 1-2: one stage per threshold on the loader waves of
 // sparse_lc_kernel, 0.29 ms per threshold; now 0.07).
-template <typename T, bool VEC, int NPOW = 1, bool EDD = false>
+template <typename T, bool VEC, int NPOW = 1, bool EDD = false, bool GT = false>
 __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot,
                                                                 int64_t ldx, int64_t G, T *__restrict__ out, int64_t ldo,
                                                                 int n_norm, long long n_items,
@@ -1202,6 +1202,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     constexpr int E = 16 / (int)sizeof(T);           // elements per 16-byte piece: 4 / 2
     constexpr int LPQ = 4 / E;                       // lanes per 4-cell quad of the plan: 1 / 2
     static_assert(!EDD || sizeof(T) == 4, "degree days: fp32 (a row holds both fields of a 128-cell chunk)");
+    static_assert(!(EDD && GT), "degree days of (gridcell, time) data take the chunk-walking kernel");
+    // GT ((gridcell, time) data): a cell's 64 timesteps are PPC contiguous pieces; one load instruction fetches them for CPL cells
+    constexpr int PPC = 64 / E, CPL = 64 / PPC;      // fp32: 16 pieces per cell, 4 cells (one quad) per load; fp64: 32, 2
+    constexpr int CELLB = 64 * (int)sizeof(T);       // GT: bytes of a cell's row in the image
     typedef T vecE __attribute__((ext_vector_type(E)));
     typedef int int4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1258,7 +1262,12 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         };
         // first cell of this lane's 16 bytes: quad lane / LPQ of the chunk (clamped), half lane % LPQ of it
         // (degree days: lanes 0-31 fetch the chunk's 32 quads of tasmin, lanes 32-63 the same quads of tasmax)
+        // (GT: lane L holds the first cell of quad (first quad of this wave) + L % (quads per wave); issue() broadcasts it)
         auto load_cell = [&](const StreamDesc &d) {
+            if (GT) {
+                const int q = (tw0 * CPL) / 4 + lane % (TPW * CPL / 4);
+                return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)];
+            }
             const int q = EDD ? (lane & 31) : lane / LPQ;
             return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (EDD ? 0 : (lane % LPQ) * E);
         };
@@ -1280,6 +1289,27 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
             int cnt = nt - tw0;
             cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
+            if constexpr (GT) {
+                // load i of this wave = cells CPL * (tw0 + i) .. + CPL - 1 of the chunk, 64 timesteps each: lane -> (cell of the
+                // load, piece of its row).  Pieces behind the last timestep repeat the last one (their lanes are never stored);
+                // cells behind G (a quad at the end of a grid that is not a whole number of quads) repeat cell G - 1
+                const int piece = lane % PPC, jl = lane / PPC;
+                const int np = (nt + E - 1) / E;
+                const int pc = piece < np ? piece : np - 1;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int w = tw0 + i;
+                    int64_t c = (int64_t)__builtin_amdgcn_readlane(cell0, (i * CPL) / 4) + ((w * CPL) % 4) + jl;
+                    c = c < G ? c : G - 1;
+                    const T *pg = X + c * ldx + t0;
+                    if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(pg + E * pc);
+                    else {
+#pragma unroll
+                        for (int e2 = 0; e2 < E; ++e2) R.v[i][e2] = pg[E * pc + e2 < nt ? E * pc + e2 : nt - 1];
+                    }
+                }
+                return;
+            }
             const T *p = Xl + (t0 + rbase) * ldx + cell0;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -1334,6 +1364,12 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                 inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
             }
             if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;            // every wave, every item: no reset needed
+            if constexpr (GT) {
+                // the image is cell-major, [cell][64 timesteps]: load i is 1 KiB of it as it comes; the consumers' lanes read
+                // consecutive words of a cell's row (no conflicts, no swizzle)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) *reinterpret_cast<vecE *>(im + (size_t)(tw0 + i) * LV_ROWB + 16 * lane) = R.v[i];
+            } else
             // row t = tw0 + i: piece `lane` goes to piece lane ^ (t / E), its elements permuted by t % E = i % E
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -1409,9 +1445,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         // at a multiple of its row size -- at 0 in fact, the kernel has no static LDS -- so the XOR stays inside the row)
         typedef const T __attribute__((address_space(3))) *lds_cptr;
         const unsigned img0 = (unsigned)reinterpret_cast<uintptr_t>(img);
-        if (img0 & (LV_ROWB - 1)) __builtin_trap();
+        if (img0 & (GT ? 0xffffu : (unsigned)(LV_ROWB - 1))) __builtin_trap();
         // this lane's image row, with the swizzle folded in: element u sits at rowoff ^ (u * sizeof(T))
-        const unsigned rowoff = img0 + ((unsigned)lane * LV_ROWB | ((unsigned)lane * (unsigned)sizeof(T)));
+        // (GT: cell u's row starts at u * CELLB, this lane's timestep sits lane * sizeof(T) into it: the same XOR, as an add)
+        const unsigned rowoff = img0 + (GT ? 0u : (unsigned)lane * LV_ROWB) + (unsigned)lane * (unsigned)sizeof(T);
         typedef T pair2 __attribute__((ext_vector_type(2)));
         constexpr bool PK = NPOW > 1 && sizeof(T) == 4 && !EDD;   // fp32 powers: two segments per packed instruction
         for (int st = 0; st < nst; ++st) {
@@ -1454,7 +1491,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                             // lane j holds segment base + j (padding lanes: cell 0, weight 0: they add exactly 0 to finite data)
                             const int n = s1 - base < 64 ? s1 - base : 64;
                             const int k = base + (lane < n ? lane : 0);
-                            int ul = (sm_u[buf * LC_SEGS + k] & 0xff) * (int)sizeof(T);     // byte offset of the cell in a row
+                            int ul = (sm_u[buf * LC_SEGS + k] & 0xff) * (GT ? CELLB : (int)sizeof(T));   // byte offset of the cell in a row (GT: of its row)
                             T wl = sm_w[buf * LC_SEGS + k];
                             if (lane >= n) { ul = 0; wl = T(0); }
                             for (int j0 = 0; j0 < n; j0 += 8) {
@@ -1704,12 +1741,17 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                          n_thr >= 1 && n_thr <= 4;
     const bool use_lines = edd_lcv || ((sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG &&
                                        xpow != XF_EDD && (nfuse == 1 || (nfuse <= 4 && !lcv_off)));
-    const auto &d = use_lines ? (sizeof(T) == 4 && !edd_lcv ? plan->dl : plan->dl64) : plan->d;
+    // (gridcell, time) data in sparse_lcv_kernel: every cell of a chunk is fetched by itself (64 timesteps = two or four whole
+    // lines), so fp32 takes the region-shaped chunks (fewest cells); fp64 the 128-cell whole-line chunking (a region-shaped
+    // chunk holds 256)
+    const bool gt_lcv = layout == WAGG_LAYOUT_GT && !lcv_off && xpow != XF_EDD && nfuse <= 4 && (sizeof(T) == 4 || plan->has_lines64);
+    const auto &d = gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64)
+                           : (use_lines ? (sizeof(T) == 4 && !edd_lcv ? plan->dl : plan->dl64) : plan->d);
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
         // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
-        const bool lc_ok = layout == WAGG_LAYOUT_TG && !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) &&
-                           (int)d.n_groups - d.g0_normal > 0 && Ttot > 0 && (sizeof(T) == 4 || (use_lines && !lcv_off));
+        const bool lc_ok = ((layout == WAGG_LAYOUT_TG && (sizeof(T) == 4 || (use_lines && !lcv_off))) || gt_lcv) &&
+                           !(plan->flags & (WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LC)) && (int)d.n_groups - d.g0_normal > 0 && Ttot > 0;
         if (!lc_ok || nfuse > 4) {
             for (int i = 0; i < nfuse; ++i) {
                 const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
@@ -1764,7 +1806,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // degree days (two fields): fp32 (time, gridcell) data in the loader/consumer kernel, everything else in the
     // chunk-walking kernel
     const bool edd = xpow == XF_EDD;
-    const bool stream_path = layout == WAGG_LAYOUT_TG && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
+    const bool stream_path = (layout == WAGG_LAYOUT_TG || gt_lcv) && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
     const int n_norm = (int)d.n_groups - d.g0_normal;
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
@@ -1779,6 +1821,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         if (nfuse == 2) { kern = vec ? sparse_lcv_kernel<T, true, 2> : sparse_lcv_kernel<T, false, 2>; lds_bytes = LvLds<T, 2>::total; }
         if (nfuse == 3) { kern = vec ? sparse_lcv_kernel<T, true, 3> : sparse_lcv_kernel<T, false, 3>; lds_bytes = LvLds<T, 3>::total; }
         if (nfuse == 4) { kern = vec ? sparse_lcv_kernel<T, true, 4> : sparse_lcv_kernel<T, false, 4>; lds_bytes = LvLds<T, 4>::total; }
+        if (gt_lcv) {
+            kern = vec ? sparse_lcv_kernel<T, true, 1, false, true> : sparse_lcv_kernel<T, false, 1, false, true>;
+            if (nfuse == 2) kern = vec ? sparse_lcv_kernel<T, true, 2, false, true> : sparse_lcv_kernel<T, false, 2, false, true>;
+            if (nfuse == 3) kern = vec ? sparse_lcv_kernel<T, true, 3, false, true> : sparse_lcv_kernel<T, false, 3, false, true>;
+            if (nfuse == 4) kern = vec ? sparse_lcv_kernel<T, true, 4, false, true> : sparse_lcv_kernel<T, false, 4, false, true>;
+        }
         if constexpr (sizeof(T) == 4) {
             if (edd_lcv) {
                 const int kt = pv.n_thr;
