@@ -310,6 +310,11 @@ def test_c2_c3_full_size_vs_oracle(torch_cuda, c2_real, wname, dtype, rtol):
     got = plan.apply(X).cpu().numpy()
     ref = O.agg_coded(Xh, cell, codes, w_eff, len(uniq))
     _rel_ok(got, ref, rtol)
+    # the same field in (gridcell, time) order -- the reference's (lat, lon, time) fixture layout -- at full size
+    got_gt = plan.apply(X.t().contiguous(), layout="GT").cpu().numpy()
+    _rel_ok(got_gt, ref, rtol)
+    _rel_ok(got_gt, got, 2e-6 if dtype == np.float32 else 1e-13)
+    del got_gt
     # size-independent properties at full size
     const = plan.apply(torch.full((3, G), 7.25, dtype=X.dtype, device="cuda")).cpu().numpy()
     np.testing.assert_allclose(const, 7.25, rtol=1e-6 if dtype == np.float32 else 1e-12)   # constant field
