@@ -1202,7 +1202,6 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     constexpr int E = 16 / (int)sizeof(T);           // elements per 16-byte piece: 4 / 2
     constexpr int LPQ = 4 / E;                       // lanes per 4-cell quad of the plan: 1 / 2
     static_assert(!EDD || sizeof(T) == 4, "degree days: fp32 (a row holds both fields of a 128-cell chunk)");
-    static_assert(!(EDD && GT), "degree days of (gridcell, time) data take the chunk-walking kernel");
     // GT ((gridcell, time) data): a cell's 64 timesteps are PPC contiguous pieces; one load instruction fetches them for CPL cells
     constexpr int PPC = 64 / E, CPL = 64 / PPC;      // fp32: 16 pieces per cell, 4 cells (one quad) per load; fp64: 32, 2
     constexpr int CELLB = 64 * (int)sizeof(T);       // GT: bytes of a cell's row in the image
@@ -1264,8 +1263,8 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         // (degree days: lanes 0-31 fetch the chunk's 32 quads of tasmin, lanes 32-63 the same quads of tasmax)
         // (GT: lane L holds the first cell of quad (first quad of this wave) + L % (quads per wave); issue() broadcasts it)
         auto load_cell = [&](const StreamDesc &d) {
-            if (GT) {
-                const int q = (tw0 * CPL) / 4 + lane % (TPW * CPL / 4);
+            if (GT) {      // (degree days: loads 0-31 of an item are tasmin of the chunk's 32 quads, loads 32-63 tasmax of the same)
+                const int q = ((EDD ? tw0 & 31 : tw0) * CPL) / 4 + lane % (TPW * CPL / 4);
                 return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)];
             }
             const int q = EDD ? (lane & 31) : lane / LPQ;
@@ -1301,7 +1300,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                     const int w = tw0 + i;
                     int64_t c = (int64_t)__builtin_amdgcn_readlane(cell0, (i * CPL) / 4) + ((w * CPL) % 4) + jl;
                     c = c < G ? c : G - 1;
-                    const T *pg = X + c * ldx + t0;
+                    const T *pg = (EDD && w >= 32 ? pv.X2 : X) + c * ldx + t0;
                     if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(pg + E * pc);
                     else {
 #pragma unroll
@@ -1510,7 +1509,8 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                     xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
                                     // (degree days: tasmax of the same cell sits 512 bytes further on -- the XOR never reaches
                                     // bit 9: cells < 128, timesteps < 64 -- so the two reads fuse into one ds_read2_b32)
-                                    if constexpr (EDD) xh[j] = *(lds_cptr)(uintptr_t)((rb ^ u) + 512);
+                                    // (GT: tasmax is the second half of the image, 128 cell rows further on)
+                                    if constexpr (EDD) xh[j] = *(lds_cptr)(uintptr_t)((rb ^ u) + (GT ? 128 * CELLB : 512));
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 if constexpr (PK && !ODD) {
@@ -1737,15 +1737,15 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
     const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
     // degree days in sparse_lcv_kernel: fp32 (time, gridcell) fields on the 128-cell chunking (the fp64 one: 64-byte pieces)
-    const bool edd_lcv = xpow == XF_EDD && sizeof(T) == 4 && layout == WAGG_LAYOUT_TG && plan->has_lines64 && !lcv_off &&
-                         n_thr >= 1 && n_thr <= 4;
-    const bool use_lines = edd_lcv || ((sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG &&
+    const bool edd_lcv = xpow == XF_EDD && sizeof(T) == 4 && plan->has_lines64 && !lcv_off && n_thr >= 1 && n_thr <= 4;
+    const bool use_lines = (edd_lcv && layout == WAGG_LAYOUT_TG) || ((sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG &&
                                        xpow != XF_EDD && (nfuse == 1 || (nfuse <= 4 && !lcv_off)));
     // (gridcell, time) data in sparse_lcv_kernel: every cell of a chunk is fetched by itself (64 timesteps = two or four whole
     // lines), so fp32 takes the region-shaped chunks (fewest cells); fp64 the 128-cell whole-line chunking (a region-shaped
     // chunk holds 256)
-    const bool gt_lcv = layout == WAGG_LAYOUT_GT && !lcv_off && xpow != XF_EDD && nfuse <= 4 && (sizeof(T) == 4 || plan->has_lines64);
-    const auto &d = gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64)
+    const bool gt_lcv = layout == WAGG_LAYOUT_GT && !lcv_off && (xpow != XF_EDD || edd_lcv) && nfuse <= 4 &&
+                        (sizeof(T) == 4 || plan->has_lines64);
+    const auto &d = gt_lcv ? (sizeof(T) == 4 && !edd_lcv ? plan->d : plan->dl64)
                            : (use_lines ? (sizeof(T) == 4 && !edd_lcv ? plan->dl : plan->dl64) : plan->d);
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
@@ -1834,6 +1834,12 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                 if (kt == 2) kern = vec ? sparse_lcv_kernel<T, true, 2, true> : sparse_lcv_kernel<T, false, 2, true>;
                 if (kt == 3) kern = vec ? sparse_lcv_kernel<T, true, 3, true> : sparse_lcv_kernel<T, false, 3, true>;
                 if (kt == 4) kern = vec ? sparse_lcv_kernel<T, true, 4, true> : sparse_lcv_kernel<T, false, 4, true>;
+                if (gt_lcv) {
+                    kern = vec ? sparse_lcv_kernel<T, true, 1, true, true> : sparse_lcv_kernel<T, false, 1, true, true>;
+                    if (kt == 2) kern = vec ? sparse_lcv_kernel<T, true, 2, true, true> : sparse_lcv_kernel<T, false, 2, true, true>;
+                    if (kt == 3) kern = vec ? sparse_lcv_kernel<T, true, 3, true, true> : sparse_lcv_kernel<T, false, 3, true, true>;
+                    if (kt == 4) kern = vec ? sparse_lcv_kernel<T, true, 4, true, true> : sparse_lcv_kernel<T, false, 4, true, true>;
+                }
                 lds_bytes = LvLds<T, 4>::total;                  // (the same for 1..4 planes of fp32)
             }
         }
