@@ -46,7 +46,7 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
 
 def mean(kernel_sub, counter):
     """mean counter value per launch of the kernel.  c1 and c3-real run the SAME instantiation
-    (sparse_lcv_kernel<double, true, 1, false>): "<name>#big" / "<name>#small" select the launches above / below half of the
+    (sparse_lcv_kernel<double, true, 1, false, false>): "<name>#big" / "<name>#small" select the launches above / below half of the
     largest value (c3: 1M cells, c1: 16,200)."""
     pick = None
     if "#" in kernel_sub:
@@ -69,12 +69,12 @@ if os.path.exists(tr):
         dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     rows = []
     for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share)", "dense_mfma_kernel<float, 0, false, 22, true"),
-                     ("c2-real", "sparse_lcv_kernel<float, true, 1, false>"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false>#big"),
-                     ("c1", "sparse_lcv_kernel<double, true, 1, false>#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
+                     ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
+                     ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
                      ("c5-block-f64", "dense_mfma_kernel<double, 0, true"), ("c5-uniform", "spmm_kernel<float>"),
-                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false>"),
-                     ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true>"),
-                     ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true>"),
+                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>"),
+                     ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
+                     ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true, false>"),
                      ("c2-real combine + transpose", "combine_parts_kernel<float, true>"),
                      ("c3-real combine + transpose (and c1's)", "combine_parts_kernel<double, true>")):
         pick = None
@@ -104,7 +104,7 @@ LINES = ("whole-line chunks: every load instruction reads eight whole 128-B line
          "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T for fp32, lines64_ucells x 8 B x T for fp64, in "
          "the bench line's plan), x1 if it matches them: see `calibration`; WRITE_SIZE exact")
 for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
-                       ("c2-real", "sparse_lcv_kernel<float, true, 1, false>", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false>#big", "lines64"),
+                       ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big", "lines64"),
                        ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
