@@ -2106,17 +2106,24 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         bool lines_plan = want_lines;
         if (lines_plan) {
             struct LSeg { int64_t line; int32_t region, col; double w; };
+            // segments by (line, region, column), line = strip * n_rows + row: `segs` is sorted by (region, cell), so a STABLE
+            // counting sort on the line alone gives that order (cells of one line and region ascend with their column)
+            const int64_t n_rows_ = G / row_len, n_strips_ = (row_len + LINE - 1) / LINE;
             std::vector<LSeg> ls((size_t)nnz);
-            for (int64_t i = 0; i < nnz; ++i) {
-                const int64_t row = segs[(size_t)i].cell / row_len, col = segs[(size_t)i].cell % row_len;
-                ls[(size_t)i] = {(col / LINE) * (G / row_len) + row, segs[(size_t)i].region, (int32_t)(col % LINE), segs[(size_t)i].w};
+            {
+                std::vector<int64_t> first((size_t)(n_rows_ * n_strips_) + 1, 0);
+                std::vector<int64_t> line_of((size_t)nnz);
+                for (int64_t i = 0; i < nnz; ++i) {
+                    const int64_t row = segs[(size_t)i].cell / row_len, col = segs[(size_t)i].cell % row_len;
+                    line_of[(size_t)i] = (col / LINE) * n_rows_ + row;
+                    ++first[(size_t)line_of[(size_t)i] + 1];
+                }
+                for (size_t l = 1; l < first.size(); ++l) first[l] += first[l - 1];
+                for (int64_t i = 0; i < nnz; ++i) {
+                    const int64_t col = segs[(size_t)i].cell % row_len;
+                    ls[(size_t)first[(size_t)line_of[(size_t)i]]++] = {line_of[(size_t)i], segs[(size_t)i].region, (int32_t)(col % LINE), segs[(size_t)i].w};
+                }
             }
-            // (strip-major line key: strip * n_rows + row)
-            std::sort(ls.begin(), ls.end(), [](const LSeg &a, const LSeg &b) {
-                if (a.line != b.line) return a.line < b.line;
-                if (a.region != b.region) return a.region < b.region;
-                return a.col < b.col;
-            });
             const int64_t n_rows = G / row_len;
             std::vector<std::vector<int32_t>> parts((size_t)R);
             std::vector<int32_t> region_mark((size_t)R, -1);
