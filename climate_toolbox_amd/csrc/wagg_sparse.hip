@@ -1815,7 +1815,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         (sizeof(T) == 4 || lines)) {
         const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * ((Ttot + LV_TB - 1) / LV_TB);
-        const long long nw = n_items < ncu ? n_items : ncu;
+        long long nw = n_items < ncu ? n_items : ncu;
+        if (const int v = diag_env("WAGG_LCV_NW")) { if (v >= 1 && v < nw) nw = v; }      // (diagnostic build: fewer workgroups = CUs)
         auto kern = vec ? sparse_lcv_kernel<T, true> : sparse_lcv_kernel<T, false>;
         size_t lds_bytes = LvLds<T>::total;
         if (nfuse == 2) { kern = vec ? sparse_lcv_kernel<T, true, 2> : sparse_lcv_kernel<T, false, 2>; lds_bytes = LvLds<T, 2>::total; }
