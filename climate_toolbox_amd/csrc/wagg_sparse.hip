@@ -1312,7 +1312,8 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             const T *p = Xl + (t0 + rbase) * ldx + cell0;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(p);
+                if (VEC && (knob & 2)) R.v[i] = __builtin_nontemporal_load(reinterpret_cast<const vecE *>(p));   // (diagnostic build: nt loads)
+                else if (VEC) R.v[i] = *reinterpret_cast<const vecE *>(p);
                 else {
                     const int64_t lim = G - 1 - cell0;
 #pragma unroll
