@@ -91,6 +91,8 @@ struct wagg_plan {
     bool has_lines = false;       // kernel, which is bound by line requests
     wagg::SparsePlanDev dl64;     // the same for fp64 data: 8 lines x 16 cells (a line = 128 bytes of a row in both)
     bool has_lines64 = false;
+    wagg::SparsePlanDev dl64e;    // 4 lines x 16 cells: fp64 degree days (both fields of a 64-cell chunk fill one image row)
+    bool has_lines64e = false;
     int device = 0;
     int ncu = 256;                 // compute units of `device` (read once, at plan creation)
     int flags = 0;                 // WAGG_PLAN_* kernel-form switches, fixed at plan creation
@@ -1178,8 +1180,9 @@ template <typename T, int NPOW = 1> struct LvLds {
 // that overflows gives +-inf as it does in the reference (transformations.py:188 then aggregations.py:78); what needs
 // the general form is a NaN PRODUCT (inf times a zero weight), hence the loaders also flag |y| >= ylim, the largest
 // value whose highest power is finite.
-// EDD (fused Snyder degree days, fp32; NPOW = number of thresholds of the pass, <= 4): the chunks are the
-// 128-cell ones (eight 64-byte pieces per field and timestep), an image row holds tasmin of the chunk in its first 512
+// EDD (fused Snyder degree days; NPOW = number of thresholds of the pass, <= 4): the chunks are the
+// 128-cell ones in fp32 (eight 64-byte pieces per field and timestep), 64-cell ones in fp64 (four whole lines, a
+// chunking of their own), an image row holds tasmin of the chunk in its first 512
 // bytes and tasmax in the second (lanes 0-31 / 32-63 of the loaders fetch one field each, both shifted by pv.xoff), and
 // the CONSUMERS evaluate snyder_edd1(tasmin, tasmax, thr[k]) for every (segment, timestep) and threshold -- so the
 // arithmetic (about 15 vector instructions per value, wagg_common.h::snyder_edd1_finite) runs on eight waves beside the
@@ -1201,7 +1204,6 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
 #endif
     constexpr int E = 16 / (int)sizeof(T);           // elements per 16-byte piece: 4 / 2
     constexpr int LPQ = 4 / E;                       // lanes per 4-cell quad of the plan: 1 / 2
-    static_assert(!EDD || sizeof(T) == 4, "degree days: fp32 (a row holds both fields of a 128-cell chunk)");
     // GT ((gridcell, time) data): a cell's 64 timesteps are PPC contiguous pieces; one load instruction fetches them for CPL cells
     constexpr int PPC = 64 / E, CPL = 64 / PPC;      // fp32: 16 pieces per cell, 4 cells (one quad) per load; fp64: 32, 2
     constexpr int CELLB = 64 * (int)sizeof(T);       // GT: bytes of a cell's row in the image
@@ -1267,8 +1269,9 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                 const int q = ((EDD ? tw0 & 31 : tw0) * CPL) / 4 + lane % (TPW * CPL / 4);
                 return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)];
             }
-            const int q = EDD ? (lane & 31) : lane / LPQ;
-            return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (EDD ? 0 : (lane % LPQ) * E);
+            const int l2 = EDD ? (lane & 31) : lane;              // (degree days: 32 lanes per field)
+            const int q = l2 / LPQ;
+            return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (l2 % LPQ) * E;
         };
         const T *const Xl = EDD && lane >= 32 ? pv.X2 : X;        // this lane's field
         struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; };
@@ -1511,7 +1514,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                     // (degree days: tasmax of the same cell sits 512 bytes further on -- the XOR never reaches
                                     // bit 9: cells < 128, timesteps < 64 -- so the two reads fuse into one ds_read2_b32)
                                     // (GT: tasmax is the second half of the image, 128 cell rows further on)
-                                    if constexpr (EDD) xh[j] = *(lds_cptr)(uintptr_t)((rb ^ u) + (GT ? 128 * CELLB : 512));
+                                    if constexpr (EDD) xh[j] = *(lds_cptr)(uintptr_t)((rb ^ u) + (GT ? 32768 : 512));
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 if constexpr (PK && !ODD) {
@@ -1536,8 +1539,10 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                                             if constexpr (ODD) {
                                                 const T p = ev * wv[j];
                                                 acc[pw] += (p == p) ? p : T(0);
-                                            } else {
+                                            } else if constexpr (sizeof(T) == 4) {
                                                 acc[pw] = __builtin_fmaf(ev, wv[j], acc[pw]);
+                                            } else {
+                                                acc[pw] = __builtin_fma(ev, wv[j], acc[pw]);
                                             }
                                         }
                                     }
@@ -1738,7 +1743,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // 0.43 ms for powers 1..4 and 1.37 vs 1.09 ms for three thresholds)
     const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
     // degree days in sparse_lcv_kernel: fp32 (time, gridcell) fields on the 128-cell chunking (the fp64 one: 64-byte pieces)
-    const bool edd_lcv = xpow == XF_EDD && sizeof(T) == 4 && plan->has_lines64 && !lcv_off && n_thr >= 1 && n_thr <= 4;
+    const bool edd_lcv = xpow == XF_EDD && (sizeof(T) == 4 ? plan->has_lines64 : plan->has_lines64e) && !lcv_off && n_thr >= 1 && n_thr <= 4;
+    const auto &d_edd = sizeof(T) == 4 ? plan->dl64 : plan->dl64e;     // chunks whose two fields fill one 64 KiB image
     const bool use_lines = (edd_lcv && layout == WAGG_LAYOUT_TG) || ((sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && layout == WAGG_LAYOUT_TG &&
                                        xpow != XF_EDD && (nfuse == 1 || (nfuse <= 4 && !lcv_off)));
     // (gridcell, time) data in sparse_lcv_kernel: every cell of a chunk is fetched by itself (64 timesteps = two or four whole
@@ -1746,8 +1752,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // chunk holds 256)
     const bool gt_lcv = layout == WAGG_LAYOUT_GT && !lcv_off && (xpow != XF_EDD || edd_lcv) && nfuse <= 4 &&
                         (sizeof(T) == 4 || plan->has_lines64);
-    const auto &d = gt_lcv ? (sizeof(T) == 4 && !edd_lcv ? plan->d : plan->dl64)
-                           : (use_lines ? (sizeof(T) == 4 && !edd_lcv ? plan->dl : plan->dl64) : plan->d);
+    const auto &d = edd_lcv ? d_edd
+                            : (gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64) : (use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d));
     if (int rc = check_timeout(plan)) return rc;
     if (nfuse > 1) {
         // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
@@ -1807,7 +1813,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     // degree days (two fields): fp32 (time, gridcell) data in the loader/consumer kernel, everything else in the
     // chunk-walking kernel
     const bool edd = xpow == XF_EDD;
-    const bool stream_path = (layout == WAGG_LAYOUT_TG || gt_lcv) && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4);
+    const bool stream_path = (layout == WAGG_LAYOUT_TG || gt_lcv) && !(plan->flags & WAGG_PLAN_NO_STREAM) && (!edd || sizeof(T) == 4 || edd_lcv);
     const int n_norm = (int)d.n_groups - d.g0_normal;
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
@@ -1829,7 +1835,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (nfuse == 3) kern = vec ? sparse_lcv_kernel<T, true, 3, false, true> : sparse_lcv_kernel<T, false, 3, false, true>;
             if (nfuse == 4) kern = vec ? sparse_lcv_kernel<T, true, 4, false, true> : sparse_lcv_kernel<T, false, 4, false, true>;
         }
-        if constexpr (sizeof(T) == 4) {
+        {
             if (edd_lcv) {
                 const int kt = pv.n_thr;
                 kern = vec ? sparse_lcv_kernel<T, true, 1, true> : sparse_lcv_kernel<T, false, 1, true>;
@@ -2082,7 +2088,9 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         }
         // one chunking of the table -> device arrays `d`; returns false when the whole-line chunking does not apply
         // (line_cells: 0 = region-shaped chunks; 32 / 16 = whole lines of that many cells, 128 bytes of a fp32 / fp64 row)
-        auto build = [&](int line_cells, int lines_per_chunk, bool for_f64, SparsePlanDev &d) -> bool {
+        // (kind: 0 region-shaped, 1 whole lines fp32, 2 whole lines fp64, 3 the 64-cell chunks of fp64 degree days)
+        auto build = [&](int line_cells, int lines_per_chunk, int kind, SparsePlanDev &d) -> bool {
+        const bool for_f64 = kind >= 2;
         const bool want_lines = line_cells > 0;
         std::vector<int32_t> grp_chunk_begin{0}, grp_giant, chunk_u_begin{0}, chunk_e_begin{0};
         std::vector<int32_t> ucell, ent_region, ent_seg_begin{0}, seg_u;   // ucell = first cell of each quad
@@ -2417,6 +2425,8 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             plan->info.n_ucells = (int64_t)ucell.size() * 4;    // cells fetched per timestep (whole quads)
             plan->info.n_giant = n_giant;
             plan->info.n_empty = (int64_t)empty.size();
+        } else if (kind == 3) {
+            plan->info.lines |= 4;
         } else if (!for_f64) {
             plan->info.lines |= 1;
             plan->info.n_partial_rows = n_part_rows;
@@ -2439,7 +2449,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
         }
         if (!want_lines) { plan->info.n_lines128 = l128s; plan->info.n_sectors64 = s64s; }
-        else if (!for_f64) plan->info.lines_lines128 = l128s;
+        else if (kind == 1) plan->info.lines_lines128 = l128s;
 #ifdef WAGG_DIAG
         if (diag_set("WAGG_PLAN_STATS"))      // plan statistics without a device (host experiments on the chunk builder)
             fprintf(stderr, "[wagg plan] line_cells=%d band_rows=%d chunks=%lld groups=%lld giant=%lld ucells=%lld lines128=%lld sectors64=%lld nnz=%lld partial_rows=%lld\n",
@@ -2469,7 +2479,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         return true;
         };   // build
 
-        build(0, 0, false, plan->d);
+        build(0, 0, 0, plan->d);
         // the whole-line chunking as well, for the kernel that is bound by line requests; its extra bytes (ocean cells of
         // coastal lines) cost the other kernels more than the aligned lines save them (c3, fp64: 0.47 -> 0.52 ms)
         if (!(flags & (WAGG_PLAN_NO_LINES | WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM)) && row_len < G && G % row_len == 0 &&
@@ -2479,12 +2489,13 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             int mult = diag_env("WAGG_LINE_MULT");
             if (mult != 2 && mult != 4 && mult != 8) mult = 1;
             if (diag_env("WAGG_LINE_MULT") == 16) {                      // ... and 16: half lines (64 bytes), 16 per chunk
-                plan->has_lines = build(16, 16, false, plan->dl);
-                if (he == hipSuccess) plan->has_lines64 = build(8, 16, true, plan->dl64);
+                plan->has_lines = build(16, 16, 1, plan->dl);
+                if (he == hipSuccess) plan->has_lines64 = build(8, 16, 2, plan->dl64);
             } else {
-            plan->has_lines = build(32 * mult, 8 / mult, false, plan->dl);
-            if (he == hipSuccess) plan->has_lines64 = build(16 * mult, 8 / mult, true, plan->dl64);
+            plan->has_lines = build(32 * mult, 8 / mult, 1, plan->dl);
+            if (he == hipSuccess) plan->has_lines64 = build(16 * mult, 8 / mult, 2, plan->dl64);
             }
+            if (he == hipSuccess) plan->has_lines64e = build(16, 4, 3, plan->dl64e);
         }
         if (he != hipSuccess) {
             set_error("plan upload failed: %s", hipGetErrorString(he));

@@ -63,7 +63,8 @@ typedef struct wagg_plan_info {
     int64_t G;
     int32_t R;
     int32_t lines;       /* bit 0: the plan also holds the whole-line chunking for fp32 (time, gridcell) data (lines of 32 cells);
-                            bit 1: the one for fp64 data (lines of 16 cells).  Both serve the loader/consumer kernel.             */
+                            bit 1: the one for fp64 data (lines of 16 cells); bit 2: the 64-cell one of fp64 degree days (four
+                            lines of 16 cells: both fields of a chunk in one image).  All serve the loader/consumer kernel.       */
     int64_t n_lines128;  /* sum over chunks of distinct 128-byte lines (32 fp32 cells) their quads touch */
     int64_t n_sectors64; /* ... of distinct 64-byte sectors */
     /* whole-line chunkings (else 0): chunks of eight whole 128-byte lines (32 fp32 / 16 fp64 cells) of one column strip */

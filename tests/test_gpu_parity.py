@@ -554,7 +554,7 @@ def test_fused_tas_poly_matches_transform_then_aggregate(torch_cuda, dtype, layo
     #  everything else: a multi-chunk "giant" group)
     from climate_toolbox_amd import _lib
     plan = SparsePlan(cell, code, w, G, Rn, row_len=nlon, flags=0 if lines else _lib.PLAN_NO_LINES)
-    assert plan.info["lines"] == (3 if lines else 0) and plan.info["n_giant"] >= 1   # both whole-line chunkings (fp32, fp64) or none
+    assert plan.info["lines"] == (7 if lines else 0) and plan.info["n_giant"] >= 1   # all three whole-line chunkings or none
     Xd = torch.from_numpy(X if layout == "TG" else np.ascontiguousarray(X.T)).cuda()
     got = plan.apply_poly(Xd, -273.15, 4, layout=layout).cpu().numpy()
     assert got.shape == (4, T, Rn)

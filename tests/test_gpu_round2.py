@@ -366,7 +366,7 @@ def test_whole_line_plan_against_region_shaped_chunks_and_the_oracle(torch_cuda,
         got = {}
         for flags in (0, _lib.PLAN_NO_LINES):
             plan = SparsePlan(cell, code, w, G, R, row_len=nlon, flags=flags)
-            assert plan.info["lines"] == (3 if flags == 0 else 0)       # the fp32 and the fp64 whole-line chunking, or neither
+            assert plan.info["lines"] == (7 if flags == 0 else 0)       # the fp32, the fp64 and the fp64 degree-day chunking, or none
             if flags == 0:
                 assert plan.info["n_partial_rows"] >= len(uniq) - 1 and plan.info["lines_chunks"] > 0
                 assert plan.info["n_partial_rows64"] >= plan.info["n_partial_rows"] and plan.info["lines64_chunks"] >= plan.info["lines_chunks"]

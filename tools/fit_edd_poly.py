@@ -51,3 +51,43 @@ with np.errstate(all="ignore"):
     th = np.arcsin(np.clip((float(e) - M64) / w64, -1, 1))
     ref = np.where(tmin < e, np.where(tmax > e, ((M64 - float(e)) * (np.pi / 2 - th) + w64 * np.cos(th)) / np.pi, 0.0), M64 - float(e))
 print("fp32 formula vs fp64 libm: max abs error %.3g, mean %.3g" % (np.abs(got - ref).max(), np.abs(got - ref).mean()))
+
+# fp64: degree-13 fit of P against a 40-digit evaluation (mpmath), for snyder_edd1_finite(double, ...)
+try:
+    import mpmath as mp
+except ImportError:
+    mp = None
+if mp is not None:
+    mp.mp.dps = 40
+
+    def Pm(x):
+        x = mp.mpf(x)
+        return (mp.sqrt(1 - x * x) - x * mp.acos(x)) / mp.pi / (1 - x) ** mp.mpf(1.5) if x < 1 else 2 * mp.sqrt(2) / (3 * mp.pi)
+
+    nn = 600
+    xs = (np.cos(np.pi * (np.arange(nn) + 0.5) / nn) + 1) / 2
+    c13 = C.chebfit(2 * xs - 1, np.array([float(Pm(float(x))) for x in xs]), 13)
+    xt = np.linspace(0, 1, 20001)
+    yt = np.array([float(Pm(float(x))) for x in xt])
+    print("fp64, degree 13: max |fit - P| on [0, 1]:", np.abs(C.chebval(2 * xt - 1, c13) - yt).max())
+    T = [[mp.mpf(1)], [mp.mpf(0), mp.mpf(1)]]
+    for k in range(2, 14):
+        a = [mp.mpf(0)] + [2 * v for v in T[k - 1]]
+        b = T[k - 2] + [mp.mpf(0)] * (len(a) - len(T[k - 2]))
+        T.append([a[i] - b[i] for i in range(len(a))])
+    pu = [mp.mpf(0)] * 14
+    for k in range(14):
+        for i, v in enumerate(T[k]):
+            pu[i] += mp.mpf(float(c13[k])) * v
+    px13 = [mp.mpf(0)] * 14
+    for k, a in enumerate(pu):
+        term = [mp.mpf(1)]
+        for _ in range(k):
+            nt = [mp.mpf(0)] * (len(term) + 1)
+            for i, v in enumerate(term):
+                nt[i] += -v
+                nt[i + 1] += 2 * v
+            term = nt
+        for i, v in enumerate(term):
+            px13[i] += a * v
+    print("Horner coefficients, high to low:", [repr(float(v)) for v in px13[::-1]])
