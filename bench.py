@@ -367,7 +367,19 @@ def main():
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_sparse(Xs.cpu().numpy(), cell, codes, w_eff, Rr, Gs,
                                                       "the FULL workload (all %d timesteps, full segment table)" % T)
-        if dtype == "float32" and world == 1 and not small and extras:
+        if world == 1 and not small and extras:
+            # the same field in (gridcell, time) order -- the reference's (lat, lon, time) fixture layout
+            XT = Xs.t().contiguous()
+            gout = torch.empty((T, Rr), dtype=Xs.dtype, device="cuda")
+            for _ in range(3):
+                plan.apply(XT, layout="GT", out=gout)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                plan.apply(XT, layout="GT", out=gout)
+            torch.cuda.synchronize()
+            res["layout_gridcell_time"] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3}
+            del XT, gout
             # fused tas_poly: (tas - 273.15)^p, p = 1..4, one pass over the field
             pout = torch.empty((4, T, Rr), dtype=Xs.dtype, device="cuda")
             for _ in range(2):
