@@ -90,14 +90,21 @@ __device__ __forceinline__ float snyder_edd1_finite(float tmin, float tmax, floa
     const float q = __builtin_amdgcn_sqrtf(t) * t;                     // (1 - |z|)^(3/2)
     return __builtin_fmaf(w, q * p, __builtin_fmaxf(d, 0.0f));
 }
-// fp64: the same expression with a degree-13 fit of P (|error| <= 4.4e-15, tools/fit_edd_poly.py): one division, one square
-// root and 13 fused multiply-adds where asin + sqrt of libm take several hundred instructions; used by the
+// fp64: the same expression with a degree-13 fit of P (|error| <= 4.4e-15, tools/fit_edd_poly.py): a reciprocal, a reciprocal
+// square root and 13 fused multiply-adds where asin + sqrt of libm take several hundred instructions; used by the
 // loader/consumer kernel for finite fields (everything else keeps the libm form above, from which it differs by ~1e-14).
 __device__ __forceinline__ double snyder_edd1_finite(double tmin, double tmax, double e) {
     const double M = 0.5 * (tmax + tmin), w = 0.5 * (tmax - tmin);
     const double d = M - e;
-    const double az = __builtin_fmin(__builtin_fabs(d / w), 1.0);      // |z|, z = (e - M) / w (w = 0: inf or NaN -> 1)
+    // 1 / w and sqrt(t) from v_rcp_f64 / v_rsq_f64 with one Newton step each (~2^-52 relative; the IEEE division and
+    // square-root sequences are a third of this function's instructions)
+    double rw = __builtin_amdgcn_rcp(w);
+    rw = __builtin_fma(rw, __builtin_fma(-w, rw, 1.0), rw);
+    const double az = __builtin_fmin(__builtin_fabs(d * rw), 1.0);     // |z|, z = (e - M) / w (w = 0: inf or NaN -> 1)
     const double t = 1.0 - az;
+    const double ty = __builtin_amdgcn_rsq(__builtin_fmax(t, 1e-300));  // (t = 0: 0 * 1e150 = 0 below)
+    double st = t * ty;                                                 // sqrt(t) to ~2^-26 ...
+    st = __builtin_fma(__builtin_fma(-st, st, t), 0.5 * ty, st);        // ... and one step: s + (t - s^2) / (2 s)
     double p = -8.644295123170258e-07;
     p = __builtin_fma(p, az, 7.147532263874047e-06);
     p = __builtin_fma(p, az, -2.807399717529102e-05);
@@ -112,7 +119,7 @@ __device__ __forceinline__ double snyder_edd1_finite(double tmin, double tmax, d
     p = __builtin_fma(p, az, 0.005985979570242935);
     p = __builtin_fma(p, az, -0.0225351707225776);
     p = __builtin_fma(p, az, 0.3183098861837864);
-    return __builtin_fma(w, __builtin_sqrt(t) * t * p, __builtin_fmax(d, 0.0));
+    return __builtin_fma(w, st * t * p, __builtin_fmax(d, 0.0));
 }
 template <> __device__ __forceinline__ float snyder_edd1<float>(float tmin, float tmax, float e) {
     const float d = 0.5f * (tmax + tmin) - e;
