@@ -1274,6 +1274,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             return pv.ucell[d.u0 + (q < d.nq ? q : d.nq - 1)] + (l2 % LPQ) * E;
         };
         const T *const Xl = EDD && lane >= 32 ? pv.X2 : X;        // this lane's field
+        [[maybe_unused]] int dma_buf = 0;        // (diagnostic build, knob 0x4000: image buffer the NEXT item's rows are sent to by LDS-DMA)
         struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; };
         static_assert(LC_SEGS <= LV_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
@@ -1312,6 +1313,24 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                 }
                 return;
             }
+#ifdef WAGG_DIAG
+            if (VEC && !EDD && (knob & 0x4000)) {
+                // TIMING ONLY (results are wrong): the rows go straight to the image by LDS-DMA (no register staging, no NaN
+                // rule, no swizzle; the consumers may still be reading that buffer) -- does the CU sustain more bytes per clock
+                // when the data does not return through the vector registers?
+                const unsigned lbase = (unsigned)reinterpret_cast<uintptr_t>(img) + (unsigned)(dma_buf * LV_TB + tw0) * LV_ROWB;
+                const T *rowp = X + (t0 + rbase) * ldx;
+                const unsigned voff = (unsigned)cell0 * (unsigned)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    int m0save;
+                    asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[src]\n\ts_mov_b32 m0, %[sv]"
+                                 : [sv] "=&s"(m0save) : [l0] "s"(lbase + (unsigned)i * LV_ROWB), [vo] "v"(voff), [src] "s"(rowp) : "memory");
+                    if (i + 1 < cnt) rowp += ldx;
+                }
+                return;
+            }
+#endif
             const T *p = Xl + (t0 + rbase) * ldx + cell0;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -1327,6 +1346,18 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         };
         auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
             char *im = img + (size_t)buf * LV_TB * LV_ROWB;
+#ifdef WAGG_DIAG
+            if (VEC && !EDD && (knob & 0x4000)) {            // (timing only: the rows came by LDS-DMA; 13 younger loads may stay out)
+                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                if (lane == 0) hdr[buf * 16 + 8 + wave] = 0;
+                if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
+                if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
+                if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
+                if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 2] = 0; hdr[buf * 16 + 3] = tb; }
+                dma_buf = buf;          // the item issued next lands where this one was
+                return;
+            }
+#endif
             bool odd = false;
             if (EDD) {                                            // both fields shifted (transformations.py:64-66)
 #pragma unroll
@@ -1399,6 +1430,7 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         cellq[1] = load_cell(dq[1]);
         Regs RA, RB;
         issue(RA, dq[0], cellq[0], itq[0].tb);
+        dma_buf = 1;
         StreamDesc dPark = dq[0];
         int tbPark = itq[0].tb;
         struct Ahead { Item nx; StreamDesc dn; int cn; };
