@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Phase stamps of the loader/consumer kernel on c2-real (diagnostic library, WAGG_SPARSE_STAMP=1), optionally with
-parts of the consumers left out (WAGG_LC_KNOB: 128 = no result stores, 256 = no segment walk, 1 = consumers idle;
-results are wrong with any of them -- timing only).  Run on the GPU box after `make -C climate_toolbox_amd/csrc diag`."""
+parts of the kernel left out or changed (WAGG_LC_KNOB: 128 = no result stores, 256 = no segment walk, 1 = consumers idle,
+2 = non-temporal loads (results stay right), 16384 = rows sent straight to the image by LDS-DMA; results are wrong with
+all but 2 -- timing only; WAGG_LCV_NW = number of workgroups, i.e. CUs used).  Run on the GPU box after `make -C climate_toolbox_amd/csrc diag`."""
 import os
 import sys
 import time
