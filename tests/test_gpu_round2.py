@@ -1098,3 +1098,34 @@ def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
     del keep
     gc.collect()
     assert A._PINNED_OUT["bytes"] == base
+
+
+@pytest.mark.parametrize("layout", ["TG", "GT"])
+def test_fp64_degree_days_in_the_loader_consumer_kernel_keep_fp64_accuracy(torch_cuda, layout):
+    """fp64 Snyder degree days of finite fields run in sparse_lcv_kernel on the 64-cell chunking with the band value in
+    the form w (1 - |z|)^(3/2) P(|z|) + max(d, 0) (degree-13 fit of P, reciprocal and square root by one Newton step:
+    csrc/wagg_common.h::snyder_edd1_finite) instead of libm's asin: the result must still be an fp64 result -- 1e-12
+    against the oracle's formula (transformations.py:64-87), including cells with tasmin == tasmax and thresholds below,
+    inside and above the data."""
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    nlat, nlon, T = 64, 128, 130
+    G = nlat * nlon
+    cell = np.arange(G, dtype=np.int32)
+    code = ((cell // nlon) // 8 * (nlon // 16) + (cell % nlon) // 16).astype(np.int32)
+    R = int(code.max()) + 1
+    w = rng.uniform(0.1, 1, G)
+    tmin = rng.uniform(-20, 40, (T, G)) + 273.15
+    tmax = tmin + rng.uniform(0, 20, (T, G))
+    tmax[3, :50] = tmin[3, :50]                                  # zero daily range
+    plan = SparsePlan(cell, code, w, G, R, row_len=nlon)
+    assert plan.info["lines"] == 7                               # the 64-cell chunking is there
+    thr = [-30.0, 5.0, 17.3, 31.0, 70.0]                         # (five: a pass of four and one of one)
+    a, b = (tmin, tmax) if layout == "TG" else (np.ascontiguousarray(tmin.T), np.ascontiguousarray(tmax.T))
+    got = plan.apply_edd(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), thr, offset=-273.15, layout=layout).cpu().numpy()
+    for k, e in enumerate(thr):
+        ref = O.agg_coded(O.snyder_edd_values(tmin - 273.15, tmax - 273.15, e), cell, code, w, R)
+        _rel_ok(got[k], ref, 1e-12, scale=1e-3)
+    plan.status()
