@@ -35,6 +35,7 @@ EXPORTS = (
     "wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32", "wagg_dense_apply_host_multi_f64",
     "wagg_host_block_plan", "wagg_host_stats_read",
     "wagg_combine_planes_f32", "wagg_combine_planes_f64", "wagg_take_axis", "wagg_relayout_f32", "wagg_relayout_f64",
+    "wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64", "wagg_synth_table_csr",
 )
 
 
@@ -62,7 +63,8 @@ def host_block_plan(T, row_bytes, quantum, n_devices=1):
 class DenseInfo(C.Structure):
     _fields_ = [("G", C.c_int64), ("n_tiles", C.c_int64), ("w_bytes", C.c_int64),
                 ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32),
-                ("form", C.c_int32), ("elem_bytes", C.c_int32), ("nnz", C.c_int64)]
+                ("form", C.c_int32), ("elem_bytes", C.c_int32), ("nnz", C.c_int64),
+                ("build_s", C.c_double), ("build_upload_s", C.c_double)]
 
 
 class WaggError(RuntimeError):
@@ -163,6 +165,9 @@ def load():
     L.wagg_dense_create_synth_blocklocal_f64.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_create_host_f64.argtypes = [f64p, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.wagg_dense_create_from_segments_f64.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    for name in ("wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64"):
+        getattr(L, name).argtypes = [i64p, i32p, f64p, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.wagg_synth_table_csr.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_int, i64p, i32p, f64p, C.c_int64, i64p]
     L.wagg_dense_apply_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
     L.wagg_dense_apply_poly_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, vp, C.c_int64, C.c_int, vp]
     L.wagg_dense_apply_edd_f64.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_double, vp, C.c_int64,

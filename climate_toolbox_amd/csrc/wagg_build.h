@@ -1,0 +1,63 @@
+// Device-side plan building for caller-supplied weight tables (wagg_build.hip): the coded segment table -- COO triples
+// (cell, region, weight) or CSR (rowptr over cells, region columns, weights) -- is sorted, coalesced and summed ON THE
+// DEVICE, so that a table of BASELINE configs[4] size (2.5e8 entries, 3 GB) costs the host nothing but the upload.
+// The dense-family constructors (wagg_dense.hip) turn the result into one of their three forms.
+//
+// Everything here is deterministic: a stable LSD radix sort (no atomics on data, integer histograms only), duplicate
+// (cell, region) rows added in their input order (aggregations.py:78 -- S5), denominators (aggregations.py:79) added in a
+// fixed order.
+#pragma once
+#include "wagg_common.h"
+
+namespace wagg {
+
+// Sort key of an entry = its place in the entry-list form (wagg_spmm.hip): one list per bucket = (region block rb, chunk
+// of 128 cells, wave), numbered as the plan numbers them, cell-major inside a list:
+//   key = (bucket * 128 + cell_in_chunk) * rw + j,  bucket = (rb * n_chunks + chunk) * 16 + wave,
+//   region = (rb * 16 + wave) * rw + j.
+// The other forms only need duplicates to be neighbours, which any total order gives.
+struct EntryKeyGeom {
+    int rw = 1, n_rb = 1, n_chunks = 1;
+    __host__ __device__ uint64_t range() const { return (uint64_t)n_rb * (uint64_t)n_chunks * 16u * 128u * (uint64_t)rw; }
+    __host__ __device__ uint64_t key(int64_t cell, int32_t region) const {
+        const uint64_t wv = (uint64_t)(region / rw), j = (uint64_t)(region % rw);
+        const uint64_t bucket = ((wv >> 4) * (uint64_t)n_chunks + (uint64_t)(cell >> 7)) * 16u + (wv & 15u);
+        return (bucket * 128u + (uint64_t)(cell & 127)) * (uint64_t)rw + j;
+    }
+    __host__ __device__ int64_t bucket_of(uint64_t k) const { return (int64_t)((k / (uint64_t)rw) >> 7); }
+    __host__ __device__ void decode(uint64_t k, int64_t &cell, int32_t &region, int &cic, int &j) const {
+        j = (int)(k % (uint64_t)rw);
+        k /= (uint64_t)rw;
+        cic = (int)(k & 127u);
+        k >>= 7;
+        const uint64_t wave = k & 15u;
+        k >>= 4;
+        const uint64_t chunk = k % (uint64_t)n_chunks, rb = k / (uint64_t)n_chunks;
+        cell = (int64_t)(chunk * 128u) + cic;
+        region = (int32_t)((rb * 16u + wave) * (uint64_t)rw) + j;
+    }
+};
+
+struct BuildTimes { double upload_s = 0, device_s = 0, total_s = 0; };
+
+// the coalesced table on the device: n_u distinct (cell, region) pairs in key order
+struct SortedEntries {
+    EntryKeyGeom geom;
+    int64_t n_in = 0, n_valid = 0, n_u = 0;           // rows handed in; with a label and a weight that is not NaN; distinct pairs
+    DevBuf<uint64_t> key;                             // [n_u] ascending
+    DevBuf<double> w;                                 // [n_u] fp64 sum of the pair's rows, in input order
+    DevBuf<double> den;                               // [R]   sum of the weights of a region's pairs (aggregations.py:79)
+};
+
+// Inputs are DEVICE arrays.  Exactly one of cell_dev (COO) / rowptr_dev (CSR, G + 1 offsets) is given.  region < 0 and NaN
+// weights drop the row (S3, S4); an index outside the grid / the regions fails with WAGG_EINVAL (first bad row in the text).
+int build_sorted_entries(const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev, const double *w_dev,
+                         int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out);
+
+// primitives (also used by the synthetic-table generator)
+int scan_u32_exclusive(uint32_t *data_dev, int64_t n, uint32_t *total_dev /* may be NULL */);
+// stable LSD radix sort of (key, value) pairs on the low 8 * passes bits; the sorted pairs end in (keys, vals) -- the
+// alternates are scratch of the same size
+int radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes);
+
+}  // namespace wagg

@@ -1,0 +1,443 @@
+// Device-side plan building for caller-supplied weight tables (see wagg_build.h): scan, stable radix sort, key
+// generation from COO / CSR, coalescing of duplicate (cell, region) rows, denominators -- and the synthetic c5 tables in
+// CSR form (wagg_synth_table_csr), the benchmark's stand-in for a caller's file.
+//
+// The reference's only weights type is a caller-supplied table (aggregations.py:64-73, :128-152); BASELINE configs[4]
+// calls it "sparse CSR weights (<= 1 % nnz)": 2.53e8 entries.  Rounds 1-3 sorted such a table on the host with two
+// single-threaded std::stable_sort passes; here the host only uploads it.
+#include <utility>
+
+#include "wagg_build.h"
+#include "wagg_host.h"
+
+namespace wagg {
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of uint32 (three kernels: tile sums, one block over the sums, tiles again)
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_THREADS = 256, SC_PER = 8, SC_TILE = SC_THREADS * SC_PER;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive prefix of v over the workgroup (any whole number of waves <= 16) and the workgroup's total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds /* [16] */, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+    for (int w = 0; w < nw; ++w) {
+        const uint32_t s = lds[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_sums_kernel(const uint32_t *__restrict__ data, int64_t n,
+                                                               uint32_t *__restrict__ sums) {
+    __shared__ uint32_t lds[16];
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_PER;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k)
+        if (base + k < n) s += data[base + k];
+    uint32_t total;
+    (void)block_excl_scan(s, lds, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t *__restrict__ sums, int64_t m, uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t lds[16];
+    uint32_t carry = 0;
+    for (int64_t b = 0; b < m; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const uint32_t v = i < m ? sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, lds, tot);
+        if (i < m) sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t *__restrict__ data, int64_t n,
+                                                                const uint32_t *__restrict__ sums) {
+    __shared__ uint32_t lds[16];
+    const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_PER;
+    uint32_t v[SC_PER], s = 0;
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k) {
+        v[k] = base + k < n ? data[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(s, lds, total) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SC_PER; ++k) {
+        if (base + k < n) data[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+int scan_u32_exclusive(uint32_t *data, int64_t n, uint32_t *total_dev) {
+    if (n <= 0) {
+        if (total_dev) WAGG_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), nullptr));
+        return WAGG_OK;
+    }
+    const int64_t m = (n + SC_TILE - 1) / SC_TILE;
+    WAGG_REQUIRE(m < (int64_t)0x7fffffff, "scan too long");
+    DevBuf<uint32_t> sums;
+    WAGG_HIP(sums.alloc((size_t)m));
+    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, nullptr, (const uint32_t *)data, n, sums.p);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, nullptr, sums.p, m, total_dev);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, nullptr, data, n, (const uint32_t *)sums.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());            // `sums` is freed on return
+    return WAGG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable LSD radix sort of (uint64 key, uint64 value) pairs, 8 bits per pass
+// ---------------------------------------------------------------------------------------------
+// A workgroup owns a tile of 8,192 consecutive pairs, wave w the 1,024 at [1024 w, 1024 w + 1024): round r of a wave is
+// the 64 consecutive pairs at 64 r (coalesced).  Pass = histogram per (digit, tile) -> exclusive scan over the digit-major
+// table -> scatter, where a pair's place is  scanned[digit][tile] + (same digit in lower waves of the tile) + (same digit
+// in earlier rounds of its wave) + (same digit in lower lanes of its round): input order is kept among equal digits.
+constexpr int RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_ROUNDS = 16, RS_TILE = RS_THREADS * RS_ROUNDS;
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift,
+                                                             uint32_t *__restrict__ hist, int64_t NB) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_ROUNDS; ++k) {
+        const int64_t i = base + (int64_t)k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(unsigned)(keys[i] >> shift) & 255u], 1u);      // integer counts: order-free
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(int64_t)threadIdx.x * NB + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals,
+                                                                int64_t n, int shift, const uint32_t *__restrict__ offs, int64_t NB,
+                                                                uint64_t *__restrict__ keys_out, uint64_t *__restrict__ vals_out) {
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (64 * RS_ROUNDS) + lane;
+    uint64_t k[RS_ROUNDS], v[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = wbase + 64 * r;
+        const bool ok = i < n;
+        k[r] = ok ? keys[i] : 0ull;
+        v[r] = ok ? vals[i] : 0ull;
+        if (ok) atomicAdd(&cnt[wave][(unsigned)(k[r] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {                       // counts -> first place of (wave, digit)
+        uint32_t run = offs[(int64_t)threadIdx.x * NB + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const uint32_t c = cnt[w][threadIdx.x];
+            cnt[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const uint64_t below_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const bool ok = wbase + 64 * r < n;
+        const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+        uint64_t peers = __ballot(ok);             // lanes of this round with my digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        if (ok) {
+            const uint32_t first = cnt[wave][d];   // the wave's LDS operations retire in order: every lane reads before the
+            const uint32_t at = first + (uint32_t)__popcll(peers & below_mask);      // lowest peer writes the new count
+            keys_out[at] = k[r];
+            vals_out[at] = v[r];
+            if ((peers & below_mask) == 0) cnt[wave][d] = first + (uint32_t)__popcll(peers);
+        }
+    }
+}
+
+int radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes) {
+    if (n <= 1 || passes <= 0) return WAGG_OK;
+    WAGG_REQUIRE(n < (int64_t)0x7fffffff, "too many entries to sort (%lld)", (long long)n);
+    const int64_t NB = (n + RS_TILE - 1) / RS_TILE;
+    DevBuf<uint32_t> hist;
+    WAGG_HIP(hist.alloc((size_t)(256 * NB)));
+    uint64_t *ks = keys, *vs = vals, *kd = keys_alt, *vd = vals_alt;
+    for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, nullptr, (const uint64_t *)ks, n, 8 * p, hist.p, NB);
+        WAGG_HIP(hipGetLastError());
+        if (int rc = scan_u32_exclusive(hist.p, 256 * NB, nullptr)) return rc;
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, nullptr, (const uint64_t *)ks, (const uint64_t *)vs, n,
+                           8 * p, (const uint32_t *)hist.p, NB, kd, vd);
+        WAGG_HIP(hipGetLastError());
+        std::swap(ks, kd);
+        std::swap(vs, vd);
+    }
+    if (ks != keys) {
+        WAGG_HIP(hipMemcpyAsync(keys, ks, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, nullptr));
+        WAGG_HIP(hipMemcpyAsync(vals, vs, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, nullptr));
+    }
+    WAGG_HIP(hipDeviceSynchronize());            // `hist` is freed on return
+    return WAGG_OK;
+}
+
+static int passes_for(uint64_t range) {          // 8-bit digits covering [0, range] (range itself = the sentinel's floor)
+    int bits = 0;
+    while (bits < 64 && (range >> bits) != 0) ++bits;
+    return bits == 0 ? 1 : (bits + 7) / 8;
+}
+
+// ---------------------------------------------------------------------------------------------
+// table -> sorted keys
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t KEY_DROPPED = ~0ull;           // null label / NaN weight: sorts behind every real key
+
+__global__ __launch_bounds__(256) void keygen_kernel(const int32_t *__restrict__ cell, const int64_t *__restrict__ rowptr,
+                                                     const int32_t *__restrict__ region, const double *__restrict__ w, int64_t n,
+                                                     int64_t G, int32_t R, EntryKeyGeom geom, uint64_t *__restrict__ keys,
+                                                     uint64_t *__restrict__ vals, unsigned long long *__restrict__ note) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool dropped = false;
+    if (i < n) {
+        int64_t c;
+        if (rowptr) {                              // CSR: the row that holds entry i = the last g with rowptr[g] <= i
+            int64_t lo = 0, hi = G;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (rowptr[mid] <= i) lo = mid; else hi = mid;
+            }
+            c = lo;
+        } else {
+            c = cell[i];
+        }
+        const int32_t r = region[i];
+        const double wv = w[i];
+        uint64_t key = KEY_DROPPED;
+        if (r >= R || c < 0 || c >= G) atomicMin(&note[0], (unsigned long long)i);           // first bad row
+        else if (r >= 0 && wv == wv) key = geom.key(c, r);
+        dropped = key == KEY_DROPPED;
+        keys[i] = key;
+        vals[i] = __builtin_bit_cast(uint64_t, wv);
+    }
+    const uint64_t m = __ballot(dropped);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&note[1], (unsigned long long)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void heads_kernel(const uint64_t *__restrict__ key, int64_t n, uint32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+
+// rows of one (cell, region) pair are neighbours now, in input order: add them in that order (S5)
+__global__ __launch_bounds__(256) void coalesce_kernel(const uint64_t *__restrict__ key, const uint64_t *__restrict__ val, int64_t n,
+                                                       const uint32_t *__restrict__ rank, uint64_t *__restrict__ ukey,
+                                                       double *__restrict__ uw, uint64_t *__restrict__ rkey, EntryKeyGeom geom) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    if (i > 0 && key[i - 1] == k) return;
+    double s = 0.0;
+    for (int64_t j = i; j < n && key[j] == k; ++j) s += __builtin_bit_cast(double, val[j]);
+    const uint32_t u = rank[i];
+    ukey[u] = k;
+    uw[u] = s;
+    int64_t cellv;
+    int32_t regionv;
+    int cic, jj;
+    geom.decode(k, cellv, regionv, cic, jj);
+    rkey[u] = (uint64_t)regionv;
+}
+
+// den[r] = sum of the weights of region r's pairs (aggregations.py:79), pairs in (region, key) order: one wave per
+// region, lane-strided partial sums, then the fixed shuffle tree
+__global__ __launch_bounds__(256) void den_kernel(const uint64_t *__restrict__ rkey, const uint64_t *__restrict__ w, int64_t n,
+                                                  int32_t R, double *__restrict__ den) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    auto lower = [&](uint64_t v) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rkey[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int64_t b = lower((uint64_t)r), e = lower((uint64_t)r + 1);
+    double s = 0.0;
+    for (int64_t i = b + lane; i < e; i += 64) s += __builtin_bit_cast(double, w[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) den[r] = s;
+}
+
+int build_sorted_entries(const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev, const double *w_dev,
+                         int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out) {
+    WAGG_REQUIRE(out != nullptr, "out is NULL");
+    WAGG_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff, "table of %lld rows: at most 2^31 - 1", (long long)n);
+    WAGG_REQUIRE((cell_dev != nullptr) != (rowptr_dev != nullptr) || n == 0, "exactly one of cell / rowptr");
+    WAGG_REQUIRE(geom.range() < (1ull << 62), "grid x regions too large for the sort key");
+    out->geom = geom;
+    out->n_in = n;
+    out->n_valid = out->n_u = 0;
+    WAGG_HIP(out->den.alloc((size_t)R));
+    WAGG_HIP(hipMemset(out->den.p, 0, sizeof(double) * (size_t)R));
+    if (n == 0) return WAGG_OK;
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    DevBuf<uint64_t> ka, va, kb, vb;
+    DevBuf<unsigned long long> note;
+    WAGG_HIP(ka.alloc((size_t)n));
+    WAGG_HIP(va.alloc((size_t)n));
+    WAGG_HIP(kb.alloc((size_t)n));
+    WAGG_HIP(vb.alloc((size_t)n));
+    WAGG_HIP(note.alloc(2));
+    {
+        const unsigned long long init[2] = {~0ull, 0ull};
+        WAGG_HIP(staged_h2d(note.p, init, sizeof(init), nullptr));
+    }
+    hipLaunchKernelGGL(keygen_kernel, dim3(nblk), dim3(256), 0, nullptr, cell_dev, rowptr_dev, region_dev, w_dev, n, G, R, geom,
+                       ka.p, va.p, note.p);
+    WAGG_HIP(hipGetLastError());
+    unsigned long long noted[2];
+    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(staged_d2h(noted, note.p, sizeof(noted)));
+    WAGG_REQUIRE(noted[0] == ~0ull, "segment %llu out of range", noted[0]);
+    const int64_t n_valid = n - (int64_t)noted[1];
+    out->n_valid = n_valid;
+    if (int rc = radix_sort_pairs(ka.p, va.p, kb.p, vb.p, n, passes_for(geom.range()))) return rc;
+    if (n_valid == 0) return WAGG_OK;
+    // distinct pairs: rank of every run's head, then one sum per run
+    DevBuf<uint32_t> rank, total;
+    WAGG_HIP(rank.alloc((size_t)n_valid));
+    WAGG_HIP(total.alloc(1));
+    const unsigned vblk = (unsigned)((n_valid + 255) / 256);
+    hipLaunchKernelGGL(heads_kernel, dim3(vblk), dim3(256), 0, nullptr, (const uint64_t *)ka.p, n_valid, rank.p);
+    WAGG_HIP(hipGetLastError());
+    if (int rc = scan_u32_exclusive(rank.p, n_valid, total.p)) return rc;
+    uint32_t n_u32 = 0;
+    WAGG_HIP(staged_d2h(&n_u32, total.p, sizeof(n_u32)));
+    const int64_t n_u = n_u32;
+    out->n_u = n_u;
+    WAGG_HIP(out->key.alloc((size_t)n_u));
+    WAGG_HIP(out->w.alloc((size_t)n_u));
+    // kb <- region of every distinct pair (the key of the denominator sort), vb <- a copy of the sums to sort along
+    hipLaunchKernelGGL(coalesce_kernel, dim3(vblk), dim3(256), 0, nullptr, (const uint64_t *)ka.p, (const uint64_t *)va.p, n_valid,
+                       (const uint32_t *)rank.p, out->key.p, out->w.p, kb.p, geom);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipMemcpyAsync(vb.p, out->w.p, sizeof(double) * (size_t)n_u, hipMemcpyDeviceToDevice, nullptr));
+    if (int rc = radix_sort_pairs(kb.p, vb.p, ka.p, va.p, n_u, passes_for((uint64_t)R))) return rc;
+    hipLaunchKernelGGL(den_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nullptr, (const uint64_t *)kb.p, (const uint64_t *)vb.p,
+                       n_u, R, out->den.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());            // the scratch pairs are freed on return
+    return WAGG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic c5 tables in CSR form (device-generated, copied to the caller's host arrays)
+// ---------------------------------------------------------------------------------------------
+// W[g][r] = hash_u01(g R + r, seed) where hash_u01(g R + r, seed ^ 0x9e3779b9) < fill; block-local: only the 256 regions of
+// column tile (97 (g / 64)) mod ceil(R / 256) are candidates of cell g.  Exactly the tables of
+// wagg_dense_create_synth_sparse / _synth_blocklocal, as a caller would hand them in: rows = cells, columns ascending.
+template <bool FILL>
+__global__ __launch_bounds__(256) void synth_csr_kernel(int64_t G, int32_t R, uint32_t seed, float fill, int blocklocal,
+                                                        uint32_t *__restrict__ counts, const uint32_t *__restrict__ first,
+                                                        int32_t *__restrict__ col, double *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int n_nt = (int)(((int64_t)R + 255) / 256);
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < G; g += nwaves) {
+        int64_t r0 = 0, r1 = R;
+        if (blocklocal) {
+            r0 = (int64_t)((97 * (g / 64)) % n_nt) * 256;
+            r1 = r0 + 256 < R ? r0 + 256 : R;
+        }
+        uint32_t kept = 0;
+        const uint32_t base = FILL ? first[g] : 0u;
+        for (int64_t rb = r0; rb < r1; rb += 64) {
+            const int64_t r = rb + lane;
+            const uint64_t id = (uint64_t)g * (uint64_t)R + (uint64_t)r;
+            const bool keep = r < r1 && hash_u01(id, seed ^ 0x9e3779b9u) < fill;
+            const uint64_t m = __ballot(keep);
+            if (FILL && keep) {
+                const uint32_t at = base + kept + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                col[at] = (int32_t)r;
+                val[at] = (double)hash_u01(id, seed);
+            }
+            kept += (uint32_t)__popcll(m);
+        }
+        if (!FILL && lane == 0) counts[g] = kept;
+    }
+}
+
+__global__ void widen_rowptr_kernel(const uint32_t *__restrict__ first, int64_t G, uint32_t total, int64_t *__restrict__ rowptr) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < G) rowptr[g] = first[g];
+    if (g == G) rowptr[g] = total;
+}
+
+}  // namespace wagg
+
+using namespace wagg;
+
+extern "C" int wagg_synth_table_csr(int64_t G, int32_t R, uint32_t seed, double fill, int blocklocal, int64_t *rowptr_host,
+                                    int32_t *col_host, double *val_host, int64_t capacity, int64_t *nnz_out) {
+    clear_error();
+    WAGG_REQUIRE(G > 0 && R > 0 && fill > 0.0 && fill <= 1.0, "bad arguments");
+    WAGG_REQUIRE(rowptr_host != nullptr && nnz_out != nullptr, "NULL pointer");
+    WAGG_REQUIRE((col_host == nullptr) == (val_host == nullptr), "col and val go together");
+    DevBuf<uint32_t> first, total;
+    WAGG_HIP(first.alloc((size_t)G));
+    WAGG_HIP(total.alloc(1));
+    hipLaunchKernelGGL((synth_csr_kernel<false>), dim3(256 * 32), dim3(256), 0, nullptr, G, R, seed, (float)fill, blocklocal, first.p,
+                       (const uint32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
+    WAGG_HIP(hipGetLastError());
+    if (int rc = scan_u32_exclusive(first.p, G, total.p)) return rc;
+    uint32_t nnz = 0;
+    WAGG_HIP(staged_d2h(&nnz, total.p, sizeof(nnz)));
+    *nnz_out = nnz;
+    DevBuf<int64_t> rowptr;
+    WAGG_HIP(rowptr.alloc((size_t)G + 1));
+    hipLaunchKernelGGL(widen_rowptr_kernel, dim3((unsigned)((G + 256) / 256)), dim3(256), 0, nullptr, (const uint32_t *)first.p, G, nnz,
+                       rowptr.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(staged_d2h(rowptr_host, rowptr.p, sizeof(int64_t) * ((size_t)G + 1)));
+    if (!col_host) return WAGG_OK;
+    WAGG_REQUIRE(capacity >= (int64_t)nnz, "capacity %lld below the table's %u entries", (long long)capacity, nnz);
+    if (nnz == 0) return WAGG_OK;
+    DevBuf<int32_t> col;
+    DevBuf<double> val;
+    WAGG_HIP(col.alloc(nnz));
+    WAGG_HIP(val.alloc(nnz));
+    hipLaunchKernelGGL((synth_csr_kernel<true>), dim3(256 * 32), dim3(256), 0, nullptr, G, R, seed, (float)fill, blocklocal,
+                       (uint32_t *)nullptr, (const uint32_t *)first.p, col.p, val.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());
+    if (int rc = copy_rows_to_host(col_host, col.p, 1, sizeof(int32_t) * (size_t)nnz, sizeof(int32_t) * (size_t)nnz, true)) return rc;
+    return copy_rows_to_host(val_host, val.p, 1, sizeof(double) * (size_t)nnz, sizeof(double) * (size_t)nnz, true);
+}

@@ -25,6 +25,7 @@
 //   * fp32 partial slabs per (tile, k-slice), then one reduce kernel fuses the division by den[r]
 //     (deterministic, no atomics).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <cstdlib>
@@ -729,102 +730,151 @@ static int create_host(const T *W_host, int64_t G, int32_t R, wagg_dense **out) 
     return rc;
 }
 
+// ---- plans from a caller's table (COO segment rows or CSR), built on the device ---------------------------------------
+// which (BK-cell x 256-region) tiles of W hold a pair: one bit per tile.  Neighbouring pairs mostly share their tile
+// (key order walks a chunk's cells inside one wave's regions), so only the first of such a run touches the bitmap.
 template <typename T>
-static int create_from_segments(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff, int64_t nseg,
-                                int64_t G, int32_t R, wagg_dense **out) {
-    constexpr int BK = DT<T>::BK, E = DT<T>::EPP;
+__global__ __launch_bounds__(256) void table_tiles_kernel(const uint64_t *__restrict__ key, int64_t n, EntryKeyGeom geom, int n_kt,
+                                                          uint32_t *__restrict__ bitmap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto tile_of = [&](uint64_t k) {
+        int64_t cell; int32_t region; int cic, j;
+        geom.decode(k, cell, region, cic, j);
+        return (int64_t)(region / D_BN) * n_kt + cell / DT<T>::BK;
+    };
+    const int64_t t = tile_of(key[i]);
+    if (i > 0 && tile_of(key[i - 1]) == t) return;
+    atomicOr(&bitmap[t >> 5], 1u << (t & 31));          // idempotent: the bitmap is the same on every build
+}
+
+// distinct pairs -> packed W (full form: word_rank == NULL; tile-sparse: stored tile = rank of the pair's tile among the set bits)
+template <typename T>
+__global__ __launch_bounds__(256) void table_scatter_kernel(const uint64_t *__restrict__ key, const double *__restrict__ w, int64_t n,
+                                                            EntryKeyGeom geom, int n_kt, const uint32_t *__restrict__ bitmap,
+                                                            const uint32_t *__restrict__ word_rank, T *__restrict__ Wp) {
+    constexpr int E = DT<T>::EPP, BK = DT<T>::BK;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t cell; int32_t region; int cic, j;
+    geom.decode(key[i], cell, region, cic, j);
+    int64_t at;
+    if (word_rank) {
+        const int64_t t = (int64_t)(region / D_BN) * n_kt + cell / BK;
+        const int64_t ti = (int64_t)word_rank[t >> 5] + __popc(bitmap[t >> 5] & ((1u << (t & 31)) - 1u));
+        const int cl = region % D_BN, kk = (int)(cell % BK);
+        at = (ti * D_WSLOTS + tile_slot(cl, kk / E)) * E + (kk % E);
+    } else {
+        at = wp_index<T>(cell, region, n_kt);
+    }
+    Wp[at] = (T)w[i];
+}
+
+static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// cell_idx (COO) or rowptr (CSR: G + 1 offsets, rows = cells) -- host arrays, like region_code and w.  The host validates
+// the row offsets and uploads; sorting, coalescing duplicate rows (S5), the denominators (aggregations.py:79), the choice
+// of form and the packing all run on the device (wagg_build.hip): extra host memory is the 8-MiB staging pieces (or none:
+// large arrays are page-locked in place for the copy).
+template <typename T>
+static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, const int32_t *region_code, const double *w_eff,
+                             int64_t n, int64_t G, int32_t R, wagg_dense **out) {
+    constexpr int BK = DT<T>::BK;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
-    WAGG_REQUIRE(nseg == 0 || (cell_idx && region_code && w_eff), "NULL segment arrays");
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
-    struct Seg { int32_t region, cell; double w; };
-    std::vector<Seg> segs;
-    std::vector<double> den((size_t)R, 0.0);
-    for (int64_t i = 0; i < nseg; ++i) {
-        const int32_t r = region_code[i];
-        if (r < 0) continue;
-        WAGG_REQUIRE(r < R && cell_idx[i] >= 0 && cell_idx[i] < G, "segment %lld out of range", (long long)i);
-        if (std::isnan(w_eff[i])) continue;
-        den[(size_t)r] += w_eff[i];
-        segs.push_back({r, cell_idx[i], w_eff[i]});
+    if (rowptr) {
+        WAGG_REQUIRE(rowptr[0] == 0, "rowptr[0] must be 0");
+        for (int64_t g = 0; g < G; ++g) WAGG_REQUIRE(rowptr[g] <= rowptr[g + 1], "rowptr decreases at row %lld", (long long)g);
+        n = rowptr[G];
     }
-    std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
-        return a.region != b.region ? a.region < b.region : a.cell < b.cell; });
-    std::vector<int32_t> hc, hr; std::vector<T> hw;
-    for (size_t i = 0; i < segs.size();) {
-        double s = 0; size_t j = i;
-        while (j < segs.size() && segs[j].region == segs[i].region && segs[j].cell == segs[i].cell) s += segs[j++].w;
-        hc.push_back(segs[i].cell); hr.push_back(segs[i].region); hw.push_back((T)s);
-        i = j;
-    }
-    // which (BK-cell x 256-region) tiles of W hold anything?  Few -> tile-sparse form
+    WAGG_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff, "table of %lld rows: at most 2^31 - 1", (long long)n);
+    WAGG_REQUIRE(n == 0 || ((cell_idx || rowptr) && region_code && w_eff), "NULL table arrays");
+    const double t0 = wall_s();
+    SpmmPlan geo;
+    spmm_geometry(G, R, geo);
+    EntryKeyGeom kg;
+    kg.rw = geo.rw; kg.n_rb = geo.n_rb; kg.n_chunks = geo.n_chunks;
+    SortedEntries se;
+    double t_up = 0.0;
+    {
+        DevBuf<int32_t> dcell, dreg;
+        DevBuf<int64_t> drow;
+        DevBuf<double> dw;
+        if (n > 0) {
+            if (rowptr) WAGG_HIP(drow.alloc((size_t)G + 1)); else WAGG_HIP(dcell.alloc((size_t)n));
+            WAGG_HIP(dreg.alloc((size_t)n));
+            WAGG_HIP(dw.alloc((size_t)n));
+            int rc = rowptr ? copy_to_device(drow.p, rowptr, sizeof(int64_t) * ((size_t)G + 1), true)
+                            : copy_to_device(dcell.p, cell_idx, sizeof(int32_t) * (size_t)n, true);
+            if (rc == WAGG_OK) rc = copy_to_device(dreg.p, region_code, sizeof(int32_t) * (size_t)n, true);
+            if (rc == WAGG_OK) rc = copy_to_device(dw.p, w_eff, sizeof(double) * (size_t)n, true);
+            if (rc != WAGG_OK) return rc;
+        }
+        t_up = wall_s() - t0;
+        if (int rc = build_sorted_entries(n > 0 && !rowptr ? dcell.p : nullptr, n > 0 && rowptr ? drow.p : nullptr, dreg.p, dw.p, n, G, R,
+                                          kg, &se))
+            return rc;
+    }   // the uploaded table is released here
+    // which tiles of W hold anything?  Few -> tile-sparse form; (almost) all but few pairs in them -> entry lists
     const int n_kt = (int)((G + BK - 1) / BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
-    std::vector<int64_t> keys(hc.size());
-    for (size_t i = 0; i < hc.size(); ++i) keys[i] = (int64_t)(hr[i] / D_BN) * n_kt + hc[i] / BK;
-    std::vector<int64_t> tiles(keys);
-    std::sort(tiles.begin(), tiles.end());
-    tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
-    bool tiled = (double)tiles.size() < 0.5 * (double)n_kt * (double)n_nt;
+    const int64_t n_tiles_all = (int64_t)n_kt * n_nt, n_words = (n_tiles_all + 31) / 32;
+    DevBuf<uint32_t> bitmap, word_rank;
+    WAGG_HIP(bitmap.alloc((size_t)n_words));
+    WAGG_HIP(hipMemset(bitmap.p, 0, sizeof(uint32_t) * (size_t)n_words));
+    const unsigned nblk = (unsigned)((se.n_u + 255) / 256);
+    if (se.n_u > 0) {
+        hipLaunchKernelGGL((table_tiles_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, se.n_u, kg, n_kt, bitmap.p);
+        WAGG_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> hbits, hrank;
+    std::vector<int64_t> tiles;
+    try {
+        hbits.resize((size_t)n_words);
+        hrank.resize((size_t)n_words);
+        WAGG_HIP(hipDeviceSynchronize());
+        WAGG_HIP(staged_d2h(hbits.data(), bitmap.p, sizeof(uint32_t) * hbits.size()));
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n_words; ++i) { hrank[(size_t)i] = (uint32_t)cnt; cnt += __builtin_popcount(hbits[(size_t)i]); }
+        tiles.reserve((size_t)cnt);
+        for (int64_t i = 0; i < n_words; ++i)
+            for (uint32_t m = hbits[(size_t)i]; m; m &= m - 1) tiles.push_back(i * 32 + __builtin_ctz(m));
+    } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
+    bool tiled = (double)tiles.size() < 0.5 * (double)n_tiles_all;
 #ifdef WAGG_DIAG
     if (getenv("WAGG_DENSE_NO_TILED")) tiled = false;
 #endif
-    int rc = WAGG_OK;
-    {
-        // tiles mostly occupied but few non-zeros in them (scattered weights): entry lists
-        if (!tiled && (double)hc.size() < SPMM_MAX_FILL * (double)G * (double)R) {
-            rc = dense_alloc<T>(G, R, out, -1, true);
-            if (rc != WAGG_OK) return rc;
-            wagg_dense *d = *out;
-            rc = spmm_build_from_coo<T>(d, hc, hr, hw);
-            std::vector<float> den32s(den.size());
-            for (size_t i = 0; i < den.size(); ++i) den32s[i] = (float)den[i];
-            hipError_t es = rc == WAGG_OK ? staged_h2d(d->den64.p, den.data(), sizeof(double) * den.size(), nullptr) : hipSuccess;
-            if (es == hipSuccess && rc == WAGG_OK) es = staged_h2d(d->den32.p, den32s.data(), sizeof(float) * den32s.size(), nullptr);
-            if (es != hipSuccess) { set_error("entry lists: %s", hipGetErrorString(es)); rc = WAGG_EHIP; }
-            if (rc != WAGG_OK) { delete d; *out = nullptr; return rc; }
-            d->den_host = den;
-            return WAGG_OK;
-        }
-    }
-    rc = dense_alloc<T>(G, R, out, tiled ? (int64_t)tiles.size() : -1);
+    const bool entries = !tiled && (double)se.n_u < SPMM_MAX_FILL * (double)G * (double)R;
+    int rc = dense_alloc<T>(G, R, out, tiled ? (int64_t)tiles.size() : -1, entries);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    DevBuf<int32_t> dc, dr; DevBuf<T> dw; DevBuf<int64_t> dat;
-    hipError_t e = hipMemset(d->W.p, 0, 16 * (size_t)d->w_slots());
-    if (e == hipSuccess) e = dw.upload(hw);
-    if (tiled) {
-        std::vector<int64_t> at(hc.size());
-        for (size_t i = 0; i < hc.size(); ++i) {
-            const int64_t ti = std::lower_bound(tiles.begin(), tiles.end(), keys[i]) - tiles.begin();
-            const int cl = hr[i] % D_BN, kk = hc[i] % BK;
-            at[i] = (ti * D_WSLOTS + tile_slot(cl, kk / E)) * E + (kk % E);
-        }
-        if (e == hipSuccess) e = dat.upload(at);
-        if (e == hipSuccess) e = dense_set_tiles(d, tiles);
-        if (e == hipSuccess && !hc.empty()) {
-            hipLaunchKernelGGL((dense_scatter_at_kernel<T>), dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                               reinterpret_cast<T *>(d->W.p), (const int64_t *)dat.p, (const T *)dw.p, (int64_t)hc.size());
-            e = hipGetLastError();
-        }
+    auto fail = [&](int code) { delete d; *out = nullptr; return code; };
+    if (entries) {
+        rc = spmm_build_from_sorted<T>(d, se);
+        if (rc != WAGG_OK) return fail(rc);
     } else {
-        if (e == hipSuccess) e = dc.upload(hc);
-        if (e == hipSuccess) e = dr.upload(hr);
-        if (e == hipSuccess && !hc.empty()) {
-            hipLaunchKernelGGL((dense_scatter_kernel<T>), dim3((unsigned)((hc.size() + 255) / 256)), dim3(256), 0, nullptr,
-                               reinterpret_cast<T *>(d->W.p), d->n_kt, (const int32_t *)dc.p, (const int32_t *)dr.p,
-                               (const T *)dw.p, (int64_t)hc.size());
+        hipError_t e = hipMemset(d->W.p, 0, 16 * (size_t)d->w_slots());
+        if (e == hipSuccess && tiled) e = dense_set_tiles(d, tiles);
+        if (e == hipSuccess && tiled) e = word_rank.upload(hrank);
+        if (e == hipSuccess && se.n_u > 0) {
+            hipLaunchKernelGGL((table_scatter_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, (const double *)se.w.p,
+                               se.n_u, kg, n_kt, (const uint32_t *)bitmap.p, tiled ? (const uint32_t *)word_rank.p : (const uint32_t *)nullptr,
+                               reinterpret_cast<T *>(d->W.p));
             e = hipGetLastError();
         }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { set_error("densify: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
     }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { set_error("densify: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
-    // denominators from the fp64 segment sums (aggregations.py:79), not from the stored matrix
-    std::vector<float> den32(den.size());
-    for (size_t i = 0; i < den.size(); ++i) den32[i] = (float)den[i];
-    e = staged_h2d(d->den64.p, den.data(), sizeof(double) * den.size(), nullptr);
-    if (e == hipSuccess) e = staged_h2d(d->den32.p, den32.data(), sizeof(float) * den32.size(), nullptr);
-    if (e != hipSuccess) { set_error("densify den: %s", hipGetErrorString(e)); delete d; *out = nullptr; return WAGG_EHIP; }
-    d->den_host = den;
+    // denominators from the fp64 sums of the table (aggregations.py:79), not from the stored (rounded) weights
+    hipError_t e = hipMemcpy(d->den64.p, se.den.p, sizeof(double) * (size_t)R, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { set_error("densify den: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
+    rc = dense_den_to_host(d);
+    if (rc != WAGG_OK) return fail(rc);
+    if (entries) d->sp.nnz = se.n_u;
+    d->nnz_table = se.n_u;
+    d->build.upload_s = t_up;
+    d->build.total_s = wall_s() - t0;
+    d->build.device_s = d->build.total_s - t_up;
     return WAGG_OK;
 }
 
@@ -1044,12 +1094,25 @@ extern "C" int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32
 extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                                const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                                wagg_dense **out) {
-    return wagg::create_from_segments<float>(cell_idx, region_code, w_eff, nseg, G, R, out);
+    return wagg::create_from_table<float>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, out);
 }
 extern "C" int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
                                                    const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                                    wagg_dense **out) {
-    return wagg::create_from_segments<double>(cell_idx, region_code, w_eff, nseg, G, R, out);
+    return wagg::create_from_table<double>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, out);
+}
+
+extern "C" int wagg_dense_create_from_csr(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
+                                          wagg_dense **out) {
+    using namespace wagg;
+    WAGG_REQUIRE(rowptr != nullptr, "rowptr is NULL");
+    return create_from_table<float>(nullptr, rowptr, col, val, 0, G, R, out);
+}
+extern "C" int wagg_dense_create_from_csr_f64(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
+                                              wagg_dense **out) {
+    using namespace wagg;
+    WAGG_REQUIRE(rowptr != nullptr, "rowptr is NULL");
+    return create_from_table<double>(nullptr, rowptr, col, val, 0, G, R, out);
 }
 
 extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
@@ -1060,7 +1123,9 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 4 * (d->f64 ? wagg::SpT<double>::GW : wagg::SpT<float>::GW) : d->w_slots() * 16;
     info->form = d->spmm ? WAGG_FORM_ENTRIES : (d->tiled ? WAGG_FORM_TILES : WAGG_FORM_FULL);
     info->elem_bytes = d->f64 ? 8 : 4;
-    info->nnz = d->spmm ? d->sp.nnz : -1;
+    info->nnz = d->spmm ? d->sp.nnz : d->nnz_table;
+    info->build_s = d->build.total_s;
+    info->build_upload_s = d->build.upload_s;
     return WAGG_OK;
 }
 

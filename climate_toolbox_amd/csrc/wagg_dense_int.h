@@ -1,6 +1,7 @@
 // Internal layout of a dense-family plan (wagg_dense) shared by wagg_dense.hip (full / tile-sparse
 // MFMA forms) and wagg_spmm.hip (entry-list form for scattered weights).
 #pragma once
+#include "wagg_build.h"
 #include "wagg_host.h"
 
 namespace wagg {
@@ -95,14 +96,16 @@ struct wagg_dense {
     int *inf_host = nullptr, *inf_dev = nullptr;
     // pack-free tile-sparse apply: "a numerator of the first pass was not finite" (device word, gates the exact second pass)
     wagg::DevBuf<int> nonfinite;
+    int64_t nnz_table = -1;            // distinct (cell, region) pairs of the caller's table (constructors that take one)
+    wagg::BuildTimes build;            // constructors that take a caller's table: where the seconds went
     ~wagg_dense() { if (inf_host) wagg::note_cleanup(hipHostFree(inf_host), "hipHostFree(inf note)"); }
 };
 
 namespace wagg {
 // wagg_spmm.hip
 template <typename T> int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill);
-template <typename T> int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
-                                              const std::vector<T> &w);
+void spmm_geometry(int64_t G, int32_t R, SpmmPlan &sp);
+template <typename T> int spmm_build_from_sorted(wagg_dense *d, const SortedEntries &se);
 template <typename T> int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out,
                                      int64_t ldo, hipStream_t stream);
 // wagg_dense.hip

@@ -343,11 +343,10 @@ __global__ void spmm_den32_kernel(const double *__restrict__ den64, float *__res
     if (r < R) den32[r] = (float)den64[r];
 }
 
-static void spmm_geometry(wagg_dense *d) {
-    SpmmPlan &sp = d->sp;
-    sp.n_rb = (int)(((int64_t)d->R + SP_WAVES * SP_RW_MAX - 1) / (SP_WAVES * SP_RW_MAX));
-    sp.rw = (int)(((int64_t)d->R + (int64_t)sp.n_rb * SP_WAVES - 1) / ((int64_t)sp.n_rb * SP_WAVES));   // balanced, <= 95
-    sp.n_chunks = (int)((d->G + SP_KC - 1) / SP_KC);
+void spmm_geometry(int64_t G, int32_t R, SpmmPlan &sp) {
+    sp.n_rb = (int)(((int64_t)R + SP_WAVES * SP_RW_MAX - 1) / (SP_WAVES * SP_RW_MAX));
+    sp.rw = (int)(((int64_t)R + (int64_t)sp.n_rb * SP_WAVES - 1) / ((int64_t)sp.n_rb * SP_WAVES));   // balanced, <= SP_RW_MAX
+    sp.n_chunks = (int)((G + SP_KC - 1) / SP_KC);
 }
 
 // counts per (region block, chunk, wave) -> first 8-entry group of each list (+ total at the end)
@@ -375,7 +374,7 @@ static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
 
 template <typename T>
 int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
-    spmm_geometry(d);
+    spmm_geometry(d->G, d->R, d->sp);
     SpmmPlan &sp = d->sp;
     const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
     WAGG_REQUIRE((int64_t)sp.n_rb * sp.n_chunks < (int64_t)0x7fffffff, "grid too large");
@@ -405,50 +404,84 @@ int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill) {
 template int spmm_build_synth<float>(wagg_dense *, uint32_t, double);
 template int spmm_build_synth<double>(wagg_dense *, uint32_t, double);
 
-// coalesced (cell, region, weight) triples, sorted by (region, cell) -> entry lists (host side)
-template <typename T>
-int spmm_build_from_coo(wagg_dense *d, const std::vector<int32_t> &cell, const std::vector<int32_t> &region,
-                        const std::vector<T> &w) {
-    constexpr int GW = SpT<T>::GW;
-    spmm_geometry(d);
-    SpmmPlan &sp = d->sp;
-    const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
-    const int wave_regions = sp.rw;
-    auto bucket_of = [&](size_t i) {
-        const int64_t wv = region[i] / wave_regions;            // global wave index = rb * 16 + wave
-        return ((wv / SP_WAVES) * sp.n_chunks + cell[i] / SP_KC) * SP_WAVES + wv % SP_WAVES;
-    };
-    try {
-        std::vector<int32_t> counts((size_t)n_buckets, 0);
-        for (size_t i = 0; i < cell.size(); ++i) counts[(size_t)bucket_of(i)]++;
-        if (int rc = spmm_offsets<T>(d, counts)) return rc;
-        std::vector<int32_t> off((size_t)n_buckets);
-        {
-            int64_t g = 0;
-            for (int64_t b = 0; b < n_buckets; ++b) { off[(size_t)b] = (int32_t)g; g += (counts[(size_t)b] + SP_GROUP - 1) / SP_GROUP; }
-        }
-        std::vector<uint32_t> ent((size_t)sp.n_groups * GW, 0u);
-        for (int64_t pos = 0; pos < sp.n_groups * SP_GROUP; ++pos) sp_store_entry<T>(ent.data(), pos, (unsigned)SP_TRASH, T(0));
-        std::vector<int32_t> cur((size_t)n_buckets, 0);
-        // visit the triples cell-major so that a list is ordered like the synthetic builder's
-        std::vector<size_t> order(cell.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cell[a] < cell[b]; });
-        for (size_t i : order) {
-            const int64_t b = bucket_of(i);
-            const unsigned lo = sp_entry_lo(cell[i] % SP_KC, region[i] % wave_regions);
-            const size_t pos = (size_t)off[(size_t)b] * SP_GROUP + (size_t)cur[(size_t)b]++;
-            sp_store_entry<T>(ent.data(), (int64_t)pos, lo, w[i]);
-        }
-        if (!ent.empty()) WAGG_HIP(staged_h2d(sp.ent.p, ent.data(), sizeof(uint32_t) * ent.size(), nullptr));
-    } catch (const std::bad_alloc &) {
-        set_error("host allocation failed while building the entry lists");
-        return WAGG_ENOMEM;
+// ---- entry lists from a caller's table, coalesced and sorted on the device (wagg_build.hip) ----------------------------
+// The distinct pairs arrive in key order = (bucket, cell in chunk, region in wave): every list is one run of them, already
+// in the order the synthetic builder produces (cell-major, regions ascending), so a table that holds the synthetic weights
+// gives the same lists -- and with them the same fp32 sums -- bit for bit.
+__global__ __launch_bounds__(256) void spmm_bounds_kernel(const uint64_t *__restrict__ key, int64_t n, EntryKeyGeom geom,
+                                                          int32_t *__restrict__ first, int32_t *__restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t b = geom.bucket_of(key[i]);
+    if (i == 0 || geom.bucket_of(key[i - 1]) != b) {
+        int64_t e = i + 1;                              // a list is short (c5: ~55 entries): walk to its end
+        while (e < n && geom.bucket_of(key[e]) == b) ++e;
+        first[b] = (int32_t)i;
+        counts[b] = (int32_t)(e - i);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_fill_kernel(const uint64_t *__restrict__ key, const double *__restrict__ w, int64_t n,
+                                                        EntryKeyGeom geom, const int32_t *__restrict__ first,
+                                                        const int32_t *__restrict__ grp_off, uint32_t *__restrict__ ent) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    int64_t cell;
+    int32_t region;
+    int cic, j;
+    geom.decode(k, cell, region, cic, j);
+    const int64_t b = geom.bucket_of(k);
+    const int64_t pos = (int64_t)grp_off[b] * SP_GROUP + (i - first[b]);
+    sp_store_entry<T>(ent, pos, sp_entry_lo(cic, j), (T)w[i]);
+}
+
+// the last group of every list is filled up with w = 0 entries aimed at the trash accumulator
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_pad_kernel(const int32_t *__restrict__ counts, const int32_t *__restrict__ grp_off,
+                                                       int64_t n_buckets, uint32_t *__restrict__ ent) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets) return;
+    const int c = counts[b], padded = (c + SP_GROUP - 1) / SP_GROUP * SP_GROUP;
+    for (int e = c; e < padded; ++e) sp_store_entry<T>(ent, (int64_t)grp_off[b] * SP_GROUP + e, (unsigned)SP_TRASH, T(0));
+}
+
+template <typename T>
+int spmm_build_from_sorted(wagg_dense *d, const SortedEntries &se) {
+    spmm_geometry(d->G, d->R, d->sp);
+    SpmmPlan &sp = d->sp;
+    WAGG_REQUIRE(se.geom.rw == sp.rw && se.geom.n_rb == sp.n_rb && se.geom.n_chunks == sp.n_chunks, "sort key of another geometry");
+    const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
+    WAGG_REQUIRE(n_buckets < (int64_t)0x7fffffff, "grid too large");
+    DevBuf<int32_t> first, dcounts;
+    WAGG_HIP(first.alloc((size_t)n_buckets));
+    WAGG_HIP(dcounts.alloc((size_t)n_buckets));
+    WAGG_HIP(hipMemset(dcounts.p, 0, sizeof(int32_t) * (size_t)n_buckets));
+    const unsigned nblk = (unsigned)((se.n_u + 255) / 256);
+    if (se.n_u > 0) {
+        hipLaunchKernelGGL(spmm_bounds_kernel, dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, se.n_u, se.geom, first.p,
+                           dcounts.p);
+        WAGG_HIP(hipGetLastError());
+    }
+    std::vector<int32_t> counts;
+    try { counts.resize((size_t)n_buckets); } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
+    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(staged_d2h(counts.data(), dcounts.p, sizeof(int32_t) * counts.size()));
+    if (int rc = spmm_offsets<T>(d, counts)) return rc;
+    if (se.n_u > 0) {
+        hipLaunchKernelGGL((spmm_fill_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, (const double *)se.w.p,
+                           se.n_u, se.geom, (const int32_t *)first.p, (const int32_t *)sp.grp_off.p, sp.ent.p);
+        WAGG_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((spmm_pad_kernel<T>), dim3((unsigned)((n_buckets + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dcounts.p,
+                       (const int32_t *)sp.grp_off.p, n_buckets, sp.ent.p);
+    WAGG_HIP(hipGetLastError());
+    WAGG_HIP(hipDeviceSynchronize());            // `first` / `dcounts` are freed on return
     return WAGG_OK;
 }
-template int spmm_build_from_coo<float>(wagg_dense *, const std::vector<int32_t> &, const std::vector<int32_t> &, const std::vector<float> &);
-template int spmm_build_from_coo<double>(wagg_dense *, const std::vector<int32_t> &, const std::vector<int32_t> &, const std::vector<double> &);
+template int spmm_build_from_sorted<float>(wagg_dense *, const SortedEntries &);
+template int spmm_build_from_sorted<double>(wagg_dense *, const SortedEntries &);
 
 template <typename T>
 int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out, int64_t ldo,

@@ -235,7 +235,7 @@ class DensePlan:
         self.den = den
         inf = _lib.DenseInfo()
         _lib.check(_lib.load().wagg_dense_get_info(self._h, C.byref(inf)), "wagg_dense_get_info")
-        self.info = {k: int(getattr(inf, k)) for k, _ in _lib.DenseInfo._fields_}
+        self.info = {k: (float if ct is C.c_double else int)(getattr(inf, k)) for k, ct in _lib.DenseInfo._fields_}
         self.dtype = "float64" if self.info["elem_bytes"] == 8 else "float32"
 
     @staticmethod
@@ -299,6 +299,27 @@ class DensePlan:
             _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
                           int(R), C.byref(h)), "wagg_dense_create_from_segments")
         return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype)))
+
+    @classmethod
+    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None):
+        """From a caller's table in CSR form (``wagg_dense_create_from_csr*``; BASELINE configs[4] "sparse CSR weights"):
+        ``rowptr`` (G + 1 offsets, rows = grid cells), ``col`` = region codes, ``val`` = fp64 weights -- the coded form of
+        the reference's weights table (aggregations.py:64-73).  The arrays are uploaded as they are (no host copy when
+        they already have the dtypes int64 / int32 / float64); everything else happens on the device."""
+        require_gpu()
+        rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        co = np.ascontiguousarray(col, dtype=np.int32)
+        va = np.ascontiguousarray(val, dtype=np.float64)
+        if rp.shape != (int(G) + 1,) or co.shape != va.shape or co.ndim != 1 or (len(rp) and int(rp[-1]) != len(co)):
+            raise ValueError("rowptr must hold G + 1 offsets ending at len(col) == len(val)")
+        h = C.c_void_p()
+        L = _lib.load()
+        fn = L.wagg_dense_create_from_csr_f64 if cls._is64(dtype) else L.wagg_dense_create_from_csr
+        with _on_device(device):
+            dev = _current_device()
+            _lib.check(fn(_np_ptr(rp, C.c_int64), _np_ptr(co, C.c_int32), _np_ptr(va, C.c_double), int(G), int(R), C.byref(h)),
+                       "wagg_dense_create_from_csr")
+        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype)))
 
     def replica(self, device):
         """The same weights as a plan of its own on ``device`` (multi-device host streaming; a dense-family plan
@@ -541,6 +562,23 @@ def synth_field(T, G, seed, base, amp, dtype="float32", device="cuda"):
     _lib.check(fn(C.c_void_p(X.data_ptr()), T, G, G, int(seed), base, amp, _stream_handle(None)),
                "wagg_synth_field")
     return X
+
+
+def synth_table_csr(G, R, seed, fill, blocklocal=False):
+    """The c5 weight tables of :meth:`DensePlan.synth` / :meth:`DensePlan.synth_blocklocal` as host CSR arrays
+    ``(rowptr int64, col int32, val float64)`` -- what a caller with a real table would hand to
+    :meth:`DensePlan.from_csr` (``wagg_synth_table_csr``: generated on the device, copied out)."""
+    require_gpu()
+    L = _lib.load()
+    rowptr = np.empty(int(G) + 1, dtype=np.int64)
+    nnz = C.c_int64(0)
+    args = (int(G), int(R), int(seed), float(fill), 1 if blocklocal else 0, _np_ptr(rowptr, C.c_int64))
+    _lib.check(L.wagg_synth_table_csr(*args, None, None, 0, C.byref(nnz)), "wagg_synth_table_csr")
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.float64)
+    _lib.check(L.wagg_synth_table_csr(*args, _np_ptr(col, C.c_int32), _np_ptr(val, C.c_double), nnz.value, C.byref(nnz)),
+               "wagg_synth_table_csr")
+    return rowptr, col, val
 
 
 def profile_enable(on=True):

@@ -289,6 +289,17 @@ int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense
 int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                     const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                     wagg_dense **out);
+/* The same table in CSR form -- BASELINE configs[4] "sparse CSR weights (<= 1 % nnz)": rows = grid cells (rowptr[G + 1],
+ * rowptr[0] = 0, non-decreasing), col = region codes (-1 = null label, dropped), val = fp64 weights (NaN: dropped);
+ * columns of a row in any order, repeated (cell, region) pairs add in the order they are stored (S5).
+ * Both constructors only UPLOAD the host arrays (page-locked in place for the copy when they are large, through the
+ * library's staging pieces otherwise: no host copy of the table is made); sorting into the kernels' order, coalescing,
+ * the denominators (aggregations.py:79), the tile census that picks the form, and the packing run on the device
+ * (stable radix sort, fixed summation orders: the same table gives the same plan, bit for bit; csrc/wagg_build.hip).
+ * Up to 2^31 - 1 entries; a configs[4]-sized table (2.53e8 entries, 3 GB) needs ~13 GB of device scratch while it is
+ * built.  wagg_dense_info.build_s / build_upload_s report where the time went.                                        */
+int wagg_dense_create_from_csr(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
+                               wagg_dense **out);
 /* synthetic block-local weights (SURVEY 8d, c5 "each 64-cell run touches <= 256 regions"): run j of
  * 64 cells touches the 256 regions of column tile (97 j) mod ceil(R/256); inside, W[g,r] =
  * hash_u01(g*R + r, seed) where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill, else 0.  Generated on
@@ -308,12 +319,17 @@ int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32_t R, wagg_
 int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
                                         const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                         wagg_dense **out);
+int wagg_dense_create_from_csr_f64(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
+                                   wagg_dense **out);
 int wagg_dense_create_synth_blocklocal_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 typedef struct wagg_dense_info {
     int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles; bytes of W (or of the entry lists) in HBM */
     int32_t R, n_kt, n_nt, tiled;  /* k tiles, column tiles, 1 = tile-sparse form */
     int32_t form, elem_bytes;      /* WAGG_FORM_*; 4 = fp32 plan, 8 = fp64 plan */
-    int64_t nnz;                   /* entry-list form: kept (cell, region) pairs; else -1 */
+    int64_t nnz;                   /* kept distinct (cell, region) pairs: entry-list form and every plan built from a
+                                      caller's table (from_segments / from_csr); else -1 */
+    double build_s, build_upload_s; /* plans built from a caller's table: wall seconds of the constructor, and the part of
+                                      them spent moving the table to the device (else 0) */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);
@@ -365,6 +381,11 @@ int wagg_dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices
 int wagg_dense_saw_inf(wagg_dense *d, void *stream, int *saw);
 
 /* ---- synthetic data generators (device side, shared with the CPU oracle bit for bit) ------- */
+/* The c5 weight tables of wagg_dense_create_synth_sparse (blocklocal = 0) / _synth_blocklocal (1) as a caller would hand
+ * them in: CSR on the HOST (rows = cells, columns ascending, fp64 values = the fp32 hashes).  Generated on the device and
+ * copied out; call with col_host = val_host = NULL first to get rowptr and *nnz_out, then with arrays of that capacity.  */
+int wagg_synth_table_csr(int64_t G, int32_t R, uint32_t seed, double fill, int blocklocal, int64_t *rowptr_host,
+                         int32_t *col_host, double *val_host, int64_t capacity, int64_t *nnz_out);
 /* X[t*ldx + g] = base + amp * (hash_u01(t*G + g, seed) - 0.5)                                   */
 int wagg_synth_field_f32(float *X_dev, int64_t T, int64_t G, int64_t ldx, uint32_t seed,
                          float base, float amp, void *stream);

@@ -219,3 +219,115 @@ int wagg_oracle_dense_synth_cols_f32(const float *X, int64_t T, int64_t ldx, int
     }
     return failed ? -2 : 0;
 }
+
+/* The c5 weight tables (uniform-random, or block-local with blocklocal != 0; see wagg_oracle_dense_synth2_f32) as the
+ * CSR table a caller would hold: rows = grid cells, columns = region codes ascending, fp64 values = the fp32 hashes.
+ * Rows [g0, g1).  Call with col == NULL to get rowptr (g1 - g0 + 1 offsets, rowptr[0] = 0) and the entry count;
+ * then with arrays of that capacity.  Returns the number of entries, or -2 when capacity is too small.
+ * (Test infrastructure: the input of the "caller-supplied table" parity tests, generated independently of the
+ * device generator wagg_synth_table_csr, which must agree with it bit for bit.) */
+/* keep[r - r0] = hash_u01(g R + r, seed2) < fill for r in [r0, r1), in a form the compiler vectorises: the high word of
+ * the 64-bit counter changes at most once inside a row, and hash_u01 < fill compares 24-bit integers
+ * (hash_u01 = (h >> 8) 2^-24 exactly, so it is below fill iff h >> 8 < ceil(fill 2^24)). */
+static int64_t keep_flags(int64_t g, int64_t R, int64_t r0, int64_t r1, uint32_t seed2, uint32_t thr, uint8_t *keep) {
+    const uint64_t base = (uint64_t)g * (uint64_t)R;
+    int64_t n = 0, r = r0;
+    while (r < r1) {
+        const uint64_t id0 = base + (uint64_t)r;
+        const uint32_t lo0 = (uint32_t)id0, hi = (uint32_t)(id0 >> 32);
+        int64_t seg = (int64_t)(0x100000000ull - (uint64_t)lo0);          /* counters left before the low word wraps */
+        if (seg > r1 - r) seg = r1 - r;
+        const uint32_t hmix = (hi * 0x85EBCA6Bu) ^ (seed2 * 0x9E3779B9u);
+        uint8_t *k = keep + (r - r0);
+        int64_t m = 0;
+        for (int64_t i = 0; i < seg; ++i) {
+            uint32_t x = (lo0 + (uint32_t)i) ^ hmix;
+            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+            const uint8_t f = (x >> 8) < thr;
+            k[i] = f;
+            m += f;
+        }
+        n += m;
+        r += seg;
+    }
+    return n;
+}
+
+int64_t wagg_oracle_synth_csr(int64_t G, int64_t R, uint32_t seed, double fill, int blocklocal, int64_t g0, int64_t g1,
+                              int64_t *rowptr, int32_t *col, double *val, int64_t capacity) {
+    const int64_t n_nt = (R + 255) / 256;
+    const float ffill = (float)fill;
+    const double scaled = (double)ffill * 16777216.0;
+    const uint32_t thr = scaled >= 16777216.0 ? 0x1000000u : (uint32_t)ceil(scaled);
+    const int64_t width = blocklocal ? 256 : R;
+    int failed = 0;
+    (void)G;
+    rowptr[0] = 0;
+    for (int pass = 0; pass < (col ? 2 : 1); ++pass) {
+        if (pass == 1 && capacity < rowptr[g1 - g0]) return -2;
+#pragma omp parallel
+        {
+            uint8_t *keep = (uint8_t *)malloc((size_t)width + 8);
+            if (!keep) {
+#pragma omp atomic write
+                failed = 1;
+            }
+#pragma omp for schedule(static, 64)
+            for (int64_t g = g0; g < g1; ++g) {
+                if (!keep) continue;
+                int64_t r0 = 0, r1 = R;
+                if (blocklocal) { r0 = ((97 * (g / 64)) % n_nt) * 256; r1 = r0 + 256 < R ? r0 + 256 : R; }
+                const int64_t n = keep_flags(g, R, r0, r1, seed ^ 0x9e3779b9u, thr, keep);
+                if (pass == 0) { rowptr[g - g0 + 1] = n; continue; }
+                int64_t at = rowptr[g - g0];
+                for (int64_t r = r0; r < r1; ++r) {
+                    if (!keep[r - r0]) continue;
+                    col[at] = (int32_t)r;
+                    val[at] = (double)wagg_oracle_hash_u01((uint64_t)g * (uint64_t)R + (uint64_t)r, seed);
+                    ++at;
+                }
+            }
+            free(keep);
+        }
+        if (failed) return -3;
+        if (pass == 0)
+            for (int64_t i = 0; i < g1 - g0; ++i) rowptr[i + 1] += rowptr[i];
+    }
+    return rowptr[g1 - g0];
+}
+
+/* Best-effort CPU form of the segment-table aggregation (SURVEY 8d "threaded C++ SpMM over all host cores"): the same
+ * arithmetic as wagg_oracle_segments_* (fp64 products, skipna, IEEE division), the timesteps dealt to OpenMP threads;
+ * per timestep the sums run in table order, so the result equals the single-threaded form bit for bit. */
+#define DEFINE_SEGMENTS_OMP(NAME, TYPE)                                                           \
+    int NAME(const TYPE *X, int64_t T, int64_t ldx, int layout, const int32_t *cell_idx,          \
+             const int32_t *region_code, const double *w_eff, int64_t nseg, int64_t G, int32_t R, \
+             double *out) {                                                                       \
+        double *den = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));                  \
+        if (!den) return -2;                                                                      \
+        for (int64_t i = 0; i < nseg; ++i) {                                                      \
+            int32_t r = region_code[i];                                                           \
+            if (r < 0) continue;                                                                  \
+            if (r >= R || cell_idx[i] < 0 || cell_idx[i] >= G) { free(den); return -1; }          \
+            if (!isnan(w_eff[i])) den[r] += w_eff[i];                                             \
+        }                                                                                         \
+        _Pragma("omp parallel for schedule(static)")                                              \
+        for (int64_t t = 0; t < T; ++t) {                                                         \
+            double *row = out + t * (int64_t)R;                                                   \
+            for (int32_t r = 0; r < R; ++r) row[r] = 0.0;                                         \
+            for (int64_t i = 0; i < nseg; ++i) {                                                  \
+                int32_t r = region_code[i];                                                       \
+                if (r < 0) continue;                                                              \
+                int64_t g = cell_idx[i];                                                          \
+                double x = (double)(layout == WAGG_LAYOUT_TG ? X[t * ldx + g] : X[g * ldx + t]);  \
+                double p = x * w_eff[i];                                                          \
+                if (!isnan(p)) row[r] += p;                                                       \
+            }                                                                                     \
+            for (int32_t r = 0; r < R; ++r) row[r] = row[r] / den[r];                             \
+        }                                                                                         \
+        free(den);                                                                                \
+        return 0;                                                                                 \
+    }
+
+DEFINE_SEGMENTS_OMP(wagg_oracle_segments_omp_f32, float)
+DEFINE_SEGMENTS_OMP(wagg_oracle_segments_omp_f64, double)

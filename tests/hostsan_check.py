@@ -79,6 +79,18 @@ for nseg, giant in ((0, 0), (1, 0), (40000, 0), (30000, 3)):
     assert rcode in (0, -1, -2, -3, -4), (rcode, L.wagg_last_error())
     if rcode == 0:
         L.wagg_dense_destroy(h2)
+    # the CSR form of the same table: the host validates the row offsets, then the upload fails with a status
+    order = np.argsort(ci, kind="stable")
+    rowptr = np.zeros(G + 1, np.int64); np.add.at(rowptr, ci.astype(np.int64) + 1, 1); rowptr = np.cumsum(rowptr)
+    col, val = np.ascontiguousarray(rc[order]), np.ascontiguousarray(ww[order])
+    h3 = C.c_void_p()
+    rcode = L.wagg_dense_create_from_csr(p(rowptr, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), C.byref(h3))
+    assert rcode in (0, -1, -2, -3, -4), (rcode, L.wagg_last_error())
+    if rcode == 0:
+        L.wagg_dense_destroy(h3)
+    if nseg > 1:
+        bad = rowptr.copy(); bad[G // 2] = bad[G // 2 + 1] + 1
+        assert L.wagg_dense_create_from_csr(p(bad, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), C.byref(h3)) == -1
 # compact regions on a grid whose rows are not a whole number of 32-cell lines: the whole-line plan (chunks of eight
 # lines per column strip, partial rows) and, with WAGG_PLAN_NO_LINES = 4, the region-shaped chunks
 nlat, nlon = 61, 100

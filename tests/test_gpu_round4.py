@@ -1,0 +1,188 @@
+"""GPU parity tests added in round 4 (run with -m gpu on an MI355X): weight tables HANDED IN BY THE CALLER -- COO segment
+rows and CSR (BASELINE configs[4] "sparse CSR weights") -- built into plans on the device, up to the full configs[4]
+size, where the plan must equal the one the on-device hash generator builds, bit for bit.  Every comparison goes through
+the C-ABI; the oracle is only the checker (and the independent generator of the caller's arrays)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import RTOL32, _rel_ok
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
+def _csr_of(cell, code, w, G, rng=None):
+    """CSR arrays of a COO table: rows = cells, the entries of a row in table order (so repeated pairs keep their order),
+    or shuffled inside the rows when ``rng`` is given (columns of a row may come in any order)."""
+    order = np.argsort(cell, kind="stable")
+    if rng is not None:
+        order = order[np.lexsort((rng.random(len(order)), cell[order]))]
+    rowptr = np.zeros(G + 1, dtype=np.int64)
+    np.add.at(rowptr, cell + 1, 1)
+    return np.cumsum(rowptr), code[order].astype(np.int32), w[order].astype(np.float64)
+
+
+def _table(kind, G, R, rng):
+    """A caller's table with everything S3-S5 allow: repeated (cell, region) rows, null labels, NaN weights, no order."""
+    if kind == "scattered":                           # ~2 % of the pairs, every tile touched -> entry lists
+        n = int(0.02 * G * R)
+        flat = rng.choice(G * R, size=n, replace=False)
+        cell, code = flat // R, flat % R
+    elif kind == "blocks":                            # each run of 64 cells touches one column tile -> tile-sparse
+        n_nt = (R + 255) // 256
+        cell = np.repeat(np.arange(G), 12)
+        tile = (97 * (cell // 64)) % n_nt
+        code = np.minimum(tile * 256 + rng.integers(0, 256, len(cell)), R - 1)
+    else:                                             # 30 % of all pairs -> full matrix
+        n = int(0.3 * G * R)
+        flat = rng.choice(G * R, size=n, replace=False)
+        cell, code = flat // R, flat % R
+    w = rng.uniform(0.1, 1.0, len(cell))
+    dup = rng.integers(0, len(cell), len(cell) // 7)  # repeated pairs (S5): they add, in table order
+    cell = np.concatenate([cell, cell[dup]]); code = np.concatenate([code, code[dup]]); w = np.concatenate([w, rng.uniform(0.1, 1.0, len(dup))])
+    perm = rng.permutation(len(cell))
+    cell, code, w = cell[perm], code[perm].astype(np.int64), w[perm]
+    code[rng.random(len(code)) < 0.01] = -1           # null labels leave both sums (S3)
+    w[rng.random(len(w)) < 0.01] = np.nan             # NaN weights too (S4)
+    return cell.astype(np.int32), code.astype(np.int32), w
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float32, RTOL32), (np.float64, 1e-11)])
+@pytest.mark.parametrize("kind,G,R,form", [("scattered", 64 * 96 + 5, 1600, 2), ("scattered", 300, 5, 2), ("blocks", 64 * 40, 700, 1),
+                                           ("dense", 1537, 96, 0), ("blocks", 64 * 9 + 3, 600, 1)])
+def test_tables_built_on_the_device_vs_oracle(torch_cuda, kind, G, R, form, dtype, rtol):
+    """wagg_dense_create_from_segments* / _from_csr* (sort, coalesce, denominators, form choice and packing on the device,
+    csrc/wagg_build.hip) against the oracle's aggregation of the same rows (aggregations.py:73-80), all three forms."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(G + R)
+    cell, code, w = _table(kind, G, R, rng)
+    T = 70
+    X = (280 + 15 * rng.standard_normal((T, G))).astype(dtype)
+    X[6, G // 3] = np.nan
+    ref = O.agg_coded(X, cell, code, w, R)
+    keep = (code >= 0) & ~np.isnan(w)
+    den = np.bincount(code[keep], weights=w[keep], minlength=R)
+    Xd = torch.from_numpy(X).cuda()
+    seg = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype)
+    assert seg.info["form"] == form and seg.dtype == np.dtype(dtype).name
+    assert seg.info["nnz"] == len(np.unique(cell[keep].astype(np.int64) * R + code[keep]))
+    np.testing.assert_allclose(seg.den, den, rtol=1e-13)
+    got = seg.apply(Xd).cpu().numpy()
+    _rel_ok(got, ref, rtol)
+    # the same table as CSR (rows in table order inside a cell: repeated pairs add in the same order) -> the same plan, bit for bit
+    csr = DensePlan.from_csr(*_csr_of(cell, code, w, G), G, R, dtype=dtype)
+    assert csr.info["form"] == form and csr.info["nnz"] == seg.info["nnz"]
+    np.testing.assert_array_equal(csr.den, seg.den)
+    np.testing.assert_array_equal(csr.apply(Xd).cpu().numpy(), got)
+    # ... and with the columns of every row in a random order: still the oracle's numbers
+    mix = DensePlan.from_csr(*_csr_of(cell, code, w, G, rng), G, R, dtype=dtype)
+    _rel_ok(mix.apply(Xd).cpu().numpy(), ref, rtol)
+    # a second build of the same table is the same plan (stable sort, fixed summation orders, no atomics on data)
+    again = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype)
+    np.testing.assert_array_equal(again.den, seg.den)
+    np.testing.assert_array_equal(again.apply(Xd).cpu().numpy(), got)
+    assert seg.info["build_s"] > 0 and 0 <= seg.info["build_upload_s"] <= seg.info["build_s"]
+
+
+def test_table_builder_edge_cases(torch_cuda):
+    """Empty tables, tables that drop every row, one row; bad row offsets and out-of-range codes are rejected with a status."""
+    from climate_toolbox_amd import _lib
+    from climate_toolbox_amd.engine import DensePlan
+    torch = torch_cuda
+    G, R = 500, 20
+    X = torch.ones((3, G), dtype=torch.float32, device="cuda")
+    e = np.zeros(0, np.int32)
+    for plan in (DensePlan.from_segments(e, e, np.zeros(0), G, R), DensePlan.from_csr(np.zeros(G + 1, np.int64), e, np.zeros(0), G, R),
+                 DensePlan.from_segments(np.array([3, 4], np.int32), np.array([-1, 2], np.int32), np.array([1.0, np.nan]), G, R)):
+        assert plan.info["nnz"] == 0 and (plan.den == 0).all()
+        assert torch.isnan(plan.apply(X)).all()                                    # 0 / 0 (S7)
+    one = DensePlan.from_segments(np.array([7], np.int32), np.array([5], np.int32), np.array([0.25]), G, R, dtype="float64")
+    out = one.apply(X.double() * 3.0).cpu().numpy()
+    assert (out[:, 5] == 3.0).all() and np.isnan(np.delete(out, 5, axis=1)).all()
+    rp = np.zeros(G + 1, np.int64); rp[5:] = 2; rp[9] = 1
+    with pytest.raises(_lib.WaggError, match="rowptr decreases at row 8"):
+        DensePlan.from_csr(rp, np.zeros(2, np.int32), np.ones(2), G, R)
+    with pytest.raises(ValueError):
+        DensePlan.from_csr(np.zeros(G + 1, np.int64), np.zeros(2, np.int32), np.ones(2), G, R)
+    with pytest.raises(_lib.WaggError, match="segment 1 out of range"):
+        DensePlan.from_segments(np.array([1, 2, 3], np.int32), np.array([0, R, 1], np.int32), np.ones(3), G, R)
+    with pytest.raises(_lib.WaggError, match="segment 2 out of range"):
+        DensePlan.from_segments(np.array([1, 2, G], np.int32), np.array([0, 1, 1], np.int32), np.ones(3), G, R)
+
+
+@pytest.mark.parametrize("blocklocal,fill", [(False, 0.02), (True, 0.952)])
+def test_device_table_generator_equals_the_oracle_generator(torch_cuda, blocklocal, fill):
+    """wagg_synth_table_csr (the benchmark's stand-in for a caller's file) against the oracle's generator of the same
+    hashes: identical arrays, and -- uniform structure -- against the NumPy restatement of the hash."""
+    from climate_toolbox_amd import engine
+    from oracle import c_oracle, ref_numpy as O
+    G, R, seed = 64 * 123 + 17, 2500, 9
+    rp, col, val = engine.synth_table_csr(G, R, seed, fill, blocklocal=blocklocal)
+    rp2, col2, val2 = c_oracle.synth_csr(G, R, seed, fill, blocklocal=blocklocal)
+    np.testing.assert_array_equal(rp, rp2)
+    np.testing.assert_array_equal(col, col2)
+    np.testing.assert_array_equal(val, val2)
+    W = O.blocklocal_weights_oracle(G, R, seed, fill) if blocklocal else O.dense_weights_oracle(G, R, seed, fill)
+    gi, ri = np.nonzero(W)
+    np.testing.assert_array_equal(np.repeat(np.arange(G), np.diff(rp)), gi)
+    np.testing.assert_array_equal(col, ri)
+    np.testing.assert_array_equal(val, W[gi, ri].astype(np.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] with the table handed in by the caller, at full size
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("structure", ["uniform", "block_local"])
+def test_c5_table_from_the_caller_at_full_size(torch_cuda, structure):
+    """G = 1,036,800 cells x R = 24,378 regions, ~2.5e8 pairs as host CSR arrays (3 GB) from the ORACLE's generator ->
+    wagg_dense_create_from_csr[_f64]: the plan has the form, the pair count and the denominators of the plan that
+    wagg_dense_create_synth_sparse / _synth_blocklocal generates from the same hashes on the device, and its apply over
+    the full rank shard (T = 2,282 of 18,250 rows) is bit-equal -- fp32 and fp64.  (The synthetic plans themselves are
+    checked against the oracle's arithmetic in test_c5_full_size_rank_shard.)"""
+    from climate_toolbox_amd import _lib, engine
+    from climate_toolbox_amd.timeshard import shard_bounds
+    from oracle import c_oracle
+    torch = torch_cuda
+    G, R, seed = 720 * 1440, 24378, 2
+    T = shard_bounds(50 * 365, 8)[0][1]
+    uniform = structure == "uniform"
+    fill = 0.01 if uniform else 0.952
+    t0 = time.time()
+    rowptr, col, val = c_oracle.synth_csr(G, R, seed, fill, blocklocal=not uniform)
+    t_gen = time.time() - t0
+    assert abs(len(col) - 0.01 * G * R) < 1e-2 * 0.01 * G * R
+    X32 = engine.synth_field(T, G, seed=1000, base=280.0, amp=60.0)
+    for dtype in ("float32", "float64"):
+        if not uniform and dtype == "float64":
+            X = X32[:600].double()                      # (the fp64 tile-sparse plan at 600 rows: the same code, a third of the time)
+        else:
+            X = X32 if dtype == "float32" else X32.double()
+        t0 = time.time()
+        plan = engine.DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype)
+        t_build = time.time() - t0
+        ref = (engine.DensePlan.synth(G, R, seed, fill=fill, dtype=dtype) if uniform
+               else engine.DensePlan.synth_blocklocal(G, R, seed, fill=fill, dtype=dtype))
+        assert plan.info["form"] == ref.info["form"] == (_lib.FORM_ENTRIES if uniform else _lib.FORM_TILES)
+        assert plan.info["nnz"] == len(col) and plan.info["w_bytes"] == ref.info["w_bytes"] and plan.info["n_tiles"] == ref.info["n_tiles"]
+        if uniform:
+            assert ref.info["nnz"] == len(col)
+        np.testing.assert_array_equal(plan.den, ref.den)        # (24-bit weights: every fp64 summation order is exact)
+        got, want = plan.apply(X), ref.apply(X)
+        assert torch.equal(got, want)
+        print("c5-%s %s: oracle generator %.1f s, from_csr %.2f s (library: %.2f s, of which upload %.2f s)" % (
+            structure, dtype, t_gen, t_build, plan.info["build_s"], plan.info["build_upload_s"]))
+        del got, want, X
+        plan.close(); ref.close()
+        torch.cuda.empty_cache()

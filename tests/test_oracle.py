@@ -165,3 +165,48 @@ def test_oracle_reproduces_the_numbers_the_reference_tests_hold(golden_dir):
     # fp32 fields give the same answers (both cells lie in the "tmax < e" / "tmin >= e" branches)
     assert O.snyder_edd_values(h["edd_tmin"].astype(np.float32), h["edd_tmax"].astype(np.float32),
                                float(h["edd_threshold"])).sum() == 0.0
+
+
+def test_c_oracle_csr_generator_is_the_numpy_hash_table():
+    """oracle/wagg_oracle.c::wagg_oracle_synth_csr (the caller-side arrays of the full-size c5 parity test, vectorised
+    integer form of the hash test) against the NumPy restatement of the same hashes, both structures, and across the
+    row where the 64-bit counter g R + r crosses 2^32."""
+    G, R = 5000, 300
+    rp, col, val = c_oracle.synth_csr(G, R, 7, 0.02)
+    W = O.dense_weights_oracle(G, R, 7, 0.02)
+    gi, ri = np.nonzero(W)
+    np.testing.assert_array_equal(np.repeat(np.arange(G), np.diff(rp)), gi)
+    np.testing.assert_array_equal(col, ri)
+    np.testing.assert_array_equal(val, W[gi, ri].astype(np.float64))
+    Gs, Rs = 64 * 30 + 7, 700
+    Wb = O.blocklocal_weights_oracle(Gs, Rs, 5)
+    rp, col, val = c_oracle.synth_csr(Gs, Rs, 5, 0.952, blocklocal=True)
+    gi, ri = np.nonzero(Wb)
+    np.testing.assert_array_equal(np.repeat(np.arange(Gs), np.diff(rp)), gi)
+    np.testing.assert_array_equal(col, ri)
+    np.testing.assert_array_equal(val, Wb[gi, ri].astype(np.float64))
+    G, R, g0 = 720 * 1440, 24378, 176170                          # g R = 2^32 inside row 176,181
+    rp, col, val = c_oracle.synth_csr(G, R, 2, 0.01, g0=g0, g1=g0 + 30)
+    for g in (176180, 176181, 176182):
+        idx = np.uint64(g) * np.uint64(R) + np.arange(R, dtype=np.uint64)
+        keep = O.hash_u01(idx, np.uint32(2) ^ np.uint32(0x9e3779b9)) < np.float32(0.01)
+        a, b = rp[g - g0], rp[g - g0 + 1]
+        np.testing.assert_array_equal(col[a:b], np.flatnonzero(keep))
+        np.testing.assert_array_equal(val[a:b], O.hash_u01(idx, 2)[keep].astype(np.float64))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_threaded_c_oracle_equals_the_single_threaded_one(dtype):
+    """bench.py's best-effort CPU leg (timesteps dealt to OpenMP threads) gives the faithful port's bits."""
+    rng = np.random.default_rng(4)
+    T, G, R, nseg = 37, 900, 40, 5000
+    X = rng.standard_normal((T, G)).astype(dtype)
+    X[3, 10] = np.nan
+    ci = rng.integers(0, G, nseg)
+    rc = rng.integers(-1, R, nseg)
+    w = rng.uniform(0, 1, nseg)
+    w[::17] = np.nan
+    a = c_oracle.segments(X, ci, rc, w, R)
+    b = c_oracle.segments(X, ci, rc, w, R, threaded=True)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(c_oracle.segments(X.T.copy(), ci, rc, w, R, layout="GT", threaded=True), a)
