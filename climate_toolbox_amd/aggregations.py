@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import functools
 import hashlib
+import os
 import threading
 from collections import OrderedDict
 
@@ -24,6 +25,7 @@ import numpy as np
 import pandas as pd
 
 from . import engine as _engine, minixr
+from ._lib import FORM_ENTRIES
 from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
 
 try:  # optional: return real xarray objects when the caller hands us xarray objects
@@ -478,35 +480,61 @@ def _flatten_for_device(values, dims):
     return X2, layout, others_shape, unflatten
 
 
-# Host-resident fields stream through EVERY visible GPU of the process (one row-block pipeline per device, each on
-# its own PCIe link; SURVEY 8b `n_devices`, 8e "one process driving all devices"): None = all visible devices; a list
-# of device ordinals pins the choice (a device may be listed twice: two pipelines on one GPU).
+# Host-resident fields stream through the CURRENT device only by default.  Several row-block pipelines from one process
+# (one per device, each on its own PCIe link; SURVEY 8b `n_devices`, 8e "one process driving all devices") are an explicit
+# opt-in: HOST_DEVICES = "all" (every visible device -- never inside a one-process-per-GPU job, where every rank sees all
+# devices: such processes, recognised by WORLD_SIZE > 1 in the environment, stay on their own device) or a list of device
+# ordinals (a device may be listed twice: two pipelines on one GPU).  The multi-device form has only ever run with several
+# pipelines on ONE physical device (gpurun exposes one GPU), hence the conservative default.
 HOST_DEVICES = None
 _REPLICA_MAX_BYTES = 8 << 30          # plans above this (the 101 GB dense operand) are not replicated
 
 
-def _host_replicas(plan, n_rows, row_bytes):
-    """Replicas of a leased plan on the other devices of HOST_DEVICES, built once and kept with the plan; () when one
-    device serves the call (a single GPU, a field of few blocks, a plan too large to copy around)."""
+def _host_devices():
     import torch
-    devs = list(range(torch.cuda.device_count())) if HOST_DEVICES is None else [int(d) for d in HOST_DEVICES]
+    if HOST_DEVICES is None:
+        return []
+    if isinstance(HOST_DEVICES, str):
+        if HOST_DEVICES != "all":
+            raise ValueError('HOST_DEVICES must be None, "all" or a list of device ordinals')
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            return []                  # one process per GPU: the other devices belong to the other ranks
+        return list(range(torch.cuda.device_count()))
+    return [int(d) for d in HOST_DEVICES]
+
+
+def _host_quantum(plan):
+    """Rows one launch of the plan's kernel handles well (what wagg_host_block_plan sizes the row blocks by)."""
+    if isinstance(plan, DensePlan):
+        f64 = plan.dtype == "float64"
+        if plan.info["form"] == FORM_ENTRIES:
+            return 64 if f64 else 128
+        return 176 if f64 else 368
+    return 64
+
+
+def _host_replicas(plan, n_rows, row_bytes):
+    """Replicas of a leased plan for the other pipelines of HOST_DEVICES, built once and kept with the plan; () when one
+    device serves the call (the default, a field of few blocks, a plan too large to copy around).  The plan itself
+    serves the first pipeline on its own device (the first pipeline at all when its device is not listed, in place of
+    that entry): len(devices) pipelines in every case."""
+    devs = _host_devices()
     if len(devs) < 2 or _plan_bytes(plan) > _REPLICA_MAX_BYTES:
         return ()
     from ._lib import host_block_plan
-    if host_block_plan(n_rows, row_bytes, 64, len(devs))[1] < 2 * len(devs):
+    if host_block_plan(n_rows, row_bytes, _host_quantum(plan), len(devs))[1] < 2 * len(devs):
         return ()                      # not enough blocks for every device to overlap its copies with its kernels
+    own = devs.index(plan.device) if plan.device in devs else 0
     cache = plan.__dict__.setdefault("_replicas", {})
     out = []
-    first = True
     for slot, d in enumerate(devs):
-        if first and d == plan.device:
-            first = False              # the plan itself serves its own device once
-            continue
+        if slot == own:
+            continue                   # the plan itself
         key = (slot, d)
         if key not in cache:
             cache[key] = plan.replica(d)
         out.append(cache[key])
-    return tuple(out)                  # (a plan whose device is not listed still serves the first pipeline itself)
+    return tuple(out)
 
 
 DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins

@@ -1224,11 +1224,18 @@ static int dense_apply_host_multi(wagg_dense *const *plans, const int *devices, 
     WAGG_REQUIRE(X_host && out_host, "X/out is NULL");
     wagg_dense *d0 = plans[0];
     WAGG_REQUIRE(ldx >= d0->G && ldo >= d0->R, "ldx/ldo too small");
-    return stream_host_rows<T>(X_host, Tn, ldx, d0->G, out_host, ldo, d0->R, flags, d0->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16, n, devices,
-                               [&](int s, const T *xd, int64_t rows, T *od, hipStream_t st) {
-                                   return dense_apply<T>(plans[s], xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
-                               },
-                               [](int, hipStream_t) {});
+    const int rc = stream_host_rows<T>(X_host, Tn, ldx, d0->G, out_host, ldo, d0->R, flags, d0->spmm ? SpT<T>::TB : DT<T>::MT_MAX * 16, n, devices,
+                                       [&](int s, const T *xd, int64_t rows, T *od, hipStream_t st) {
+                                           return dense_apply<T>(plans[s], xd, rows, ldx, PackXfT<T>{}, od, ldo, 0, (void *)st);
+                                       },
+                                       [](int, hipStream_t) {});
+    // Every pipeline has drained.  A replica's pack stage leaves its +-inf note in the replica's own word: the caller asks
+    // plans[0] (wagg_dense_saw_inf), so the notes of the other replicas move there (and are cleared: a replica is reused).
+    for (int s = 1; s < n; ++s) {
+        volatile int *note = plans[s]->inf_host;
+        if (note[0]) { *(volatile int *)d0->inf_host = 1; note[0] = 0; }
+    }
+    return rc;
 }
 }  // namespace wagg
 

@@ -367,7 +367,8 @@ int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int
 int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
                               double *out_host, int64_t ldo, int flags);
 /* ... and over several devices, one replica of the plan per device (as wagg_apply_host_multi_*; a dense-family plan
- * owns its workspaces, so every slot needs a replica of its own)                                                      */
+ * owns its workspaces, so every slot needs a replica of its own).  The +-inf notes of all replicas (wagg_dense_saw_inf)
+ * are collected in plans[0] before the call returns and cleared in the others.                                       */
 int wagg_dense_apply_host_multi_f32(wagg_dense *const *plans, const int *devices, int n_devices, const float *X_host,
                                     int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags);
 int wagg_dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices, int n_devices, const double *X_host,

@@ -186,3 +186,65 @@ def test_c5_table_from_the_caller_at_full_size(torch_cuda, structure):
         del got, want, X
         plan.close(); ref.close()
         torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------
+# +-inf met by a REPLICA of an MFMA-form plan must reach the caller
+# ---------------------------------------------------------------------------------------------
+def test_inf_in_a_block_dealt_to_a_replica_is_not_lost(torch_cuda):
+    """Multi-device host streaming of a dense-family plan (wagg_dense_apply_host_multi_*): row blocks are dealt round-robin
+    to replica plans, each of which notes +-inf in its own word.  The notes are collected in plans[0] (and cleared in the
+    replicas), so wagg_dense_saw_inf on the primary answers for the whole call and the drop-in redoes the field through the
+    exact segment-table form: inf stays with the regions that own the cell (S6) instead of turning other regions NaN."""
+    import pandas as pd
+    from climate_toolbox_amd import _lib, aggregations as A, minixr
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    rng = np.random.default_rng(21)
+    # library level: a full-matrix plan and one replica on the same device, +-inf only in rows of the SECOND block
+    G, R, T = 32 * 1300, 300, 1500
+    W = rng.uniform(0, 1, (G, R)).astype(np.float32)
+    plan = DensePlan.from_host(W)
+    rep = plan.replica(0)
+    block_rows, n_blocks = _lib.host_block_plan(T, G * 4, 368, 2)
+    assert n_blocks >= 2
+    X = (280 + 10 * rng.standard_normal((T, G))).astype(np.float32)
+    assert not plan.saw_inf() and not rep.saw_inf()
+    plan.apply_host(X, flags=0, replicas=[rep])
+    assert not plan.saw_inf()
+    X[block_rows + 3, 77] = np.inf                       # block 1 -> pipeline 1 = the replica
+    plan.apply_host(X, flags=0, replicas=[rep])
+    assert plan.saw_inf() and not rep.saw_inf()          # collected in the primary, cleared in the replica
+    assert not plan.saw_inf()                            # ... and reading clears it
+    plan.close(); rep.close()
+    # drop-in level: a scattered, dense-ish table takes the full MFMA form; HOST_DEVICES = [0, 0]
+    nlat, nlon, R, T = 96, 192, 40, 2200
+    lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0
+    n = int(0.3 * nlat * nlon * R)
+    flat = rng.choice(nlat * nlon * R, size=n, replace=False)
+    cell, lab = flat // R, flat % R
+    df = pd.DataFrame({"lat": lat[cell // nlon], "lon": lon[cell % nlon], "areawt": rng.uniform(0.1, 1, n), "hierid": lab})
+    tas = (280 + 10 * rng.standard_normal((T, nlat, nlon))).astype(np.float32)
+    block_rows, n_blocks = _lib.host_block_plan(T, nlat * nlon * 4, 368, 2)
+    assert n_blocks >= 4
+    tas[block_rows + 5, 5, 7] = np.inf                   # a row of block 1 (the replica's)
+    tas[3 * block_rows + 1, 9, 1] = -np.inf              # ... and of block 3
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": np.arange(T), "lat": lat, "lon": lon})
+    saved = A.HOST_DEVICES
+    try:
+        A.HOST_DEVICES = [0, 0]
+        A._PLAN_CACHE.clear()
+        out = A.weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values
+        (plan,) = [p for p in A._PLAN_CACHE.values() if isinstance(p, DensePlan)]
+        assert plan.info["form"] == _lib.FORM_FULL and len(plan._replicas) == 1
+    finally:
+        A.HOST_DEVICES = saved
+    args = (("time", "lat", "lon"), lat, lon, df["lat"].values, df["lon"].values, df["areawt"].values, df["areawt"].values, df["hierid"].values)
+    ref = O.agg_scatter(tas, *args, group_dim="hierid")[0]
+    assert np.isinf(ref).any() and not np.isnan(ref).any()
+    assert not np.isnan(out).any()
+    _rel_ok(out, ref, RTOL32)
+    # the default keeps host fields on the current device: no replicas are built
+    A._PLAN_CACHE.clear()
+    A.weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    assert all(not getattr(p, "_replicas", {}) for p in A._PLAN_CACHE.values())
