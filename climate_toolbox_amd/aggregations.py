@@ -441,8 +441,7 @@ def _flatten_for_device(values, dims):
     if on_dev:
         import torch
         if values.dtype not in (torch.float32, torch.float64):
-            raise TypeError("a device-resident variable must be float32 or float64 (got %s): the library moves device data "
-                            "with its own kernels only" % (values.dtype,))
+            values = _engine.to_float64(values)      # the reference's promotion (S8), in the library's own kernel
         # the re-layout of a device field runs in the library's own kernel (wagg_relayout_*), not in a torch one
         contig = lambda a: a if a.is_contiguous() else _engine.relayout(a)
         transpose = lambda a, order: _engine.relayout(a, order)
@@ -603,24 +602,45 @@ def _drop_plan(plan):
     plan.close()
 
 
+_BUILDING = {}        # plan key -> threading.Event of the thread that is building that plan right now (under _CACHE_LOCK)
+
+
 def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
     """The cached plan of this table, LEASED: ``plan._lease`` is held on return and the caller releases
-    it when its device work is done (see _CACHE_LOCK)."""
+    it when its device work is done (see _CACHE_LOCK).  A table that is not cached is built by ONE thread, outside the
+    cache lock (a dense-family plan can be GBs: other tables must not wait for it); threads that want the same table
+    meanwhile wait for that build instead of starting their own."""
     key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
-    with _CACHE_LOCK:
-        plan = _PLAN_CACHE.get(key)
+    while True:
+        with _CACHE_LOCK:
+            plan = _PLAN_CACHE.get(key)
+            pending = None
+            if plan is not None:
+                _PLAN_CACHE.move_to_end(key)
+            else:
+                pending = _BUILDING.get(key)
+                if pending is None:
+                    _BUILDING[key] = threading.Event()
         if plan is not None:
-            _PLAN_CACHE.move_to_end(key)
-    if plan is not None:
-        plan._lease.acquire()                      # waits for a thread that is applying the same table
-        if plan._h.value:
-            return plan
-        plan._lease.release()                      # closed in the meantime (failed on the device): build anew
+            plan._lease.acquire()                  # waits for a thread that is applying the same table
+            if plan._h.value:
+                return plan
+            plan._lease.release()                  # closed in the meantime (failed on the device): forget it, build anew
+            with _CACHE_LOCK:
+                if _PLAN_CACHE.get(key) is plan:
+                    del _PLAN_CACHE[key]
+            continue
+        if pending is not None:
+            pending.wait()                         # another thread builds this very table: take its plan from the cache
+            continue
+        break
     import torch
-    with _CACHE_LOCK:
-        free_bytes, total_bytes = torch.cuda.mem_get_info()
-        # keep the cache under its plan count and byte budget (what a sparse plan adds is a few MB)
-        free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes, keep=_PLAN_CACHE_MAX - 1)
+    plan = None
+    try:
+        with _CACHE_LOCK:
+            free_bytes, total_bytes = torch.cuda.mem_get_info()
+            # keep the cache under its plan count and byte budget (what a sparse plan adds is a few MB)
+            free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes, keep=_PLAN_CACHE_MAX - 1)
         need = _dense_bytes(G, R, is_f32, nseg=len(cell_idx))
 
         def dense_fits():
@@ -628,7 +648,8 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
             # the dense form is declined for lack of memory
             nonlocal free_bytes
             if need >= 0.6 * free_bytes:
-                free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - need, keep=_PLAN_CACHE_MAX - 1)
+                with _CACHE_LOCK:
+                    free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - need, keep=_PLAN_CACHE_MAX - 1)
             return need < 0.6 * free_bytes
 
         dt = "float32" if is_f32 else "float64"
@@ -643,7 +664,11 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
                 plan.close()
                 plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
         plan._lease.acquire()
-        _PLAN_CACHE[key] = plan
+    finally:
+        with _CACHE_LOCK:
+            if plan is not None and plan._h.value:
+                _PLAN_CACHE[key] = plan
+            _BUILDING.pop(key).set()               # (a failed build wakes the waiters too: the first of them tries again)
     return plan
 
 

@@ -8,10 +8,14 @@
 namespace wagg {
 
 HostStats g_host_stats;
+// failures while resources were released, counted per THREAD as well: a call compares its own threads' counts, so a
+// concurrent call on another thread that hits a cleanup failure does not fail this one
+static thread_local int64_t tl_release_failures = 0;
 
 void note_cleanup(hipError_t e, const char *what) {
     if (e == hipSuccess) return;
     g_host_stats.cleanup_failed++;
+    tl_release_failures++;
     if (wagg_last_error()[0] == '\0') set_error("%s -> %s", what, hipGetErrorString(e));
 }
 
@@ -55,6 +59,7 @@ hipError_t HostPin::release() {
         g_host_stats.unregistered++;
     } else {
         g_host_stats.unregister_failed++;
+        tl_release_failures++;
         if (wagg_last_error()[0] == '\0') set_error("hipHostUnregister -> %s", hipGetErrorString(e));
     }
     return e;
@@ -223,7 +228,16 @@ DevicePipe::~DevicePipe() {
 }
 
 // ---- the pipeline of one device: blocks slot, slot + n_dev, ... ---------------------------------------------------------
-static int run_device(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o) {
+static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o);
+// *release_failures: what this thread's share of the call failed to release (DevicePipe's destructor has run by then)
+static int run_device(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o,
+                      int64_t *release_failures) {
+    const int64_t before = tl_release_failures;
+    const int rc = run_device_(a, slot, set_device, B, nb, pin_x, pin_o);
+    *release_failures = tl_release_failures - before;
+    return rc;
+}
+static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o) {
     const int64_t my_blocks = nb > slot ? (nb - slot + a.n_dev - 1) / a.n_dev : 0;
     if (my_blocks == 0) return WAGG_OK;
     DevicePipe P;
@@ -231,9 +245,12 @@ static int run_device(const HostRowsArgs &a, int slot, bool set_device, int64_t 
     int cur = 0;
     if (!set_device) WAGG_HIP(hipGetDevice(&cur));
     WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * a.ldx_bytes), (size_t)(B * a.ldo_bytes), my_blocks >= 2 ? 2 : 1));
-    struct Releaser {                                   // per-stream plan state keyed by P.sk goes before the stream does
-        const HostRowsArgs &a; int slot; hipStream_t s;
-        ~Releaser() { if (a.release) a.release(slot, s); }
+    struct Releaser {                                   // per-stream plan state keyed by P.sk goes before the stream does --
+        const HostRowsArgs &a; int slot; hipStream_t s; // and, on every path (also the early returns), only once nothing on
+        ~Releaser() {                                   // that stream can still be using it (this runs BEFORE ~DevicePipe)
+            note_cleanup(hipStreamSynchronize(s), "hipStreamSynchronize(kernel stream, before its plan state is dropped)");
+            if (a.release) a.release(slot, s);
+        }
     } rel{a, slot, P.sk};
     auto span = [](int64_t rows, int64_t ld, int64_t row) { return (size_t)((rows - 1) * ld + row); };
     int64_t prev_r0 = -1, prev_rows = 0;
@@ -292,7 +309,8 @@ int stream_host_rows_any(const HostRowsArgs &a) {
     if (a.Tn == 0) return WAGG_OK;
     WAGG_REQUIRE(a.n_dev >= 1 && a.n_dev <= 64, "n_devices must lie in [1, 64], got %d", a.n_dev);
     g_host_stats.calls++;
-    const int64_t fail0 = g_host_stats.cleanup_failed + g_host_stats.unregister_failed;
+    int64_t release_failures = 0;                        // of THIS call: its own threads' counts
+    const int64_t fail0 = tl_release_failures;
     int64_t B, nb;
     host_block_plan(a.Tn, a.ldx_bytes, a.quantum, a.n_dev, &B, &nb);
     const size_t xbytes = (size_t)((a.Tn - 1) * a.ldx_bytes + a.xrow_bytes), obytes = (size_t)((a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
@@ -303,21 +321,27 @@ int stream_host_rows_any(const HostRowsArgs &a) {
         const bool pin_x = want && px.acquire(a.X_host, xbytes, a.n_dev > 1);
         const bool pin_o = want && po.acquire(a.out_host, obytes, a.n_dev > 1);
         if (a.n_dev == 1 && a.devices == nullptr) {
-            rc = run_device(a, 0, false, B, nb, pin_x, pin_o);
+            int64_t f = 0;
+            rc = run_device(a, 0, false, B, nb, pin_x, pin_o, &f);      // (this thread: counted through fail0 below)
         } else {
             // one host thread per device: each drives its own copy engines and kernels, results land straight in the
             // caller's rows (no exchange between devices)
             std::vector<int> rcs((size_t)a.n_dev, WAGG_OK);
+            std::vector<int64_t> fails((size_t)a.n_dev, 0);
             std::vector<std::string> msgs((size_t)a.n_dev);
             std::vector<std::thread> th;
             int home = 0;
             WAGG_HIP(hipGetDevice(&home));
             for (int s = 0; s < a.n_dev; ++s)
                 th.emplace_back([&, s]() {
-                    rcs[(size_t)s] = run_device(a, s, true, B, nb, pin_x, pin_o);
-                    if (rcs[(size_t)s] != WAGG_OK) msgs[(size_t)s] = wagg_last_error();
+                    rcs[(size_t)s] = run_device(a, s, true, B, nb, pin_x, pin_o, &fails[(size_t)s]);
+                    if (rcs[(size_t)s] != WAGG_OK || fails[(size_t)s]) msgs[(size_t)s] = wagg_last_error();
                 });
             for (auto &t : th) t.join();
+            for (int s = 0; s < a.n_dev; ++s) {
+                release_failures += fails[(size_t)s];
+                if (fails[(size_t)s] && wagg_last_error()[0] == '\0' && !msgs[(size_t)s].empty()) set_error("device slot %d: %s", s, msgs[(size_t)s].c_str());
+            }
             for (int s = 0; s < a.n_dev && rc == WAGG_OK; ++s)
                 if (rcs[(size_t)s] != WAGG_OK) { rc = rcs[(size_t)s]; set_error("device slot %d: %s", s, msgs[(size_t)s].c_str()); }
             (void)home;                                  // (the calling thread's current device was never changed)
@@ -329,7 +353,8 @@ int stream_host_rows_any(const HostRowsArgs &a) {
             rc = WAGG_EHIP;
         }
     }
-    if (rc == WAGG_OK && g_host_stats.cleanup_failed + g_host_stats.unregister_failed != fail0) {
+    release_failures += tl_release_failures - fail0;
+    if (rc == WAGG_OK && release_failures != 0) {
         if (wagg_last_error()[0] == '\0') set_error("a HIP call failed while the host pipeline released its resources");
         rc = WAGG_EHIP;
     }

@@ -189,6 +189,22 @@ __global__ void relayout_kernel(const T *__restrict__ src, RelayoutDims d, int64
     }
 }
 
+// ... and the same strided walk for a device field of ANOTHER element type, converted to fp64 on the way (the reference
+// multiplies by float64 weights, so every dtype ends in float64: S8)
+template <typename S> __device__ __forceinline__ double to_f64(S v) { return (double)v; }
+template <> __device__ __forceinline__ double to_f64<_Float16>(_Float16 v) { return (double)(float)v; }
+struct bf16_bits { uint16_t b; };
+template <> __device__ __forceinline__ double to_f64<bf16_bits>(bf16_bits v) { return (double)__builtin_bit_cast(float, (uint32_t)v.b << 16); }
+template <typename S>
+__global__ void relayout_to_f64_kernel(const S *__restrict__ src, RelayoutDims d, int64_t total, double *__restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        int64_t rem = p, off = 0;
+        for (int k = d.nd - 1; k >= 0; --k) { off += (rem % d.shape[k]) * d.sstride[k]; rem /= d.shape[k]; }
+        dst[p] = to_f64<S>(src[off]);
+    }
+}
+
 template <typename T>
 static int transform_poly(const T *X, int64_t n, double offset, int power, T *out, void *stream) {
     WAGG_REQUIRE(n >= 0 && power >= 1 && power <= 16, "bad arguments (n=%lld, power=%d)", (long long)n, power);
@@ -293,8 +309,42 @@ static int relayout(const T *src, int nd, const int64_t *shape, const int64_t *s
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }
+
+static int relayout_to_f64(const void *src, int src_type, int nd, const int64_t *shape, const int64_t *sstride, double *dst, void *stream) {
+    WAGG_REQUIRE(nd >= 1 && nd <= 6 && shape && sstride, "1..6 dimensions");
+    RelayoutDims d;
+    d.nd = nd;
+    int64_t total = 1;
+    for (int k = 0; k < 6; ++k) {
+        d.shape[k] = k < nd ? shape[k] : 1; d.sstride[k] = k < nd ? sstride[k] : 0;
+        WAGG_REQUIRE(d.shape[k] >= 0 && d.sstride[k] >= 0, "negative extent or stride");
+        total *= d.shape[k];
+    }
+    if (total == 0) return WAGG_OK;
+    WAGG_REQUIRE(src && dst, "NULL pointer");
+#define WAGG_TO_F64(S) hipLaunchKernelGGL((relayout_to_f64_kernel<S>), dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const S *)src, d, total, dst)
+    switch (src_type) {
+        case WAGG_T_F16: WAGG_TO_F64(_Float16); break;
+        case WAGG_T_BF16: WAGG_TO_F64(bf16_bits); break;
+        case WAGG_T_I8: WAGG_TO_F64(int8_t); break;
+        case WAGG_T_U8: WAGG_TO_F64(uint8_t); break;
+        case WAGG_T_I16: WAGG_TO_F64(int16_t); break;
+        case WAGG_T_I32: WAGG_TO_F64(int32_t); break;
+        case WAGG_T_I64: WAGG_TO_F64(int64_t); break;
+        case WAGG_T_F32: WAGG_TO_F64(float); break;
+        case WAGG_T_F64: WAGG_TO_F64(double); break;
+        default: WAGG_REQUIRE(false, "unknown element type %d", src_type);
+    }
+#undef WAGG_TO_F64
+    WAGG_HIP(hipGetLastError());
+    return WAGG_OK;
+}
 }  // namespace wagg
 
+extern "C" int wagg_relayout_to_f64(const void *src_dev, int src_type, int ndim, const int64_t *shape, const int64_t *src_strides,
+                                    double *dst_dev, void *stream) {
+    return wagg::relayout_to_f64(src_dev, src_type, ndim, shape, src_strides, dst_dev, stream);
+}
 extern "C" int wagg_combine_planes_f32(const float *planes_dev, int n_planes, int64_t plane_stride, const double *coefs,
                                        int64_t n, float *out_dev, void *stream) {
     return wagg::combine_planes<float>(planes_dev, n_planes, plane_stride, coefs, n, out_dev, stream);

@@ -491,21 +491,26 @@ def take_axis(t, axis, index, stream=None):
     """``t`` with only the positions ``index`` (host integers) kept / re-ordered along ``axis`` (``wagg_take_axis``):
     the leap-day drop and the lon re-ordering of a device-resident field, without a torch kernel."""
     import torch
-    if not (isinstance(t, torch.Tensor) and t.is_cuda):
-        raise TypeError("expected a CUDA tensor")
-    t = relayout(t) if not t.is_contiguous() else t
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch tensor")
+    axis = int(axis) % t.dim()
     idx = np.ascontiguousarray(index, dtype=np.int64)
     if len(idx) and (idx.min() < 0 or idx.max() >= t.shape[axis]):
         raise IndexError("index out of range")
+    if not t.is_cuda:                                # host tensor: a host copy, nothing for the device to do
+        return torch.from_numpy(np.take(t.numpy(), idx, axis=axis))
+    if t.dtype not in (torch.float32, torch.float64):
+        t = to_float64(t)                            # (rows of 1- and 2-byte elements are not whole words: promote first, S8)
+    t = relayout(t) if not t.is_contiguous() else t
     outer = int(np.prod(t.shape[:axis], dtype=np.int64))
     inner_bytes = int(np.prod(t.shape[axis + 1:], dtype=np.int64)) * t.element_size()
-    if inner_bytes % 4:
-        raise TypeError("rows of whole 4-byte words only (dtype %s)" % t.dtype)
     out = torch.empty(tuple(t.shape[:axis]) + (len(idx),) + tuple(t.shape[axis + 1:]), dtype=t.dtype, device=t.device)
     idx_dev = torch.from_numpy(idx).to(t.device)
     _lib.check(_lib.load().wagg_take_axis(C.c_void_p(t.data_ptr()), outer, int(t.shape[axis]), inner_bytes,
                                           C.c_void_p(idx_dev.data_ptr()), len(idx), C.c_void_p(out.data_ptr()),
                                           _stream_handle(stream)), "wagg_take_axis")
+    if stream is not None:                           # idx_dev goes back to torch's allocator on return: keep it alive until
+        idx_dev.record_stream(stream)                # the kernel on the caller's stream has read it
     return out
 
 
@@ -526,6 +531,32 @@ def relayout(t, order=None, stream=None):
     L = _lib.load()
     fn = L.wagg_relayout_f32 if t.dtype == torch.float32 else L.wagg_relayout_f64
     _lib.check(fn(C.c_void_p(t.data_ptr()), len(shape), sh, st, C.c_void_p(out.data_ptr()), _stream_handle(stream)), "wagg_relayout")
+    return out
+
+
+_TO_F64_TYPES = {"torch.float16": 0, "torch.bfloat16": 1, "torch.int8": 2, "torch.uint8": 3, "torch.int16": 4, "torch.int32": 5,
+                 "torch.int64": 6, "torch.float32": 7, "torch.float64": 8}
+
+
+def to_float64(t, order=None, stream=None):
+    """A contiguous float64 copy of a CUDA tensor of another dtype (any strides; dims in ``order`` if given), converted in
+    the library's own kernel (``wagg_relayout_to_f64``) -- the reference's promotion: data times float64 weights is float64."""
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError("expected a CUDA tensor")
+    code = _TO_F64_TYPES.get(str(t.dtype))
+    if code is None:
+        raise TypeError("device-resident fields of dtype %s are not supported" % (t.dtype,))
+    order = list(range(t.dim())) if order is None else [int(i) for i in order]
+    if t.dim() > 6 or t.dim() < 1:
+        raise ValueError("1..6 dimensions")
+    shape = [int(t.shape[i]) for i in order]
+    strides = [int(t.stride(i)) for i in order]
+    out = torch.empty(shape, dtype=torch.float64, device=t.device)
+    sh = (C.c_int64 * len(shape))(*shape)
+    st = (C.c_int64 * len(shape))(*strides)
+    _lib.check(_lib.load().wagg_relayout_to_f64(C.c_void_p(t.data_ptr()), code, len(shape), sh, st, C.c_void_p(out.data_ptr()),
+                                                _stream_handle(stream)), "wagg_relayout_to_f64")
     return out
 
 

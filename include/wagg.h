@@ -257,6 +257,19 @@ int wagg_take_axis(const void *src_dev, int64_t outer, int64_t n_src, int64_t in
                    int64_t n_idx, void *dst_dev, void *stream);
 int wagg_relayout_f32(const float *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, float *dst_dev, void *stream);
 int wagg_relayout_f64(const double *src_dev, int ndim, const int64_t *shape, const int64_t *src_strides, double *dst_dev, void *stream);
+/* a device field of another element type as a contiguous fp64 array (the reference's own promotion: any dtype times float64
+ * weights is float64, S8), strided source as for wagg_relayout_* with strides in elements of the source type */
+#define WAGG_T_F16 0
+#define WAGG_T_BF16 1
+#define WAGG_T_I8 2
+#define WAGG_T_U8 3
+#define WAGG_T_I16 4
+#define WAGG_T_I32 5
+#define WAGG_T_I64 6
+#define WAGG_T_F32 7
+#define WAGG_T_F64 8
+int wagg_relayout_to_f64(const void *src_dev, int src_type, int ndim, const int64_t *shape, const int64_t *src_strides,
+                         double *dst_dev, void *stream);
 int wagg_any_less_f32(const float *a_dev, const float *b_dev, int64_t n, int *result, void *stream);
 int wagg_any_less_f64(const double *a_dev, const double *b_dev, int64_t n, int *result, void *stream);
 
