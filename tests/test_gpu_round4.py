@@ -248,3 +248,44 @@ def test_inf_in_a_block_dealt_to_a_replica_is_not_lost(torch_cuda):
     A._PLAN_CACHE.clear()
     A.weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
     assert all(not getattr(p, "_replicas", {}) for p in A._PLAN_CACHE.values())
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident fields of other dtypes, take_axis corner cases
+# ---------------------------------------------------------------------------------------------
+def test_device_fields_of_other_dtypes_are_promoted_by_the_library(torch_cuda):
+    """A device-resident variable that is not float32/float64 is promoted to float64 like the reference promotes it (data
+    times float64 weights, S8) -- by wagg_relayout_to_f64, strided sources included; take_axis accepts negative axes, host
+    tensors and narrow dtypes."""
+    from climate_toolbox_amd import engine, minixr, synth, weighted_aggregate_grid_to_regions
+    torch = torch_cuda
+    rng = np.random.default_rng(2)
+    a = rng.integers(-100, 100, (5, 12, 9))
+    for tdt, ndt in ((torch.int16, np.int16), (torch.int32, np.int32), (torch.int64, np.int64), (torch.uint8, np.uint8),
+                     (torch.int8, np.int8), (torch.float16, np.float16), (torch.bfloat16, None), (torch.float32, np.float32)):
+        t = torch.from_numpy(a.astype(np.float32)).to(tdt).cuda() if ndt is None else torch.from_numpy(a.astype(ndt)).cuda()
+        want = t.cpu().to(torch.float64).numpy()
+        np.testing.assert_array_equal(engine.to_float64(t).cpu().numpy(), want)
+        np.testing.assert_array_equal(engine.to_float64(t[:, ::2, 1:7], order=(2, 0, 1)).cpu().numpy(),
+                                      np.transpose(want[:, ::2, 1:7], (2, 0, 1)))
+    t16 = torch.from_numpy(a.astype(np.int16)).cuda()
+    idx = [8, 0, 3]
+    np.testing.assert_array_equal(engine.take_axis(t16, -1, idx).cpu().numpy(), np.take(a, idx, axis=2).astype(np.float64))
+    np.testing.assert_array_equal(engine.take_axis(torch.from_numpy(a), 1, [4, 4, 0]).numpy(), np.take(a, [4, 4, 0], axis=1))
+    f = torch.from_numpy(a.astype(np.float32)).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = engine.take_axis(f, -2, [1, 11], stream=side)
+    side.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), np.take(a, [1, 11], axis=1).astype(np.float32))
+    # the drop-in on an int16 device field = the drop-in on the same numbers as a float64 host array
+    nlat, nlon, T = 48, 96, 12
+    lat, lon, df = synth.realistic_segments(nlat, nlon, R=40, seed=4, string_labels=False)
+    vals = rng.integers(250, 320, (T, nlat, nlon)).astype(np.int16)
+    outs = []
+    for v in (vals.astype(np.float64), torch.from_numpy(vals).cuda()):
+        ds = minixr.Dataset({"tas": (("time", "lat", "lon"), v)}, coords={"time": np.arange(T), "lat": lat, "lon": lon})
+        outs.append(weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values)
+    assert outs[1].dtype == np.float64
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-12)
