@@ -164,6 +164,8 @@ def sparse_algorithmic_bytes(T, G, R, nnz, b):
 
 
 def timed_steps(torch, dist, step, finish, steps, warmup, world):
+    """(wall seconds of exactly `steps` steps between barrier + synchronize on both sides, max over ranks;
+    per-step milliseconds from event pairs on the compute stream -- recorded without any synchronisation)."""
     world = world if not (dist.is_available() and dist.is_initialized()) else max(world, 2)   # forced-dist rehearsal
     for _ in range(warmup):
         step()
@@ -172,9 +174,12 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for a_, b_ in ev:
+        a_.record()
         step()
+        b_.record()
     finish()                               # every queued gather has completed
     torch.cuda.synchronize()
     if world > 1:
@@ -185,7 +190,12 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt
+    return dt, sorted(a_.elapsed_time(b_) for a_, b_ in ev)
+
+
+def step_stats(per_step_ms):
+    """median and minimum of the per-step device times (SURVEY 8d's timing protocol asks for both)."""
+    return {"median_ms": per_step_ms[len(per_step_ms) // 2], "min_ms": per_step_ms[0]}
 
 
 # ---- CPU baselines (rank 0, N = 1 only; bounded samples; the oracle is the thing timed here) -------
@@ -211,15 +221,16 @@ def cpu_baseline_dense(T, G, R, seed_w, fill=1.0, blocklocal=False):
 def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
     """The oracle's faithful single-threaded restatement (gather -> fp64 multiply -> group-sum ->
     divide, like the reference) on the sample handed in (the FULL workload for the segment-table
-    configs: it is only ~0.4 s of CPU work), median of up to 15 repeats inside ~10 s; plus a
-    best-effort CPU path (scipy CSC SpMM in fp64, also one thread) on the same sample."""
+    configs: it is only ~0.4 s of CPU work), median and minimum of up to 15 repeats inside ~10 s; plus the
+    best-effort CPU leg SURVEY 8d asks for -- the same sums with the timesteps dealt to all host cores
+    (OpenMP, oracle/wagg_oracle.c::wagg_oracle_segments_omp_*) -- and scipy's CSC SpMM (one thread) for reference."""
     import numpy as np
     import scipy.sparse as sp
     from oracle import c_oracle
     Ts = X_host.shape[0]
     c_oracle.segments(X_host[:1], cell, codes, w_eff, R)
 
-    def median_time(fn, budget_s=10.0, max_reps=15):
+    def timed(fn, budget_s=10.0, max_reps=15):
         ts, t_start = [], time.perf_counter()
         while len(ts) < max_reps and (len(ts) < 3 or time.perf_counter() - t_start < budget_s):
             t0 = time.perf_counter()
@@ -227,25 +238,31 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
             ts.append(time.perf_counter() - t0)
             if time.perf_counter() - t_start > budget_s and len(ts) >= 1:
                 break
-        return sorted(ts)[len(ts) // 2], len(ts)
+        ts.sort()
+        return ts[len(ts) // 2], ts[0], len(ts)
 
-    dt, reps = median_time(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R))
+    dt, dmin, reps = timed(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R))
+    c_oracle.segments(X_host[:c_oracle.threads()], cell, codes, w_eff, R, threaded=True)          # (thread pool start-up)
+    dto, domin, repso = timed(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R, threaded=True))
     keep = (codes >= 0) & ~np.isnan(w_eff)
     W = sp.coo_matrix((w_eff[keep], (cell[keep], codes[keep])), shape=(G, R)).tocsc()
     den = np.asarray(W.sum(axis=0)).ravel()
 
-    def best():
+    def scipy_leg():
         Xs = np.nan_to_num(X_host.astype(np.float64), nan=0.0, posinf=np.inf, neginf=-np.inf)
         with np.errstate(divide="ignore", invalid="ignore"):
             return (W.T @ Xs.T).T / den[None, :]
 
-    dtb, repsb = median_time(best)
+    dtb, dbmin, repsb = timed(scipy_leg, budget_s=5.0, max_reps=5)
     return {"value": Ts * G * R / dt, "unit": "gridcell-region-timesteps/s", "cores": 1, "kind": "port",
-            "wall_s": round(dt, 4), "repeats": reps, "nnz_timesteps_per_s": Ts * len(cell) / dt,
+            "wall_s": round(dt, 4), "wall_s_min": round(dmin, 4), "repeats": reps, "nnz_timesteps_per_s": Ts * len(cell) / dt,
             "sample": "oracle/wagg_oracle.c segments_%s (single thread, like the reference), %s"
                       % ("f32" if X_host.dtype == np.float32 else "f64", what),
-            "cpu_best": {"value": Ts * G * R / dtb, "wall_s": round(dtb, 4), "cores": 1, "repeats": repsb,
-                         "what": "scipy.sparse CSC^T @ X^T in fp64 (one thread), same sample"}}
+            "cpu_best": {"value": Ts * G * R / dto, "wall_s": round(dto, 4), "wall_s_min": round(domin, 4), "cores": c_oracle.threads(),
+                         "repeats": repso, "kind": "port",
+                         "what": "the same C restatement with the timesteps dealt to every host core (OpenMP), same sample"},
+            "cpu_scipy": {"value": Ts * G * R / dtb, "wall_s": round(dtb, 4), "wall_s_min": round(dbmin, 4), "cores": 1, "repeats": repsb,
+                          "what": "scipy.sparse CSC^T @ X^T in fp64 (one thread), same sample"}}
 
 
 def main():
@@ -308,6 +325,14 @@ def main():
         return ShardedStep(apply_fn, lambda: torch.empty((Tn, Rr), dtype=dtype, device="cuda"), rows=rows_all, dst=0,
                            distributed=use_dist)
 
+    def gather_check(st, Tn):
+        """rank 0, distributed runs: the reassembled series holds this rank's last block in this rank's rows (the other
+        ranks' rows are theirs to vouch for: the CPU gloo tests compare every block)."""
+        if not use_dist or rank != 0:
+            return None
+        got = st.finish()
+        return bool(got is not None and got.shape[0] == sum(st.rows) and torch.equal(got[:Tn], st.bufs[(st.k - 1) & 1]))
+
     def kernel_avg_ms(kms, warmup):
         kms = kms[warmup:] if len(kms) > warmup else kms
         return sum(kms) / max(1, len(kms))
@@ -324,6 +349,65 @@ def main():
                                 "`frac_on_traffic` is the one that says how close to the HBM the kernel runs")
         return roof
 
+    def boundary_legs(Xs, lat, lon, df, plan, T, Gs, Rr):
+        """What the kernel numbers leave out, on c2-real: the PCIe-inclusive rate of a host-resident
+        field, the reference-named function end to end (device- and host-resident variable, cached plan), and the country
+        level of the same table (agglev = "ISO": the other level the reference's docstring names, aggregations.py:104-106)."""
+        from climate_toolbox_amd import _lib as L_, aggregations as A, minixr, weighted_aggregate_grid_to_regions
+        out = {}
+        Xh = Xs.cpu().numpy()
+        plan.apply_host(Xh, flags=L_.HOST_PIN)                       # (first call: staging pieces, registration path warm)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            plan.apply_host(Xh, flags=L_.HOST_PIN)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out["host_resident"] = {"ms_per_step": ts[1] * 1e3, "min_ms": ts[0] * 1e3, "h2d_gbs": Xh.nbytes / ts[1] / 1e9,
+                                "what": "wagg_apply_host_f32 (row-block pipeline, arrays page-locked in place): X from host memory, result "
+                                        "back to host memory; PCIe-bound, never the headline value"}
+
+        def calls(ds, n=20, warm=3):
+            for _ in range(warm):
+                weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ts.sort()
+            return {"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "calls": n}
+
+        shape = (T, len(lat), len(lon))
+        A._PLAN_CACHE.clear()
+        dsd = minixr.Dataset({"tas": (("time", "lat", "lon"), Xs.reshape(shape))}, coords={"lat": lat, "lon": lon})
+        dsh = minixr.Dataset({"tas": (("time", "lat", "lon"), Xh.reshape(shape))}, coords={"lat": lat, "lon": lon})
+        out["dropin_ms"] = {"device_resident": calls(dsd), "host_resident": calls(dsh, n=10),
+                            "what": "weighted_aggregate_grid_to_regions(ds, 'tas', 'areawt', 'hierid', df) end to end (aggregations.py:87), "
+                                    "cached plan, result returned as a host array; c2-real table (%d rows)" % len(df)}
+        A._PLAN_CACHE.clear()
+        del dsd, dsh, Xh
+        cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, "areawt", "ISO")
+        t0 = time.perf_counter()
+        iso = engine.SparsePlan(cell, codes, w_eff, Gs, len(uniq), row_len=len(lon))
+        tb = time.perf_counter() - t0
+        o = torch.empty((T, len(uniq)), dtype=Xs.dtype, device="cuda")
+        for _ in range(3):
+            iso.apply(Xs, out=o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            iso.apply(Xs, out=o)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        out["agglev_ISO"] = {"R": len(uniq), "ms_per_step": ms, "value": T * Gs * len(uniq) / (ms * 1e-3),
+                             "unit": "gridcell-region-timesteps/s", "plan_build_s": round(tb, 4), "n_giant": int(iso.info["n_giant"]),
+                             "what": "the same segment table aggregated to the country level (regions of thousands of cells each)"}
+        iso.close()
+        return out
+
     def run_sparse(dtype, small=False, steps=None, warmup=None, extras=True):
         steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
         T, rows_all, _ = rows_for("c1" if small else "c2-real")
@@ -339,13 +423,16 @@ def main():
             wname, lev = ("areawt" if dtype == "float32" else "popwt"), "hierid"
             Xs = engine.synth_field(T, Gs, seed=1000 + rank, base=280.0, amp=60.0, dtype=dtype)
         cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, wname, lev)
+        t0 = time.perf_counter()
         plan = engine.SparsePlan(cell, codes, w_eff, Gs, len(uniq), row_len=nlon)
+        plan_build_s = time.perf_counter() - t0
         Rr = len(uniq)
         st = stepper(lambda out: plan.apply(Xs, out=out), T, rows_all, Rr, Xs.dtype)
         engine.profile_enable(True)       # event records only, no synchronisation
-        dt = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
+        dt, per_step = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
         kavg = kernel_avg_ms(engine.profile_read(), warmup) * 1e-3
         engine.profile_enable(False)
+        gok = gather_check(st, T)
         plan.status()
         b = 4 if dtype == "float32" else 8
         nnz = plan.info["nnz"]
@@ -357,7 +444,9 @@ def main():
         res = {
             "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "T_job": T_job, "G": Gs, "R": Rr, "nnz": int(nnz),
             "value": T_job * Gs * Rr * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": dt / steps * 1e3, "nnz_timesteps_per_s": T_job * nnz * steps / dt,
+            "ms_per_step": dt / steps * 1e3, **step_stats(per_step), "nnz_timesteps_per_s": T_job * nnz * steps / dt,
+            **({"gather_ok": gok} if gok is not None else {}),
+            "plan_build_s": round(plan_build_s, 4),      # wagg_plan_create on the coded table (host-side chunking + upload), once per table
             "plan": {k: int(v) for k, v in plan.info.items()},
             "roofline": on_traffic({"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
@@ -410,10 +499,13 @@ def main():
                 del eout
             res["fused_snyder_edd"] = edd
             del tmax
+        if world == 1 and not small and extras and dtype == "float32":
+            res.update(boundary_legs(Xs, lat, lon, df, plan, T, Gs, Rr))
         plan.close()
         return res
 
     cpu_dense_memo = {}
+    c5_tables = {}                       # block-local? -> (rowptr, col, val) host CSR of the synthetic c5 table
 
     def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False, share=False):
         """c2-dense / c4 (full matrix), c5-uniform[-f64] (entry lists), c5-block[-f64] (tile-sparse)."""
@@ -423,20 +515,35 @@ def main():
         f64 = wl.endswith("-f64")
         dt_name = "float64" if f64 else "float32"
         X = engine.synth_field(T, G, seed=1000 + rank, base=280.0, amp=60.0, dtype=dt_name)
-        if wl.startswith("c5-uniform"):
-            fill, bl = 0.01, False
-            plan = plan or engine.DensePlan.synth(G, R, seed=2, fill=0.01, dtype=dt_name)
-        elif wl.startswith("c5-block"):
-            fill, bl = 0.952, True
-            plan = plan or engine.DensePlan.synth_blocklocal(G, R, seed=2, dtype=dt_name)
+        build = None
+        if wl.startswith("c5"):
+            # configs[4] "sparse CSR weights": the table is HANDED IN as host CSR arrays (3 GB; here written by the
+            # library's generator of the synthetic tables, outside the timed build) and the plan is what
+            # wagg_dense_create_from_csr* makes of it -- bit-equal to the plan generated on the device from the same
+            # hashes (tests/test_gpu_round4.py)
+            bl = wl.startswith("c5-block")
+            fill = 0.952 if bl else 0.01
+            if plan is None:
+                if bl not in c5_tables:
+                    c5_tables.clear()                            # one table (3 GB of host memory) at a time
+                    c5_tables[bl] = engine.synth_table_csr(G, R, 2, fill, blocklocal=bl)
+                rowptr, col, val = c5_tables[bl]
+                t0 = time.perf_counter()
+                plan = engine.DensePlan.from_csr(rowptr, col, val, G, R, dtype=dt_name)
+                build = {"plan_build_s": round(time.perf_counter() - t0, 4), "library_s": round(plan.info["build_s"], 4),
+                         "upload_s": round(plan.info["build_upload_s"], 4), "table_entries": int(len(col)),
+                         "table_bytes": int(rowptr.nbytes + col.nbytes + val.nbytes),
+                         "what": "wagg_dense_create_from_csr%s on host CSR arrays: upload, device radix sort + coalesce + "
+                                 "denominators + form choice + packing" % ("_f64" if f64 else "")}
         else:
             fill, bl = 1.0, False
             plan = plan or engine.DensePlan.synth(G, R, seed=2)
         st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), T, rows_all, R, X.dtype)
         engine.profile_enable(True)       # event records only (no sync)
-        dt = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
+        dt, per_step = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
         kms = engine.profile_read()
         engine.profile_enable(False)
+        gok = gather_check(st, T)
         form = int(plan.info["form"])
         # one apply = one dominant-kernel launch (a full-form apply of several row blocks is one launch too)
         kavg = kernel_avg_ms(kms, warmup) * 1e-3
@@ -455,11 +562,17 @@ def main():
         peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
         res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "T_job": T_job, "G": G, "R": R, "nnz": nnz,
                "value": T_job * G * R * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
-               "ms_per_step": dt / steps * 1e3, "plan": {k: int(v) for k, v in plan.info.items()}, "scaling": scal,
+               "ms_per_step": dt / steps * 1e3, **step_stats(per_step),
+               "plan": {k: (int(v) if isinstance(v, int) else round(v, 4)) for k, v in plan.info.items()}, "scaling": scal,
                "roofline": {"bound": "mfma" if form != 2 else "valu", "achieved": flops / kavg / 1e12, "peak": peak,
                             "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / peak,
                             "traffic": traffic, "traffic_source": tsrc, "kernel": kname,
                             "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops}}
+        if gok is not None:
+            res["gather_ok"] = gok
+        if build:
+            res["plan_build"] = build
+            res["plan_build_s"] = build["plan_build_s"]
         if wl != "c2-dense":
             res["rows"] = ("one rank's share: %d of the job's %d rows (shard 0 of %d)"
                            % (T, C4_TOTAL if wl == "c4" else C5_TOTAL, a.shards or 8)) if world == 1 else "rows %r" % (rows_all,)
@@ -478,7 +591,7 @@ def main():
     sec_steps = max(1, min(a.steps, 5))
     if a.workload in DENSE_FAMILY:
         want_secondary = a.workload == "c2-dense" and world == 1 and not a.no_secondary
-        main_res, plan = run_dense_family(a.workload, keep_plan=want_secondary)
+        main_res, plan = run_dense_family(a.workload, keep_plan=want_secondary or (a.workload == "c2-dense" and world > 1 and not a.no_secondary))
         scaling = main_res.get("scaling", "weak")
         if want_secondary:
             # every other BASELINE config on this GPU (N = 1): c4's rank share on the SAME 101 GB operand, then the rest
@@ -493,6 +606,17 @@ def main():
             for wl in ("c5-block", "c5-block-f64", "c5-uniform", "c5-uniform-f64"):
                 torch.cuda.empty_cache()
                 secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2, share=True)[0])
+        elif a.workload == "c2-dense" and world > 1 and not a.no_secondary:
+            # multi-GPU run: after the weak-scaled headline the STRONG splits of the two 8-GPU configs BASELINE names --
+            # configs[3] (10,950 rows over the ranks, on the operand already resident) and configs[4] (18,250 rows,
+            # entry lists) -- so that the scaling line speaks to them too.  Every rank takes part (the gather is inside).
+            a_shards = a.shards
+            a.shards = world
+            r4, _ = run_dense_family("c4", plan=plan, steps=2, warmup=1)
+            torch.cuda.empty_cache()
+            r5, _ = run_dense_family("c5-uniform", steps=3, warmup=1)
+            a.shards = a_shards
+            secondary.extend([r4, r5])
     elif a.workload == "c1":
         main_res = run_sparse("float64", small=True)
     else:
@@ -512,7 +636,9 @@ def main():
         line = {
             "metric": "gridcell-region-timesteps/sec", "value": main_res["value"],
             "unit": "gridcell-region-timesteps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": scaling,
+            "ms_per_step": main_res["ms_per_step"], "median_ms": main_res.get("median_ms"), "min_ms": main_res.get("min_ms"),
+            "higher_is_better": True, "scaling": scaling,
+            "scaling_measured": world > 1,     # a one-GPU line says nothing about scaling; the driver computes efficiency from its N = 1, 2, 4, 8 runs
             "vs_baseline": None, "dtype": main_res["dtype"], "data": "synthetic",
             "config": {"workload": "%s: daily tas, T=%d rows on this GPU (%d in the job), grid G=%d, R=%d regions, %s; "
                                    "time axis sharded over %d GPU(s) + RCCL gather"
@@ -522,6 +648,9 @@ def main():
             "roofline": main_res["roofline"],
             "cpu_baseline": main_res.get("cpu_baseline"),
         }
+        for k in ("plan_build_s", "plan_build", "gather_ok"):
+            if k in main_res:
+                line[k] = main_res[k]
         if "nnz" in main_res:
             line["config"]["nnz"] = main_res["nnz"]
             line["config"]["plan"] = main_res["plan"]

@@ -289,3 +289,66 @@ def test_device_fields_of_other_dtypes_are_promoted_by_the_library(torch_cuda):
         outs.append(weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values)
     assert outs[1].dtype == np.float64
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# RCCL on the hardware at hand: one rank, backend "nccl", device tensors
+# ---------------------------------------------------------------------------------------------
+def test_bench_over_rccl_with_one_rank():
+    """bench.py as a FRESH child process with WAGG_BENCH_FORCE_DIST=1: RCCL initialises on the GPU, every timed step
+    queues ShardedStep's asynchronous dist.gather of a device tensor into row views of the destination, and the line says
+    the reassembled series is right.  Still one rank: what it proves is that RCCL accepts the calls, not how they scale."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WAGG_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29531")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2-real", "--steps", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["scaling_measured"] is False
+    assert rec["roofline"]["bound"] == "hbm" and rec["value"] > 0 and rec["min_ms"] <= rec["median_ms"]
+
+
+_RCCL_CHILD = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["WAGG_ROOT"])
+from climate_toolbox_amd.timeshard import ShardedStep, gather_time_shards
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+T, R = 37, 1000
+blk = torch.arange(T * R, dtype=torch.float32, device="cuda").reshape(T, R)
+# the ragged route (grouped point-to-point into row views) and the equal route (dist.gather into row views), both async
+for rows in ([T], None):
+    dst = torch.full((T, R), -1.0, device="cuda")
+    res, h = gather_time_shards(blk, dst=0, rows=rows, out=dst, async_op=True)
+    h.wait(); torch.cuda.synchronize()
+    assert res is dst and torch.equal(dst, blk), rows
+    assert torch.equal(gather_time_shards(blk * 2, rows=rows), blk * 2)
+k = [0]
+def apply(out):
+    k[0] += 1
+    out.fill_(float(k[0]))
+st = ShardedStep(apply, lambda: torch.empty((T, R), device="cuda"), rows=[T], dst=0, distributed=True)
+for _ in range(5):
+    st.step()
+got = st.finish(); torch.cuda.synchronize()
+assert bool((got == 5.0).all())
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-OK")
+"""
+
+
+def test_time_shard_gather_over_rccl_with_one_rank():
+    """climate_toolbox_amd/timeshard.py on backend "nccl" (= RCCL) with device tensors, one rank, in a fresh child process:
+    the ragged route, the equal route and the double-buffered ShardedStep."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WAGG_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_CHILD], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
