@@ -384,9 +384,17 @@ def main():
         A._PLAN_CACHE.clear()
         dsd = minixr.Dataset({"tas": (("time", "lat", "lon"), Xs.reshape(shape))}, coords={"lat": lat, "lon": lon})
         dsh = minixr.Dataset({"tas": (("time", "lat", "lon"), Xh.reshape(shape))}, coords={"lat": lat, "lon": lon})
-        out["dropin_ms"] = {"device_resident": calls(dsd), "host_resident": calls(dsh, n=10),
+        from climate_toolbox_amd import prepare_weights
+        df_plain = df
+        prep = prepare_weights(df, "areawt", "hierid", lat=lat, lon=lon)
+        d_dev, d_host = calls(dsd), calls(dsh, n=10)
+        df = prep                                                  # (calls() reads `df` of this scope)
+        p_dev = calls(dsd)
+        df = df_plain
+        out["dropin_ms"] = {"device_resident": d_dev, "host_resident": d_host, "device_resident_prepared_weights": p_dev,
                             "what": "weighted_aggregate_grid_to_regions(ds, 'tas', 'areawt', 'hierid', df) end to end (aggregations.py:87), "
-                                    "cached plan, result returned as a host array; c2-real table (%d rows)" % len(df)}
+                                    "cached plan, result returned as a host array; c2-real table (%d rows) as a DataFrame (fingerprinted "
+                                    "by content on every call) and as prepare_weights(df, ...) (coded once)" % len(df_plain)}
         A._PLAN_CACHE.clear()
         del dsd, dsh, Xh
         cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, "areawt", "ISO")

@@ -6,6 +6,8 @@ __version__ = "0.1.0"
 from .aggregations import (  # noqa: F401
     weighted_aggregate_grid_to_regions,
     prepare_spatial_weights_data,
+    prepare_weights,
+    PreparedWeights,
     _reindex_spatial_data_to_regions,
     _aggregate_reindexed_data_to_regions,
 )

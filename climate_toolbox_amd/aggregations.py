@@ -33,7 +33,7 @@ try:  # optional: return real xarray objects when the caller hands us xarray obj
 except Exception:  # pragma: no cover - xarray is absent from this image
     _xr = None
 
-__all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data",
+__all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data", "prepare_weights", "PreparedWeights",
            "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
 
 try:  # optional: a 10 GB/s hash for the table fingerprints below (blake2b, ~1 GB/s, otherwise)
@@ -364,6 +364,9 @@ class ReindexedDataset(minixr.Dataset):
         shape = dict(zip(dims, self._src_values[name].shape))
         ia, io, *_ = _spatial_layout(dims)
         perm = self._lon_perms.get(name)
+        ready = getattr(self, "_row_major_cell", None)
+        if ready is not None and perm is None and ia < io and (shape["lat"], shape["lon"]) == ready[1:]:
+            return ready[0], shape["lat"] * shape["lon"]                          # a PreparedWeights' own (frozen) index
         ilon = self._ilon if perm is None else np.asarray(perm)[self._ilon]
         if ia < io:
             return (self._ilat * shape["lon"] + ilon).astype(np.int32), shape["lat"] * shape["lon"]
@@ -605,12 +608,15 @@ def _drop_plan(plan):
 _BUILDING = {}        # plan key -> threading.Event of the thread that is building that plan right now (under _CACHE_LOCK)
 
 
-def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG"):
+def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", prepared=None):
     """The cached plan of this table, LEASED: ``plan._lease`` is held on return and the caller releases
     it when its device work is done (see _CACHE_LOCK).  A table that is not cached is built by ONE thread, outside the
     cache lock (a dense-family plan can be GBs: other tables must not wait for it); threads that want the same table
     meanwhile wait for that build instead of starting their own."""
-    key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
+    if prepared is not None:
+        key = prepared.plan_key(cell_idx, G, R, row_len, is_f32, layout)       # hashed once per (table, grid)
+    else:
+        key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
     while True:
         with _CACHE_LOCK:
             plan = _PLAN_CACHE.get(key)
@@ -709,6 +715,101 @@ def _xforms(ds):
 
 
 # ----------------------------------------------------------------------------------------------
+# A weights table coded ONCE: a pipeline that loops over variables, files or years with one table pays
+# the label join, the backup fill, the factorisation and the fingerprints a single time instead of re-hashing ~16 MB of
+# table columns on every call to find out that nothing changed.
+# ----------------------------------------------------------------------------------------------
+class PreparedWeights:
+    """A SNAPSHOT of one segment-weights table, coded for one ``(aggwt, agglev, backup_aggwt)``: backup-filled weights
+    (aggregations.py:73), sorted unique region labels and per-row codes (:78), and -- per grid it has met -- the resolved
+    cell of every row (:27) and the key of its plan.  Pass it as ``weights`` to :func:`weighted_aggregate_grid_to_regions`
+    (or the two helpers) wherever the DataFrame went; ``aggwt`` / ``agglev`` of the call must be the ones it was prepared
+    for.  It copies what it needs: later edits of the DataFrame do not reach it (a bare DataFrame is still fingerprinted by
+    content on every call, so edits of THAT are always seen)."""
+
+    def __init__(self, df, aggwt, agglev, backup_aggwt="areawt"):
+        self.aggwt, self.agglev, self.backup_aggwt = aggwt, agglev, backup_aggwt
+        self.seg_lat = _frozen(np.array(df["lat"].values, dtype=np.float64, copy=True))
+        self.seg_lon = _frozen(np.array(df["lon"].values, dtype=np.float64, copy=True))
+        self.w_eff = _frozen(_backup_fill(df[aggwt].values, df[backup_aggwt].values))
+        self.labels = _frozen(np.array(df[agglev].values, copy=True))
+        uniq, codes = _factorize_labels(self.labels)
+        self.uniq, self.codes = uniq, codes                       # (codes is read-only; uniq is handed out as a copy)
+        self.nseg = len(self.w_eff)
+        self.table_key = _fingerprint(self.codes, self.w_eff)[0]
+        self._grids = {}        # (nlat, nlon, lat[0], lon[0]) -> [(lat, lon, cell, ilat, ilon)]
+        self._plan_keys = {}    # (id of a cell array this object owns, G, R, row_len, is_f32, layout) -> plan key
+        self._lock = threading.Lock()
+
+    # DataFrame-like access for code that reads the columns the reference reads (weights[aggwt].values ...)
+    def __getitem__(self, col):
+        if col == "lat":
+            return pd.Series(self.seg_lat)
+        if col == "lon":
+            return pd.Series(self.seg_lon)
+        if col == self.agglev:
+            return pd.Series(self.labels)
+        if col == self.aggwt:
+            return pd.Series(self.w_eff)
+        raise KeyError("%r: this PreparedWeights holds lat, lon, %r (backup-filled) and %r" % (col, self.aggwt, self.agglev))
+
+    def __len__(self):
+        return self.nseg
+
+    def check(self, aggwt, agglev, backup_aggwt="areawt"):
+        if (aggwt, agglev, backup_aggwt) != (self.aggwt, self.agglev, self.backup_aggwt):
+            raise ValueError("weights were prepared for aggwt=%r, agglev=%r, backup_aggwt=%r; the call asks for %r, %r, %r"
+                             % (self.aggwt, self.agglev, self.backup_aggwt, aggwt, agglev, backup_aggwt))
+
+    def cells_for(self, lat, lon):
+        """(cell, ilat, ilon) of every row on this grid (exact label match, KeyError on a miss: S1), resolved once per grid."""
+        lat, lon = np.asarray(lat), np.asarray(lon)
+        gk = (len(lat), len(lon), float(lat[0]) if len(lat) else 0.0, float(lon[0]) if len(lon) else 0.0)
+        with self._lock:
+            for glat, glon, cell, ilat, ilon in self._grids.get(gk, ()):
+                if np.array_equal(glat, lat) and np.array_equal(glon, lon):
+                    return cell, ilat, ilon
+        cell = _resolve_cells(lat, lon, self.seg_lat, self.seg_lon)
+        ilat, ilon = _frozen((cell // len(lon)).astype(np.int64)), _frozen((cell % len(lon)).astype(np.int64))
+        with self._lock:
+            self._grids.setdefault(gk, []).append((_f64(lat).copy(), _f64(lon).copy(), cell, ilat, ilon))
+        return cell, ilat, ilon
+
+    def plan_key(self, cell_idx, G, R, row_len, is_f32, layout):
+        """Key of the plan of (this table, this cell index): hashed once per cell array this object owns, else per call."""
+        extra = repr((int(G), int(R), int(row_len), bool(is_f32), layout))
+        owned = any(cell_idx is c for entries in self._grids.values() for _, _, c, _, _ in entries)
+        if not owned:                                  # e.g. a lon-permuted or lon-major index: a fresh array every call
+            return _fingerprint(cell_idx, extra=self.table_key + extra)[0]
+        k = (id(cell_idx), extra)
+        with self._lock:
+            key = self._plan_keys.get(k)
+        if key is None:
+            key = _fingerprint(cell_idx, extra=self.table_key + extra)[0]
+            with self._lock:
+                self._plan_keys[k] = key
+        return key
+
+
+def prepare_weights(weights, aggwt, agglev, backup_aggwt="areawt", lat=None, lon=None):
+    """Code a segment-weights table (DataFrame, or the path of its CSV) once for ``(aggwt, agglev)``; with the grid's
+    ``lat`` / ``lon`` labels the cells are resolved now (KeyError on a label that is not on the grid), else at first use."""
+    if isinstance(weights, PreparedWeights):
+        weights.check(aggwt, agglev, backup_aggwt)
+        prep = weights
+    else:
+        if isinstance(weights, str):
+            weights = prepare_spatial_weights_data(weights)
+        prep = PreparedWeights(weights, aggwt, agglev, backup_aggwt)
+    if lat is not None and lon is not None:
+        prep.cells_for(lat, lon)
+    return prep
+
+
+_PREPARED_BY_PATH = {}      # (path, aggwt, agglev) -> PreparedWeights: the CSV route is memoised on the path like the reference (:127)
+
+
+# ----------------------------------------------------------------------------------------------
 # the reference's functions
 # ----------------------------------------------------------------------------------------------
 def _reindex_spatial_data_to_regions(ds, df):
@@ -724,8 +825,14 @@ def _reindex_spatial_data_to_regions(ds, df):
         raise KeyError("dataset must have 'lat' and 'lon' coordinates (aggregations.py:27)")
     lat = np.asarray(coords["lat"].values)
     lon = np.asarray(coords["lon"].values)
-    cell = _resolve_cells(lat, lon, df["lat"].values, df["lon"].values)      # native, KeyError on a miss
-    ilat, ilon = (cell // len(lon)).astype(np.int64), (cell % len(lon)).astype(np.int64)
+    prepared = df if isinstance(df, PreparedWeights) else None
+    if prepared is not None:
+        cell, ilat, ilon = prepared.cells_for(lat, lon)                          # resolved once per grid
+        seg_lat, seg_lon = prepared.seg_lat, prepared.seg_lon
+    else:
+        seg_lat, seg_lon = df["lat"].values, df["lon"].values
+        cell = _resolve_cells(lat, lon, seg_lat, seg_lon)                        # native, KeyError on a miss
+        ilat, ilon = (cell // len(lon)).astype(np.int64), (cell % len(lon)).astype(np.int64)
     # xarray's vectorised sel indexes EVERY data variable (S9); variables without lat/lon dims
     # are carried through untouched
     keep_vals, keep_dims = {}, {}
@@ -735,8 +842,10 @@ def _reindex_spatial_data_to_regions(ds, df):
             keep_vals[k], keep_dims[k] = src_values[k], dims
         else:
             passthrough[k] = minixr.DataArray(src_values[k], dims)
-    out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, df["lat"].values, df["lon"].values,
+    out = ReindexedDataset(keep_vals, keep_dims, coords, ilat, ilon, seg_lat, seg_lon,
                            was_xr, lon_perms=_lon_perms(ds), xforms=_xforms(ds), edds=_edds(ds))
+    if prepared is not None:
+        out._row_major_cell = (cell, len(lat), len(lon))                         # = ilat * nlon + ilon, already int32
     for k, v in passthrough.items():
         out.data_vars[k] = v
     return out
@@ -747,9 +856,14 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     own lazy transform, if it carries one).  ``powers=[p, ...]``: aggregate ``(x + offset) ** p``
     for every p in ONE pass over the data.  Returns (list of result arrays, result
     dims, coords, was_xarray)."""
-    w_eff = _backup_fill(weights[aggwt].values, weights[backup_aggwt].values)   # :73 (native)
-    labels = np.asarray(weights[agglev].values)
-    uniq, codes = _factorize_labels(labels)                              # :78 group keys
+    prepared = weights if isinstance(weights, PreparedWeights) else None
+    if prepared is not None:
+        prepared.check(aggwt, agglev, backup_aggwt)
+        w_eff, labels, uniq, codes = prepared.w_eff, prepared.labels, prepared.uniq.copy(), prepared.codes
+    else:
+        w_eff = _backup_fill(weights[aggwt].values, weights[backup_aggwt].values)   # :73 (native)
+        labels = np.asarray(weights[agglev].values)
+        uniq, codes = _factorize_labels(labels)                          # :78 group keys
 
     xform = edd = None
     if isinstance(ds, ReindexedDataset) and variable in ds._src_values:
@@ -878,7 +992,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
         coords[agglev] = uniq
         return (res[0] if single or edd is not None else res), rdims, coords, was_xr
 
-    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout)
+    plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout, prepared=prepared)
     try:
         return _aggregate_on_plan(plan)
     except _engine.WaggError:
@@ -934,7 +1048,16 @@ def weighted_aggregate_grid_to_regions(ds, variable, aggwt, agglev, weights=None
     if weights is None:
         weights = prepare_spatial_weights_data()          # TypeError, like the reference
     elif isinstance(weights, str):
-        weights = prepare_spatial_weights_data(weights)
+        # the reference memoises the table on its path (:127): so is its coded form -- a loop over variables that names
+        # the file pays for the label work once
+        pk = (weights, aggwt, agglev)
+        with _CACHE_LOCK:
+            prep = _PREPARED_BY_PATH.get(pk)
+        if prep is None:
+            prep = PreparedWeights(prepare_spatial_weights_data(weights), aggwt, agglev)
+            with _CACHE_LOCK:
+                _PREPARED_BY_PATH[pk] = prep
+        weights = prep
 
     ds = _reindex_spatial_data_to_regions(ds, weights)
     ds = _aggregate_reindexed_data_to_regions(ds, variable, aggwt, agglev, weights)

@@ -373,6 +373,11 @@ def test_c2_dense_full_size_properties(torch_cuda):
     X365 = engine.synth_field(365, G, seed=5, base=280.0, amp=60.0)
     got365 = plan.apply(X365).cpu().numpy()
     np.testing.assert_array_equal(got365[:T], got)
+    # ... and one row of EVERY one of the 23 sixteen-row MFMA blocks of that launch (a different row inside each), the same
+    # 96 column windows, all 1,036,800 cells, against the C oracle (rows 0-23 alone touch two blocks)
+    rows = np.array([16 * m + (7 * m) % 16 for m in range(23)])
+    assert rows.max() < 365 and len(set(rows // 16)) == 23
+    _rel_ok(got365[rows][:, cols], c_oracle.dense_synth_cols(X365[torch.from_numpy(rows).cuda()].cpu().numpy(), G, R, cols, seed), RTOL32)
     del X365, got365
     # configs[3] in the dense form: one rank's 1,369-row shard = four row blocks, whose first pass reads X in place
     # (no packed copy); same bits for the shared rows, the last rows against the C oracle

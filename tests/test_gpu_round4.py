@@ -352,3 +352,68 @@ def test_time_shard_gather_over_rccl_with_one_rank():
     env.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WAGG_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", _RCCL_CHILD], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------
+# prepare_weights: the table coded once
+# ---------------------------------------------------------------------------------------------
+def test_prepared_weights_give_the_dataframe_results(torch_cuda, tmp_path):
+    """weights=prepare_weights(df, ...) through the three reference-named functions, the fused tas_poly and the CSV path
+    route: the same bits as the DataFrame (which is fingerprinted by content on every call), one plan for both, no
+    re-hashing of the table columns on the prepared route."""
+    import pandas as pd
+    from climate_toolbox_amd import (aggregations as A, minixr, prepare_weights, synth, tas_poly_aggregate,
+                                     weighted_aggregate_grid_to_regions, _aggregate_reindexed_data_to_regions,
+                                     _reindex_spatial_data_to_regions)
+    torch = torch_cuda
+    nlat, nlon, T = 96, 192, 40
+    lat, lon, df = synth.realistic_segments(nlat, nlon, R=150, seed=6, string_labels=True)
+    df["popwt"] = np.random.default_rng(1).lognormal(0, 1, len(df))
+    df.loc[::5, "popwt"] = np.nan
+    rng = np.random.default_rng(3)
+    tas = (280 + 10 * rng.standard_normal((T, nlat, nlon))).astype(np.float32)
+    tas[3, 4, 5] = np.nan
+    for dev in (False, True):
+        v = torch.from_numpy(tas).cuda() if dev else tas
+        ds = minixr.Dataset({"tas": (("time", "lat", "lon"), v)},
+                            coords={"time": pd.date_range("2001-01-01", periods=T).values, "lat": lat, "lon": lon})
+        A._PLAN_CACHE.clear()
+        want = weighted_aggregate_grid_to_regions(ds, "tas", "popwt", "hierid", df)
+        prep = prepare_weights(df, "popwt", "hierid")
+        calls = {"n": 0}
+        real = A._fingerprint
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return real(*a, **k)
+
+        A._fingerprint = counting
+        try:
+            got = weighted_aggregate_grid_to_regions(ds, "tas", "popwt", "hierid", prep)
+            first = calls["n"]
+            got2 = weighted_aggregate_grid_to_regions(ds, "tas", "popwt", "hierid", prep)
+            assert calls["n"] == first                                   # second call: nothing hashed at all
+        finally:
+            A._fingerprint = real
+        assert len(A._PLAN_CACHE) == 1                                    # the DataFrame and its snapshot share the plan
+        for g in (got, got2):
+            np.testing.assert_array_equal(g.tas.values, want.tas.values)
+            assert list(g["hierid"].values) == list(want["hierid"].values)
+        re = _reindex_spatial_data_to_regions(ds, prep)
+        np.testing.assert_array_equal(_aggregate_reindexed_data_to_regions(re, "tas", "popwt", "hierid", prep).tas.values, want.tas.values)
+        with pytest.raises(ValueError, match="prepared for"):
+            weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", prep)
+        p1 = tas_poly_aggregate(ds, [1, 2], "popwt", "hierid", df)
+        p2 = tas_poly_aggregate(ds, [1, 2], "popwt", "hierid", prep)
+        for k in ("tas-poly-1", "tas-poly-2"):
+            np.testing.assert_array_equal(p2[k].values, p1[k].values)
+    # the CSV route: memoised on the path (aggregations.py:127), coded once per (path, aggwt, agglev)
+    csv = df.rename(columns={"lon": "pix_cent_x", "lat": "pix_cent_y"})
+    path = str(tmp_path / "weights.csv")
+    csv.to_csv(path, index=False)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": np.arange(T), "lat": lat, "lon": lon})
+    a = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", path)
+    assert (path, "areawt", "hierid") in A._PREPARED_BY_PATH
+    b = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", path)
+    np.testing.assert_array_equal(a.tas.values, b.tas.values)
+    np.testing.assert_allclose(a.tas.values, weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values, rtol=1e-6)

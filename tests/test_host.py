@@ -510,3 +510,40 @@ def test_plan_cache_leases_and_eviction_budget(monkeypatch):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs and len(A._TABLE_MEMO) <= A._TABLE_MEMO_MAX
+
+
+def test_prepared_weights_is_a_snapshot_of_the_coded_table():
+    """prepare_weights: backup fill, factorisation and the label join happen once; the object answers
+    for the columns the reference reads, refuses a call for another (aggwt, agglev), resolves a grid once, raises KeyError
+    for a label that is not on the grid (S1) and is not reached by later edits of the DataFrame.  Host-side only."""
+    from climate_toolbox_amd import aggregations as A, prepare_weights
+    rng = np.random.default_rng(9)
+    lat, lon = np.arange(-44.5, 45, 1.0), np.arange(-89.5, 90, 1.0)
+    n = 5000
+    df = pd.DataFrame({"lat": rng.choice(lat, n), "lon": rng.choice(lon, n), "areawt": rng.uniform(0.1, 1, n),
+                       "popwt": rng.uniform(-0.2, 1, n), "hierid": ["R%03d" % k for k in rng.integers(0, 70, n)]})
+    df.loc[::9, "popwt"] = np.nan
+    prep = prepare_weights(df, "popwt", "hierid", lat=lat, lon=lon)
+    w = np.where(df["popwt"].values > 0, df["popwt"].values, df["areawt"].values)
+    np.testing.assert_array_equal(prep["popwt"].values, w)                       # aggregations.py:73 per row
+    ec, eu = pd.factorize(df["hierid"].values, sort=True)
+    np.testing.assert_array_equal(prep.codes, ec.astype(np.int32))
+    assert list(prep.uniq) == list(eu) and len(prep) == n
+    cell, ilat, ilon = prep.cells_for(lat, lon)
+    np.testing.assert_array_equal(lat[ilat], df["lat"].values)
+    np.testing.assert_array_equal(lon[ilon], df["lon"].values)
+    assert prep.cells_for(lat.copy(), lon.copy())[0] is cell                     # the same grid again: nothing recomputed
+    assert prep.cells_for(lat[::-1].copy(), lon)[0] is not cell                  # another grid: its own entry
+    assert prep.plan_key(cell, len(lat) * len(lon), 70, len(lon), True, "TG") == prep.plan_key(cell, len(lat) * len(lon), 70, len(lon), True, "TG")
+    assert prep.plan_key(cell, len(lat) * len(lon), 70, len(lon), True, "TG") != prep.plan_key(cell, len(lat) * len(lon), 70, len(lon), False, "TG")
+    with pytest.raises(ValueError, match="prepared for aggwt='popwt'"):
+        prep.check("areawt", "hierid")
+    with pytest.raises(KeyError):
+        prep["cropwt"]
+    with pytest.raises(KeyError, match="not all values found"):
+        prep.cells_for(lat + 0.25, lon)
+    df.loc[0, "popwt"] = 123.0                                                  # a snapshot: the edit does not reach it
+    assert prep["popwt"].values[0] == w[0]
+    with pytest.raises(ValueError):
+        prep.w_eff[0] = 1.0                                                      # and nobody can edit the snapshot
+    assert prepare_weights(prep, "popwt", "hierid") is prep
