@@ -656,7 +656,8 @@ def main():
             "roofline": main_res["roofline"],
             "cpu_baseline": main_res.get("cpu_baseline"),
         }
-        for k in ("plan_build_s", "plan_build", "gather_ok"):
+        for k in ("plan_build_s", "plan_build", "gather_ok", "host_resident", "dropin_ms", "agglev_ISO", "layout_gridcell_time",
+                  "fused_tas_poly_1to4", "fused_snyder_edd"):
             if k in main_res:
                 line[k] = main_res[k]
         if "nnz" in main_res:

@@ -736,7 +736,6 @@ class PreparedWeights:
         uniq, codes = _factorize_labels(self.labels)
         self.uniq, self.codes = uniq, codes                       # (codes is read-only; uniq is handed out as a copy)
         self.nseg = len(self.w_eff)
-        self.table_key = _fingerprint(self.codes, self.w_eff)[0]
         self._grids = {}        # (nlat, nlon, lat[0], lon[0]) -> [(lat, lon, cell, ilat, ilon)]
         self._plan_keys = {}    # (id of a cell array this object owns, G, R, row_len, is_f32, layout) -> plan key
         self._lock = threading.Lock()
@@ -780,12 +779,12 @@ class PreparedWeights:
         extra = repr((int(G), int(R), int(row_len), bool(is_f32), layout))
         owned = any(cell_idx is c for entries in self._grids.values() for _, _, c, _, _ in entries)
         if not owned:                                  # e.g. a lon-permuted or lon-major index: a fresh array every call
-            return _fingerprint(cell_idx, extra=self.table_key + extra)[0]
+            return _fingerprint(cell_idx, self.codes, self.w_eff, extra=extra)[0]
         k = (id(cell_idx), extra)
         with self._lock:
             key = self._plan_keys.get(k)
-        if key is None:
-            key = _fingerprint(cell_idx, extra=self.table_key + extra)[0]
+        if key is None:                                # the key a bare DataFrame of the same content gets: one plan serves both
+            key = _fingerprint(cell_idx, self.codes, self.w_eff, extra=extra)[0]
             with self._lock:
                 self._plan_keys[k] = key
         return key
