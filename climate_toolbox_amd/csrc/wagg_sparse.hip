@@ -1635,6 +1635,312 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     }
 }
 
+#ifdef WAGG_DIAG
+// ---------------------------------------------------------------------------------------------
+// sparse_lcd_kernel (round 4 EXPERIMENT, diagnostic build only; WAGG_LCD = 1 / 2 selects it): the loader/consumer kernel
+// with an LDS-DMA LOADER -- plain aggregation of (time, gridcell) data, fp32 and fp64, on the chunkings sparse_lcv_kernel
+// uses.  Correct (it passes the parity suite) and NOT faster: profiles/r04_lds_dma_loader.txt, DESIGN.md (d).  c2-real kernel
+// 0.2495 ms with two buffers of 64 rows (one item in flight: the loaders alone take 0.232), 0.2955 ms with three buffers of
+// 48 rows (two items in flight, but a 48-row item costs the consumers what a 64-row item does and there are a third more of
+// them: the consumers alone take 0.244) against 0.229-0.234 ms of sparse_lcv_kernel; c3 0.352 ms (64 x 2) against 0.353.
+//
+// What changes against sparse_lcv_kernel: the rows never pass through vector registers.  The 8 loader waves send every
+// 256 bytes of an image row straight to LDS with global_load_lds_dword -- FOUR-byte pieces, because the image has to stay
+// conflict-free for consumers whose 64 lanes read one cell of 64 timesteps: a 16-byte piece pins four cells of a timestep
+// to four neighbouring banks, so whatever the piece order, lanes = timesteps meet four ways; with 4-byte pieces the per-lane
+// SOURCE address does the swizzle (LDS position p of row t holds element p ^ t, as in sparse_lcv_kernel) and the consumers
+// read without conflicts.  The loader waves therefore block at nothing but the memory system: no register staging, no
+// parking pass over the data.  The loader's only vector-memory instructions are its own (inline) DMA pieces, so
+// `s_waitcnt vmcnt(pieces of one item)` is an exact "the item before has landed"; everything else the loaders need (a
+// chunk's cell table) they read from LDS, where the CONSUMER waves publish it: those have time to spare (they are busy
+// 60 % of an item) and own all the metadata traffic -- descriptors, segment lists, entry tables, fetched two to five
+// items ahead with ordinary loads.
+//   * NBUF image buffers of TB rows: 3 x 48 rows (144 KiB) keep two items in flight -- item st + 2 is issued behind the
+//     barrier that releases item st, into the buffer the consumers left at that barrier; 2 x 64 rows have one.
+//   * S6 moves to the consumers: an entry is summed as it is; if any timestep's sum is not finite (NaN data, +-inf, or a
+//     product of the two) the entry is summed again in the general form (NaN product counts 0).  Finite fields pay one
+//     ballot per entry.
+//   * results leave as one 4- / 8-byte store per lane (256 / 512 contiguous bytes per entry and item).
+// ---------------------------------------------------------------------------------------------
+constexpr int LD_LW = 8, LD_CW = 8, LD_THREADS = (LD_LW + LD_CW) * 64;
+constexpr int LD_DQ = 4;                         // published cell tables: items st .. st + 3
+template <typename T, int TB, int NBUF> struct LdLds {
+    static constexpr size_t img = 0;                                            // [NBUF][TB][1024 B]
+    static constexpr size_t m_seg_w = 0;                                        // one metadata set: [LC_SEGS] T
+    static constexpr size_t m_seg_u = m_seg_w + sizeof(T) * LC_SEGS;            // [LC_SEGS] u8 (cell of the row)
+    static constexpr size_t m_ent_r = m_seg_u + LC_SEGS;                        // [LC_ENT] i32
+    static constexpr size_t m_ent_d = m_ent_r + sizeof(int32_t) * LC_ENT;       // [LC_ENT] T
+    static constexpr size_t m_ent_s = m_ent_d + sizeof(T) * LC_ENT;             // [LC_ENT + 2] u16
+    static constexpr size_t m_hdr = (m_ent_s + sizeof(uint16_t) * (LC_ENT + 2) + 15) / 16 * 16;   // i32: ne, entry counter, tb, -
+    static constexpr size_t m_size = m_hdr + 16;
+    static constexpr size_t meta = img + (size_t)NBUF * TB * LV_ROWB;           // [2 sets]
+    static constexpr size_t dq = meta + 2 * m_size;                             // [LD_DQ][64 cells i32 | tb, valid, -, -]
+    static constexpr size_t dq_size = 64 * 4 + 16;
+    static constexpr size_t total = dq + LD_DQ * dq_size;
+    static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
+    static_assert(m_ent_d % sizeof(T) == 0 && meta % 16 == 0 && m_size % 16 == 0, "alignment");
+};
+
+template <typename T, int TB, int NBUF>
+__global__ __launch_bounds__(LD_THREADS) void sparse_lcd_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot, int64_t ldx,
+                                                                int64_t G, T *__restrict__ out, int64_t ldo, int n_norm,
+                                                                long long n_items, int knob_arg) {
+#ifdef WAGG_DIAG
+    const int knob = knob_arg;                       // (diagnostic build, timing only: 1 = no segment walk, 2 = no DMA pieces)
+#else
+    constexpr int knob = 0;
+    (void)knob_arg;
+#endif
+    static_assert(TB % LD_LW == 0 && TB <= 64 && (NBUF == 2 || NBUF == 3), "geometry");
+    constexpr int TPW = TB / LD_LW;                  // image rows per loader wave
+    constexpr int NPIECE = TPW * 4;                  // DMA instructions per loader wave and item (256 bytes each)
+    constexpr int AHEAD = NBUF - 1;                  // item st + AHEAD is issued behind barrier st
+    static_assert(NPIECE <= 63, "vmcnt");
+    using L = LdLds<T, TB, NBUF>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)smem_raw);
+    if (lds0 & (unsigned)(LV_ROWB - 1)) __builtin_trap();          // (0: the kernel has no static LDS)
+    // XCD-contiguous ids (speed only), as in sparse_lcv_kernel
+    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
+    const long long NW = NWu;
+    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
+    if (w0 >= n_items) return;
+    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
+    const int nst = (int)((n_items - 1 - w0) / NW) + 1;
+    struct Item { int g, tb; };
+    auto advance = [&](Item a) {
+        Item b{a.g + dg, a.tb + dtb};
+        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
+        return b;
+    };
+    auto item_at = [&](int st) {                                   // (prologue only)
+        const long long i = w0 + (long long)st * NW;
+        return Item{(int)(i % n_norm), (int)(i / n_norm)};
+    };
+
+    if (wave < LD_LW) {
+        // =============================== loader waves: LDS-DMA only ===============================
+        const int tw0 = wave * TPW;
+        // LDS dword d = 64 k + lane of a row holds element position p = 4 d / sizeof(T), half (4 d) % sizeof(T); position p of
+        // row t holds element e = p ^ t (t < 64 only reaches the low six bits): its quad is (p >> 2) ^ (t >> 2), its cell in
+        // the quad (p ^ t) & 3
+        constexpr int DPE = (int)sizeof(T) / 4;                    // dwords per element: 1 / 2
+        auto issue = [&](int st, int tb) {
+            const int buf = st % NBUF, sl = st % LD_DQ;
+            const unsigned dqb = lds0 + (unsigned)(L::dq + sl * L::dq_size);
+            const int64_t t0 = (int64_t)tb * TB;
+            const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
+            // all source offsets first (independent LDS reads, in flight together), then the pieces back to back: an inline
+            // DMA statement is a memory barrier for the compiler, a table read between two of them would be waited for in place
+            unsigned voff[TPW][4];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int t = tw0 + i;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = (64 * k + lane) / DPE;
+                    const int q = (p >> 2) ^ (t >> 2);
+                    const int c = (p ^ t) & 3;
+                    int cell = *(const int __attribute__((address_space(3))) *)(uintptr_t)(dqb + 4u * (unsigned)q) + c;
+                    cell = cell < G ? cell : (int)(G - 1);          // a quad at the end of a grid that is not whole quads
+                    voff[i][k] = (unsigned)cell * (unsigned)sizeof(T) + (unsigned)(((64 * k + lane) % DPE) * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int t = tw0 + i;
+                const int tr = t < nt ? t : nt - 1;                 // rows behind the last timestep repeat it (never stored)
+                const T *rowp = X + (t0 + tr) * ldx;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned ldst = lds0 + (unsigned)((buf * TB + t) * LV_ROWB + 256 * k);
+                    int m0save;
+                    if (!(knob & 2))
+                    asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dword %[vo], %[src]\n\ts_mov_b32 m0, %[sv]"
+                                 : [sv] "=&s"(m0save) : [l0] "s"(ldst), [vo] "v"(voff[i][k]), [src] "s"(rowp) : "memory");
+                }
+            }
+        };
+        lds_only_barrier();                                          // the consumers have published the first cell tables
+        Item it = item_at(0);
+        for (int j = 0; j < AHEAD && j < nst; ++j) { issue(j, it.tb); it = advance(it); }      // `it` = item st + AHEAD
+        for (int st = 0; st < nst; ++st) {
+            // item st has landed once at most the pieces of the items issued behind it are outstanding
+            const int younger = nst - 1 - st < AHEAD - 1 ? nst - 1 - st : AHEAD - 1;
+            if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_only_barrier();                                      // barrier st: item st to the consumers, item st - 1 is done
+            if (st + AHEAD < nst) { issue(st + AHEAD, it.tb); it = advance(it); }
+        }
+    } else {
+        // ========================= consumer waves: metadata servers + the reduction =========================
+        const int ctid = tid - LD_LW * 64;                           // 0 .. 511
+        auto load_desc = [&](Item a, StreamDesc &d) {
+            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
+            const int4v x = *reinterpret_cast<const int4v *>(p);
+            const int4v y = *reinterpret_cast<const int4v *>(p + 4);
+            d.u0 = __builtin_amdgcn_readfirstlane(x[0]); d.nq = __builtin_amdgcn_readfirstlane(x[1]);
+            d.e0 = __builtin_amdgcn_readfirstlane(x[2]); d.ne = __builtin_amdgcn_readfirstlane(x[3]);
+            d.sb = __builtin_amdgcn_readfirstlane(y[0]); d.ns = __builtin_amdgcn_readfirstlane(y[1]); d.split = 0;
+        };
+        struct Meta { int mu; T mw; int er, es; T ed; };
+        auto load_meta = [&](const StreamDesc &d, Meta &m) {
+            const int k = ctid < d.ns ? ctid : d.ns - 1;
+            m.mu = pv.seg_u[d.sb + k];
+            m.mw = pv.seg_w[d.sb + k];
+            m.er = pv.ent_region[d.e0 + (ctid < d.ne ? ctid : d.ne - 1)];
+            m.ed = pv.ent_den[d.e0 + (ctid < d.ne ? ctid : d.ne - 1)];
+            m.es = pv.ent_seg_begin[d.e0 + (ctid < d.ne ? ctid : d.ne)];
+        };
+        auto put_meta = [&](const StreamDesc &d, const Meta &m, int tb, int set) {
+            char *ms = smem_raw + L::meta + (size_t)set * L::m_size;
+            if (ctid < d.ns) {
+                reinterpret_cast<T *>(ms + L::m_seg_w)[ctid] = m.mw;
+                reinterpret_cast<uint8_t *>(ms + L::m_seg_u)[ctid] = (uint8_t)(m.mu & 0xff);
+            }
+            if (ctid < d.ne) {
+                reinterpret_cast<int32_t *>(ms + L::m_ent_r)[ctid] = m.er;
+                reinterpret_cast<T *>(ms + L::m_ent_d)[ctid] = m.ed;
+            }
+            if (ctid <= d.ne) reinterpret_cast<uint16_t *>(ms + L::m_ent_s)[ctid] = (uint16_t)(m.es - d.sb);
+            if (ctid == 0) {
+                int32_t *h = reinterpret_cast<int32_t *>(ms + L::m_hdr);
+                h[0] = d.ne; h[1] = 0; h[2] = tb;
+            }
+        };
+        // a chunk's cell table for the loaders: first cell of quad q, quads behind the last one repeat it (never read back)
+        auto load_cells = [&](const StreamDesc &d) { return pv.ucell[d.u0 + (ctid < d.nq ? ctid : d.nq - 1)]; };
+        auto put_cells = [&](int cells, int st) {
+            if (ctid < 64) *reinterpret_cast<int32_t *>(smem_raw + L::dq + (size_t)(st % LD_DQ) * L::dq_size + 4 * ctid) = cells;
+        };
+        // Descriptors are fetched one stage before the loads that need them (raw, in vector registers: decoding -- the point
+        // where the wave waits for them -- happens a stage later), those loads one stage before their values are published:
+        //   stage st fetches the descriptors of items st + 2 (metadata) and st + LD_DQ + 1 (cell table), loads the metadata
+        //   of item st + 1 and the cell table of item st + LD_DQ, and has published item st's metadata and item
+        //   st + LD_DQ - 1's table before barrier st.
+        struct RawDesc { int4v x, y; };
+        auto fetch_desc = [&](Item a) {
+            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
+            return RawDesc{*reinterpret_cast<const int4v *>(p), *reinterpret_cast<const int4v *>(p + 4)};
+        };
+        auto decode = [&](const RawDesc &r, StreamDesc &d) {
+            d.u0 = __builtin_amdgcn_readfirstlane(r.x[0]); d.nq = __builtin_amdgcn_readfirstlane(r.x[1]);
+            d.e0 = __builtin_amdgcn_readfirstlane(r.x[2]); d.ne = __builtin_amdgcn_readfirstlane(r.x[3]);
+            d.sb = __builtin_amdgcn_readfirstlane(r.y[0]); d.ns = __builtin_amdgcn_readfirstlane(r.y[1]); d.split = 0;
+        };
+        Item im = item_at(0), ic = item_at(0);                       // im: item whose metadata is in `mcur`; ic: ... cell table in `ccur`
+        StreamDesc dmeta, dc;
+        Meta mcur;
+        int ccur = 0;
+        {
+            // prologue (blocking, once): cell tables of items 0 .. LD_DQ - 2 published; item LD_DQ - 1's table and item 0's
+            // metadata in registers
+            load_desc(im, dmeta);
+            load_meta(dmeta, mcur);
+            for (int j = 0; j < LD_DQ - 1; ++j) {
+                if (j < nst) { load_desc(ic, dc); put_cells(load_cells(dc), j); }
+                ic = j + 1 < nst ? advance(ic) : ic;
+            }
+            load_desc(ic, dc);                                       // item LD_DQ - 1 (or the last one again)
+            ccur = load_cells(dc);
+        }
+        int tbm = im.tb;
+        Item im1 = nst > 1 ? advance(im) : im;                       // item st + 1 / its descriptor, fetched a stage ahead
+        Item ic1 = LD_DQ < nst ? advance(ic) : ic;                   // item st + LD_DQ
+        RawDesc rm = fetch_desc(im1), rc = fetch_desc(ic1);
+        lds_only_barrier();                                          // the loaders may start
+        const unsigned rowoff = lds0 + (unsigned)lane * LV_ROWB + (unsigned)lane * (unsigned)sizeof(T);
+        typedef const T __attribute__((address_space(3))) *lds_cptr;
+        for (int st = 0; st < nst; ++st) {
+            put_meta(dmeta, mcur, tbm, st & 1);
+            put_cells(ccur, st + LD_DQ - 1);
+            lds_only_barrier();                                      // barrier st
+            // fetch ahead (ordinary loads: these waves issue no DMA): item st + 1's metadata, item st + LD_DQ's cell table,
+            // and the descriptors of the items one further on
+            if (st + 1 < nst) {
+                decode(rm, dmeta);
+                load_meta(dmeta, mcur);
+                tbm = im1.tb;
+                if (st + 2 < nst) { im1 = advance(im1); rm = fetch_desc(im1); }
+            }
+            if (st + LD_DQ < nst) {
+                decode(rc, dc);
+                ccur = load_cells(dc);
+                if (st + LD_DQ + 1 < nst) { ic1 = advance(ic1); rc = fetch_desc(ic1); }
+            }
+            const char *ms = smem_raw + L::meta + (size_t)(st & 1) * L::m_size;
+            const T *sm_w = reinterpret_cast<const T *>(ms + L::m_seg_w);
+            const uint8_t *sm_u = reinterpret_cast<const uint8_t *>(ms + L::m_seg_u);
+            const int32_t *sm_er = reinterpret_cast<const int32_t *>(ms + L::m_ent_r);
+            const T *sm_ed = reinterpret_cast<const T *>(ms + L::m_ent_d);
+            const uint16_t *sm_es = reinterpret_cast<const uint16_t *>(ms + L::m_ent_s);
+            int32_t *hdr = reinterpret_cast<int32_t *>(const_cast<char *>(ms) + L::m_hdr);
+            const int ne = __builtin_amdgcn_readfirstlane(hdr[0]);
+            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[2]) * TB;
+            const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
+            const unsigned rb = rowoff + (unsigned)((st % NBUF) * TB) * LV_ROWB;
+            for (;;) {
+                int e = 0;
+                if (lane == 0) e = __hip_atomic_fetch_add(&hdr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                e = __builtin_amdgcn_readfirstlane(e);
+                if (e >= ne) break;
+                const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[e]);
+                const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[e + 1]);
+                auto sum = [&](auto odd_tag) {
+                    constexpr bool ODD = decltype(odd_tag)::value;
+                    T acc = T(0);
+                    for (int base = (knob & 1) ? s1 : s0; base < s1; base += 64) {
+                        const int n = s1 - base < 64 ? s1 - base : 64;
+                        const int k = base + (lane < n ? lane : 0);
+                        int ul = (int)sm_u[k] * (int)sizeof(T);
+                        T wl = sm_w[k];
+                        if (lane >= n) { ul = 0; wl = T(0); }          // padding lanes add exactly 0 to finite data
+                        for (int j0 = 0; j0 < n; j0 += 8) {
+                            T xv[8], wv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {             // 8 independent LDS reads in flight
+                                const unsigned u = (unsigned)__builtin_amdgcn_readlane(ul, j0 + j);
+                                if constexpr (sizeof(T) == 4) {
+                                    wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
+                                } else {
+                                    const long long wb = __builtin_bit_cast(long long, wl);
+                                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(wb & 0xffffffffll), j0 + j);
+                                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), j0 + j);
+                                    wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+                                }
+                                xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                if constexpr (ODD) {
+                                    const T p = xv[j] * wv[j];                 // aggregations.py:78, skipna (S6)
+                                    acc += (p == p) ? p : T(0);
+                                } else if constexpr (sizeof(T) == 4) {
+                                    acc = __builtin_fmaf(xv[j], wv[j], acc);
+                                } else {
+                                    acc = __builtin_fma(xv[j], wv[j], acc);
+                                }
+                            }
+                        }
+                    }
+                    return acc;
+                };
+                T acc = sum(std::false_type{});
+                // a sum that is not finite (rows behind the last timestep repeat it; lanes behind TB read another buffer)
+                const bool bad = lane < nt && !(__builtin_fabs(acc) <= std::numeric_limits<T>::max());
+                if (__builtin_amdgcn_readfirstlane(__ballot(bad) != 0ull)) acc = sum(std::true_type{});
+                if (lane < nt) out[(int64_t)sm_er[e] * ldo + t0 + lane] = acc / sm_ed[e];          // :77-80
+            }
+        }
+    }
+}
+#endif  // WAGG_DIAG
+
 // (R x T) -> (T x R) through a padded 64x64 LDS tile: both sides coalesced.  The gather kernel
 // stores region-major (lane = timestep: 256 contiguous bytes per region) because a (T x R) store
 // from it would scatter single dwords over R-strided lines (7x write amplification measured).
@@ -1850,7 +2156,29 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
     // whole-line chunking only (a region-shaped chunk of 64 quads is 2 KiB of a fp64 row: twice the image row)
-    if (stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && (!edd || edd_lcv) && nfuse <= 4 &&
+#ifdef WAGG_DIAG
+    // (diagnostic build, WAGG_LCD = 1: three image buffers of 48 rows, 2: two of 64) the LDS-DMA loader experiment
+    if (const int lcd_mode = diag_env("WAGG_LCD"); lcd_mode && stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) &&
+        !edd && xpow == 0 && nfuse == 1 && layout == WAGG_LAYOUT_TG && (sizeof(T) == 4 || lines) && plan->info.G < (int64_t)(1u << 28)) {
+        const int ncu = plan->ncu;
+        const int tb = lcd_mode == 2 ? 64 : 48;
+        const long long n_items = (long long)n_norm * ((Ttot + tb - 1) / tb);
+        long long nw = n_items < ncu ? n_items : ncu;
+        if (const int v = diag_env("WAGG_LCV_NW")) { if (v >= 1 && v < nw) nw = v; }
+        auto kern = sparse_lcd_kernel<T, 48, 3>;
+        size_t lds_bytes = LdLds<T, 48, 3>::total;
+        if (lcd_mode == 2) { kern = sparse_lcd_kernel<T, 64, 2>; lds_bytes = LdLds<T, 64, 2>::total; }
+        WAGG_HIP(allow_dynamic_lds((const void *)kern, lds_bytes));
+        profile_mark(stream, true);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LD_THREADS), lds_bytes, stream, pv, X, Ttot, ldx, plan->info.G, kout, kldo,
+                           n_norm, n_items, diag_env("WAGG_LCD_KNOB"));
+        profile_mark(stream, false);
+        WAGG_HIP(hipGetLastError());
+        pv.n_groups = d.g0_normal;
+        lc_done = true;
+    }
+#endif
+    if (!lc_done && stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && (!edd || edd_lcv) && nfuse <= 4 &&
         (sizeof(T) == 4 || lines)) {
         const int ncu = plan->ncu;
         const long long n_items = (long long)n_norm * ((Ttot + LV_TB - 1) / LV_TB);
