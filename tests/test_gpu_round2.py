@@ -313,8 +313,10 @@ def test_mfma_forms_pack_stage_transforms_and_inf_note(torch_cuda):
 # kernel-form flags and the device-failure status
 # ---------------------------------------------------------------------------------------------
 def test_plan_flags_pin_the_kernel_form(torch_cuda):
-    """WAGG_PLAN_* (wagg_plan_create flags): the fp32 kernels (loader/consumer with vector-ALU or dense-tile MFMA
-    consumers, persistent stream kernel, chunk-walking kernel) and both chunk shapes agree."""
+    """WAGG_PLAN_* (wagg_plan_create flags): the fp32 kernels (loader/consumer kernel, persistent stream kernel,
+    chunk-walking kernel) and both chunk shapes agree.  The dense-tile MFMA consumers (WAGG_PLAN_LC_MFMA) left the production
+    library in round 4 (the only kernel with a bounded-spin barrier): the flag is refused there and checked against the
+    same numbers in the diagnostic build, in a child process."""
     from climate_toolbox_amd import _lib, synth
     from climate_toolbox_amd.engine import SparsePlan
     torch = torch_cuda
@@ -324,8 +326,7 @@ def test_plan_flags_pin_the_kernel_form(torch_cuda):
     X = torch.from_numpy((280 + np.random.default_rng(1).standard_normal((130, G))).astype(np.float32)).cuda()
     outs = []
     NL = _lib.PLAN_NO_LINES
-    for flags in (0, _lib.PLAN_LC_MFMA, _lib.PLAN_NO_LC, _lib.PLAN_NO_STREAM, NL, NL | _lib.PLAN_LC_MFMA, NL | _lib.PLAN_NO_LC,
-                  NL | _lib.PLAN_NO_STREAM):
+    for flags in (0, _lib.PLAN_NO_LC, _lib.PLAN_NO_STREAM, NL, NL | _lib.PLAN_NO_LC, NL | _lib.PLAN_NO_STREAM):
         plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=flags)
         outs.append(plan.apply(X).cpu().numpy())
         plan.status()
@@ -333,6 +334,34 @@ def test_plan_flags_pin_the_kernel_form(torch_cuda):
         np.testing.assert_allclose(o, outs[0], rtol=3e-6)
     with pytest.raises(_lib.WaggError):
         SparsePlan(cell, code, w, G, len(uniq), flags=64)
+    with pytest.raises(_lib.WaggError, match="diagnostic build"):
+        SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=_lib.PLAN_LC_MFMA)
+    diag = os.path.join(ROOT, "climate_toolbox_amd", "lib", "libwagg_diag.so")
+    if not os.path.exists(diag):
+        return
+    ref_path = os.path.join(str(os.environ.get("TMPDIR", "/tmp")), "wagg_flags_ref_%d.npy" % os.getpid())
+    np.save(ref_path, outs[0])
+    code_ = r'''
+import numpy as np, torch
+from climate_toolbox_amd import _lib, synth
+_lib.LIB_PATH = %r
+from climate_toolbox_amd.engine import SparsePlan
+lat, lon, df = synth.realistic_segments(96, 192, R=300, seed=4, string_labels=False)
+cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+G = len(lat) * len(lon)
+X = torch.from_numpy((280 + np.random.default_rng(1).standard_normal((130, G))).astype(np.float32)).cuda()
+ref = np.load(%r)
+for flags in (_lib.PLAN_LC_MFMA, _lib.PLAN_NO_LINES | _lib.PLAN_LC_MFMA):
+    plan = SparsePlan(cell, code, w, G, len(uniq), row_len=len(lon), flags=flags)
+    np.testing.assert_allclose(plan.apply(X).cpu().numpy(), ref, rtol=3e-6)
+    plan.status()
+print("MFMA-CONSUMERS-OK")
+''' % (diag, ref_path)
+    try:
+        r = subprocess.run([sys.executable, "-c", code_], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    finally:
+        os.remove(ref_path)
+    assert "MFMA-CONSUMERS-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("nlat,nlon", [(96, 192), (61, 100), (40, 36)])
