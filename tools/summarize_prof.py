@@ -76,7 +76,13 @@ if os.path.exists(tr):
                      ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
                      ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true, false>"),
                      ("c2-real combine + transpose", "combine_parts_kernel<float, true>"),
-                     ("c3-real combine + transpose (and c1's)", "combine_parts_kernel<double, true>")):
+                     ("c3-real combine + transpose (and c1's)", "combine_parts_kernel<double, true>"),
+                     # round 4: plans built on the device from the caller's CSR table (c5: 2.5e8 entries; four plans per run)
+                     ("c5 table -> plan: sort keys", "keygen_kernel"), ("c5 table -> plan: radix histogram (per pass)", "rs_hist_kernel"),
+                     ("c5 table -> plan: radix scatter (per pass)", "rs_scatter_kernel"), ("c5 table -> plan: coalesce duplicates", "coalesce_kernel"),
+                     ("c5 table -> plan: denominators", "den_kernel"), ("c5 table -> plan: tile census", "table_tiles_kernel"),
+                     ("c5 table -> plan: entry lists", "spmm_fill_kernel"), ("c5 table -> plan: packed tiles", "table_scatter_kernel"),
+                     ("synthetic c5 table (CSR generator)", "synth_csr_kernel")):
         pick = None
         if "#" in ksub:
             ksub, pick = ksub.split("#")
