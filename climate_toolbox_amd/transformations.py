@@ -29,8 +29,15 @@ KELVIN = 273.15
 
 
 def ordinal(n):
-    """Converts numbers into ordinal strings (transformations.py:211-214)."""
-    return "%d%s" % (n, "tsnrhtdd"[(n // 10 % 10 != 1) * (n % 10 < 4) * n % 10::4])
+    """1 -> "1st", 2 -> "2nd", 3 -> "3rd", 4 -> "4th", 11 -> "11th", 22 -> "22nd" ...: the wording of the power in tas_poly's
+    description attribute (same outputs as the reference's helper, transformations.py:211-214)."""
+    n = int(n)
+    last_two, last = n % 100, n % 10
+    if 11 <= last_two <= 13 or last in (0, 4, 5, 6, 7, 8, 9):
+        suffix = "th"
+    else:
+        suffix = {1: "st", 2: "nd", 3: "rd"}[last]
+    return str(n) + suffix
 
 
 def _month_day(time_values):

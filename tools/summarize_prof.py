@@ -69,14 +69,18 @@ if os.path.exists(tr):
         dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     rows = []
     for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share)", "dense_mfma_kernel<float, 0, false, 22, true"),
-                     ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
+                     # (round 4: the default line's host-resident / drop-in / country-level legs launch the c2-real instantiation on row blocks
+                     #  and on another table as well: "#big" keeps the full-field launches of the c2-real table)
+                     ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
                      ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
                      ("c5-block-f64", "dense_mfma_kernel<double, 0, true"), ("c5-uniform", "spmm_kernel<float>"),
                      ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>"),
                      ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
                      ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true, false>"),
-                     ("c2-real combine + transpose", "combine_parts_kernel<float, true>"),
-                     ("c3-real combine + transpose (and c1's)", "combine_parts_kernel<double, true>"),
+                     ("c2-real combine + transpose, one plane", "combine_parts_kernel<float, true>#band:0.02:0.04"),
+                     ("c2-real combine + transpose, 3-4 planes (fused transforms)", "combine_parts_kernel<float, true>#big"),
+                     ("c3-real combine + transpose, one plane", "combine_parts_kernel<double, true>#band:0.035:0.07"),
+                     ("c3-real combine + transpose, 3-4 planes (fused transforms)", "combine_parts_kernel<double, true>#big"),
                      # round 4: plans built on the device from the caller's CSR table (c5: 2.5e8 entries; four plans per run)
                      ("c5 table -> plan: sort keys", "keygen_kernel"), ("c5 table -> plan: radix histogram (per pass)", "rs_hist_kernel"),
                      ("c5 table -> plan: radix scatter (per pass)", "rs_scatter_kernel"), ("c5 table -> plan: coalesce duplicates", "coalesce_kernel"),
@@ -88,7 +92,10 @@ if os.path.exists(tr):
             ksub, pick = ksub.split("#")
         for k, v in dur.items():
             if ksub in k:
-                if pick:
+                if pick and pick.startswith("band:"):       # durations inside [lo, hi] ms
+                    lo, hi = (float(x) for x in pick.split(":")[1:])
+                    v = [x for x in v if lo <= x <= hi]
+                elif pick:
                     top = max(v)
                     v = [x for x in v if (x >= 0.5 * top) == (pick == "big")]
                 if v:
@@ -110,7 +117,7 @@ LINES = ("whole-line chunks: every load instruction reads eight whole 128-B line
          "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T for fp32, lines64_ucells x 8 B x T for fp64, in "
          "the bench line's plan), x1 if it matches them: see `calibration`; WRITE_SIZE exact")
 for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
-                       ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big", "lines64"),
+                       ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big", "lines64"),
                        ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
