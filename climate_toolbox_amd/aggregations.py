@@ -777,7 +777,8 @@ class PreparedWeights:
     def plan_key(self, cell_idx, G, R, row_len, is_f32, layout):
         """Key of the plan of (this table, this cell index): hashed once per cell array this object owns, else per call."""
         extra = repr((int(G), int(R), int(row_len), bool(is_f32), layout))
-        owned = any(cell_idx is c for entries in self._grids.values() for _, _, c, _, _ in entries)
+        with self._lock:
+            owned = any(cell_idx is c for entries in self._grids.values() for _, _, c, _, _ in entries)
         if not owned:                                  # e.g. a lon-permuted or lon-major index: a fresh array every call
             return _fingerprint(cell_idx, self.codes, self.w_eff, extra=extra)[0]
         k = (id(cell_idx), extra)
