@@ -367,7 +367,9 @@ def main():
                                 "what": "wagg_apply_host_f32 (row-block pipeline, arrays page-locked in place): X from host memory, result "
                                         "back to host memory; PCIe-bound, never the headline value"}
 
-        def calls(ds, n=20, warm=3):
+        def calls(ds, n=30, warm=15):
+            # (15 warm-up calls: the first dozen calls after an idle spell run 2-3x slower on this platform whatever they do --
+            #  host cores and the copy engines come out of their idle states; tools/dropin_split_timing.py shows the switch)
             for _ in range(warm):
                 weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
             ts = []
@@ -387,7 +389,7 @@ def main():
         from climate_toolbox_amd import prepare_weights
         df_plain = df
         prep = prepare_weights(df, "areawt", "hierid", lat=lat, lon=lon)
-        d_dev, d_host = calls(dsd), calls(dsh, n=10)
+        d_dev, d_host = calls(dsd), calls(dsh, n=10, warm=5)
         df = prep                                                  # (calls() reads `df` of this scope)
         p_dev = calls(dsd)
         df = df_plain

@@ -45,7 +45,7 @@ _PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
 _PLAN_CACHE_MAX = 8                 # plans
 _PLAN_CACHE_MAX_FRAC = 0.5          # ... and at most this share of the device's memory (dense plans are GBs)
 # One lock for every look-up / insert / evict of the module-level caches below (_PLAN_CACHE, _TABLE_MEMO,
-# _PINNED_OUT): the drop-in may be called from several Python threads (ctypes releases the GIL inside the
+# _PINNED_POOL): the drop-in may be called from several Python threads (ctypes releases the GIL inside the
 # library).  A plan handed out by _plan_for is LEASED: its own lock is held until the caller is done with it, and
 # eviction skips leased plans, so no thread can close a plan another one is applying.
 _CACHE_LOCK = threading.RLock()
@@ -85,6 +85,7 @@ class _Unhashable(Exception):
 
 
 _POINTER_SAFE = ("string", "bytes", "empty")
+_POINTER_TABLES: "OrderedDict[tuple, np.ndarray]" = OrderedDict()     # pointer tables already found to hold immutable labels only
 
 
 def _raw_view(a):
@@ -98,9 +99,23 @@ def _raw_view(a):
     if not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)
     if a.dtype.kind == "O":
-        if pd.api.types.infer_dtype(a, skipna=True) not in _POINTER_SAFE:     # C loop over the pointers
-            raise _Unhashable("object column with labels other than str / bytes / None")
-        return a, (C.string_at(a.ctypes.data, a.nbytes) if a.nbytes else b"")
+        raw = C.string_at(a.ctypes.data, a.nbytes) if a.nbytes else b""
+        # whether the pointer table identifies the labels (str / bytes / None only) is a property of the very objects it points
+        # to: it is decided once per pointer table (pandas' C loop over 400k pointers costs 2 ms -- per call and column, before
+        # round 4) and remembered under the table's own hash, with a copy of the array that keeps those objects alive
+        tag = (_xxhash.xxh3_128_digest(raw) if _xxhash is not None else hashlib.blake2b(raw, digest_size=16).digest(), a.shape)
+        with _CACHE_LOCK:
+            known = tag in _POINTER_TABLES
+            if known:
+                _POINTER_TABLES.move_to_end(tag)
+        if not known:
+            if pd.api.types.infer_dtype(a, skipna=True) not in _POINTER_SAFE:     # C loop over the pointers
+                raise _Unhashable("object column with labels other than str / bytes / None")
+            with _CACHE_LOCK:
+                _POINTER_TABLES[tag] = np.array(a, dtype=object, copy=True)
+                while len(_POINTER_TABLES) > _TABLE_MEMO_MAX:
+                    _POINTER_TABLES.popitem(last=False)
+        return a, raw
     if a.dtype.kind in "Mm":               # datetime64 / timedelta64 refuse the buffer protocol
         return a, memoryview(a.reshape(-1).view(np.int64)).cast("B")
     try:
@@ -391,36 +406,48 @@ class ReindexedDataset(minixr.Dataset):
 
 
 # Results go back to the host through page-locked memory (one DMA at PCIe speed instead of the runtime's staged
-# pageable copy: 36 MB in 0.8 instead of 3.6 ms).  torch's caching host allocator recycles the blocks once the
-# caller drops the result; the amount handed out at any time is capped, beyond it the pageable copy is used.
-_PINNED_OUT = {"bytes": 0}
+# pageable copy: 36 MB in 0.8 instead of 3.6 ms).  The blocks come from a small pool of the module's own (round 4): a block
+# returns to the pool when the caller drops the result and is handed out again as it is -- page-locking 36 MB anew costs
+# 3-4 ms, and whether torch's caching host allocator had a recycled block ready decided between a 3 ms and an 8 ms call.
+# The amount of pooled memory is capped; beyond it (and for small results) the pageable copy is used.
+_PINNED_POOL = {"bytes": 0, "free": {}}            # free: rounded size -> [uint8 pinned tensors]
 _PINNED_OUT_CAP = 512 << 20
 
 
-def _release_pinned(n):
+def _pinned_return(block):
     with _CACHE_LOCK:
-        _PINNED_OUT["bytes"] -= n
+        _PINNED_POOL["free"].setdefault(block.numel(), []).append(block)
 
 
 def _to_host(o):
     import weakref
     import torch
     n = o.numel() * o.element_size()
+    if n < (1 << 20):
+        return o.cpu().numpy()
+    size = (n + (1 << 20) - 1) >> 20 << 20                          # blocks of whole MiB: results of one shape share them
+    block = None
     with _CACHE_LOCK:
-        take = n >= (1 << 20) and _PINNED_OUT["bytes"] + n <= _PINNED_OUT_CAP
-        if take:
-            _PINNED_OUT["bytes"] += n
-    if take:
+        free = _PINNED_POOL["free"].get(size)
+        if free:
+            block = free.pop()
+        elif _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP:
+            _PINNED_POOL["bytes"] += size
+            block = False                                            # allocate below, outside the lock
+    if block is None:
+        return o.cpu().numpy()                                       # the pool is at its cap and every block is in use
+    if block is False:
         try:
-            host = torch.empty(o.shape, dtype=o.dtype, pin_memory=True)
-        except RuntimeError:                      # no page-locked memory to be had: pageable copy
-            _release_pinned(n)
+            block = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+        except RuntimeError:                                         # no page-locked memory to be had: pageable copy
+            with _CACHE_LOCK:
+                _PINNED_POOL["bytes"] -= size
             return o.cpu().numpy()
-        host.copy_(o)
-        arr = host.numpy()                        # shares the block; views of `arr` keep `arr` (their base) alive
-        weakref.finalize(arr, _release_pinned, n)
-        return arr
-    return o.cpu().numpy()
+    host = block[:n].view(o.dtype).view(o.shape)
+    host.copy_(o)
+    arr = host.numpy()                            # shares the block; views of `arr` keep `arr` (their base) alive
+    weakref.finalize(arr, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
+    return arr
 
 
 def _is_device_tensor(values):

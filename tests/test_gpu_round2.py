@@ -1095,7 +1095,8 @@ def test_host_forms_respect_the_pitch_of_host_arrays(torch_cuda, dtype):
 
 
 def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
-    """The drop-in's D2H copy: page-locked while the cap allows, released when the caller drops the result, same
+    """The drop-in's D2H copy: through a pool of page-locked blocks while the cap allows; a block returns to the pool when
+    the caller drops the result (views included) and is handed out again as it is; beyond the cap the pageable copy; same
     numbers either way."""
     import gc
     from climate_toolbox_amd import aggregations as A, minixr, synth, weighted_aggregate_grid_to_regions
@@ -1105,28 +1106,40 @@ def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
     X = (280 + 10 * np.random.default_rng(0).standard_normal((T, len(lat), len(lon)))).astype(np.float32)
     ds = minixr.Dataset({"tas": (("time", "lat", "lon"), torch.from_numpy(X).cuda())}, coords={"lat": lat, "lon": lon})
     gc.collect()
-    base = A._PINNED_OUT["bytes"]
+    pool = A._PINNED_POOL
+    n_free = lambda: sum(len(v) for v in pool["free"].values())
+    base, free0 = pool["bytes"], n_free()
     a = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
     n = a.tas.values.nbytes
-    assert n >= 1 << 20 and A._PINNED_OUT["bytes"] == base + n
+    size = (n + (1 << 20) - 1) >> 20 << 20
+    took_new = pool["bytes"] - base                             # 0 if an earlier test left a free block of this size
+    assert n >= 1 << 20 and took_new in (0, size)
     b = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
-    assert A._PINNED_OUT["bytes"] == base + 2 * n
+    in_use_bytes = pool["bytes"]
     np.testing.assert_array_equal(a.tas.values, b.tas.values)
-    keep = a.tas.values[3:5]                                    # a view keeps its block alive
+    pa = a.tas.values.ctypes.data
+    keep = a.tas.values[3:5]                                    # a view keeps its block out of the pool
     del a, b
     gc.collect()
-    assert A._PINNED_OUT["bytes"] == base + n
+    free1 = n_free()                                            # b's block is back, a's is not
+    c = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    assert pool["bytes"] == in_use_bytes and n_free() == free1 - 1          # a pooled block was reused: nothing new page-locked
+    assert c.tas.values.ctypes.data != pa
+    np.testing.assert_array_equal(c.tas.values[3:5], keep)
     old_cap = A._PINNED_OUT_CAP
     try:
-        A._PINNED_OUT_CAP = 0                                   # beyond the cap: pageable copy, same numbers
-        c = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
-        np.testing.assert_array_equal(c.tas.values[3:5], keep)
-        assert A._PINNED_OUT["bytes"] == base + n
+        A._PINNED_OUT_CAP = 0                                   # at the cap with every block in use: pageable copy, same numbers
+        for blocks in pool["free"].values():
+            blocks.clear()
+        d = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+        np.testing.assert_array_equal(d.tas.values[3:5], keep)
+        assert pool["bytes"] == in_use_bytes and n_free() == 0
     finally:
         A._PINNED_OUT_CAP = old_cap
-    del keep
+    del keep, c, d
     gc.collect()
-    assert A._PINNED_OUT["bytes"] == base
+    assert n_free() >= 2                                        # both blocks (a's via its view, c's) came back
+    assert free0 >= 0
 
 
 @pytest.mark.parametrize("layout", ["TG", "GT"])
