@@ -127,18 +127,19 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
 #define WAGG_PLAN_NO_LC 1     /* (time, gridcell) data: the persistent one-role kernel instead of the loader/consumer kernels */
 #define WAGG_PLAN_NO_STREAM 2 /* every group through the chunk-walking kernel */
 #define WAGG_PLAN_NO_LINES 4  /* region-shaped chunks only (rounds 1-2) even where the whole-line chunkings apply */
-#define WAGG_PLAN_LC_MFMA 8   /* fp32 loader/consumer kernel with dense-tile MFMA consumers (rounds 1-2) instead of the vector-ALU
-                                 consumers of sparse_lcv_kernel; fp64 then takes the one-role kernel */
+#define WAGG_PLAN_LC_MFMA 8   /* DIAGNOSTIC BUILD ONLY (libwagg_diag.so): fp32 loader/consumer kernel with dense-tile MFMA consumers
+                                 (rounds 1-2) -- the one kernel with a bounded-spin barrier; libwagg.so refuses the flag with
+                                 WAGG_EUNSUPPORTED */
 int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
                      int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
                      wagg_plan **out);
 int wagg_plan_destroy(wagg_plan *plan);
 int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info);
 int wagg_plan_get_den(const wagg_plan *plan, double *den_host /* R values */); /* :79 */
-/* Blocks until `stream` is idle, then reports whether any apply on this plan failed on the device
- * (a consumer-wave barrier of the loader/consumer kernel timed out: WAGG_EHIP, results incomplete).
- * The same check runs at the start of every later apply on the plan and inside the *_host_ forms,
- * so a device-side failure always surfaces as a status, never as silent garbage.               */
+/* Blocks until `stream` is idle, then reports whether any apply on this plan failed on the device.  No kernel of
+ * libwagg.so can: none waits on another wave's progress (the diagnostic build's MFMA-consumer kernel can time out at its
+ * consumer barrier: WAGG_EHIP, results incomplete -- there the same check also runs at the start of every later apply on the
+ * plan and inside the *_host_ forms, so a device-side failure surfaces as a status, never as silent garbage).          */
 int wagg_plan_status(const wagg_plan *plan, void *stream);
 
 /* ---- apply: replaces aggregations.py:78-80 (and the gather of :27, fused) ------------------ */
