@@ -547,3 +547,40 @@ def test_prepared_weights_is_a_snapshot_of_the_coded_table():
     with pytest.raises(ValueError):
         prep.w_eff[0] = 1.0                                                      # and nobody can edit the snapshot
     assert prepare_weights(prep, "popwt", "hierid") is prep
+
+
+def test_host_devices_default_and_opt_in(monkeypatch):
+    """host-resident fields stay on the caller's device unless HOST_DEVICES opts in; "all" is ignored
+    inside a one-process-per-GPU job (every rank sees every device there); the row blocks are sized by the plan's own
+    launch quantum.  Host-side logic only."""
+    import torch
+    from climate_toolbox_amd import aggregations as A
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(A, "HOST_DEVICES", None)
+    assert A._host_devices() == []
+    monkeypatch.setattr(A, "HOST_DEVICES", "all")
+    assert A._host_devices() == list(range(8))
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert A._host_devices() == []                                   # torchrun rank: the other devices are not ours
+    monkeypatch.setattr(A, "HOST_DEVICES", [2, 2, 5])
+    assert A._host_devices() == [2, 2, 5]                            # an explicit list is taken as it is
+    monkeypatch.setattr(A, "HOST_DEVICES", "every")
+    with pytest.raises(ValueError):
+        A._host_devices()
+
+    class FakeSparse:
+        pass
+
+    class FakeDense(A.DensePlan):
+        def __init__(self, form, dtype):                             # (no device object behind it)
+            self.info, self.dtype = {"form": form}, dtype
+
+        def close(self):
+            pass
+
+        __del__ = close
+
+    assert A._host_quantum(FakeSparse()) == 64
+    assert A._host_quantum(FakeDense(0, "float32")) == 368 and A._host_quantum(FakeDense(1, "float64")) == 176
+    assert A._host_quantum(FakeDense(2, "float32")) == 128 and A._host_quantum(FakeDense(2, "float64")) == 64
