@@ -417,3 +417,52 @@ def test_prepared_weights_give_the_dataframe_results(torch_cuda, tmp_path):
     b = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", path)
     np.testing.assert_array_equal(a.tas.values, b.tas.values)
     np.testing.assert_allclose(a.tas.values, weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float32, RTOL32), (np.float64, 1e-11)])
+def test_table_builder_corner_shapes_vs_oracle(torch_cuda, dtype, rtol):
+    """Shapes at the edges of the device builder's geometry, each against the oracle's aggregation of the same rows: one
+    grid cell; one region; every row in ONE cell; one pair repeated 5,000 times (a single run for the coalescing kernel);
+    a region whose weights cancel to 0 and one that is all zeros (S7: inf / NaN); negative weights; G and R that are not
+    multiples of anything (chunks of 128 cells, 16-wave region blocks, 256-region tiles); a table larger than one sort
+    tile per wave (> 8,192 rows) with most rows dropped (null labels), so the dropped keys cross tile borders."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    cases = []
+    cases.append(("one cell", 1, 7, np.zeros(30, np.int32), rng.integers(0, 7, 30).astype(np.int32), rng.uniform(0.1, 1, 30)))
+    cases.append(("one region", 777, 1, rng.integers(0, 777, 400).astype(np.int32), np.zeros(400, np.int32), rng.uniform(0.1, 1, 400)))
+    cases.append(("one cell of many", 1000, 50, np.full(300, 613, np.int32), rng.integers(0, 50, 300).astype(np.int32), rng.uniform(0.1, 1, 300)))
+    cases.append(("one pair 5000 times", 130, 20, np.full(5000, 129, np.int32), np.full(5000, 19, np.int32), rng.uniform(0.1, 1, 5000)))
+    w = rng.uniform(0.1, 1, 200)
+    code = rng.integers(2, 9, 200).astype(np.int32)
+    cell = rng.integers(0, 257, 200).astype(np.int32)
+    cell = np.concatenate([cell, [5, 6, 7, 8]]).astype(np.int32)
+    code = np.concatenate([code, [0, 0, 1, 1]]).astype(np.int32)        # region 0: +2 - 2 = 0 (x / 0 = +-inf, or NaN); region 1: 0 + 0
+    w = np.concatenate([w, [2.0, -2.0, 0.0, 0.0]])
+    w[::17] *= -1.0                                                      # negative weights are weights (the backup fill is upstream)
+    cases.append(("zero denominators, negative weights", 257, 9, cell, code, w))
+    n = 40000
+    code = rng.integers(0, 1201, n).astype(np.int32)
+    code[rng.random(n) < 0.9] = -1                                       # nine rows in ten carry no label
+    cases.append(("mostly dropped rows", 129 * 7 + 1, 1201, rng.integers(0, 129 * 7 + 1, n).astype(np.int32), code, rng.uniform(0.1, 1, n)))
+    for name, G, R, cell, code, w in cases:
+        T = 33
+        X = (5 + rng.standard_normal((T, G))).astype(dtype)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ref = O.agg_coded(X, cell, code, w, R)
+        Xd = torch.from_numpy(X).cuda()
+        seg = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype)
+        got = seg.apply(Xd).cpu().numpy()
+        keep = (code >= 0) & ~np.isnan(w)
+        assert seg.info["nnz"] == len(np.unique(cell[keep].astype(np.int64) * R + code[keep])), name
+        np.testing.assert_allclose(seg.den, np.bincount(code[keep], weights=w[keep], minlength=R), rtol=1e-12, atol=1e-15, err_msg=name)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~fin & ~np.isnan(ref)], ref[~fin & ~np.isnan(ref)]), name
+        _rel_ok(np.where(fin, got, 0.0), np.where(fin, ref, 0.0), rtol)
+        order = np.argsort(cell, kind="stable")
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(cell, minlength=G))]).astype(np.int64)
+        csr = DensePlan.from_csr(rowptr, code[order], w[order], G, R, dtype=dtype)
+        np.testing.assert_array_equal(csr.apply(Xd).cpu().numpy(), got, err_msg=name)
+        seg.close(); csr.close()
