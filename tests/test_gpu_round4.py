@@ -466,3 +466,28 @@ def test_table_builder_corner_shapes_vs_oracle(torch_cuda, dtype, rtol):
         csr = DensePlan.from_csr(rowptr, code[order], w[order], G, R, dtype=dtype)
         np.testing.assert_array_equal(csr.apply(Xd).cpu().numpy(), got, err_msg=name)
         seg.close(); csr.close()
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """`bench.py --gpus 3` with WAGG_BENCH_REHEARSE=gloo (every rank on device 0, blocks gathered through host memory): the
+    N > 1 control flow the driver's scaling run takes -- the weak-scaled headline, then the STRONG splits of configs[3] and
+    configs[4] as `secondary` (equal and ragged row counts), every gather checked -- on a small grid.  Control flow only:
+    the line says it is not a measurement, and RCCL is covered by the one-rank tests above."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WAGG_BENCH_REHEARSE="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--nlat", "180", "--nlon", "360", "--R", "600",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 3 and rec["scaling"] == "weak" and rec["scaling_measured"] is False and "rehearsal" in rec
+    assert rec["gather_ok"] is True and rec["config"]["T_job"] == 3 * 365
+    sec = {s["workload"]: s for s in rec["secondary"]}
+    assert set(sec) == {"c4", "c5-uniform"}
+    assert sec["c4"]["scaling"] == "strong" and sec["c4"]["T_job"] == 10950 and sec["c4"]["gather_ok"] is True
+    assert sec["c5-uniform"]["scaling"] == "strong" and sec["c5-uniform"]["T_job"] == 18250 and sec["c5-uniform"]["gather_ok"] is True
+    assert sec["c5-uniform"]["T"] == 6084                                # ragged: 6084 + 6083 + 6083 rows
