@@ -491,3 +491,37 @@ def test_bench_multi_rank_control_flow_rehearsal():
     assert sec["c4"]["scaling"] == "strong" and sec["c4"]["T_job"] == 10950 and sec["c4"]["gather_ok"] is True
     assert sec["c5-uniform"]["scaling"] == "strong" and sec["c5-uniform"]["T_job"] == 18250 and sec["c5-uniform"]["gather_ok"] is True
     assert sec["c5-uniform"]["T"] == 6084                                # ragged: 6084 + 6083 + 6083 rows
+
+
+def test_integration_md_csr_binding_runs_as_written(torch_cuda):
+    """The ctypes stub INTEGRATION.md shows for a table that is already CSR is executed as written (in the namespace of the
+    stub of section 2), on a scipy.sparse matrix, and its plan applied through wagg_dense_apply_f32."""
+    import ctypes as C
+    import re
+    import scipy.sparse as sp
+    from climate_toolbox_amd import _lib
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    base = re.search(r"```python\n(# climate_toolbox/aggregations/_wagg.py.*?)```", text, re.S).group(1)
+    base = base.replace('C.CDLL("libwagg.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    block = re.search(r"```python\n(def plan_from_csr.*?)```", text, re.S).group(1)
+    L = _lib.load()
+    ns = {}
+    exec(compile(base, "INTEGRATION.md", "exec"), ns)
+    exec(compile(block, "INTEGRATION.md#csr", "exec"), ns)
+    rng = np.random.default_rng(5)
+    G, R, T = 3000, 120, 40
+    W = sp.random(G, R, density=0.03, format="csr", random_state=7, data_rvs=lambda k: rng.uniform(0.1, 1, k))
+    h = ns["plan_from_csr"](W.indptr.astype(np.int64), W.indices.astype(np.int32), W.data.astype(np.float64), G, R)
+    try:
+        X = (280 + 10 * rng.standard_normal((T, G))).astype(np.float32)
+        Xd = torch.from_numpy(X).cuda()
+        out = torch.empty((T, R), dtype=torch.float32, device="cuda")
+        rc = L.wagg_dense_apply_f32(h, C.c_void_p(Xd.data_ptr()), T, G, C.c_void_p(out.data_ptr()), R, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.wagg_last_error()
+        torch.cuda.synchronize()
+    finally:
+        L.wagg_dense_destroy(h)
+    coo = W.tocoo()
+    _rel_ok(out.cpu().numpy(), O.agg_coded(X, coo.row.astype(np.int32), coo.col.astype(np.int32), coo.data, R), RTOL32)
