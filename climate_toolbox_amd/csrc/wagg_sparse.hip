@@ -2104,6 +2104,20 @@ template <typename T> static const LcvEntry<T> &lcv_pick(bool vec, bool edd, boo
     return table[vec ? 1 : 0][edd ? 1 : 0][gt ? 1 : 0][planes - 1];
 }
 
+// (diagnostic build, WAGG_SPARSE_STAMP) phase stamps of a loader/consumer launch: mean cycles per stage and phase, to stderr
+static int report_lc_stamps(unsigned long long *lc_stamps, long long nw, long long n_items, hipStream_t stream) {
+    std::vector<unsigned long long> h(8 * (size_t)nw);
+    WAGG_HIP(hipStreamSynchronize(stream));
+    WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
+    WAGG_HIP(hipFree(lc_stamps));
+    double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
+    const double stg = (double)n_items;
+    fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
+            n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
+    return WAGG_OK;
+}
+
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
@@ -2231,17 +2245,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                            plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
         profile_mark(stream, false);
         WAGG_HIP(hipGetLastError());
-        if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
-            std::vector<unsigned long long> h(8 * (size_t)nw);
-            WAGG_HIP(hipStreamSynchronize(stream));
-            WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
-            WAGG_HIP(hipFree(lc_stamps));
-            double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
-            const double stg = (double)n_items;
-            fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
-                    n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
-        }
+        if (lc_stamps) { if (int rc = report_lc_stamps(lc_stamps, nw, n_items, stream)) return rc; }
         pv.n_groups = d.g0_normal;
         lc_done = true;
     }
@@ -2269,17 +2273,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
                                diag_env("WAGG_LC_KNOB"), kpstride, ylim);
             profile_mark(stream, false);
             WAGG_HIP(hipGetLastError());
-            if (lc_stamps) {          // diagnostic: mean cycles per stage and phase
-                std::vector<unsigned long long> h(8 * (size_t)nw);
-                WAGG_HIP(hipStreamSynchronize(stream));
-                WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
-                WAGG_HIP(hipFree(lc_stamps));
-                double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
-                const double stg = (double)n_items;
-                fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
-                        n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
-            }
+            if (lc_stamps) { if (int rc = report_lc_stamps(lc_stamps, nw, n_items, stream)) return rc; }
             pv.n_groups = d.g0_normal;
             lc_done = true;
         }

@@ -16,7 +16,7 @@ if [ "$1" = build ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DWAGG_SPMM_ASM_INC="\"_obj/spmm_abl_$tag.inc\"" \
         -c $CS/wagg_spmm.hip -o $CS/_obj/spmm_abl_$tag.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o climate_toolbox_amd/lib/libwagg_abl_$tag.so \
-        $CS/_obj/wagg_util.o $CS/_obj/wagg_host.o $CS/_obj/wagg_labels.o $CS/_obj/wagg_sparse.o $CS/_obj/wagg_dense.o $CS/_obj/spmm_abl_$tag.o 2>/dev/null
+        $CS/_obj/wagg_util.o $CS/_obj/wagg_host.o $CS/_obj/wagg_labels.o $CS/_obj/wagg_build.o $CS/_obj/wagg_sparse.o $CS/_obj/wagg_dense.o $CS/_obj/spmm_abl_$tag.o 2>/dev/null
     echo built $tag
   done
 else
