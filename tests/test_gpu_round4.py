@@ -183,6 +183,19 @@ def test_c5_table_from_the_caller_at_full_size(torch_cuda, structure):
         assert torch.equal(got, want)
         print("c5-%s %s: oracle generator %.1f s, from_csr %.2f s (library: %.2f s, of which upload %.2f s)" % (
             structure, dtype, t_gen, t_build, plan.info["build_s"], plan.info["build_upload_s"]))
+        if uniform and dtype == "float32":
+            # the same table as COO segment rows in REVERSE order (wagg_dense_create_from_segments, 4 GB of host arrays):
+            # nothing about the row order survives the sort -- the same plan again
+            cell = np.repeat(np.arange(G, dtype=np.int32), np.diff(rowptr))[::-1].copy()
+            t0 = time.time()
+            coo = engine.DensePlan.from_segments(cell, col[::-1].copy(), val[::-1].copy(), G, R, dtype=dtype)
+            t_coo = time.time() - t0
+            del cell
+            assert coo.info["form"] == plan.info["form"] and coo.info["nnz"] == len(col) and coo.info["w_bytes"] == plan.info["w_bytes"]
+            np.testing.assert_array_equal(coo.den, plan.den)
+            assert torch.equal(coo.apply(X[:256].contiguous()), plan.apply(X[:256].contiguous()))
+            print("c5-uniform float32 as 2.5e8 COO rows in reverse order: from_segments %.2f s" % t_coo)
+            coo.close()
         del got, want, X
         plan.close(); ref.close()
         torch.cuda.empty_cache()
