@@ -8,6 +8,7 @@ from .aggregations import (  # noqa: F401
     prepare_spatial_weights_data,
     prepare_weights,
     PreparedWeights,
+    clear_caches,
     _reindex_spatial_data_to_regions,
     _aggregate_reindexed_data_to_regions,
 )

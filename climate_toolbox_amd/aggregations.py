@@ -33,7 +33,7 @@ try:  # optional: return real xarray objects when the caller hands us xarray obj
 except Exception:  # pragma: no cover - xarray is absent from this image
     _xr = None
 
-__all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data", "prepare_weights", "PreparedWeights",
+__all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data", "prepare_weights", "PreparedWeights", "clear_caches",
            "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
 
 try:  # optional: a 10 GB/s hash for the table fingerprints below (blake2b, ~1 GB/s, otherwise)
@@ -448,6 +448,27 @@ def _to_host(o):
     arr = host.numpy()                            # shares the block; views of `arr` keep `arr` (their base) alive
     weakref.finalize(arr, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
     return arr
+
+
+def clear_caches():
+    """Give back what the module keeps between calls: cached plans that no call is using (device memory), the table memos,
+    the coded tables of the CSV route and the FREE blocks of the page-locked result pool (blocks behind results the caller
+    still holds return to the pool when those are dropped, and go with the next call of this function)."""
+    with _CACHE_LOCK:
+        for key in list(_PLAN_CACHE):
+            plan = _PLAN_CACHE[key]
+            if plan._lease.acquire(blocking=False):
+                try:
+                    del _PLAN_CACHE[key]
+                    plan.close()
+                finally:
+                    plan._lease.release()
+        _TABLE_MEMO.clear()
+        _POINTER_TABLES.clear()
+        _PREPARED_BY_PATH.clear()
+        for size, blocks in _PINNED_POOL["free"].items():
+            _PINNED_POOL["bytes"] -= size * len(blocks)
+            blocks.clear()
 
 
 def _is_device_tensor(values):

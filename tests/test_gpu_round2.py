@@ -1140,6 +1140,10 @@ def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
     gc.collect()
     assert n_free() >= 2                                        # both blocks (a's via its view, c's) came back
     assert free0 >= 0
+    A.clear_caches()                                            # plans, memos and the free blocks of the pool go
+    assert n_free() == 0 and pool["bytes"] == 0 and len(A._PLAN_CACHE) == 0
+    e = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)      # ... and everything comes back on demand
+    np.testing.assert_array_equal(e.tas.values[3:5], weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df).tas.values[3:5])
 
 
 @pytest.mark.parametrize("layout", ["TG", "GT"])
