@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launcher and the rank plumbing on CPU (gloo, no kernels, value 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--budget-s", type=float, default=480.0,
+                    help="wall-clock budget of the whole run: secondaries that would start beyond it are dropped with "
+                         "\"skipped\": \"budget\" (the driver ends a run at 600 s)")
     ap.add_argument("--diag-lib", nargs="?", const="libwagg_diag.so", default=None, metavar="NAME",
                     help="load climate_toolbox_amd/lib/NAME (default libwagg_diag.so, `make diag`) instead of libwagg.so: "
                          "the build with the ablation knobs, or an experiment's variant; timing experiments only")
@@ -110,8 +113,12 @@ def dry_run(a, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from climate_toolbox_amd.timeshard import ShardedStep, shard_bounds
+    ranks_seen = None
     if world > 1:
         dist.init_process_group("gloo")
+        one = torch.ones(1)
+        dist.all_reduce(one)                 # = world only if every rank took part (the N > 1 line's `rccl_ranks`, here over gloo)
+        ranks_seen = int(round(float(one.item())))
     rows = [e - s0 for s0, e in shard_bounds(365 * world, world)]
     R = 16
     st = ShardedStep(lambda out: out.fill_(float(rank + 1)), lambda: torch.empty((rows[rank], R)), rows=rows, dst=0,
@@ -130,7 +137,8 @@ def dry_run(a, rank, local_rank, world):
         print(json.dumps({"metric": "gridcell-region-timesteps/sec", "value": 0.0, "unit": "gridcell-region-timesteps/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / max(1, a.steps) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "dry_run": True, "gather_ok": ok,
+                          "data": "synthetic", "dry_run": True, "gather_ok": ok, "rccl_ranks": ranks_seen,
+                          "backend": "gloo" if world > 1 else None,
                           "config": {"workload": "dry run: launcher + gloo gather only, no kernels", "T_job": sum(rows)}}),
               flush=True)
     if world > 1:
@@ -163,17 +171,55 @@ def sparse_algorithmic_bytes(T, G, R, nnz, b):
     return b * T * G + (b + 4) * nnz + 4 * (G + 1) + b * T * R + b * R
 
 
-def timed_steps(torch, dist, step, finish, steps, warmup, world):
+WARM_S = 0.3          # every timed region starts after at least this much of the SAME apply (clocks, caches, allocators warm)
+FILL_S = 0.5          # secondaries: as many timed steps as fill this, at least 10 (the profile ring holds 1024 kernel timings)
+MAX_AUTO_STEPS = 1000
+
+
+def _agree_max(torch, dist, n):
+    """ranks must run the same number of steps (every step holds a collective): the largest count any of them wants"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(n)
+    t = torch.tensor([int(n)], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=None, auto_steps=False, min_steps=10):
     """(wall seconds of exactly `steps` steps between barrier + synchronize on both sides, max over ranks;
-    per-step milliseconds from event pairs on the compute stream -- recorded without any synchronisation)."""
+    per-step milliseconds from event pairs on the compute stream -- recorded without any synchronisation;
+    the number of timed steps; the number of warm-up steps actually run).
+    Warm-up = the `warmup` steps asked for, then more of the same until WARM_S seconds of this very apply have run (a
+    two-step warm-up of a 9 ms apply after seconds of plan building times a device that is still waking up).
+    ``auto_steps``: the timed steps are max(min_steps, what fills FILL_S) instead of `steps` (>= 10 repeats).
+    ``profile_reset()`` is called right before the timed region, so the library's kernel timings cover exactly it."""
     world = world if not (dist.is_available() and dist.is_initialized()) else max(world, 2)   # forced-dist rehearsal
-    for _ in range(warmup):
+    import math
+    t0 = time.perf_counter()
+    n_warm = max(1, warmup) if auto_steps or warmup > 0 else 0
+    for _ in range(n_warm):
         step()
     finish()
     torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    est = el / max(1, n_warm)                       # seconds per step (an over-estimate while things are cold)
+    if n_warm and el < WARM_S:
+        extra = _agree_max(torch, dist, min(4000, int(math.ceil((WARM_S - el) / max(est, 1e-6)))))
+        t1 = time.perf_counter()
+        for _ in range(extra):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        if extra:
+            est = (time.perf_counter() - t1) / extra
+        n_warm += extra
+    if auto_steps:
+        steps = _agree_max(torch, dist, max(min_steps, min(MAX_AUTO_STEPS, int(math.ceil(FILL_S / max(est, 1e-6))))))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if profile_reset is not None:
+        profile_reset()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for a_, b_ in ev:
@@ -190,12 +236,44 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world):
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, sorted(a_.elapsed_time(b_) for a_, b_ in ev)
+    return dt, sorted(a_.elapsed_time(b_) for a_, b_ in ev), steps, n_warm
+
+
+def _spread(sorted_ms, prefix):
+    """median / min / max of a sorted list of milliseconds, the list itself when it is short (quantiles otherwise), and
+    `outlier` when the slowest sample is more than 1.5 x the median."""
+    n = len(sorted_ms)
+    if n == 0:
+        return {}
+    med = sorted_ms[n // 2]
+    d = {prefix + "median": med, prefix + "min": sorted_ms[0], prefix + "max": sorted_ms[-1]}
+    if n <= 64:
+        d[prefix + "sorted"] = [round(x, 4) for x in sorted_ms]
+    else:
+        d[prefix + "quantiles"] = {q: round(sorted_ms[min(n - 1, int(n * f))], 4) for q, f in
+                                   (("p01", 0.01), ("p10", 0.10), ("p50", 0.50), ("p90", 0.90), ("p99", 0.99))}
+    d[prefix + "outlier"] = bool(sorted_ms[-1] > 1.5 * med)
+    return d
 
 
 def step_stats(per_step_ms):
-    """median and minimum of the per-step device times (SURVEY 8d's timing protocol asks for both)."""
-    return {"median_ms": per_step_ms[len(per_step_ms) // 2], "min_ms": per_step_ms[0]}
+    """median / minimum / maximum of the per-step device times (SURVEY 8d's timing protocol asks for median and min)."""
+    d = _spread(per_step_ms, "step_ms_")
+    return {"median_ms": d.get("step_ms_median"), "min_ms": d.get("step_ms_min"), "max_ms": d.get("step_ms_max"),
+            "step_outlier": d.get("step_ms_outlier"),
+            **({"step_ms_sorted": d["step_ms_sorted"]} if "step_ms_sorted" in d else {"step_ms_quantiles": d.get("step_ms_quantiles")})}
+
+
+def kernel_stats(kms):
+    """The dominant kernel's own durations over the timed steps (hipExtLaunchKernel start / stop events: the dispatch
+    itself, no host time): the roofline is priced on the MEDIAN; mean, min, max and the sorted list ride along, and
+    `outlier` says when the slowest launch took more than 1.5 x the median.  (step_ms_max >> kernel_ms_max = a gap between
+    launches, i.e. the host; kernel_ms_max >> kernel_ms_median = the device itself ran a launch slowly.)"""
+    ks = sorted(kms)
+    d = _spread(ks, "kernel_ms_")
+    d["kernel_ms_avg"] = sum(ks) / max(1, len(ks))
+    d["kernel_launches"] = len(ks)
+    return d
 
 
 # ---- CPU baselines (rank 0, N = 1 only; bounded samples; the oracle is the thing timed here) -------
@@ -223,14 +301,18 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
     divide, like the reference) on the sample handed in (the FULL workload for the segment-table
     configs: it is only ~0.4 s of CPU work), median and minimum of up to 15 repeats inside ~10 s; plus the
     best-effort CPU leg SURVEY 8d asks for -- the same sums with the timesteps dealt to all host cores
-    (OpenMP, oracle/wagg_oracle.c::wagg_oracle_segments_omp_*) -- and scipy's CSC SpMM (one thread) for reference."""
+    (OpenMP, oracle/wagg_oracle.c::wagg_oracle_segments_omp_*; threads pinned one per core by OMP_PROC_BIND=spread
+    OMP_PLACES=cores, which main() sets before anything loads an OpenMP runtime; result buffer allocated and touched once;
+    3 warm calls, then 15 timed: median, min and the thread count) -- and scipy's CSC SpMM (one thread) for reference."""
     import numpy as np
     import scipy.sparse as sp
     from oracle import c_oracle
     Ts = X_host.shape[0]
     c_oracle.segments(X_host[:1], cell, codes, w_eff, R)
 
-    def timed(fn, budget_s=10.0, max_reps=15):
+    def timed(fn, budget_s=10.0, max_reps=15, warm=0):
+        for _ in range(warm):
+            fn()
         ts, t_start = [], time.perf_counter()
         while len(ts) < max_reps and (len(ts) < 3 or time.perf_counter() - t_start < budget_s):
             t0 = time.perf_counter()
@@ -242,8 +324,9 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
         return ts[len(ts) // 2], ts[0], len(ts)
 
     dt, dmin, reps = timed(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R))
-    c_oracle.segments(X_host[:c_oracle.threads()], cell, codes, w_eff, R, threaded=True)          # (thread pool start-up)
-    dto, domin, repso = timed(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R, threaded=True))
+    buf = np.zeros((Ts, R), dtype=np.float64)                       # (touched: its pages exist before the first timed call)
+    dto, domin, repso = timed(lambda: c_oracle.segments(X_host, cell, codes, w_eff, R, threaded=True, out=buf), warm=3)
+    del buf
     keep = (codes >= 0) & ~np.isnan(w_eff)
     W = sp.coo_matrix((w_eff[keep], (cell[keep], codes[keep])), shape=(G, R)).tocsc()
     den = np.asarray(W.sum(axis=0)).ravel()
@@ -258,17 +341,25 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
             "wall_s": round(dt, 4), "wall_s_min": round(dmin, 4), "repeats": reps, "nnz_timesteps_per_s": Ts * len(cell) / dt,
             "sample": "oracle/wagg_oracle.c segments_%s (single thread, like the reference), %s"
                       % ("f32" if X_host.dtype == np.float32 else "f64", what),
-            "cpu_best": {"value": Ts * G * R / dto, "wall_s": round(dto, 4), "wall_s_min": round(domin, 4), "cores": c_oracle.threads(),
-                         "repeats": repso, "kind": "port",
-                         "what": "the same C restatement with the timesteps dealt to every host core (OpenMP), same sample"},
+            "cpu_best": {"value": Ts * G * R / dto, "wall_s": round(dto, 5), "wall_s_min": round(domin, 5), "cores": c_oracle.threads(),
+                         "repeats": repso, "warm_calls": 3, "kind": "port",
+                         "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_DYNAMIC")},
+                         "what": "the same C restatement with the timesteps dealt to every host core (OpenMP, one warm team, threads "
+                                 "bound to cores, result buffer reused), same sample"},
             "cpu_scipy": {"value": Ts * G * R / dtb, "wall_s": round(dtb, 4), "wall_s_min": round(dbmin, 4), "cores": 1, "repeats": repsb,
                           "what": "scipy.sparse CSC^T @ X^T in fp64 (one thread), same sample"}}
 
 
 def main():
+    t_start = time.perf_counter()
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)              # before anything that could initialise the GPU
+    # the CPU legs' OpenMP team: one thread per core, bound, no dynamic adjustment -- set before ANY OpenMP runtime loads
+    # (torch brings one; the oracle links another): a team placed by chance gave medians 6x their minimum in round 4
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_DYNAMIC", "false")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,6 +397,22 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # proof that the collective backend saw every rank: an all-reduce of ones on device tensors (= N only if all took part)
+    rccl_ranks = None
+    if use_dist:
+        one = torch.ones(1, dtype=torch.float32, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(one)
+        rccl_ranks = int(round(float(one.item())))
+
+    def out_of_budget():
+        """a rank-consistent answer to "has the run used up --budget-s?" (every rank skips, or none: the steps hold collectives)"""
+        over = 1 if time.perf_counter() - t_start > a.budget_s else 0
+        if use_dist:
+            t = torch.tensor([over], dtype=torch.int32, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            over = int(t.item())
+        return bool(over)
 
     from climate_toolbox_amd import _lib, engine, synth
     if a.diag_lib:
@@ -349,9 +456,30 @@ def main():
         got = st.finish()
         return bool(got is not None and got.shape[0] == sum(st.rows) and torch.equal(got[:Tn], st.bufs[(st.k - 1) & 1]))
 
-    def kernel_avg_ms(kms, warmup):
-        kms = kms[warmup:] if len(kms) > warmup else kms
-        return sum(kms) / max(1, len(kms))
+    def gather_timing(st, Tn, per_step_sorted):
+        """N > 1 lines: what the driver needs to check the collective -- `gather_ms`: one BLOCKING gather of the real block
+        (event pair / wall clock around timeshard.gather_time_shards, max over ranks); `per_rank_ms`: every rank's median
+        step (all-gathered), so a straggler shows; `rccl_ranks`: the all-reduce proof from start-up."""
+        if not use_dist:
+            return {}
+        from climate_toolbox_amd.timeshard import gather_time_shards
+        block = st.bufs[(st.k - 1) & 1]
+        dev = "cpu" if rehearse else "cuda"
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        gather_time_shards(block, dst=0, rows=st.rows, out=st.gathered)
+        if not rehearse:
+            torch.cuda.synchronize()
+        g_ms = (time.perf_counter() - t0) * 1e3
+        t = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med = torch.tensor([per_step_sorted[len(per_step_sorted) // 2]], dtype=torch.float64, device=dev)
+        allm = [torch.zeros_like(med) for _ in range(dist.get_world_size())]
+        dist.all_gather(allm, med)
+        return {"rccl_ranks": rccl_ranks, "backend": dist.get_backend(), "gather_ms": float(t.item()),
+                "gather_bytes": int(sum(st.rows) * block.shape[1] * block.element_size()),
+                "per_rank_ms": [round(float(x.item()), 4) for x in allm]}
 
     def on_traffic(roof, kavg, peak_gbs=PEAK_HBM_GBS):
         """The same roofline priced on the bytes the counters saw move (profiles/traffic.json), next to the
@@ -408,11 +536,17 @@ def main():
         d_dev, d_host = calls(dsd), calls(dsh, n=10, warm=5)
         df = prep                                                  # (calls() reads `df` of this scope)
         p_dev = calls(dsd)
+        from climate_toolbox_amd import results_on_device
+        with results_on_device():                                  # the result stays a CUDA tensor: no D2H copy, no wait
+            r_dev = calls(dsd)
         df = df_plain
         out["dropin_ms"] = {"device_resident": d_dev, "host_resident": d_host, "device_resident_prepared_weights": p_dev,
+                            "device_resident_device_result": r_dev,
                             "what": "weighted_aggregate_grid_to_regions(ds, 'tas', 'areawt', 'hierid', df) end to end (aggregations.py:87), "
                                     "cached plan, result returned as a host array; c2-real table (%d rows) as a DataFrame (fingerprinted "
-                                    "by content on every call) and as prepare_weights(df, ...) (coded once)" % len(df_plain)}
+                                    "by content on every call) and as prepare_weights(df, ...) (coded once); "
+                                    "device_resident_device_result: prepared weights inside `with results_on_device():` -- the "
+                                    "returned variable is a torch CUDA tensor" % len(df_plain)}
         A._PLAN_CACHE.clear()
         del dsd, dsh, Xh
         cell, codes, w_eff, uniq = synth.code_segments(df, lat, lon, "areawt", "ISO")
@@ -434,7 +568,10 @@ def main():
         iso.close()
         return out
 
-    def run_sparse(dtype, small=False, steps=None, warmup=None, extras=True):
+    def profile_reset():
+        engine.profile_enable(True)       # (resets the ring: the timings read afterwards are those of the timed steps only)
+
+    def run_sparse(dtype, small=False, steps=None, warmup=None, extras=True, auto=False):
         steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
         T, rows_all, _ = rows_for("c1" if small else "c2-real")
         T_job = sum(rows_all)
@@ -454,11 +591,12 @@ def main():
         plan_build_s = time.perf_counter() - t0
         Rr = len(uniq)
         st = stepper(lambda out: plan.apply(Xs, out=out), T, rows_all, Rr, Xs.dtype)
-        engine.profile_enable(True)       # event records only, no synchronisation
-        dt, per_step = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
-        kavg = kernel_avg_ms(engine.profile_read(), warmup) * 1e-3
+        dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto)
+        kst = kernel_stats(engine.profile_read())
         engine.profile_enable(False)
+        kmed = kst["kernel_ms_median"] * 1e-3          # the roofline is priced on the MEDIAN launch
         gok = gather_check(st, T)
+        gt = gather_timing(st, T, per_step)
         plan.status()
         b = 4 if dtype == "float32" else 8
         nnz = plan.info["nnz"]
@@ -470,14 +608,16 @@ def main():
         res = {
             "workload": wl, "dtype": "f32" if b == 4 else "f64", "T": T, "T_job": T_job, "G": Gs, "R": Rr, "nnz": int(nnz),
             "value": T_job * Gs * Rr * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
+            "warmup_done": warm_done,
             "ms_per_step": dt / steps * 1e3, **step_stats(per_step), "nnz_timesteps_per_s": T_job * nnz * steps / dt,
-            **({"gather_ok": gok} if gok is not None else {}),
+            **({"gather_ok": gok} if gok is not None else {}), **gt,
             "plan_build_s": round(plan_build_s, 4),      # wagg_plan_create on the coded table (host-side chunking + upload), once per table
             "plan": {k: int(v) for k, v in plan.info.items()},
-            "roofline": on_traffic({"bound": "hbm", "achieved": abytes / kavg / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": abytes / kavg / 1e9 / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": tsrc,
-                                    "kernel": kname, "kernel_ms_avg": kavg * 1e3, "algorithmic_bytes_per_launch": abytes},
-                                   kavg),
+            "roofline": on_traffic({"bound": "hbm", "achieved": abytes / kmed / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": abytes / kmed / 1e9 / PEAK_HBM_GBS, "frac_basis": "median kernel time",
+                                    "traffic": traffic, "traffic_source": tsrc,
+                                    "kernel": kname, **kst, "algorithmic_bytes_per_launch": abytes},
+                                   kmed),
         }
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_sparse(Xs.cpu().numpy(), cell, codes, w_eff, Rr, Gs,
@@ -527,13 +667,22 @@ def main():
             del tmax
         if world == 1 and not small and extras and dtype == "float32":
             res.update(boundary_legs(Xs, lat, lon, df, plan, T, Gs, Rr))
+            if "cpu_baseline" in res and "host_resident" in res:
+                cb = res["cpu_baseline"]["cpu_best"]
+                res["host_memory_comparison"] = {
+                    "host_resident_gpu_ms": round(res["host_resident"]["ms_per_step"], 3), "cpu_best_ms": round(cb["wall_s"] * 1e3, 3),
+                    "cpu_best_min_ms": round(cb["wall_s_min"] * 1e3, 3), "cpu_threads": cb["cores"],
+                    "device_resident_step_ms": round(res["median_ms"], 4),
+                    "what": "for data that STARTS in host memory the GPU path is bound by PCIe (X crosses it once per call); "
+                            "the all-cores CPU restatement reads X from DRAM.  The device-resident step beside them is what a "
+                            "pipeline that keeps the field in HBM pays"}
         plan.close()
         return res
 
     cpu_dense_memo = {}
     c5_tables = {}                       # block-local? -> (rowptr, col, val) host CSR of the synthetic c5 table
 
-    def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False, share=False):
+    def run_dense_family(wl, plan=None, steps=None, warmup=None, keep_plan=False, share=False, auto=False, min_steps=10):
         """c2-dense / c4 (full matrix), c5-uniform[-f64] (entry lists), c5-block[-f64] (tile-sparse)."""
         steps, warmup = steps or a.steps, a.warmup if warmup is None else warmup
         T, rows_all, scal = rows_for(wl, share)
@@ -565,14 +714,16 @@ def main():
             fill, bl = 1.0, False
             plan = plan or engine.DensePlan.synth(G, R, seed=2)
         st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), T, rows_all, R, X.dtype)
-        engine.profile_enable(True)       # event records only (no sync)
-        dt, per_step = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world)
-        kms = engine.profile_read()
+        dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto,
+                                                     min_steps=min_steps)
+        kst = kernel_stats(engine.profile_read())
         engine.profile_enable(False)
         gok = gather_check(st, T)
+        gt = gather_timing(st, T, per_step)
         form = int(plan.info["form"])
-        # one apply = one dominant-kernel launch (a full-form apply of several row blocks is one launch too)
-        kavg = kernel_avg_ms(kms, warmup) * 1e-3
+        # one apply = one dominant-kernel launch (a full-form apply of several row blocks is one launch too); the roofline
+        # is priced on the MEDIAN launch
+        kmed = kst["kernel_ms_median"] * 1e-3
         if wl.startswith("c5-uniform"):
             nnz = int(plan.info["nnz"])
         elif wl.startswith("c5-block"):
@@ -588,14 +739,16 @@ def main():
         peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
         res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "T_job": T_job, "G": G, "R": R, "nnz": nnz,
                "value": T_job * G * R * steps / dt, "unit": "gridcell-region-timesteps/s", "steps": steps, "warmup": warmup,
+               "warmup_done": warm_done,
                "ms_per_step": dt / steps * 1e3, **step_stats(per_step),
-               "plan": {k: (int(v) if isinstance(v, int) else round(v, 4)) for k, v in plan.info.items()}, "scaling": scal,
-               "roofline": {"bound": "mfma" if form != 2 else "valu", "achieved": flops / kavg / 1e12, "peak": peak,
-                            "unit": "TFLOP/s", "frac": flops / kavg / 1e12 / peak,
+               "plan": {k: (int(v) if isinstance(v, int) else float("%.4g" % v)) for k, v in plan.info.items()}, "scaling": scal,
+               "roofline": {"bound": "mfma" if form != 2 else "valu", "achieved": flops / kmed / 1e12, "peak": peak,
+                            "unit": "TFLOP/s", "frac": flops / kmed / 1e12 / peak, "frac_basis": "median kernel time",
                             "traffic": traffic, "traffic_source": tsrc, "kernel": kname,
-                            "kernel_ms_avg": kavg * 1e3, "algorithmic_flops_per_launch": flops}}
+                            **kst, "algorithmic_flops_per_launch": flops}}
         if gok is not None:
             res["gather_ok"] = gok
+        res.update(gt)
         if build:
             res["plan_build"] = build
             res["plan_build_s"] = build["plan_build_s"]
@@ -614,35 +767,46 @@ def main():
         return res, plan
 
     secondary = []
-    sec_steps = max(1, min(a.steps, 5))
+
+    def budgeted(wl, fn):
+        """run a secondary unless the run's wall-clock budget is spent (the driver ends a run at 600 s; a line with a
+        skipped entry beats no line)"""
+        if out_of_budget():
+            secondary.append({"workload": wl, "skipped": "budget", "elapsed_s": round(time.perf_counter() - t_start, 1),
+                              "budget_s": a.budget_s})
+            return None
+        r = fn()
+        secondary.append(r[0] if isinstance(r, tuple) else r)
+        return r
+
     if a.workload in DENSE_FAMILY:
         want_secondary = a.workload == "c2-dense" and world == 1 and not a.no_secondary
         main_res, plan = run_dense_family(a.workload, keep_plan=want_secondary or (a.workload == "c2-dense" and world > 1 and not a.no_secondary))
         scaling = main_res.get("scaling", "weak")
         if want_secondary:
-            # every other BASELINE config on this GPU (N = 1): c4's rank share on the SAME 101 GB operand, then the rest
-            r4, _ = run_dense_family("c4", plan=plan, steps=min(sec_steps, 3), warmup=1, share=True)
-            secondary.append(r4)
+            # every other BASELINE config on this GPU (N = 1): c4's rank share on the SAME 101 GB operand, then the rest.
+            # SURVEY 8d's protocol for each: >= WARM_S of the same apply as warm-up, then max(10, what fills FILL_S) timed
+            # steps (c4, 0.49 s per step: 5), median-based roofline, min / max / outlier flag in the entry.
+            budgeted("c4", lambda: run_dense_family("c4", plan=plan, warmup=1, share=True, auto=True, min_steps=5))
+            plan = None
             torch.cuda.empty_cache()
-            # the segment-table steps take 0.04-0.4 ms: 100 of them after 10 warm-up (five would time 2 ms of a cold start)
-            seg_steps = max(sec_steps, 100)
-            secondary.append(run_sparse("float32", steps=seg_steps, warmup=10))        # c2-real: segment-table form, fp32, area weights
-            secondary.append(run_sparse("float64", steps=seg_steps, warmup=10))        # c3-real: fp64 data, pop weights with backup fill
-            secondary.append(run_sparse("float64", small=True, steps=seg_steps, warmup=10))   # c1
+            budgeted("c2-real", lambda: run_sparse("float32", warmup=10, auto=True))     # segment-table form, fp32, area weights
+            budgeted("c3-real", lambda: run_sparse("float64", warmup=10, auto=True))     # fp64 data, pop weights with backup fill
+            budgeted("c1", lambda: run_sparse("float64", small=True, warmup=10, auto=True))
             for wl in ("c5-block", "c5-block-f64", "c5-uniform", "c5-uniform-f64"):
                 torch.cuda.empty_cache()
-                secondary.append(run_dense_family(wl, steps=sec_steps, warmup=2, share=True)[0])
+                budgeted(wl, lambda wl=wl: run_dense_family(wl, warmup=2, share=True, auto=True))
         elif a.workload == "c2-dense" and world > 1 and not a.no_secondary:
             # multi-GPU run: after the weak-scaled headline the STRONG splits of the two 8-GPU configs BASELINE names --
             # configs[3] (10,950 rows over the ranks, on the operand already resident) and configs[4] (18,250 rows,
             # entry lists) -- so that the scaling line speaks to them too.  Every rank takes part (the gather is inside).
             a_shards = a.shards
             a.shards = world
-            r4, _ = run_dense_family("c4", plan=plan, steps=2, warmup=1)
+            budgeted("c4", lambda: run_dense_family("c4", plan=plan, steps=2, warmup=1))
+            plan = None
             torch.cuda.empty_cache()
-            r5, _ = run_dense_family("c5-uniform", steps=3, warmup=1)
+            budgeted("c5-uniform", lambda: run_dense_family("c5-uniform", steps=3, warmup=1))
             a.shards = a_shards
-            secondary.extend([r4, r5])
     elif a.workload == "c1":
         main_res = run_sparse("float64", small=True)
     else:
@@ -677,15 +841,44 @@ def main():
             "cpu_baseline": main_res.get("cpu_baseline"),
         }
         for k in ("plan_build_s", "plan_build", "gather_ok", "host_resident", "dropin_ms", "agglev_ISO", "layout_gridcell_time",
-                  "fused_tas_poly_1to4", "fused_snyder_edd"):
+                  "fused_tas_poly_1to4", "fused_snyder_edd", "host_memory_comparison"):
             if k in main_res:
                 line[k] = main_res[k]
         if "nnz" in main_res:
             line["config"]["nnz"] = main_res["nnz"]
             line["config"]["plan"] = main_res["plan"]
+        if rccl_ranks is not None:
+            line["rccl_ranks"] = rccl_ranks
+            for k in ("backend", "gather_ms", "gather_bytes", "per_rank_ms"):
+                if k in main_res:
+                    line[k] = main_res[k]
+        line["warmup_done"] = main_res.get("warmup_done")
+        line["max_ms"] = main_res.get("max_ms")
+        line["step_outlier"] = main_res.get("step_outlier")
+        line["elapsed_s"] = round(time.perf_counter() - t_start, 1)
         if secondary:
             line["secondary"] = secondary
-        print(json.dumps(line), flush=True)
+        # the driver keeps the last 8 KB of stdout: one compact record per workload goes LAST, so every config's step,
+        # kernel and roofline figures survive in that tail whatever the length of the entries above
+        def brief(r):
+            if "skipped" in r:
+                return {"wl": r["workload"], "skipped": r["skipped"]}
+            rf = r["roofline"]
+            return {"wl": r["workload"], "steps": r["steps"], "step_ms": [round(r["median_ms"], 4), round(r["min_ms"], 4), round(r["max_ms"], 4)],
+                    "kernel_ms": [round(rf["kernel_ms_median"], 4), round(rf["kernel_ms_min"], 4), round(rf["kernel_ms_max"], 4)],
+                    "frac": round(rf["frac"], 4), "frac_on_traffic": (round(rf["frac_on_traffic"], 4) if "frac_on_traffic" in rf else None),
+                    "bound": rf["bound"], "outlier": bool(rf.get("kernel_ms_outlier") or r.get("step_outlier")),
+                    **({"plan_build_s": r["plan_build_s"]} if "plan_build_s" in r else {})}
+        line["summary"] = {"columns": "step_ms / kernel_ms = [median, min, max]; frac = roofline fraction on the median kernel time",
+                           "rows": [brief(main_res)] + [brief(r) for r in secondary]}
+        text = json.dumps(line)
+        try:                                        # the whole line also as a file (gpurun merges gpurun_out/ back)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_line_n%d.json" % world), "w") as f:
+                f.write(text + "\n")
+        except OSError:
+            pass
+        print(text, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,6 +9,7 @@ from .aggregations import (  # noqa: F401
     prepare_weights,
     PreparedWeights,
     clear_caches,
+    results_on_device,
     _reindex_spatial_data_to_regions,
     _aggregate_reindexed_data_to_regions,
 )

@@ -8,9 +8,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwagg.so")
 
-EKEY = -6
-PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA = 1, 2, 4, 8
+EKEY, EINTERNAL = -6, -7
+PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA, PLAN_SERIAL_BUILD = 1, 2, 4, 8, 16
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
+FORCE_FORM = {None: 0, "auto": 0, "full": 1, "tiles": 2, "entries": 3}      # WAGG_DENSE_FORCE_*
 HOST_PIN, HOST_WHOLE = 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
@@ -64,7 +65,8 @@ class DenseInfo(C.Structure):
     _fields_ = [("G", C.c_int64), ("n_tiles", C.c_int64), ("w_bytes", C.c_int64),
                 ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32),
                 ("form", C.c_int32), ("elem_bytes", C.c_int32), ("nnz", C.c_int64),
-                ("build_s", C.c_double), ("build_upload_s", C.c_double)]
+                ("build_s", C.c_double), ("build_upload_s", C.c_double),
+                ("est_full_s", C.c_double), ("est_tiles_s", C.c_double), ("est_entries_s", C.c_double), ("walked_entries", C.c_int64)]
 
 
 class WaggError(RuntimeError):
@@ -150,7 +152,7 @@ def load():
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int), vp]
     L.wagg_dense_create_synth.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.POINTER(vp)]
     L.wagg_dense_create_host.argtypes = [f32p, C.c_int64, C.c_int32, C.POINTER(vp)]
-    L.wagg_dense_create_from_segments.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32,
+    L.wagg_dense_create_from_segments.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.c_int,
                                                   C.POINTER(vp)]
     L.wagg_dense_create_synth_blocklocal.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_create_synth_sparse.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
@@ -165,9 +167,9 @@ def load():
     L.wagg_dense_create_synth_f64.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_create_synth_blocklocal_f64.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_create_host_f64.argtypes = [f64p, C.c_int64, C.c_int32, C.POINTER(vp)]
-    L.wagg_dense_create_from_segments_f64.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.wagg_dense_create_from_segments_f64.argtypes = [i32p, i32p, f64p, C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(vp)]
     for name in ("wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64"):
-        getattr(L, name).argtypes = [i64p, i32p, f64p, C.c_int64, C.c_int32, C.POINTER(vp)]
+        getattr(L, name).argtypes = [i64p, i32p, f64p, C.c_int64, C.c_int32, C.c_int, C.POINTER(vp)]
     L.wagg_synth_table_csr.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.c_int, i64p, i32p, f64p, C.c_int64, i64p]
     L.wagg_dense_apply_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
     L.wagg_dense_apply_poly_f64.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, vp, C.c_int64, C.c_int, vp]

@@ -25,7 +25,7 @@ import numpy as np
 import pandas as pd
 
 from . import engine as _engine, minixr
-from ._lib import FORM_ENTRIES
+from ._lib import FORM_ENTRIES, WaggError
 from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
 
 try:  # optional: return real xarray objects when the caller hands us xarray objects
@@ -410,13 +410,35 @@ class ReindexedDataset(minixr.Dataset):
 # returns to the pool when the caller drops the result and is handed out again as it is -- page-locking 36 MB anew costs
 # 3-4 ms, and whether torch's caching host allocator had a recycled block ready decided between a 3 ms and an 8 ms call.
 # The amount of pooled memory is capped; beyond it (and for small results) the pageable copy is used.
-_PINNED_POOL = {"bytes": 0, "free": {}}            # free: rounded size -> [uint8 pinned tensors]
+_PINNED_POOL = {"bytes": 0, "free": {}, "lru": []}  # free: rounded size -> [uint8 pinned tensors]; lru: sizes, least recently used first
 _PINNED_OUT_CAP = 512 << 20
 
 
 def _pinned_return(block):
     with _CACHE_LOCK:
         _PINNED_POOL["free"].setdefault(block.numel(), []).append(block)
+
+
+def _pinned_touch(size):
+    lru = _PINNED_POOL["lru"]
+    if size in lru:
+        lru.remove(size)
+    lru.append(size)
+
+
+def _pinned_make_room(size):
+    """Pool at its cap: give back FREE blocks of other sizes, least recently used size first, until ``size`` more bytes fit
+    (a workload whose result shapes change would otherwise fill the pool with blocks nobody asks for again and send every
+    new shape down the pageable copy for good).  Caller holds _CACHE_LOCK; returns True when the bytes fit now."""
+    free = _PINNED_POOL["free"]
+    for other in [z for z in _PINNED_POOL["lru"] if z != size] + [z for z in list(free) if z != size and z not in _PINNED_POOL["lru"]]:
+        blocks = free.get(other)
+        while blocks and _PINNED_POOL["bytes"] + size > _PINNED_OUT_CAP:
+            blocks.pop()                                             # (the tensor's storage is unpinned and freed with it)
+            _PINNED_POOL["bytes"] -= other
+        if _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP:
+            break
+    return _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP
 
 
 def _to_host(o):
@@ -431,9 +453,11 @@ def _to_host(o):
         free = _PINNED_POOL["free"].get(size)
         if free:
             block = free.pop()
-        elif _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP:
+        elif _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP or (size <= _PINNED_OUT_CAP and _pinned_make_room(size)):
             _PINNED_POOL["bytes"] += size
             block = False                                            # allocate below, outside the lock
+        if block is not None:
+            _pinned_touch(size)
     if block is None:
         return o.cpu().numpy()                                       # the pool is at its cap and every block is in use
     if block is False:
@@ -448,6 +472,34 @@ def _to_host(o):
     arr = host.numpy()                            # shares the block; views of `arr` keep `arr` (their base) alive
     weakref.finalize(arr, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
     return arr
+
+
+_TLS = threading.local()
+
+
+class results_on_device:
+    """``with climate_toolbox_amd.results_on_device(): out = weighted_aggregate_grid_to_regions(ds, ...)`` -- for a variable
+    whose buffer is a torch CUDA tensor the returned Dataset's variable is a torch CUDA tensor too (same device, queued on
+    the current stream; the call does not wait for it).  A loop over variables that feeds further GPU work then pays the
+    kernels only; everything else about the call -- names, dims, the ``agglev`` coordinate, the numbers -- is unchanged
+    (bit-equal to the host route).  Per thread; nests; host-resident variables and xarray Datasets still return host arrays.
+    The reference has no such switch (it computes on the host, aggregations.py:75-82): this is an extension."""
+
+    def __init__(self, on=True):
+        self._on = bool(on)
+
+    def __enter__(self):
+        self._prev = getattr(_TLS, "device_results", False)
+        _TLS.device_results = self._on
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.device_results = self._prev
+        return False
+
+
+def _device_results_wanted():
+    return getattr(_TLS, "device_results", False)
 
 
 def clear_caches():
@@ -466,9 +518,12 @@ def clear_caches():
         _TABLE_MEMO.clear()
         _POINTER_TABLES.clear()
         _PREPARED_BY_PATH.clear()
-        for size, blocks in _PINNED_POOL["free"].items():
+        # (a snapshot: a result dropped while we are here returns its block through _pinned_return -- same thread, the lock is
+        #  re-entrant -- and may add a size to the dict)
+        for size, blocks in list(_PINNED_POOL["free"].items()):
             _PINNED_POOL["bytes"] -= size * len(blocks)
             blocks.clear()
+        _PINNED_POOL["lru"].clear()
 
 
 def _is_device_tensor(values):
@@ -521,11 +576,13 @@ def _flatten_for_device(values, dims):
     n_before = sum(1 for i in others if i < first)
 
     def unflatten(res2d, R):
+        # (NumPy arrays, or -- under results_on_device() -- torch CUDA tensors: views only, nothing moves)
+        moveaxis = np.moveaxis if isinstance(res2d, np.ndarray) else (lambda t, src, dst: t.movedim(src, dst))
         if layout == "TG":
             arr = res2d.reshape(others_shape + (R,))
         else:
-            arr = np.moveaxis(res2d.reshape((R,) + others_shape), 0, -1)
-        return np.moveaxis(arr, -1, n_before)
+            arr = moveaxis(res2d.reshape((R,) + others_shape), 0, -1)
+        return moveaxis(arr, -1, n_before)
 
     return X2, layout, others_shape, unflatten
 
@@ -588,6 +645,8 @@ def _host_replicas(plan, n_rows, row_bytes):
 
 
 DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins
+_DENSE_BUILD_BYTES_PER_ROW = 64      # device scratch of wagg_dense_create_from_segments while it builds (48 + 16 per row)
+_ENOMEM = -3                         # wagg.h WAGG_ENOMEM
 ENTRY_LIST_MAX_FILL = 0.10   # wagg_dense.hip SPMM_MAX_FILL: below it a scattered table is stored as entry lists
 
 
@@ -695,7 +754,9 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
             free_bytes, total_bytes = torch.cuda.mem_get_info()
             # keep the cache under its plan count and byte budget (what a sparse plan adds is a few MB)
             free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes, keep=_PLAN_CACHE_MAX - 1)
-        need = _dense_bytes(G, R, is_f32, nseg=len(cell_idx))
+        # the finished plan plus what the device-side build holds while it runs (csrc/wagg_build.h: 48 bytes of arena per
+        # table row -- the sort's key / value pairs and the uploaded table -- and 16 per distinct pair)
+        need = _dense_bytes(G, R, is_f32, nseg=len(cell_idx)) + _DENSE_BUILD_BYTES_PER_ROW * len(cell_idx)
 
         def dense_fits():
             # only now is the dense byte budget charged: cached plans can be given back (oldest first) before
@@ -710,13 +771,34 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
         # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
         # form: go to the dense-family form directly instead of building the sparse plan first just to
         # read its statistics
+        keep = bool(_host_devices())               # replicas on other devices are rebuilt from the table: keep it only then
+
+        def dense_plan():
+            # a build that runs out of device memory after all (another process took it meanwhile; the estimate was short)
+            # is not the caller's problem: cached plans go and it is tried once more, then the segment-table form serves
+            nonlocal free_bytes
+            if len(cell_idx) >= 2 ** 31:           # wagg_dense_create_from_segments: at most 2^31 - 1 rows
+                return None
+            for attempt in (0, 1):
+                try:
+                    return DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt, keep_recipe=keep)
+                except WaggError as e:
+                    if "(%d)" % _ENOMEM not in str(e):
+                        raise
+                    if attempt == 0:
+                        with _CACHE_LOCK:
+                            _evict_plans(0, keep=0)
+            return None
+
         if len(cell_idx) > 4 * DENSE_SWITCH * G and _wants_dense(float("inf"), G, layout) and dense_fits():
-            plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
-        else:
+            plan = dense_plan()
+        if plan is None:
             plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
-            if _wants_dense(plan.info["n_ucells"], G, layout) and dense_fits():
-                plan.close()
-                plan = DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
+            if _wants_dense(plan.info["n_ucells"], G, layout) and len(cell_idx) <= 4 * DENSE_SWITCH * G and dense_fits():
+                dense = dense_plan()
+                if dense is not None:
+                    plan.close()
+                    plan = dense
         plan._lease.acquire()
     finally:
         with _CACHE_LOCK:
@@ -1028,8 +1110,12 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                 exact.status()
             finally:
                 exact.close()
-        res = [unflatten(_to_host(o), len(uniq)) for o in outs]
-        if isinstance(plan, SparsePlan):
+        # results_on_device(): a device-resident field's result stays a torch CUDA tensor on the caller's stream -- no D2H
+        # copy (0.8 of the 1.0 ms of a c2-real call), no wait; the Dataset's variable holds the tensor like minixr holds
+        # device buffers on the input side.  (xarray cannot carry one: xarray callers always get host arrays.)
+        keep_dev = _device_results_wanted() and _is_device_tensor(X2) and not was_xr
+        res = [unflatten(o if keep_dev else _to_host(o), len(uniq)) for o in outs]
+        if isinstance(plan, SparsePlan) and not keep_dev:
             plan.status()                                        # a device-side failure must not pass silently
         rdims = _result_dims(dims, agglev)
 

@@ -40,6 +40,50 @@ struct EntryKeyGeom {
 
 struct BuildTimes { double upload_s = 0, device_s = 0, total_s = 0; };
 
+// One plan build = one BuildCtx: a stream of its own and ONE device arena for all of the build's scratch.
+//   * The stream is non-blocking: nothing of a build is ordered against the null stream or against the streams the process
+//     applies other plans on.  (Rounds 4 ran every build kernel on the null stream and called hipDeviceSynchronize() after
+//     every scan and sort pass -- each one a stop for every stream of the process.)  The host waits exactly where it reads
+//     something back (hipStreamSynchronize on this stream): the dropped-row note, the number of distinct pairs, the tile
+//     bitmap, the list lengths.
+//   * The arena is sized from the table (build_arena_bytes) and allocated once; scratch is taken from it with stack
+//     discipline (mark / release_to).  Reuse is safe without any wait because every kernel of the build runs on the one
+//     stream, in order.  Per-pass hipMalloc / hipFree pairs are gone: hipFree waits for the whole device.
+struct BuildCtx {
+    hipStream_t st = nullptr;
+    char *base = nullptr;
+    size_t cap = 0, top = 0, high = 0, peak = 0;      // scratch grows up from 0 to `top`; inputs sit at the far end, from `high` to `cap`
+    BuildCtx() = default;
+    BuildCtx(const BuildCtx &) = delete;
+    BuildCtx &operator=(const BuildCtx &) = delete;
+    hipError_t init(size_t arena_bytes);
+    void *take_bytes(size_t bytes);                   // 256-byte aligned; NULL when the arena is exhausted
+    template <typename T> T *take(size_t count) { return static_cast<T *>(take_bytes(count * sizeof(T))); }
+    size_t mark() const { return top; }
+    void release_to(size_t m) { top = m; }
+    // the far end: a build's INPUT (the uploaded table).  build_sorted_entries drops it as soon as the kernel that reads it
+    // is queued -- what is taken there afterwards runs behind that kernel on the one stream
+    void *take_input_bytes(size_t bytes);
+    template <typename T> T *take_input(size_t count) { return static_cast<T *>(take_input_bytes(count * sizeof(T))); }
+    void drop_inputs() { high = cap; }
+    hipError_t sync() const { return hipStreamSynchronize(st); }
+    ~BuildCtx();
+};
+#define WAGG_TAKE(ptr, ctx, T, count)                                                                        \
+    do {                                                                                                     \
+        (ptr) = (ctx).template take<T>((size_t)(count));                                                     \
+        if (!(ptr)) {                                                                                        \
+            wagg::set_error("%s:%d: build arena exhausted (%zu of %zu bytes in use)", __FILE__, __LINE__,    \
+                            (ctx).top, (ctx).cap);                                                           \
+            return WAGG_ENOMEM;                                                                              \
+        }                                                                                                    \
+    } while (0)
+
+// device scratch of build_sorted_entries + the uploaded table for a table of n rows (the coalesced output -- 16 bytes per
+// distinct pair -- and the plan itself are separate allocations): 32 n for the two key / value pairs of the sort, on top of
+// them the table (12 n + 8 (G + 1) as CSR, 16 n as COO), later replaced by the histograms and the run ranks
+size_t build_arena_bytes(int64_t n, int64_t G, int32_t R, bool csr);
+
 // the coalesced table on the device: n_u distinct (cell, region) pairs in key order
 struct SortedEntries {
     EntryKeyGeom geom;
@@ -49,15 +93,18 @@ struct SortedEntries {
     DevBuf<double> den;                               // [R]   sum of the weights of a region's pairs (aggregations.py:79)
 };
 
-// Inputs are DEVICE arrays.  Exactly one of cell_dev (COO) / rowptr_dev (CSR, G + 1 offsets) is given.  region < 0 and NaN
-// weights drop the row (S3, S4); an index outside the grid / the regions fails with WAGG_EINVAL (first bad row in the text).
-int build_sorted_entries(const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev, const double *w_dev,
-                         int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out);
+// Inputs are DEVICE arrays (valid on ctx.st).  Exactly one of cell_dev (COO) / rowptr_dev (CSR, G + 1 offsets) is given.
+// region < 0 and NaN weights drop the row (S3, S4); an index outside the grid / the regions fails with WAGG_EINVAL (first bad
+// row in the text).  Everything runs on ctx.st; on return the outputs are complete on that stream (not necessarily on the
+// host's clock: the caller keeps working on ctx.st or synchronises it).  Scratch comes from ctx's arena above its current mark
+// and is released before returning; the arena's input side (where the caller put the table) is dropped once the keys exist.
+int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev,
+                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out);
 
-// primitives (also used by the synthetic-table generator)
-int scan_u32_exclusive(uint32_t *data_dev, int64_t n, uint32_t *total_dev /* may be NULL */);
+// primitives (also used by the synthetic-table generator); scratch from the arena, released before returning
+int scan_u32_exclusive(BuildCtx &ctx, uint32_t *data_dev, int64_t n, uint32_t *total_dev /* may be NULL */);
 // stable LSD radix sort of (key, value) pairs on the low 8 * passes bits; the sorted pairs end in (keys, vals) -- the
 // alternates are scratch of the same size
-int radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes);
+int radix_sort_pairs(BuildCtx &ctx, uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes);
 
 }  // namespace wagg

@@ -4,13 +4,65 @@
 //
 // The reference's only weights type is a caller-supplied table (aggregations.py:64-73, :128-152); BASELINE configs[4]
 // calls it "sparse CSR weights (<= 1 % nnz)": 2.53e8 entries.  Rounds 1-3 sorted such a table on the host with two
-// single-threaded std::stable_sort passes; here the host only uploads it.
+// single-threaded std::stable_sort passes; here the host only uploads it.  Round 5: a build runs on a stream of its
+// own out of one arena (BuildCtx, wagg_build.h) and waits only where the host reads a count back.
 #include <utility>
 
 #include "wagg_build.h"
 #include "wagg_host.h"
 
 namespace wagg {
+
+hipError_t BuildCtx::init(size_t arena_bytes) {
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    cap = (arena_bytes + 255) / 256 * 256;
+    if (cap == 0) cap = 256;
+    top = peak = 0;
+    high = cap;
+    return hipMalloc((void **)&base, cap);
+}
+
+void *BuildCtx::take_bytes(size_t bytes) {
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (!base || need > high - top) return nullptr;
+    void *p = base + top;
+    top += need;
+    if (top + (cap - high) > peak) peak = top + (cap - high);
+    return p;
+}
+
+void *BuildCtx::take_input_bytes(size_t bytes) {
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (!base || need > high - top) return nullptr;
+    high -= need;
+    if (top + (cap - high) > peak) peak = top + (cap - high);
+    return base + high;
+}
+
+BuildCtx::~BuildCtx() {
+    // nothing of the build may still be running on the arena (error paths return without having waited)
+    if (st) note_cleanup(hipStreamSynchronize(st), "hipStreamSynchronize(build stream)");
+    if (base) note_cleanup(hipFree(base), "hipFree(build arena)");
+    if (st) note_cleanup(hipStreamDestroy(st), "hipStreamDestroy(build stream)");
+}
+
+constexpr int RS_TILE_ = 512 * 16;
+static size_t scan_scratch_bytes(int64_t n) { return ((size_t)((n + 2047) / 2048) * sizeof(uint32_t) + 255) / 256 * 256 + 256; }
+
+size_t build_arena_bytes(int64_t n, int64_t G, int32_t R, bool csr) {
+    const size_t a256 = 256;
+    auto up = [&](size_t b) { return (b + a256 - 1) / a256 * a256; };
+    const size_t pairs = 4 * up(sizeof(uint64_t) * (size_t)n);
+    const size_t table = csr ? up(sizeof(int64_t) * ((size_t)G + 1)) + up(sizeof(int32_t) * (size_t)n) + up(sizeof(double) * (size_t)n)
+                             : 2 * up(sizeof(int32_t) * (size_t)n) + up(sizeof(double) * (size_t)n);
+    const int64_t NB = (n + RS_TILE_ - 1) / RS_TILE_;
+    const size_t hist = up(sizeof(uint32_t) * 256 * (size_t)NB) + scan_scratch_bytes(256 * NB);
+    const size_t rank = up(sizeof(uint32_t) * (size_t)n) + scan_scratch_bytes(n) + 2 * a256;
+    const size_t after_keys = hist > rank ? hist : rank;
+    (void)R;
+    return pairs + (table > after_keys ? table : after_keys) + 16 * a256;
+}
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan of uint32 (three kernels: tile sums, one block over the sums, tiles again)
@@ -89,20 +141,21 @@ __global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(uint32_t *__rest
     }
 }
 
-int scan_u32_exclusive(uint32_t *data, int64_t n, uint32_t *total_dev) {
+int scan_u32_exclusive(BuildCtx &ctx, uint32_t *data, int64_t n, uint32_t *total_dev) {
     if (n <= 0) {
-        if (total_dev) WAGG_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), nullptr));
+        if (total_dev) WAGG_HIP(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), ctx.st));
         return WAGG_OK;
     }
     const int64_t m = (n + SC_TILE - 1) / SC_TILE;
     WAGG_REQUIRE(m < (int64_t)0x7fffffff, "scan too long");
-    DevBuf<uint32_t> sums;
-    WAGG_HIP(sums.alloc((size_t)m));
-    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, nullptr, (const uint32_t *)data, n, sums.p);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, nullptr, sums.p, m, total_dev);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, nullptr, data, n, (const uint32_t *)sums.p);
+    const size_t mk = ctx.mark();
+    uint32_t *sums;
+    WAGG_TAKE(sums, ctx, uint32_t, m);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, ctx.st, (const uint32_t *)data, n, sums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, ctx.st, sums, m, total_dev);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)m), dim3(SC_THREADS), 0, ctx.st, data, n, (const uint32_t *)sums);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipDeviceSynchronize());            // `sums` is freed on return
+    ctx.release_to(mk);                          // (whatever takes this place next runs behind these kernels on ctx.st)
     return WAGG_OK;
 }
 
@@ -114,6 +167,7 @@ int scan_u32_exclusive(uint32_t *data, int64_t n, uint32_t *total_dev) {
 // table -> scatter, where a pair's place is  scanned[digit][tile] + (same digit in lower waves of the tile) + (same digit
 // in earlier rounds of its wave) + (same digit in lower lanes of its round): input order is kept among equal digits.
 constexpr int RS_THREADS = 512, RS_WAVES = RS_THREADS / 64, RS_ROUNDS = 16, RS_TILE = RS_THREADS * RS_ROUNDS;
+static_assert(RS_TILE == RS_TILE_, "build_arena_bytes sizes the histograms by the sort tile");
 
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t *__restrict__ keys, int64_t n, int shift,
                                                              uint32_t *__restrict__ hist, int64_t NB) {
@@ -159,6 +213,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
     __syncthreads();
     const uint64_t below_mask = (1ull << lane) - 1ull;
+    // Rounds of a wave hand the running place of (wave, digit) on through cnt[wave][d]: every lane of round r reads it, the
+    // lowest peer of each digit then stores the new place, round r + 1 reads that.  The lanes are different threads of the
+    // memory model, so the hand-over is spelled out: relaxed wavefront-scope atomics for the accesses (nothing may be cached
+    // in a register or forwarded across rounds), a wave barrier between the reads and the store, and release / acquire
+    // fences at wavefront scope around the barrier that separates the store from the next round's reads.  The stable
+    // order of the sort -- and with it the bit-for-bit plan -- no longer rests on how a compiler schedules plain LDS code.
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const bool ok = wbase + 64 * r < n;
@@ -170,38 +230,45 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
+        uint32_t first = 0;
+        if (ok) first = __hip_atomic_load(&cnt[wave][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();           // every lane of the round holds its count before any lane replaces one
         if (ok) {
-            const uint32_t first = cnt[wave][d];   // the wave's LDS operations retire in order: every lane reads before the
-            const uint32_t at = first + (uint32_t)__popcll(peers & below_mask);      // lowest peer writes the new count
+            const uint32_t at = first + (uint32_t)__popcll(peers & below_mask);
             keys_out[at] = k[r];
             vals_out[at] = v[r];
-            if ((peers & below_mask) == 0) cnt[wave][d] = first + (uint32_t)__popcll(peers);
+            if ((peers & below_mask) == 0)
+                __hip_atomic_store(&cnt[wave][d], first + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-int radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes) {
+int radix_sort_pairs(BuildCtx &ctx, uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes) {
     if (n <= 1 || passes <= 0) return WAGG_OK;
     WAGG_REQUIRE(n < (int64_t)0x7fffffff, "too many entries to sort (%lld)", (long long)n);
     const int64_t NB = (n + RS_TILE - 1) / RS_TILE;
-    DevBuf<uint32_t> hist;
-    WAGG_HIP(hist.alloc((size_t)(256 * NB)));
+    const size_t mk = ctx.mark();
+    uint32_t *hist;
+    WAGG_TAKE(hist, ctx, uint32_t, 256 * NB);
     uint64_t *ks = keys, *vs = vals, *kd = keys_alt, *vd = vals_alt;
     for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, nullptr, (const uint64_t *)ks, n, 8 * p, hist.p, NB);
+        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, ctx.st, (const uint64_t *)ks, n, 8 * p, hist, NB);
         WAGG_HIP(hipGetLastError());
-        if (int rc = scan_u32_exclusive(hist.p, 256 * NB, nullptr)) return rc;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, nullptr, (const uint64_t *)ks, (const uint64_t *)vs, n,
-                           8 * p, (const uint32_t *)hist.p, NB, kd, vd);
+        if (int rc = scan_u32_exclusive(ctx, hist, 256 * NB, nullptr)) return rc;
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)NB), dim3(RS_THREADS), 0, ctx.st, (const uint64_t *)ks, (const uint64_t *)vs, n,
+                           8 * p, (const uint32_t *)hist, NB, kd, vd);
         WAGG_HIP(hipGetLastError());
         std::swap(ks, kd);
         std::swap(vs, vd);
     }
     if (ks != keys) {
-        WAGG_HIP(hipMemcpyAsync(keys, ks, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, nullptr));
-        WAGG_HIP(hipMemcpyAsync(vals, vs, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, nullptr));
+        WAGG_HIP(hipMemcpyAsync(keys, ks, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx.st));
+        WAGG_HIP(hipMemcpyAsync(vals, vs, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx.st));
     }
-    WAGG_HIP(hipDeviceSynchronize());            // `hist` is freed on return
+    ctx.release_to(mk);
     return WAGG_OK;
 }
 
@@ -295,8 +362,8 @@ __global__ __launch_bounds__(256) void den_kernel(const uint64_t *__restrict__ r
     if (lane == 0) den[r] = s;
 }
 
-int build_sorted_entries(const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev, const double *w_dev,
-                         int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out) {
+int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev,
+                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out) {
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     WAGG_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff, "table of %lld rows: at most 2^31 - 1", (long long)n);
     WAGG_REQUIRE((cell_dev != nullptr) != (rowptr_dev != nullptr) || n == 0, "exactly one of cell / rowptr");
@@ -305,55 +372,56 @@ int build_sorted_entries(const int32_t *cell_dev, const int64_t *rowptr_dev, con
     out->n_in = n;
     out->n_valid = out->n_u = 0;
     WAGG_HIP(out->den.alloc((size_t)R));
-    WAGG_HIP(hipMemset(out->den.p, 0, sizeof(double) * (size_t)R));
+    WAGG_HIP(hipMemsetAsync(out->den.p, 0, sizeof(double) * (size_t)R, ctx.st));
     if (n == 0) return WAGG_OK;
     const unsigned nblk = (unsigned)((n + 255) / 256);
-    DevBuf<uint64_t> ka, va, kb, vb;
-    DevBuf<unsigned long long> note;
-    WAGG_HIP(ka.alloc((size_t)n));
-    WAGG_HIP(va.alloc((size_t)n));
-    WAGG_HIP(kb.alloc((size_t)n));
-    WAGG_HIP(vb.alloc((size_t)n));
-    WAGG_HIP(note.alloc(2));
+    const size_t mk = ctx.mark();
+    uint64_t *ka, *va, *kb, *vb;
+    unsigned long long *note;
+    WAGG_TAKE(ka, ctx, uint64_t, n);
+    WAGG_TAKE(va, ctx, uint64_t, n);
+    WAGG_TAKE(kb, ctx, uint64_t, n);
+    WAGG_TAKE(vb, ctx, uint64_t, n);
+    WAGG_TAKE(note, ctx, unsigned long long, 2);
     {
         const unsigned long long init[2] = {~0ull, 0ull};
-        WAGG_HIP(staged_h2d(note.p, init, sizeof(init), nullptr));
+        WAGG_HIP(staged_h2d(note, init, sizeof(init), ctx.st));
     }
-    hipLaunchKernelGGL(keygen_kernel, dim3(nblk), dim3(256), 0, nullptr, cell_dev, rowptr_dev, region_dev, w_dev, n, G, R, geom,
-                       ka.p, va.p, note.p);
+    hipLaunchKernelGGL(keygen_kernel, dim3(nblk), dim3(256), 0, ctx.st, cell_dev, rowptr_dev, region_dev, w_dev, n, G, R, geom,
+                       ka, va, note);
     WAGG_HIP(hipGetLastError());
+    ctx.drop_inputs();                           // the table has been read once this kernel is through (stream order)
     unsigned long long noted[2];
-    WAGG_HIP(hipDeviceSynchronize());
-    WAGG_HIP(staged_d2h(noted, note.p, sizeof(noted)));
+    WAGG_HIP(staged_d2h(noted, note, sizeof(noted), ctx.st));      // (waits for the copy, hence for the kernel: the host reads here)
     WAGG_REQUIRE(noted[0] == ~0ull, "segment %llu out of range", noted[0]);
     const int64_t n_valid = n - (int64_t)noted[1];
     out->n_valid = n_valid;
-    if (int rc = radix_sort_pairs(ka.p, va.p, kb.p, vb.p, n, passes_for(geom.range()))) return rc;
-    if (n_valid == 0) return WAGG_OK;
+    if (int rc = radix_sort_pairs(ctx, ka, va, kb, vb, n, passes_for(geom.range()))) return rc;
+    if (n_valid == 0) { ctx.release_to(mk); return WAGG_OK; }
     // distinct pairs: rank of every run's head, then one sum per run
-    DevBuf<uint32_t> rank, total;
-    WAGG_HIP(rank.alloc((size_t)n_valid));
-    WAGG_HIP(total.alloc(1));
+    uint32_t *rank, *total;
+    WAGG_TAKE(rank, ctx, uint32_t, n_valid);
+    WAGG_TAKE(total, ctx, uint32_t, 1);
     const unsigned vblk = (unsigned)((n_valid + 255) / 256);
-    hipLaunchKernelGGL(heads_kernel, dim3(vblk), dim3(256), 0, nullptr, (const uint64_t *)ka.p, n_valid, rank.p);
+    hipLaunchKernelGGL(heads_kernel, dim3(vblk), dim3(256), 0, ctx.st, (const uint64_t *)ka, n_valid, rank);
     WAGG_HIP(hipGetLastError());
-    if (int rc = scan_u32_exclusive(rank.p, n_valid, total.p)) return rc;
+    if (int rc = scan_u32_exclusive(ctx, rank, n_valid, total)) return rc;
     uint32_t n_u32 = 0;
-    WAGG_HIP(staged_d2h(&n_u32, total.p, sizeof(n_u32)));
+    WAGG_HIP(staged_d2h(&n_u32, total, sizeof(n_u32), ctx.st));    // (the host sizes the output from it)
     const int64_t n_u = n_u32;
     out->n_u = n_u;
     WAGG_HIP(out->key.alloc((size_t)n_u));
     WAGG_HIP(out->w.alloc((size_t)n_u));
     // kb <- region of every distinct pair (the key of the denominator sort), vb <- a copy of the sums to sort along
-    hipLaunchKernelGGL(coalesce_kernel, dim3(vblk), dim3(256), 0, nullptr, (const uint64_t *)ka.p, (const uint64_t *)va.p, n_valid,
-                       (const uint32_t *)rank.p, out->key.p, out->w.p, kb.p, geom);
+    hipLaunchKernelGGL(coalesce_kernel, dim3(vblk), dim3(256), 0, ctx.st, (const uint64_t *)ka, (const uint64_t *)va, n_valid,
+                       (const uint32_t *)rank, out->key.p, out->w.p, kb, geom);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipMemcpyAsync(vb.p, out->w.p, sizeof(double) * (size_t)n_u, hipMemcpyDeviceToDevice, nullptr));
-    if (int rc = radix_sort_pairs(kb.p, vb.p, ka.p, va.p, n_u, passes_for((uint64_t)R))) return rc;
-    hipLaunchKernelGGL(den_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nullptr, (const uint64_t *)kb.p, (const uint64_t *)vb.p,
+    WAGG_HIP(hipMemcpyAsync(vb, out->w.p, sizeof(double) * (size_t)n_u, hipMemcpyDeviceToDevice, ctx.st));
+    if (int rc = radix_sort_pairs(ctx, kb, vb, ka, va, n_u, passes_for((uint64_t)R))) return rc;
+    hipLaunchKernelGGL(den_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ctx.st, (const uint64_t *)kb, (const uint64_t *)vb,
                        n_u, R, out->den.p);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipDeviceSynchronize());            // the scratch pairs are freed on return
+    ctx.release_to(mk);                          // (reused only by later work on ctx.st, i.e. behind den_kernel)
     return WAGG_OK;
 }
 
@@ -410,23 +478,24 @@ extern "C" int wagg_synth_table_csr(int64_t G, int32_t R, uint32_t seed, double 
     WAGG_REQUIRE(G > 0 && R > 0 && fill > 0.0 && fill <= 1.0, "bad arguments");
     WAGG_REQUIRE(rowptr_host != nullptr && nnz_out != nullptr, "NULL pointer");
     WAGG_REQUIRE((col_host == nullptr) == (val_host == nullptr), "col and val go together");
-    DevBuf<uint32_t> first, total;
-    WAGG_HIP(first.alloc((size_t)G));
-    WAGG_HIP(total.alloc(1));
-    hipLaunchKernelGGL((synth_csr_kernel<false>), dim3(256 * 32), dim3(256), 0, nullptr, G, R, seed, (float)fill, blocklocal, first.p,
+    BuildCtx ctx;
+    WAGG_HIP(ctx.init(sizeof(uint32_t) * (size_t)G + sizeof(int64_t) * ((size_t)G + 1) + scan_scratch_bytes(G) + 4096));
+    uint32_t *first, *total;
+    WAGG_TAKE(first, ctx, uint32_t, G);
+    WAGG_TAKE(total, ctx, uint32_t, 1);
+    hipLaunchKernelGGL((synth_csr_kernel<false>), dim3(256 * 32), dim3(256), 0, ctx.st, G, R, seed, (float)fill, blocklocal, first,
                        (const uint32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr);
     WAGG_HIP(hipGetLastError());
-    if (int rc = scan_u32_exclusive(first.p, G, total.p)) return rc;
+    if (int rc = scan_u32_exclusive(ctx, first, G, total)) return rc;
     uint32_t nnz = 0;
-    WAGG_HIP(staged_d2h(&nnz, total.p, sizeof(nnz)));
+    WAGG_HIP(staged_d2h(&nnz, total, sizeof(nnz), ctx.st));
     *nnz_out = nnz;
-    DevBuf<int64_t> rowptr;
-    WAGG_HIP(rowptr.alloc((size_t)G + 1));
-    hipLaunchKernelGGL(widen_rowptr_kernel, dim3((unsigned)((G + 256) / 256)), dim3(256), 0, nullptr, (const uint32_t *)first.p, G, nnz,
-                       rowptr.p);
+    int64_t *rowptr;
+    WAGG_TAKE(rowptr, ctx, int64_t, G + 1);
+    hipLaunchKernelGGL(widen_rowptr_kernel, dim3((unsigned)((G + 256) / 256)), dim3(256), 0, ctx.st, (const uint32_t *)first, G, nnz,
+                       rowptr);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipDeviceSynchronize());
-    WAGG_HIP(staged_d2h(rowptr_host, rowptr.p, sizeof(int64_t) * ((size_t)G + 1)));
+    WAGG_HIP(staged_d2h(rowptr_host, rowptr, sizeof(int64_t) * ((size_t)G + 1), ctx.st));
     if (!col_host) return WAGG_OK;
     WAGG_REQUIRE(capacity >= (int64_t)nnz, "capacity %lld below the table's %u entries", (long long)capacity, nnz);
     if (nnz == 0) return WAGG_OK;
@@ -434,10 +503,10 @@ extern "C" int wagg_synth_table_csr(int64_t G, int32_t R, uint32_t seed, double 
     DevBuf<double> val;
     WAGG_HIP(col.alloc(nnz));
     WAGG_HIP(val.alloc(nnz));
-    hipLaunchKernelGGL((synth_csr_kernel<true>), dim3(256 * 32), dim3(256), 0, nullptr, G, R, seed, (float)fill, blocklocal,
-                       (uint32_t *)nullptr, (const uint32_t *)first.p, col.p, val.p);
+    hipLaunchKernelGGL((synth_csr_kernel<true>), dim3(256 * 32), dim3(256), 0, ctx.st, G, R, seed, (float)fill, blocklocal,
+                       (uint32_t *)nullptr, (const uint32_t *)first, col.p, val.p);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipDeviceSynchronize());
+    WAGG_HIP(ctx.sync());
     if (int rc = copy_rows_to_host(col_host, col.p, 1, sizeof(int32_t) * (size_t)nnz, sizeof(int32_t) * (size_t)nnz, true)) return rc;
     return copy_rows_to_host(val_host, val.p, 1, sizeof(double) * (size_t)nnz, sizeof(double) * (size_t)nnz, true);
 }

@@ -1,6 +1,7 @@
 // Internal helpers shared by the libwagg translation units (gfx950 only; no other target).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -143,8 +144,24 @@ template <typename V, typename T> __device__ __forceinline__ V xform4(V v, T off
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per apply
 hipError_t allow_dynamic_lds(const void *kern, size_t bytes);
 
-// event ring behind wagg_profile_enable / wagg_profile_read (wagg_util.hip)
-void profile_mark(hipStream_t stream, bool begin);
+// event ring behind wagg_profile_enable / wagg_profile_read (wagg_util.hip).  profile_slot hands out the next pair of the
+// ring (false: profiling is off or the ring is full); launch_timed / launch_timed_ptr give that pair to hipExtLaunchKernel,
+// so the two events stamp the START and the END OF THE DISPATCH ITSELF.  (Rounds 1-4 recorded an event on either side of the
+// launch call: whatever the host did between the first record and the dispatch -- a page fault, a descheduled thread -- was
+// booked as kernel time.)
+bool profile_slot(hipEvent_t *start, hipEvent_t *stop);
+
+inline hipError_t launch_timed_ptr(bool timed, const void *kern, dim3 grid, dim3 block, void **args, size_t shmem, hipStream_t st) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (timed && profile_slot(&a, &b)) return hipExtLaunchKernel(kern, grid, block, args, shmem, st, a, b, 0);
+    return hipLaunchKernel(kern, grid, block, args, shmem, st);
+}
+template <typename... Args, typename F = void (*)(Args...)>
+inline void launch_timed(bool timed, F kern, dim3 grid, dim3 block, size_t shmem, hipStream_t st, Args... args) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (timed && profile_slot(&a, &b)) hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)shmem, st, a, b, 0u, args...);
+    else hipLaunchKernelGGL(kern, grid, block, shmem, st, args...);
+}
 
 // host <-> device copies of library- or caller-owned pageable memory never go through a runtime copy of the pageable
 // pointer (wagg_host.h says why): small ones pass through the library's page-locked staging pieces
@@ -168,10 +185,10 @@ struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime
         n = count;
         return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
     }
-    hipError_t upload(const std::vector<T> &h) {
+    hipError_t upload(const std::vector<T> &h, hipStream_t st = nullptr) {
         hipError_t e = alloc(h.size());
         if (e != hipSuccess || h.empty()) return e;
-        return staged_h2d(p, h.data(), h.size() * sizeof(T), nullptr);
+        return staged_h2d(p, h.data(), h.size() * sizeof(T), st);
     }
 };
 

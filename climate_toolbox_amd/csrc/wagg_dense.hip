@@ -574,12 +574,12 @@ static int dense_alloc(int64_t G, int32_t R, wagg_dense **out, int64_t stored_ti
     return WAGG_OK;
 }
 
-static int dense_den_to_host(wagg_dense *d) {
-    hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, nullptr,
+static int dense_den_to_host(wagg_dense *d, hipStream_t st = nullptr) {
+    hipLaunchKernelGGL(dense_den32_kernel, dim3((unsigned)((d->R + 255) / 256)), dim3(256), 0, st,
                        d->den64.p, d->den32.p, d->R);
     WAGG_HIP(hipGetLastError());
     d->den_host.resize((size_t)d->R);
-    WAGG_HIP(staged_d2h(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R));
+    WAGG_HIP(staged_d2h(d->den_host.data(), d->den64.p, sizeof(double) * (size_t)d->R, st));
     return WAGG_OK;
 }
 
@@ -601,7 +601,8 @@ static int dense_finish_den(wagg_dense *d) {
 }
 
 // stored-tile lists of the tile-sparse form from the sorted keys nt * n_kt + kt
-static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &tiles, std::vector<int32_t> *nt_out = nullptr) {
+static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &tiles, std::vector<int32_t> *nt_out = nullptr,
+                                  hipStream_t st = nullptr) {
     constexpr int TS = wagg_dense::TS;
     std::vector<int32_t> kt(tiles.size() + 2, 0), ntv(tiles.size() + 1, 0);
     std::vector<int32_t> off((size_t)wagg_dense::off_table(2 * TS, d->n_nt), 0);
@@ -619,16 +620,45 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
             for (int k = 0; k <= ts; ++k) tab[(size_t)nt * (ts + 1) + k] = (int32_t)(b + len * k / ts);
         }
     }
-    hipError_t e = d->tile_kt.upload(kt);
-    if (e == hipSuccess) e = d->tile_off.upload(off);
+    hipError_t e = d->tile_kt.upload(kt, st);
+    if (e == hipSuccess) e = d->tile_off.upload(off, st);
     if (nt_out) *nt_out = ntv;
     return e;
 }
 
-// Below this share of non-zeros a W whose tiles are (almost) all occupied goes to the entry-list form
-// (wagg_spmm.hip, fp32 and fp64): it does 2*T*nnz flops on the vector ALU where the full MFMA form does 2*T*G*R at
-// ~90 % of the matrix peak, so the break-even is well above this; 10 % keeps a safety margin.
+// Generated tables (wagg_dense_create_synth*): below this share of non-zeros a scattered W goes to the entry-list form.
 constexpr double SPMM_MAX_FILL = 0.10;
+
+// ---- which form a caller's table takes (wagg_dense_create_from_csr* / _from_segments*) ---------------------------------
+// The reference knows one weights type (aggregations.py:64-73) and so does the caller here: the form is the library's
+// business.  It is chosen by the estimated time per row of X of the three forms, each priced at the rate its kernel was
+// MEASURED at on the c5 grid (tools/form_crossover.py -> profiles/r05_form_crossover.txt; DESIGN.md (b) has the table):
+//   full matrix     2 G R flop                          at the full-form MFMA rate
+//   tile-sparse     2 x (stored tiles x BK x 256) flop  at the tile-sparse MFMA rate (a little lower: the tile list is walked)
+//   entry lists     2 nnz flop at the entry-loop rate, but never faster than the X stream that every one of the n_rb region
+//                   blocks pulls through the LDS-DMA path (b G n_rb bytes per row at its ingest rate)
+// Rates in flop/s and byte/s; fp32 / fp64.
+struct FormRates { double full, tiled, entries, dma; };
+constexpr FormRates FORM_RATES_F32 = {145e12, 129e12, 24.8e12, 10.1e12};
+constexpr FormRates FORM_RATES_F64 = {67.7e12, 67.7e12, 10.9e12, 10.1e12};
+
+struct FormCost { double t_full, t_tiled, t_entries; };
+// seconds per row of X.  The MFMA forms multiply whole (BK x 256) tiles, padding included; the entry-list kernel walks
+// `walked` entries (spmm_list_cost: 16 x the longest per-wave list of every item, in whole groups).
+static FormCost table_form_cost(int64_t G, int elem_bytes, int64_t n_tiles_stored, int64_t n_tiles_all, int64_t walked, int n_rb) {
+    const FormRates &rt = elem_bytes == 8 ? FORM_RATES_F64 : FORM_RATES_F32;
+    const double tile_flop = 2.0 * (128.0 / elem_bytes) * 256.0;        // BK = 32 / 16 cells x 256 regions
+    FormCost c;
+    c.t_full = tile_flop * (double)n_tiles_all / rt.full;
+    c.t_tiled = tile_flop * (double)n_tiles_stored / rt.tiled;
+    const double t_loop = 2.0 * (double)walked / rt.entries, t_stream = (double)elem_bytes * (double)G * (double)n_rb / rt.dma;
+    c.t_entries = t_loop > t_stream ? t_loop : t_stream;
+    return c;
+}
+static void pick_table_form(const FormCost &c, bool *tiled, bool *entries) {
+    *entries = c.t_entries < c.t_full && c.t_entries < c.t_tiled;
+    *tiled = !*entries && c.t_tiled < c.t_full;
+}
 
 static int pick_ksplit(int64_t items, int n_kt) {
     int best = 8;
@@ -778,11 +808,12 @@ static double wall_s() { return std::chrono::duration<double>(std::chrono::stead
 // large arrays are page-locked in place for the copy).
 template <typename T>
 static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, const int32_t *region_code, const double *w_eff,
-                             int64_t n, int64_t G, int32_t R, wagg_dense **out) {
+                             int64_t n, int64_t G, int32_t R, int flags, wagg_dense **out) {
     constexpr int BK = DT<T>::BK;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
+    WAGG_REQUIRE(flags >= WAGG_DENSE_FORM_AUTO && flags <= WAGG_DENSE_FORCE_ENTRIES, "unknown form flag %d", flags);
     if (rowptr) {
         WAGG_REQUIRE(rowptr[0] == 0, "rowptr[0] must be 0");
         for (int64_t g = 0; g < G; ++g) WAGG_REQUIRE(rowptr[g] <= rowptr[g + 1], "rowptr decreases at row %lld", (long long)g);
@@ -795,36 +826,50 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     spmm_geometry(G, R, geo);
     EntryKeyGeom kg;
     kg.rw = geo.rw; kg.n_rb = geo.n_rb; kg.n_chunks = geo.n_chunks;
+    const int n_kt = (int)((G + BK - 1) / BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
+    const int64_t n_tiles_all = (int64_t)n_kt * n_nt, n_words = (n_tiles_all + 31) / 32;
+    const int64_t n_buckets = (int64_t)geo.n_rb * geo.n_chunks * SP_WAVES;
+    // one stream and one arena for the whole build (wagg_build.h): the sort's scratch first, and once that is released the
+    // tile bitmap with its ranks or the list bounds of the entry-list packing
+    const size_t after_sort = 2 * (sizeof(uint32_t) * (size_t)n_words + 512) + 2 * (sizeof(int32_t) * ((size_t)n_buckets + 1) + 512) + 4096;
+    size_t arena = build_arena_bytes(n, G, R, rowptr != nullptr);
+    if (arena < after_sort) arena = after_sort;
+    BuildCtx ctx;
+    {
+        const hipError_t e = ctx.init(arena);
+        if (e != hipSuccess) {
+            set_error("plan build: %.2f GB of device scratch for a table of %lld rows -> %s", (double)arena * 1e-9, (long long)n, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? WAGG_ENOMEM : WAGG_EHIP;
+        }
+    }
     SortedEntries se;
     double t_up = 0.0;
     {
-        DevBuf<int32_t> dcell, dreg;
-        DevBuf<int64_t> drow;
-        DevBuf<double> dw;
+        // the table goes to the input side of the arena and is dropped by build_sorted_entries once the keys exist
+        int32_t *dcell = nullptr, *dreg = nullptr;
+        int64_t *drow = nullptr;
+        double *dw = nullptr;
         if (n > 0) {
-            if (rowptr) WAGG_HIP(drow.alloc((size_t)G + 1)); else WAGG_HIP(dcell.alloc((size_t)n));
-            WAGG_HIP(dreg.alloc((size_t)n));
-            WAGG_HIP(dw.alloc((size_t)n));
-            int rc = rowptr ? copy_to_device(drow.p, rowptr, sizeof(int64_t) * ((size_t)G + 1), true)
-                            : copy_to_device(dcell.p, cell_idx, sizeof(int32_t) * (size_t)n, true);
-            if (rc == WAGG_OK) rc = copy_to_device(dreg.p, region_code, sizeof(int32_t) * (size_t)n, true);
-            if (rc == WAGG_OK) rc = copy_to_device(dw.p, w_eff, sizeof(double) * (size_t)n, true);
+            if (rowptr) { drow = ctx.take_input<int64_t>((size_t)G + 1); } else { dcell = ctx.take_input<int32_t>((size_t)n); }
+            dreg = ctx.take_input<int32_t>((size_t)n);
+            dw = ctx.take_input<double>((size_t)n);
+            if (!(drow || dcell) || !dreg || !dw) { set_error("build arena too small for the table"); return WAGG_ENOMEM; }
+            int rc = rowptr ? copy_to_device(drow, rowptr, sizeof(int64_t) * ((size_t)G + 1), true, ctx.st)
+                            : copy_to_device(dcell, cell_idx, sizeof(int32_t) * (size_t)n, true, ctx.st);
+            if (rc == WAGG_OK) rc = copy_to_device(dreg, region_code, sizeof(int32_t) * (size_t)n, true, ctx.st);
+            if (rc == WAGG_OK) rc = copy_to_device(dw, w_eff, sizeof(double) * (size_t)n, true, ctx.st);
             if (rc != WAGG_OK) return rc;
         }
         t_up = wall_s() - t0;
-        if (int rc = build_sorted_entries(n > 0 && !rowptr ? dcell.p : nullptr, n > 0 && rowptr ? drow.p : nullptr, dreg.p, dw.p, n, G, R,
-                                          kg, &se))
-            return rc;
-    }   // the uploaded table is released here
+        if (int rc = build_sorted_entries(ctx, dcell, drow, dreg, dw, n, G, R, kg, &se)) return rc;
+    }
     // which tiles of W hold anything?  Few -> tile-sparse form; (almost) all but few pairs in them -> entry lists
-    const int n_kt = (int)((G + BK - 1) / BK), n_nt = (int)(((int64_t)R + D_BN - 1) / D_BN);
-    const int64_t n_tiles_all = (int64_t)n_kt * n_nt, n_words = (n_tiles_all + 31) / 32;
-    DevBuf<uint32_t> bitmap, word_rank;
-    WAGG_HIP(bitmap.alloc((size_t)n_words));
-    WAGG_HIP(hipMemset(bitmap.p, 0, sizeof(uint32_t) * (size_t)n_words));
+    uint32_t *bitmap, *word_rank = nullptr;
+    WAGG_TAKE(bitmap, ctx, uint32_t, n_words);
+    WAGG_HIP(hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * (size_t)n_words, ctx.st));
     const unsigned nblk = (unsigned)((se.n_u + 255) / 256);
     if (se.n_u > 0) {
-        hipLaunchKernelGGL((table_tiles_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, se.n_u, kg, n_kt, bitmap.p);
+        hipLaunchKernelGGL((table_tiles_kernel<T>), dim3(nblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, se.n_u, kg, n_kt, bitmap);
         WAGG_HIP(hipGetLastError());
     }
     std::vector<uint32_t> hbits, hrank;
@@ -832,46 +877,61 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     try {
         hbits.resize((size_t)n_words);
         hrank.resize((size_t)n_words);
-        WAGG_HIP(hipDeviceSynchronize());
-        WAGG_HIP(staged_d2h(hbits.data(), bitmap.p, sizeof(uint32_t) * hbits.size()));
+        WAGG_HIP(staged_d2h(hbits.data(), bitmap, sizeof(uint32_t) * hbits.size(), ctx.st));     // (the host picks the form from it)
         int64_t cnt = 0;
         for (int64_t i = 0; i < n_words; ++i) { hrank[(size_t)i] = (uint32_t)cnt; cnt += __builtin_popcount(hbits[(size_t)i]); }
         tiles.reserve((size_t)cnt);
         for (int64_t i = 0; i < n_words; ++i)
             for (uint32_t m = hbits[(size_t)i]; m; m &= m - 1) tiles.push_back(i * 32 + __builtin_ctz(m));
     } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
-    bool tiled = (double)tiles.size() < 0.5 * (double)n_tiles_all;
+    // the form: measured crossovers (tools/form_crossover.py); a WAGG_DENSE_FORCE_* flag overrides the choice
+    const double fill_all = (double)se.n_u / ((double)G * (double)R);
+    int64_t walked = 0;
+    if (se.n_u > 0) { if (int rc = spmm_list_cost(ctx, se, &walked)) return rc; }
+    const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb);
+    bool tiled, entries;
+    pick_table_form(cost, &tiled, &entries);
+    if (flags == WAGG_DENSE_FORCE_FULL) { tiled = false; entries = false; }
+    else if (flags == WAGG_DENSE_FORCE_TILES) { tiled = true; entries = false; }
+    else if (flags == WAGG_DENSE_FORCE_ENTRIES) { tiled = false; entries = true; }
 #ifdef WAGG_DIAG
-    if (getenv("WAGG_DENSE_NO_TILED")) tiled = false;
+    if (getenv("WAGG_DENSE_NO_TILED") && tiled) { tiled = false; entries = fill_all < SPMM_MAX_FILL; }
+#else
+    (void)fill_all;
 #endif
-    const bool entries = !tiled && (double)se.n_u < SPMM_MAX_FILL * (double)G * (double)R;
     int rc = dense_alloc<T>(G, R, out, tiled ? (int64_t)tiles.size() : -1, entries);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
-    auto fail = [&](int code) { delete d; *out = nullptr; return code; };
+    auto fail = [&](int code) { (void)ctx.sync(); delete d; *out = nullptr; return code; };
     if (entries) {
-        rc = spmm_build_from_sorted<T>(d, se);
+        ctx.release_to(0);                            // (the bitmap has been read; the list bounds take its place, in stream order)
+        rc = spmm_build_from_sorted<T>(ctx, d, se);
         if (rc != WAGG_OK) return fail(rc);
     } else {
-        hipError_t e = hipMemset(d->W.p, 0, 16 * (size_t)d->w_slots());
-        if (e == hipSuccess && tiled) e = dense_set_tiles(d, tiles);
-        if (e == hipSuccess && tiled) e = word_rank.upload(hrank);
+        hipError_t e = hipMemsetAsync(d->W.p, 0, 16 * (size_t)d->w_slots(), ctx.st);
+        if (e == hipSuccess && tiled) e = dense_set_tiles(d, tiles, nullptr, ctx.st);
+        if (e == hipSuccess && tiled) {
+            word_rank = ctx.take<uint32_t>((size_t)n_words);
+            e = word_rank ? staged_h2d(word_rank, hrank.data(), sizeof(uint32_t) * hrank.size(), ctx.st) : hipErrorOutOfMemory;
+        }
         if (e == hipSuccess && se.n_u > 0) {
-            hipLaunchKernelGGL((table_scatter_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, (const double *)se.w.p,
-                               se.n_u, kg, n_kt, (const uint32_t *)bitmap.p, tiled ? (const uint32_t *)word_rank.p : (const uint32_t *)nullptr,
-                               reinterpret_cast<T *>(d->W.p));
+            hipLaunchKernelGGL((table_scatter_kernel<T>), dim3(nblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, (const double *)se.w.p,
+                               se.n_u, kg, n_kt, (const uint32_t *)bitmap, (const uint32_t *)word_rank, reinterpret_cast<T *>(d->W.p));
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) { set_error("densify: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
     }
     // denominators from the fp64 sums of the table (aggregations.py:79), not from the stored (rounded) weights
-    hipError_t e = hipMemcpy(d->den64.p, se.den.p, sizeof(double) * (size_t)R, hipMemcpyDeviceToDevice);
+    hipError_t e = hipMemcpyAsync(d->den64.p, se.den.p, sizeof(double) * (size_t)R, hipMemcpyDeviceToDevice, ctx.st);
     if (e != hipSuccess) { set_error("densify den: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
-    rc = dense_den_to_host(d);
+    rc = dense_den_to_host(d, ctx.st);
     if (rc != WAGG_OK) return fail(rc);
+    e = ctx.sync();                                   // the plan is complete before anyone applies it on another stream
+    if (e != hipSuccess) { set_error("plan build: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
     if (entries) d->sp.nnz = se.n_u;
     d->nnz_table = se.n_u;
+    d->est_row_s[0] = cost.t_full; d->est_row_s[1] = cost.t_tiled; d->est_row_s[2] = cost.t_entries;
+    d->walked_entries = walked;
     d->build.upload_s = t_up;
     d->build.total_s = wall_s() - t0;
     d->build.device_s = d->build.total_s - t_up;
@@ -930,6 +990,19 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     WAGG_REQUIRE(ldx >= d->G && ldo >= d->R, "ldx/ldo too small");
     WAGG_REQUIRE(ksplit >= 0 && ksplit % 8 == 0, "ksplit must be 0 or a multiple of 8");
     if (d->spmm) return spmm_apply<T>(d, X_dev, Tn, ldx, xf, out_dev, ldo, (hipStream_t)stream);
+    // Long batches (ensemble x time rows of a small grid: 50 members x 30 years = 547,500 rows) go through in groups of
+    // whole row blocks: the reduce kernel's grid has one y block per row (<= 65,535), and the packed copy of X and the
+    // partial slabs are sized by the rows of one launch.  Same stream, same workspaces, one group after the other.
+    constexpr int64_t ROWS_MAX = (int64_t)(65535 / (DT<T>::MT_MAX * 16)) * (DT<T>::MT_MAX * 16);
+    if (Tn > ROWS_MAX) {
+        for (int64_t t0 = 0; t0 < Tn; t0 += ROWS_MAX) {
+            PackXfT<T> xg = xf;
+            if (xg.X2) xg.X2 += t0 * ldx;
+            const int64_t rows = Tn - t0 < ROWS_MAX ? Tn - t0 : ROWS_MAX;
+            if (int rc = dense_apply<T>(d, X_dev + t0 * ldx, rows, ldx, xg, out_dev + t0 * ldo, ldo, ksplit, stream)) return rc;
+        }
+        return WAGG_OK;
+    }
     const int n_nt = d->n_nt, n_kt = d->n_kt;
     // row blocks: as few as possible (<= MT_MAX x 16 rows each), evenly filled, 16 MT rows with MT from the
     // instantiated set -- fp32: T = 365 -> one block of 23 x 16; T = 1369 -> four of 22 x 16; T = 31 -> 2 x 16
@@ -961,7 +1034,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     }
     const int kt_per_slice = (n_kt + S - 1) / S;
     const int64_t nblk = (int64_t)n_nt * n_mb * S;
-    WAGG_REQUIRE(nblk < (int64_t)0x7fffffff && Tn <= 65535, "grid too large");
+    WAGG_REQUIRE(nblk < (int64_t)0x7fffffff, "grid too large");
     const size_t need = (size_t)n_nt * n_mb * S * bm * D_BN * (sizeof(T) / 4);     // DevBuf<float>: 4-byte units
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
     const int64_t x_slots = (int64_t)n_mb * n_kt * bm * 8;
@@ -1031,9 +1104,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
         WAGG_HIP(hipMemsetAsync(d->nonfinite.p, 0, sizeof(int), st));
         const int *no_gate = nullptr;
         void *args_rm[] = {&X_dev, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &no_gate};
-        profile_mark(st, true);
-        WAGG_HIP(hipLaunchKernel(kern_rm, dim3((unsigned)nblk), dim3(D_THREADS), args_rm, shmem, st));
-        profile_mark(st, false);
+        WAGG_HIP(launch_timed_ptr(true, kern_rm, dim3((unsigned)nblk), dim3(D_THREADS), args_rm, shmem, st));
         hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
                            out_dev, ldo, d->nonfinite.p, (const int *)nullptr, d->inf_dev + 1);
         WAGG_HIP(hipGetLastError());
@@ -1042,9 +1113,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
                        aligned, reinterpret_cast<vec_t *>(d->xp.p), xf, d->inf_dev, gate);
     WAGG_HIP(hipGetLastError());
     void *args[] = {&xp, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &gate};
-    if (!rm) profile_mark(st, true);
-    WAGG_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
-    if (!rm) profile_mark(st, false);
+    WAGG_HIP(launch_timed_ptr(!rm, kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
     hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
                        out_dev, ldo, (int *)nullptr, gate, (int *)nullptr);
     WAGG_HIP(hipGetLastError());
@@ -1093,26 +1162,26 @@ extern "C" int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32
 }
 extern "C" int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                                const double *w_eff, int64_t nseg, int64_t G, int32_t R,
-                                               wagg_dense **out) {
-    return wagg::create_from_table<float>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, out);
+                                               int flags, wagg_dense **out) {
+    return wagg::create_from_table<float>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, flags, out);
 }
 extern "C" int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
                                                    const double *w_eff, int64_t nseg, int64_t G, int32_t R,
-                                                   wagg_dense **out) {
-    return wagg::create_from_table<double>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, out);
+                                                   int flags, wagg_dense **out) {
+    return wagg::create_from_table<double>(cell_idx, nullptr, region_code, w_eff, nseg, G, R, flags, out);
 }
 
 extern "C" int wagg_dense_create_from_csr(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
-                                          wagg_dense **out) {
+                                          int flags, wagg_dense **out) {
     using namespace wagg;
     WAGG_REQUIRE(rowptr != nullptr, "rowptr is NULL");
-    return create_from_table<float>(nullptr, rowptr, col, val, 0, G, R, out);
+    return create_from_table<float>(nullptr, rowptr, col, val, 0, G, R, flags, out);
 }
 extern "C" int wagg_dense_create_from_csr_f64(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
-                                              wagg_dense **out) {
+                                              int flags, wagg_dense **out) {
     using namespace wagg;
     WAGG_REQUIRE(rowptr != nullptr, "rowptr is NULL");
-    return create_from_table<double>(nullptr, rowptr, col, val, 0, G, R, out);
+    return create_from_table<double>(nullptr, rowptr, col, val, 0, G, R, flags, out);
 }
 
 extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
@@ -1126,6 +1195,8 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     info->nnz = d->spmm ? d->sp.nnz : d->nnz_table;
     info->build_s = d->build.total_s;
     info->build_upload_s = d->build.upload_s;
+    for (int k = 0; k < 3; ++k) info->est_row_s[k] = d->est_row_s[k];
+    info->walked_entries = d->walked_entries;
     return WAGG_OK;
 }
 

@@ -98,6 +98,8 @@ struct wagg_dense {
     wagg::DevBuf<int> nonfinite;
     int64_t nnz_table = -1;            // distinct (cell, region) pairs of the caller's table (constructors that take one)
     wagg::BuildTimes build;            // constructors that take a caller's table: where the seconds went
+    double est_row_s[3] = {0, 0, 0};   // ... and what the form choice went by (seconds per row of X: full, tiles, entries)
+    int64_t walked_entries = 0;
     ~wagg_dense() { if (inf_host) wagg::note_cleanup(hipHostFree(inf_host), "hipHostFree(inf note)"); }
 };
 
@@ -105,7 +107,8 @@ namespace wagg {
 // wagg_spmm.hip
 template <typename T> int spmm_build_synth(wagg_dense *d, uint32_t seed, double fill);
 void spmm_geometry(int64_t G, int32_t R, SpmmPlan &sp);
-template <typename T> int spmm_build_from_sorted(wagg_dense *d, const SortedEntries &se);
+template <typename T> int spmm_build_from_sorted(BuildCtx &ctx, wagg_dense *d, const SortedEntries &se);
+int spmm_list_cost(BuildCtx &ctx, const SortedEntries &se, int64_t *walked_entries);
 template <typename T> int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out,
                                      int64_t ldo, hipStream_t stream);
 // wagg_dense.hip

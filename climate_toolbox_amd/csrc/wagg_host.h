@@ -106,8 +106,9 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, int64_t G, T *out
 }
 
 // blocking host -> device copy of a whole buffer (plan uploads, the whole-field forms): staged, or in place under a
-// page-lock of its own for large buffers
-int copy_to_device(void *dst_dev, const void *src_host, size_t bytes, bool pin);
+// page-lock of its own for large buffers.  `st`: the stream the copy is queued on and waited for (the null stream by default;
+// a plan build passes its own so that the copy is not ordered against the null stream's work)
+int copy_to_device(void *dst_dev, const void *src_host, size_t bytes, bool pin, hipStream_t st = nullptr);
 // device (rows x ld, same pitch) -> pitched host array: only the `cols` used elements of every row are written
 int copy_rows_to_host(void *dst_host, const void *src_dev, int64_t rows, size_t ld_bytes, size_t row_bytes, bool pin);
 

@@ -156,16 +156,24 @@ hipError_t staged_d2h_rows(void *dst_host, const void *src_dev, int64_t rows, si
     return hipSuccess;
 }
 
-int copy_to_device(void *dst_dev, const void *src_host, size_t bytes, bool pin) {
+int copy_to_device(void *dst_dev, const void *src_host, size_t bytes, bool pin, hipStream_t st) {
     if (bytes == 0) return WAGG_OK;
     HostPin lock;
     if (pin && lock.acquire(src_host, bytes, false)) {
-        WAGG_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));       // from page-locked memory: one DMA
+        // from page-locked memory: one DMA, waited for before the lock goes
+        hipError_t e = st ? hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st)
+                          : hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess && st) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            (void)lock.release();
+            set_error("%s:%d: host -> device copy of %zu bytes -> %s", __FILE__, __LINE__, bytes, hipGetErrorString(e));
+            return WAGG_EHIP;
+        }
         g_host_stats.direct_h2d_bytes += (int64_t)bytes;
         WAGG_HIP(lock.release());
         return WAGG_OK;
     }
-    WAGG_HIP(staged_h2d(dst_dev, src_host, bytes, nullptr));
+    WAGG_HIP(staged_h2d(dst_dev, src_host, bytes, st));
     return WAGG_OK;
 }
 

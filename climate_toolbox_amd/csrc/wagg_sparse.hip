@@ -8,16 +8,17 @@
 //     along 8-row latitude bands, pack neighbouring regions into GROUPS whose union of cells is at
 //     most 64 aligned 4-cell quads (UC = 256 cell slots: one LDS "chunk", one 16-byte load per
 //     quad and timestep); regions larger than a chunk become "giant" groups that walk several.
-//   * sparse_lc_kernel     fp32, (time, gridcell) data, single-chunk groups: 8 loader waves stream
-//                          items into a double-buffered LDS image, 4 consumer waves reduce them on
-//                          the matrix cores (up to four fused powers of the data per pass).
+//   * sparse_lcv_kernel    fp32 and fp64, either layout, single-chunk groups (the production path): 8 loader waves
+//                          stream whole 128-byte lines into a double-buffered, swizzled LDS image, 8 consumer waves
+//                          reduce it on the vector ALU (up to four fused powers / degree-day thresholds per pass).
 //   * sparse_stream_kernel fp64 (and fp32 on request): persistent, software-pipelined, reduction by
 //                          v_readlane-broadcast segment lists.
 //   * sparse_gather_kernel the chunk-walking form: giant groups, (gridcell, time) data, two-field
 //                          degree-day transform (up to four thresholds per pass).
 //   * transpose / fill kernels for the (time, region) result layout and regions without rows.
 //
-// Common to all: the t-major LDS image xs[t][u] (row stride 260 elements), NaN products count 0
+// (The round-1/2 kernel with MFMA consumers, sparse_lc_kernel, is in wagg_sparse_diag.hip: diagnostic build only.)
+// Common to all: a t-major LDS image of the item (swizzled or padded rows), NaN products count 0
 // (S6), the division by den[r] (aggregations.py:79-80) is fused, results are stored once, no
 // atomics anywhere: bitwise reproducible.  DESIGN.md section (d) has the measurements behind the
 // shapes chosen here.
@@ -31,136 +32,10 @@
 #include <numeric>
 #include <utility>
 
-#include "wagg_host.h"
+#include "wagg_sparse_int.h"
 
 namespace wagg {
 
-// Diagnostic knobs (ablation switches, phase stamps) exist only in the -DWAGG_DIAG build
-// (`make diag` -> libwagg_diag.so, used by tools/*_ablate.sh); the production library reads no
-// environment variable on any path.
-#ifdef WAGG_DIAG
-static inline int diag_env(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
-static inline bool diag_set(const char *name) { return getenv(name) != nullptr; }
-#else
-static inline constexpr int diag_env(const char *) { return 0; }
-static inline constexpr bool diag_set(const char *) { return false; }
-#endif
-
-constexpr int UC = 256;      // cell slots per LDS chunk == workgroup size
-constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of a wave)
-[[maybe_unused]] constexpr int UROW = UC + 4; // LDS row stride in elements (t-major image, 16-byte aligned rows): fp32, 260 dwords = 4 (mod 64)
-// the same for a type: fp64 rows of UC + 2 doubles are 516 dwords = 4 (mod 64) as well (UC + 4 doubles = 8 (mod 64) made a
-// lane = timestep column read 4-way conflicted: VERDICT r2 item 5); still 16-byte aligned for the vector stores
-template <typename T> constexpr int urow() { return sizeof(T) == 8 ? UC + 2 : UC + 4; }
-constexpr int RG_MAX = 127;  // regions per group
-constexpr int SEG_MAX = 512; // segments per chunk staged in LDS
-constexpr int SEG_LAST = 0x8000;   // flag bit in a segment's local cell index: last segment of its entry
-constexpr int SEG_UMASK = 0x7fff;
-constexpr int NWAVE = 4;      // waves of the chunk-walking kernel (256 threads)
-constexpr int SWAVE = 8;      // waves of the persistent stream kernel (512 threads)
-constexpr int STHREADS = SWAVE * 64;
-
-struct SparsePlanDev {
-    DevBuf<int32_t> grp_chunk_begin, grp_giant;   // [n_groups+1], [n_groups]
-    DevBuf<int32_t> chunk_u_begin, chunk_e_begin; // [n_chunks+1]
-    DevBuf<int32_t> ucell;                        // [n_ucells]
-    DevBuf<int32_t> ent_region, ent_seg_begin;    // [n_ent], [n_ent+1]
-    DevBuf<int32_t> seg_u;                        // [nnz]
-    DevBuf<float> seg_w32;
-    DevBuf<double> seg_w64;
-    DevBuf<float> den32;
-    DevBuf<double> den64;
-    DevBuf<int32_t> empty_regions;
-    DevBuf<int32_t> chunk_desc;
-    DevBuf<float> ent_den32;
-    DevBuf<double> ent_den64;
-    int g0_normal = 0, c0_normal = 0;
-    // whole-line plan: an entry is a (chunk, region) PARTIAL sum, ent_region its row in the partial buffer;
-    // region r is the sum of rows part_begin[r] .. part_begin[r + 1] - 1 of the partial buffer, divided by den[r]
-    DevBuf<int32_t> part_begin;
-    int64_t n_part = 0;
-    int64_t n_groups = 0, n_empty = 0;          // groups of this chunking; regions without any kept row
-};
-
-}  // namespace wagg
-
-struct wagg_plan {
-    wagg_plan_info info{};
-    std::vector<double> den_host;
-    wagg::SparsePlanDev d;        // region-shaped chunks: every kernel, every layout and data type
-    wagg::SparsePlanDev dl;       // whole-line chunks (has_lines): 8 lines x 32 cells, the fp32 (time, gridcell) loader/consumer
-    bool has_lines = false;       // kernel, which is bound by line requests
-    wagg::SparsePlanDev dl64;     // the same for fp64 data: 8 lines x 16 cells (a line = 128 bytes of a row in both)
-    bool has_lines64 = false;
-    wagg::SparsePlanDev dl64e;    // 4 lines x 16 cells: fp64 degree days (both fields of a 64-cell chunk fill one image row)
-    bool has_lines64e = false;
-    int device = 0;
-    int ncu = 256;                 // compute units of `device` (read once, at plan creation)
-    int flags = 0;                 // WAGG_PLAN_* kernel-form switches, fixed at plan creation
-    // set by a kernel whose consumer-wave barrier timed out (host-mapped, so the host can read it
-    // without touching the stream); checked by the next apply, wagg_plan_status and the *_host_ forms
-    int *timeout_host = nullptr, *timeout_dev = nullptr;
-    // Region-major staging buffers of the (time, region) output form, one per stream that has applied
-    // this plan (kept until the plan is destroyed).  A stream-ordered hipMallocAsync / hipFreeAsync pair
-    // per apply made every call block for the whole kernel (0.28 ms enqueue against 0.01 ms without).
-    struct Staging { hipStream_t stream; void *p; size_t bytes; };
-    mutable std::mutex ws_mu;
-    mutable std::vector<Staging> ws;
-    void *staging(hipStream_t st, size_t bytes) const {
-        std::lock_guard<std::mutex> lock(ws_mu);
-        for (Staging &w : ws)
-            if (w.stream == st) {
-                if (w.bytes >= bytes) return w.p;
-                if (hipStreamSynchronize(st) != hipSuccess) return nullptr;      // the old buffer may still be in use on this stream
-                if (hipFree(w.p) != hipSuccess) return nullptr;
-                w.p = nullptr; w.bytes = 0;
-                if (hipMalloc(&w.p, bytes) != hipSuccess) return nullptr;
-                w.bytes = bytes;
-                return w.p;
-            }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        ws.push_back({st, p, bytes});
-        return p;
-    }
-    // the stream is about to be destroyed (the host pipeline's own compute stream): its staging goes with it, so the
-    // list stays bounded and a later stream that happens to get the same handle starts clean
-    void drop_staging(hipStream_t st) const {
-        std::lock_guard<std::mutex> lock(ws_mu);
-        for (size_t i = 0; i < ws.size(); ++i)
-            if (ws[i].stream == st) {
-                if (ws[i].p) wagg::note_cleanup(hipFree(ws[i].p), "hipFree(staging)");
-                ws.erase(ws.begin() + (long)i);
-                return;
-            }
-    }
-    ~wagg_plan() {
-        if (timeout_host) wagg::note_cleanup(hipHostFree(timeout_host), "hipHostFree(status word)");
-        for (Staging &w : ws) if (w.p) wagg::note_cleanup(hipFree(w.p), "hipFree(staging)");
-    }
-};
-
-namespace wagg {
-
-template <typename T> struct PlanView {
-    const int32_t *grp_chunk_begin, *grp_giant, *chunk_u_begin, *chunk_e_begin, *ucell;
-    const int32_t *ent_region, *ent_seg_begin, *seg_u;
-    const T *seg_w, *den, *ent_den;   // ent_den[e] = den[ent_region[e]]
-    const int32_t *chunk_desc;   // [n_chunks][8]: u0, nq, e0, ne, sb, ns, 0, 0
-    int n_groups;
-    int g0_normal;               // groups [0, g0_normal) are giant, the rest own exactly one chunk
-    int c0_normal;               // first chunk of the first normal group
-    // element transform applied to the data when it is loaded (tas_poly,
-    // transformations.py:188: (tas - 273.15) ** power): xpow = 0 -> identity, else (x + xoff)^xpow
-    T xoff;
-    int xpow;
-    // xpow == XF_EDD: Snyder exceedance degree days of (tasmin = X, tasmax = X2), both shifted by
-    // xoff, at threshold edd_thr (transformations.py:7-93); chunk-walking kernel only
-    const T *X2;
-    T edd_thr[4];                // up to four thresholds per pass over the two fields
-    int n_thr;
-    int64_t thr_pstride;         // output of threshold k goes to out + k * thr_pstride
-};
 // ---------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------
@@ -380,13 +255,6 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
 // registers (issued right after item i's registers were parked in LDS), the quad list of item
 // i+2 and the descriptor of item i+3 are being fetched -- the dependent metadata chain and the
 // LDS/compute phase no longer sit between two bursts of HBM requests.
-// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains
-// vmcnt, which would stall on the NEXT item's global loads that are deliberately in flight
-__device__ __forceinline__ void lds_only_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-struct StreamDesc { int u0, nq, e0, ne, sb, ns; unsigned long long split; };
 
 // STAMP (diagnostic build only, WAGG_SPARSE_STAMP env): per-phase s_memtime sums of wave 0 go to a
 // debug buffer that nothing else reads.
@@ -650,497 +518,6 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
         for (int i = 0; i < 10; ++i) stamps[blockIdx.x * 10 + i] = ph[i];
     }
 }
-
-// ---------------------------------------------------------------------------------------------
-// Loader/consumer form (fp32, TG layout, single-chunk groups): ONE 768-thread workgroup per CU.
-//   * 8 LOADER waves stream the next item's 64 rows x 64 quads into registers and park them in the
-//     other half of a double-buffered LDS image (NaN -> 0 on the way, S6; a flag notes +-inf);
-//     they block at VMEM issue for as long as the transfer takes -- which is why they do nothing
-//     else (microbenchmarks: a wave that issues its own loads cannot overlap them with work).
-//   * 4 CONSUMER waves reduce the current item with the matrix cores: the chunk's segment list is
-//     scattered into a dense LDS tile Aw[16 regions][256 cells] (zero elsewhere) and
-//     out[e][t] = sum_u Aw[e][u] * img[t][u] runs as 64 v_mfma_f32_16x16x4_f32 per wave (wave c
-//     owns timesteps 16c..16c+15); more than 16 regions take further passes.  ~3k cycles per
-//     pass against ~6k cycles of load time per item: the kernel is HBM-bound.
-//   * one workgroup barrier per item swaps the image halves; the consumer waves synchronise among
-//     themselves through a monotonic LDS counter (bounded spin).
-// Chunks whose data contain +-inf fall back to the exact per-segment VALU reduction.
-// ---------------------------------------------------------------------------------------------
-constexpr int LC_ENT = RG_MAX + 1;              // entries per chunk
-constexpr int LC_SEGS = SEG_MAX;                // segments per chunk the metadata block can hold
-#ifdef WAGG_DIAG    // Round 4: this kernel -- the only one with a bounded-spin barrier and a sticky timeout word -- serves no default
-                    // plan any more (sparse_lcv_kernel took the plain aggregation, the fused powers and the degree days in round
-                    // 3): it lives in the diagnostic build (plans created with WAGG_PLAN_LC_MFMA there), as the reference point
-                    // of the consumer comparison in DESIGN.md (d) and for the forced-timeout test.
-constexpr int LC_LW = 8, LC_CW = 4, LC_THREADS = (LC_LW + LC_CW) * 64;      // the MFMA-consumer form: 8 loader + 4 consumer waves
-constexpr int LC_TB = 64;
-constexpr int LC_AROW = UC + 4;                 // Aw row stride (elements)
-struct LcLds {
-    static constexpr size_t img = 0;                                            // [2][64][UROW] f32
-    static constexpr size_t aw = img + 2 * sizeof(float) * LC_TB * UROW;        // [16][LC_AROW] f32
-    static constexpr size_t seg_w = aw + sizeof(float) * 16 * LC_AROW;          // [2][LC_SEGS] f32
-    static constexpr size_t seg_u = seg_w + 2 * sizeof(float) * LC_SEGS;        // [2][LC_SEGS] i32 (packed)
-    static constexpr size_t ent_r = seg_u + 2 * sizeof(int32_t) * LC_SEGS;      // [2][LC_ENT] i32
-    static constexpr size_t ent_d = ent_r + 2 * sizeof(int32_t) * LC_ENT;       // [2][LC_ENT] f32
-    static constexpr size_t ent_s = ent_d + 2 * sizeof(float) * LC_ENT;         // [2][LC_ENT + 2] u16
-    static constexpr size_t hdr = ent_s + 2 * sizeof(uint16_t) * (LC_ENT + 2);  // [2][16] i32: ne, ns, -, tb, ..., 8 per-loader-wave inf flags
-    static constexpr size_t cnt = hdr + 2 * 16 * sizeof(int32_t);               // consumer barrier counter
-    static constexpr size_t total = (cnt + 16 + 15) / 16 * 16;
-    static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
-};
-
-// NPOW > 1 (fused tas_poly): the loaders park y = x + pv.xoff; the consumers raise each
-// fragment to the powers pv.xpow .. pv.xpow + NPOW - 1 in registers and keep NPOW accumulator sets,
-// so X is read from HBM once for NPOW powers; the i-th of them is stored at out + i * out_pstride.  A chunk whose |y| could
-// overflow fp32 at the highest power (or holds +-inf) takes the exact path, like +-inf data does.
-// EDD (fused Snyder degree days): the loaders stream BOTH fields (tasmin = X, tasmax = pv.X2)
-// and keep them in registers; one stage per threshold: they park snyder_edd1(tasmin + xoff, tasmax + xoff,
-// thr[k]) (transformations.py:64-87) into the image buffer and the consumers reduce it into output plane
-// k, so the two fields are read from HBM once for up to four thresholds.
-// Round 3: the plain aggregation left this kernel for sparse_lcv_kernel (vector-ALU consumers, below); what runs here
-// are the fused powers, the degree days, and plans created with WAGG_PLAN_LC_MFMA.
-template <bool VEC, int NPOW = 1, bool EDD = false>
-__global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float> pv, const float *__restrict__ X,
-                                                                  int64_t Ttot, int64_t ldx, int64_t G,
-                                                                  float *__restrict__ out, int64_t ldo,
-                                                                  int n_norm, long long n_items,
-                                                                  int *__restrict__ timeout_word,
-                                                                  unsigned long long *__restrict__ stamps_arg, int knob_arg,
-                                                                  int64_t out_pstride = 0, float ylim = 0.f) {
-#ifdef WAGG_DIAG
-    const int knob = knob_arg;                       // ablation switches / phase stamps: diagnostic build only
-    unsigned long long *const stamps = stamps_arg;
-#else
-    constexpr int knob = 0;
-    constexpr unsigned long long *stamps = nullptr;
-    (void)knob_arg; (void)stamps_arg;
-#endif
-    typedef float vec4 __attribute__((ext_vector_type(4)));
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *img = reinterpret_cast<float *>(smem_raw + LcLds::img);
-    float *aw = reinterpret_cast<float *>(smem_raw + LcLds::aw);
-    float *sm_w = reinterpret_cast<float *>(smem_raw + LcLds::seg_w);
-    int32_t *sm_u = reinterpret_cast<int32_t *>(smem_raw + LcLds::seg_u);
-    int32_t *sm_er = reinterpret_cast<int32_t *>(smem_raw + LcLds::ent_r);
-    float *sm_ed = reinterpret_cast<float *>(smem_raw + LcLds::ent_d);
-    uint16_t *sm_es = reinterpret_cast<uint16_t *>(smem_raw + LcLds::ent_s);
-    int32_t *hdr = reinterpret_cast<int32_t *>(smem_raw + LcLds::hdr);
-    int *ccnt = reinterpret_cast<int *>(smem_raw + LcLds::cnt);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave < LC_LW;
-    const bool out_vec = (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    // XCD-contiguous ids (speed only)
-    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
-    const long long NW = NWu;
-    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
-    if (w0 >= n_items) return;
-    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
-    const int nst = (int)((n_items - 1 - w0) / NW) + 1;
-    struct Item { int g, tb; };
-    auto advance = [&](Item a) {
-        Item b{a.g + dg, a.tb + dtb};
-        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
-        return b;
-    };
-    if (tid == 0) *ccnt = 0;
-    lds_only_barrier();
-    // diagnostic phase stamps (only when a stamp buffer is passed; nothing else reads it)
-    unsigned long long ph[4] = {0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int i) {
-        if (stamps) {
-            unsigned long long tnow;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
-            if (i >= 0) ph[i] += tnow - tprev;
-            tprev = tnow;
-        }
-    };
-
-    if (loader) {
-        // =============================== loader waves ===============================
-        constexpr int TPW = LC_TB / LC_LW;                       // 8 rows per wave
-        const int tw0 = wave * TPW;
-        auto load_desc = [&](Item a, StreamDesc &d) {
-            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
-            const int4v x = *reinterpret_cast<const int4v *>(p);
-            const int4v y = *reinterpret_cast<const int4v *>(p + 4);
-            d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
-        };
-        auto load_cell = [&](const StreamDesc &d) {
-            const int c = pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
-#ifdef WAGG_DIAG      // timing-only address patterns on the 720 x 1440 grid (results are wrong)
-            if (knob & 16) {                    // aligned 8 x 128-B patch instead of the chunk's quads
-                const int rowlen = 1440, pc = (d.u0 >> 6) % 45, pr = ((d.u0 >> 6) / 45) % 90;
-                return (pr * 8 + (lane >> 3)) * rowlen + pc * 32 + (lane & 7) * 4;
-            }
-            if (knob & 32) return ((d.u0 >> 6) % 4050) * 256 + lane * 4;      // 1 KB contiguous
-#endif
-            return c;
-        };
-        struct Regs { vec4 v[TPW]; vec4 h[EDD ? TPW : 1]; int mu; float mw; int er, es; float ed; };
-        static_assert(LC_SEGS <= LC_LW * 64, "one metadata element per loader thread");
-        auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
-            // small metadata loads first, the rows last (vmcnt retires in order)
-            if (!(knob & 2)) {
-                const int k = tid < d.ns ? tid : d.ns - 1;
-                R.mu = pv.seg_u[d.sb + k];
-                R.mw = pv.seg_w[d.sb + k];
-                R.er = pv.ent_region[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
-                R.ed = pv.ent_den[d.e0 + (tid < d.ne ? tid : d.ne - 1)];
-                R.es = pv.ent_seg_begin[d.e0 + (tid < d.ne ? tid : d.ne)];
-            }
-            const int64_t t0 = (int64_t)tb * LC_TB;
-            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
-            const int rbase = tw0 < nt - 1 ? tw0 : nt - 1;
-            int cnt = nt - tw0;
-            cnt = cnt < 1 ? 1 : (cnt > TPW ? TPW : cnt);
-            const float *p = X + (t0 + rbase) * ldx + cell0;
-            if constexpr (!EDD) {
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    if (VEC) R.v[i] = *reinterpret_cast<const vec4 *>(p);
-                    else {
-                        const int64_t lim = G - 1 - cell0;
-                        R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
-                    }
-                    if (i + 1 < cnt) p += ldx;
-                }
-            } else {
-                // degree days: the two fields row by row (tasmin row i, tasmax row i, ...): loads retire in order, so the
-                // arithmetic of row i can start while the rows behind it are still in flight
-                const float *p2 = pv.X2 + (t0 + rbase) * ldx + cell0;
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    if (VEC) { R.v[i] = *reinterpret_cast<const vec4 *>(p); R.h[i] = *reinterpret_cast<const vec4 *>(p2); }
-                    else {
-                        const int64_t lim = G - 1 - cell0;
-                        R.v[i] = vec4{p[0], p[lim < 1 ? lim : 1], p[lim < 2 ? lim : 2], p[lim < 3 ? lim : 3]};
-                        R.h[i] = vec4{p2[0], p2[lim < 1 ? lim : 1], p2[lim < 2 ? lim : 2], p2[lim < 3 ? lim : 3]};
-                    }
-                    if (i + 1 < cnt) { p += ldx; p2 += ldx; }
-                }
-            }
-        };
-        auto park_meta = [&](const Regs &R, const StreamDesc &d, int tb, int buf, int plane) {
-            if (!(knob & 2)) {
-            if (tid < d.ns) { sm_u[buf * LC_SEGS + tid] = R.mu; sm_w[buf * LC_SEGS + tid] = R.mw; }
-            if (tid < d.ne) { sm_er[buf * LC_ENT + tid] = R.er; sm_ed[buf * LC_ENT + tid] = R.ed; }
-            if (tid <= d.ne) sm_es[buf * (LC_ENT + 2) + tid] = (uint16_t)(R.es - d.sb);
-            }
-            if (tid == 0) { hdr[buf * 16 + 0] = d.ne; hdr[buf * 16 + 1] = d.ns; hdr[buf * 16 + 3] = tb; hdr[buf * 16 + 4] = plane; }
-        };
-        // degree days of threshold k from the two fields held in registers (they stay untouched for the
-        // next threshold): NaN values count 0 (S6), +-inf values send the chunk to the exact path
-        auto park_edd = [&](const Regs &R, const StreamDesc &d, int tb, int buf, int k) {
-            float *im = img + buf * LC_TB * UROW;
-            const float e = k == 0 ? pv.edd_thr[0] : (k == 1 ? pv.edd_thr[1] : (k == 2 ? pv.edd_thr[2] : pv.edd_thr[3]));
-            bool inf_seen = false;
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                vec4 val;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float y = snyder_edd1<float>(R.v[i][c] + pv.xoff, R.h[EDD ? i : 0][c] + pv.xoff, e);
-                    inf_seen |= __builtin_amdgcn_classf(y, 0x204);
-                    val[c] = (y == y) ? y : 0.0f;
-                }
-                *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = val;
-            }
-            const bool inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
-            if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;
-            park_meta(R, d, tb, buf, k);
-        };
-        auto park = [&](Regs &R, const StreamDesc &d, int tb, int buf) {
-            float *im = img + buf * LC_TB * UROW;
-            // one v_cmp_class per element finds NaN / +-inf; the select runs only if the wave saw any
-            bool odd = false;
-            if (NPOW > 1) {
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) R.v[i] = R.v[i] + pv.xoff;
-            } else if (pv.xpow > 0) {
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) R.v[i] = xform4<vec4, float>(R.v[i], pv.xoff, pv.xpow);
-            }
-            if (!(knob & 4)) {
-#pragma unroll
-            for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (NPOW > 1) odd |= !(__builtin_fabsf(R.v[i][c]) < ylim);      // NaN, +-inf, or too large to raise
-                    else odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);          // sNaN|qNaN|-inf|+inf
-                }
-            }
-            bool inf_any = false;
-            if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
-                bool inf_seen = false;
-#pragma unroll
-                for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float x = R.v[i][c];
-                        if (NPOW > 1) inf_seen |= __builtin_fabsf(x) >= ylim;     // exact path
-                        else inf_seen |= __builtin_amdgcn_classf(x, 0x204);       // -inf | +inf: exact path
-                        R.v[i][c] = (x == x) ? x : 0.0f;                           // NaN data counts 0 (S6)
-                    }
-                inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
-            }
-            if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;      // every wave, every item: no reset needed
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) *reinterpret_cast<vec4 *>(&im[(tw0 + i) * UROW + 4 * lane]) = R.v[i];
-            park_meta(R, d, tb, buf, 0);
-        };
-        // descriptors/cells run ahead: d[j] / cell[j] / it[j] describe item (parked so far) + 1 + j
-        Item itq[3];
-        StreamDesc dq[3];
-        int cellq[2];
-        itq[0] = Item{(int)(w0 % n_norm), (int)(w0 / n_norm)};
-        itq[1] = nst > 1 ? advance(itq[0]) : itq[0];
-        itq[2] = nst > 2 ? advance(itq[1]) : itq[1];
-        load_desc(itq[0], dq[0]); load_desc(itq[1], dq[1]); load_desc(itq[2], dq[2]);
-        cellq[0] = load_cell(dq[0]);
-        cellq[1] = load_cell(dq[1]);
-        Regs RA, RB;
-        // item 0 -> RA -> buffer 0; item 1 (if any) already in flight in RB while item 0 is parked
-        issue(RA, dq[0], cellq[0], itq[0].tb);
-        StreamDesc dPark = dq[0];
-        int tbPark = itq[0].tb;
-        // look-ahead queue: itq/dq/cellq[0] = next item to issue.  vmcnt retires in order, so the
-        // queue's own loads (descriptor of the item after next-next, quad list of next-next) are
-        // issued BEFORE a stage's row loads and consumed after them with a counted wait.
-        struct Ahead { Item nx; StreamDesc dn; int cn; };
-        auto ahead_load = [&](Ahead &a) {
-            a.nx = advance(itq[2]);
-            if (a.nx.tb * (long long)n_norm + a.nx.g >= n_items) a.nx = itq[2];
-            if (knob & 8) { a.dn = dq[2]; a.cn = cellq[1]; return; }   // diagnostic: no look-ahead loads
-            load_desc(a.nx, a.dn);
-            a.cn = load_cell(dq[2]);
-        };
-        auto ahead_commit = [&](const Ahead &a) {
-            itq[0] = itq[1]; itq[1] = itq[2]; itq[2] = a.nx;
-            dq[0] = dq[1]; dq[1] = dq[2]; dq[2] = a.dn;
-            cellq[0] = cellq[1]; cellq[1] = a.cn;
-        };
-        { Ahead a; ahead_load(a); ahead_commit(a); }              // queue now describes items 1, 2, 3
-        // two register sets alternate: while one item is parked, the next one's loads are in flight
-        const int K = EDD ? pv.n_thr : 1;                         // stages per item (one per degree-day threshold)
-        int sbuf = 0;                                             // image buffer of the next stage
-        auto lstage = [&](Regs &Rcur, Regs &Rnext, int st) {
-            // Rcur holds item st (in flight since the previous call); item st+1 goes to Rnext
-            const StreamDesc dn = dq[0];
-            const int tbn = itq[0].tb;
-            const bool more = st + 1 < nst;
-            Ahead a;
-            stamp(-1);
-            if (more) { ahead_load(a); issue(Rnext, dn, cellq[0], tbn); }
-            stamp(0);                                             // loader ph0: issue (blocked at VMEM)
-            for (int k = 0; k < K; ++k) {
-                park(Rcur, dPark, tbPark, sbuf);
-                stamp(2);                                         // ph2: wait for item st + park
-                if (k + 1 == K && more) { dPark = dn; tbPark = tbn; ahead_commit(a); }
-                stamp(1);                                         // ph1: queue rotation (must not wait for rows)
-                lds_only_barrier();                               // stage (st, k) is in buffer sbuf
-                stamp(3);                                         // ph3: waiting for the consumers
-                sbuf ^= 1;
-            }
-        };
-        // Degree days: ONE register set (the two fields of an item are 64 registers per lane; a second set does not
-        // fit the 168-register budget of three waves per SIMD -- tried: 400-500 spills).  The next item's loads are
-        // issued right behind the last threshold's park, so they overlap that stage's barrier and reduction only.
-        auto lstage_edd = [&](Regs &R, int st) {
-            const bool more = st + 1 < nst;
-            for (int k = 0; k < K; ++k) {
-                stamp(-1);
-                park_edd(R, dPark, tbPark, sbuf, k);
-                stamp(2);                                         // ph2: wait for the item's rows + degree-day arithmetic + park
-                if (k + 1 == K && more) {
-                    const StreamDesc dn = dq[0];
-                    const int tbn = itq[0].tb;
-                    Ahead a;
-                    ahead_load(a);
-                    issue(R, dn, cellq[0], tbn);
-                    dPark = dn; tbPark = tbn;
-                    ahead_commit(a);
-                }
-                stamp(0);                                         // ph0: issue
-                lds_only_barrier();
-                stamp(3);                                         // ph3: waiting for the consumers
-                sbuf ^= 1;
-            }
-        };
-        // Stage s = st * K + k is parked into buffer s & 1; the consumers reduce it after the barrier.
-        // The buffer is free: its previous tenant (stage s - 2) was reduced before barrier s - 1.
-        if constexpr (EDD) {
-            for (int st = 0; st < nst; ++st) lstage_edd(RA, st);
-        } else {
-            for (int st = 0; st < nst; st += 2) {
-                lstage(RA, RB, st);
-                if (st + 1 < nst) lstage(RB, RA, st + 1);
-            }
-        }
-        lds_only_barrier();                                       // consumers finish the last item
-        if (stamps && tid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + i] = ph[i];
-    } else {
-        // =============================== consumer waves, matrix cores ===============================
-        const int cw = wave - LC_LW;                              // 0..3: owns timesteps 16cw .. 16cw+15
-        const int ctid = tid - LC_LW * 64;                        // 0..255
-        const int lr = lane & 15, kq = lane >> 4;
-        int epoch = 0;
-        // A consumer wave whose barrier spin runs out marks the launch as failed (the host turns the
-        // word into WAGG_EHIP), stops computing and storing, and only keeps the workgroup barriers
-        // going so that the loaders drain; its partners then time out at their next arrival too.
-        bool dead = false;
-        auto cbarrier = [&]() {                                   // the 4 consumer waves only (bounded spin)
-            if (dead) return;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            epoch += LC_CW;
-            int gave_up = 0;
-            if (lane == 0) {
-#ifdef WAGG_DIAG
-                if ((knob & 64) && cw == 3 && epoch > LC_CW) gave_up = 1;       // test hook: wave 3 stops arriving
-                else
-#endif
-                {
-                    __hip_atomic_fetch_add(ccnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    int spins = 0;
-                    while (__hip_atomic_load(ccnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) {
-                        if (++spins > (1 << 24)) { gave_up = 1; break; }
-                    }
-                }
-                if (gave_up && timeout_word) __hip_atomic_store(timeout_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            dead = __builtin_amdgcn_readfirstlane(gave_up) != 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        // the dense weight tile starts all-zero and is returned to all-zero after every pass
-        for (int i = ctid * 4; i < 16 * LC_AROW; i += 256 * 4)
-            *reinterpret_cast<vec4 *>(&aw[i]) = vec4{0.f, 0.f, 0.f, 0.f};
-        const int nstages = nst * (EDD ? pv.n_thr : 1);
-        for (int st = 0; st < nstages; ++st) {
-            stamp(-1);
-            lds_only_barrier();                                   // stage st has been parked
-            stamp(3);                                             // consumer ph3: waiting for the loaders
-            const int buf = st & 1;
-            // degree days: the stage's threshold selects the output plane
-            const int64_t plane_off = EDD ? (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 4]) * out_pstride : 0;
-            const float *im = img + buf * LC_TB * UROW;
-            const int ne = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 0]);
-            const int ns = __builtin_amdgcn_readfirstlane(hdr[buf * 16 + 1]);
-            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[buf * 16 + 3]) * LC_TB;
-            const int nt = (int)((Ttot - t0) < LC_TB ? (Ttot - t0) : LC_TB);
-            const int fl = lane < LC_LW ? hdr[buf * 16 + 8 + lane] : 0;
-            const bool exact = __builtin_amdgcn_readfirstlane(__ballot(fl != 0) != 0ull);
-            if ((knob & 1) || dead) continue;                     // (knob: diagnostic build, consumers idle)
-            if (!exact) {
-                for (int e0 = 0; e0 < ne; e0 += 16) {
-                    // ---- dense weight tile of regions e0..e0+15: scatter the segments ----
-                    for (int k = ctid; k < ns; k += 256) {
-                        const int pu = sm_u[buf * LC_SEGS + k];
-                        const int e = (pu >> 16) & 0xff;
-                        if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = sm_w[buf * LC_SEGS + k];
-                    }
-                    cbarrier();
-                    if (dead) break;
-                    stamp(0);                                     // consumer ph0: build the weight tile
-                    // ---- out[t][e] = sum_u img[t][u] * Aw[e][u].  A = img (i = timestep), B = Aw^T
-                    // (j = region); lane group kq = lane >> 4 walks cells 64 kq .. 64 kq + 63, so one
-                    // ds_read_b128 per operand feeds four MFMA k-steps (any 4 distinct cells per step
-                    // work as long as A and B agree); conflict-free with the 260-element row stride.
-                    // With timesteps on the rows a lane ends up with FOUR CONSECUTIVE timesteps of one
-                    // region: one 16-byte store per lane instead of four scattered dwords (consumer
-                    // stores queue behind the loaders' row loads, so their count matters) ----
-                    typedef float f32x4 __attribute__((ext_vector_type(4)));
-                    f32x4 accp[NPOW][2];
-#pragma unroll
-                    for (int pp = 0; pp < NPOW; ++pp) accp[pp][0] = accp[pp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const float *ap = im + (16 * cw + lr) * UROW + 64 * kq;
-                    const float *bp = aw + lr * LC_AROW + 64 * kq;
-                    f32x4 af[2], bf[2];
-                    af[0] = *reinterpret_cast<const f32x4 *>(ap);
-                    bf[0] = *reinterpret_cast<const f32x4 *>(bp);
-#pragma unroll
-                    for (int g4 = 0; g4 < 16; ++g4) {
-                        if (g4 + 1 < 16) {
-                            af[(g4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(ap + 4 * (g4 + 1));
-                            bf[(g4 + 1) & 1] = *reinterpret_cast<const f32x4 *>(bp + 4 * (g4 + 1));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        f32x4 pw = af[g4 & 1];
-                        if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) pw = pw * af[g4 & 1];   // first power of this pass
-#pragma unroll
-                        for (int pp = 0; pp < NPOW; ++pp) {
-                            if (pp > 0) pw = pw * af[g4 & 1];          // y^(pp+1), transformations.py:188
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)                 // two chains: 40-cycle dependent latency vs 32 issue
-                                accp[pp][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pw[j], bf[g4 & 1][j], accp[pp][j & 1], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // C/D map: column (region) = lane & 15, row (timestep) = 4 * (lane >> 4) + reg
-                    const int e = e0 + lr;
-                    const int tl = 16 * cw + 4 * kq;
-                    if (e < ne && tl < nt) {
-                        const float den = sm_ed[buf * LC_ENT + e];
-#pragma unroll
-                        for (int pp = 0; pp < NPOW; ++pp) {
-                            const f32x4 acc = accp[pp][0] + accp[pp][1];
-                            float *op = out + plane_off + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + tl;
-                            const f32x4 qv = {acc[0] / den, acc[1] / den, acc[2] / den, acc[3] / den};   // :77-80
-                            if (out_vec && tl + 3 < nt) {
-                                *reinterpret_cast<f32x4 *>(op) = qv;
-                            } else {
-#pragma unroll
-                                for (int rg = 0; rg < 4; ++rg) if (tl + rg < nt) op[rg] = qv[rg];
-                            }
-                        }
-                    }
-                    stamp(1);                                     // ph1: MFMAs + stores
-                    cbarrier();                                   // every wave is done reading the tile
-                    if (dead) break;
-                    for (int k = ctid; k < ns; k += 256) {        // return the tile to all-zero
-                        const int pu = sm_u[buf * LC_SEGS + k];
-                        const int e = (pu >> 16) & 0xff;
-                        if (e >= e0 && e < e0 + 16) aw[(e - e0) * LC_AROW + (pu & 0xff)] = 0.f;
-                    }
-                    if (e0 + 16 < ne) cbarrier();                 // next pass scatters into a clean tile
-                    if (dead) break;
-                    stamp(2);                                     // ph2: un-scatter + consumer barrier
-                }
-            } else {
-                // ---- exact path (+-inf in the data): per-segment products with the skipna test ----
-                for (int e = cw; e < ne; e += LC_CW) {
-                    const int s0 = sm_es[buf * (LC_ENT + 2) + e], s1 = sm_es[buf * (LC_ENT + 2) + e + 1];
-                    float accx[NPOW];
-#pragma unroll
-                    for (int pp = 0; pp < NPOW; ++pp) accx[pp] = 0.f;
-                    for (int q = s0; q < s1; ++q) {
-                        const float y = im[lane * UROW + (sm_u[buf * LC_SEGS + q] & 0xff)], w = sm_w[buf * LC_SEGS + q];
-                        float yp = y;
-                        if (NPOW > 1) for (int i = 1; i < pv.xpow; ++i) yp *= y;
-#pragma unroll
-                        for (int pp = 0; pp < NPOW; ++pp) {
-                            if (pp > 0) yp *= y;
-                            const float p = yp * w;
-                            accx[pp] += (p == p) ? p : 0.f;
-                        }
-                    }
-                    if (lane < nt) {
-#pragma unroll
-                        for (int pp = 0; pp < NPOW; ++pp)
-                            out[plane_off + (int64_t)pp * out_pstride + (int64_t)sm_er[buf * LC_ENT + e] * ldo + t0 + lane] =
-                                accx[pp] / sm_ed[buf * LC_ENT + e];
-                    }
-                }
-            }
-        }
-        lds_only_barrier();                                       // matches the loaders' final barrier
-        if (stamps && ctid == 0) for (int i = 0; i < 4; ++i) stamps[blockIdx.x * 8 + 4 + i] = ph[i];
-    }
-}
-#endif  // WAGG_DIAG: sparse_lc_kernel
 
 // ---------------------------------------------------------------------------------------------
 // Loader/consumer form with VECTOR-ALU consumers (round 3): (time, gridcell) data, fp32 AND fp64 -- the plain aggregation,
@@ -1641,312 +1018,6 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
     }
 }
 
-#ifdef WAGG_DIAG
-// ---------------------------------------------------------------------------------------------
-// sparse_lcd_kernel (round 4 EXPERIMENT, diagnostic build only; WAGG_LCD = 1 / 2 selects it): the loader/consumer kernel
-// with an LDS-DMA LOADER -- plain aggregation of (time, gridcell) data, fp32 and fp64, on the chunkings sparse_lcv_kernel
-// uses.  Correct (it passes the parity suite) and NOT faster: profiles/r04_lds_dma_loader.txt, DESIGN.md (d).  c2-real kernel
-// 0.2495 ms with two buffers of 64 rows (one item in flight: the loaders alone take 0.232), 0.2955 ms with three buffers of
-// 48 rows (two items in flight, but a 48-row item costs the consumers what a 64-row item does and there are a third more of
-// them: the consumers alone take 0.244) against 0.229-0.234 ms of sparse_lcv_kernel; c3 0.352 ms (64 x 2) against 0.353.
-//
-// What changes against sparse_lcv_kernel: the rows never pass through vector registers.  The 8 loader waves send every
-// 256 bytes of an image row straight to LDS with global_load_lds_dword -- FOUR-byte pieces, because the image has to stay
-// conflict-free for consumers whose 64 lanes read one cell of 64 timesteps: a 16-byte piece pins four cells of a timestep
-// to four neighbouring banks, so whatever the piece order, lanes = timesteps meet four ways; with 4-byte pieces the per-lane
-// SOURCE address does the swizzle (LDS position p of row t holds element p ^ t, as in sparse_lcv_kernel) and the consumers
-// read without conflicts.  The loader waves therefore block at nothing but the memory system: no register staging, no
-// parking pass over the data.  The loader's only vector-memory instructions are its own (inline) DMA pieces, so
-// `s_waitcnt vmcnt(pieces of one item)` is an exact "the item before has landed"; everything else the loaders need (a
-// chunk's cell table) they read from LDS, where the CONSUMER waves publish it: those have time to spare (they are busy
-// 60 % of an item) and own all the metadata traffic -- descriptors, segment lists, entry tables, fetched two to five
-// items ahead with ordinary loads.
-//   * NBUF image buffers of TB rows: 3 x 48 rows (144 KiB) keep two items in flight -- item st + 2 is issued behind the
-//     barrier that releases item st, into the buffer the consumers left at that barrier; 2 x 64 rows have one.
-//   * S6 moves to the consumers: an entry is summed as it is; if any timestep's sum is not finite (NaN data, +-inf, or a
-//     product of the two) the entry is summed again in the general form (NaN product counts 0).  Finite fields pay one
-//     ballot per entry.
-//   * results leave as one 4- / 8-byte store per lane (256 / 512 contiguous bytes per entry and item).
-// ---------------------------------------------------------------------------------------------
-constexpr int LD_LW = 8, LD_CW = 8, LD_THREADS = (LD_LW + LD_CW) * 64;
-constexpr int LD_DQ = 4;                         // published cell tables: items st .. st + 3
-template <typename T, int TB, int NBUF> struct LdLds {
-    static constexpr size_t img = 0;                                            // [NBUF][TB][1024 B]
-    static constexpr size_t m_seg_w = 0;                                        // one metadata set: [LC_SEGS] T
-    static constexpr size_t m_seg_u = m_seg_w + sizeof(T) * LC_SEGS;            // [LC_SEGS] u8 (cell of the row)
-    static constexpr size_t m_ent_r = m_seg_u + LC_SEGS;                        // [LC_ENT] i32
-    static constexpr size_t m_ent_d = m_ent_r + sizeof(int32_t) * LC_ENT;       // [LC_ENT] T
-    static constexpr size_t m_ent_s = m_ent_d + sizeof(T) * LC_ENT;             // [LC_ENT + 2] u16
-    static constexpr size_t m_hdr = (m_ent_s + sizeof(uint16_t) * (LC_ENT + 2) + 15) / 16 * 16;   // i32: ne, entry counter, tb, -
-    static constexpr size_t m_size = m_hdr + 16;
-    static constexpr size_t meta = img + (size_t)NBUF * TB * LV_ROWB;           // [2 sets]
-    static constexpr size_t dq = meta + 2 * m_size;                             // [LD_DQ][64 cells i32 | tb, valid, -, -]
-    static constexpr size_t dq_size = 64 * 4 + 16;
-    static constexpr size_t total = dq + LD_DQ * dq_size;
-    static_assert(total <= 160 * 1024, "one workgroup must fit the CU's LDS");
-    static_assert(m_ent_d % sizeof(T) == 0 && meta % 16 == 0 && m_size % 16 == 0, "alignment");
-};
-
-template <typename T, int TB, int NBUF>
-__global__ __launch_bounds__(LD_THREADS) void sparse_lcd_kernel(PlanView<T> pv, const T *__restrict__ X, int64_t Ttot, int64_t ldx,
-                                                                int64_t G, T *__restrict__ out, int64_t ldo, int n_norm,
-                                                                long long n_items, int knob_arg) {
-#ifdef WAGG_DIAG
-    const int knob = knob_arg;                       // (diagnostic build, timing only: 1 = no segment walk, 2 = no DMA pieces)
-#else
-    constexpr int knob = 0;
-    (void)knob_arg;
-#endif
-    static_assert(TB % LD_LW == 0 && TB <= 64 && (NBUF == 2 || NBUF == 3), "geometry");
-    constexpr int TPW = TB / LD_LW;                  // image rows per loader wave
-    constexpr int NPIECE = TPW * 4;                  // DMA instructions per loader wave and item (256 bytes each)
-    constexpr int AHEAD = NBUF - 1;                  // item st + AHEAD is issued behind barrier st
-    static_assert(NPIECE <= 63, "vmcnt");
-    using L = LdLds<T, TB, NBUF>;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char *)smem_raw);
-    if (lds0 & (unsigned)(LV_ROWB - 1)) __builtin_trap();          // (0: the kernel has no static LDS)
-    // XCD-contiguous ids (speed only), as in sparse_lcv_kernel
-    const unsigned NWu = gridDim.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned q8 = NWu >> 3, r8 = NWu & 7u;
-    const long long NW = NWu;
-    const long long w0 = (long long)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot);
-    if (w0 >= n_items) return;
-    const int dg = (int)(NW % n_norm), dtb = (int)(NW / n_norm);
-    const int nst = (int)((n_items - 1 - w0) / NW) + 1;
-    struct Item { int g, tb; };
-    auto advance = [&](Item a) {
-        Item b{a.g + dg, a.tb + dtb};
-        if (b.g >= n_norm) { b.g -= n_norm; ++b.tb; }
-        return b;
-    };
-    auto item_at = [&](int st) {                                   // (prologue only)
-        const long long i = w0 + (long long)st * NW;
-        return Item{(int)(i % n_norm), (int)(i / n_norm)};
-    };
-
-    if (wave < LD_LW) {
-        // =============================== loader waves: LDS-DMA only ===============================
-        const int tw0 = wave * TPW;
-        // LDS dword d = 64 k + lane of a row holds element position p = 4 d / sizeof(T), half (4 d) % sizeof(T); position p of
-        // row t holds element e = p ^ t (t < 64 only reaches the low six bits): its quad is (p >> 2) ^ (t >> 2), its cell in
-        // the quad (p ^ t) & 3
-        constexpr int DPE = (int)sizeof(T) / 4;                    // dwords per element: 1 / 2
-        auto issue = [&](int st, int tb) {
-            const int buf = st % NBUF, sl = st % LD_DQ;
-            const unsigned dqb = lds0 + (unsigned)(L::dq + sl * L::dq_size);
-            const int64_t t0 = (int64_t)tb * TB;
-            const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
-            // all source offsets first (independent LDS reads, in flight together), then the pieces back to back: an inline
-            // DMA statement is a memory barrier for the compiler, a table read between two of them would be waited for in place
-            unsigned voff[TPW][4];
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int t = tw0 + i;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int p = (64 * k + lane) / DPE;
-                    const int q = (p >> 2) ^ (t >> 2);
-                    const int c = (p ^ t) & 3;
-                    int cell = *(const int __attribute__((address_space(3))) *)(uintptr_t)(dqb + 4u * (unsigned)q) + c;
-                    cell = cell < G ? cell : (int)(G - 1);          // a quad at the end of a grid that is not whole quads
-                    voff[i][k] = (unsigned)cell * (unsigned)sizeof(T) + (unsigned)(((64 * k + lane) % DPE) * 4);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int t = tw0 + i;
-                const int tr = t < nt ? t : nt - 1;                 // rows behind the last timestep repeat it (never stored)
-                const T *rowp = X + (t0 + tr) * ldx;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned ldst = lds0 + (unsigned)((buf * TB + t) * LV_ROWB + 256 * k);
-                    int m0save;
-                    if (!(knob & 2))
-                    asm volatile("s_mov_b32 %[sv], m0\n\ts_mov_b32 m0, %[l0]\n\ts_nop 0\n\tglobal_load_lds_dword %[vo], %[src]\n\ts_mov_b32 m0, %[sv]"
-                                 : [sv] "=&s"(m0save) : [l0] "s"(ldst), [vo] "v"(voff[i][k]), [src] "s"(rowp) : "memory");
-                }
-            }
-        };
-        lds_only_barrier();                                          // the consumers have published the first cell tables
-        Item it = item_at(0);
-        for (int j = 0; j < AHEAD && j < nst; ++j) { issue(j, it.tb); it = advance(it); }      // `it` = item st + AHEAD
-        for (int st = 0; st < nst; ++st) {
-            // item st has landed once at most the pieces of the items issued behind it are outstanding
-            const int younger = nst - 1 - st < AHEAD - 1 ? nst - 1 - st : AHEAD - 1;
-            if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NPIECE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_only_barrier();                                      // barrier st: item st to the consumers, item st - 1 is done
-            if (st + AHEAD < nst) { issue(st + AHEAD, it.tb); it = advance(it); }
-        }
-    } else {
-        // ========================= consumer waves: metadata servers + the reduction =========================
-        const int ctid = tid - LD_LW * 64;                           // 0 .. 511
-        auto load_desc = [&](Item a, StreamDesc &d) {
-            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
-            const int4v x = *reinterpret_cast<const int4v *>(p);
-            const int4v y = *reinterpret_cast<const int4v *>(p + 4);
-            d.u0 = __builtin_amdgcn_readfirstlane(x[0]); d.nq = __builtin_amdgcn_readfirstlane(x[1]);
-            d.e0 = __builtin_amdgcn_readfirstlane(x[2]); d.ne = __builtin_amdgcn_readfirstlane(x[3]);
-            d.sb = __builtin_amdgcn_readfirstlane(y[0]); d.ns = __builtin_amdgcn_readfirstlane(y[1]); d.split = 0;
-        };
-        struct Meta { int mu; T mw; int er, es; T ed; };
-        auto load_meta = [&](const StreamDesc &d, Meta &m) {
-            const int k = ctid < d.ns ? ctid : d.ns - 1;
-            m.mu = pv.seg_u[d.sb + k];
-            m.mw = pv.seg_w[d.sb + k];
-            m.er = pv.ent_region[d.e0 + (ctid < d.ne ? ctid : d.ne - 1)];
-            m.ed = pv.ent_den[d.e0 + (ctid < d.ne ? ctid : d.ne - 1)];
-            m.es = pv.ent_seg_begin[d.e0 + (ctid < d.ne ? ctid : d.ne)];
-        };
-        auto put_meta = [&](const StreamDesc &d, const Meta &m, int tb, int set) {
-            char *ms = smem_raw + L::meta + (size_t)set * L::m_size;
-            if (ctid < d.ns) {
-                reinterpret_cast<T *>(ms + L::m_seg_w)[ctid] = m.mw;
-                reinterpret_cast<uint8_t *>(ms + L::m_seg_u)[ctid] = (uint8_t)(m.mu & 0xff);
-            }
-            if (ctid < d.ne) {
-                reinterpret_cast<int32_t *>(ms + L::m_ent_r)[ctid] = m.er;
-                reinterpret_cast<T *>(ms + L::m_ent_d)[ctid] = m.ed;
-            }
-            if (ctid <= d.ne) reinterpret_cast<uint16_t *>(ms + L::m_ent_s)[ctid] = (uint16_t)(m.es - d.sb);
-            if (ctid == 0) {
-                int32_t *h = reinterpret_cast<int32_t *>(ms + L::m_hdr);
-                h[0] = d.ne; h[1] = 0; h[2] = tb;
-            }
-        };
-        // a chunk's cell table for the loaders: first cell of quad q, quads behind the last one repeat it (never read back)
-        auto load_cells = [&](const StreamDesc &d) { return pv.ucell[d.u0 + (ctid < d.nq ? ctid : d.nq - 1)]; };
-        auto put_cells = [&](int cells, int st) {
-            if (ctid < 64) *reinterpret_cast<int32_t *>(smem_raw + L::dq + (size_t)(st % LD_DQ) * L::dq_size + 4 * ctid) = cells;
-        };
-        // Descriptors are fetched one stage before the loads that need them (raw, in vector registers: decoding -- the point
-        // where the wave waits for them -- happens a stage later), those loads one stage before their values are published:
-        //   stage st fetches the descriptors of items st + 2 (metadata) and st + LD_DQ + 1 (cell table), loads the metadata
-        //   of item st + 1 and the cell table of item st + LD_DQ, and has published item st's metadata and item
-        //   st + LD_DQ - 1's table before barrier st.
-        struct RawDesc { int4v x, y; };
-        auto fetch_desc = [&](Item a) {
-            const int32_t *p = pv.chunk_desc + 8 * (int64_t)(pv.c0_normal + a.g);
-            return RawDesc{*reinterpret_cast<const int4v *>(p), *reinterpret_cast<const int4v *>(p + 4)};
-        };
-        auto decode = [&](const RawDesc &r, StreamDesc &d) {
-            d.u0 = __builtin_amdgcn_readfirstlane(r.x[0]); d.nq = __builtin_amdgcn_readfirstlane(r.x[1]);
-            d.e0 = __builtin_amdgcn_readfirstlane(r.x[2]); d.ne = __builtin_amdgcn_readfirstlane(r.x[3]);
-            d.sb = __builtin_amdgcn_readfirstlane(r.y[0]); d.ns = __builtin_amdgcn_readfirstlane(r.y[1]); d.split = 0;
-        };
-        Item im = item_at(0), ic = item_at(0);                       // im: item whose metadata is in `mcur`; ic: ... cell table in `ccur`
-        StreamDesc dmeta, dc;
-        Meta mcur;
-        int ccur = 0;
-        {
-            // prologue (blocking, once): cell tables of items 0 .. LD_DQ - 2 published; item LD_DQ - 1's table and item 0's
-            // metadata in registers
-            load_desc(im, dmeta);
-            load_meta(dmeta, mcur);
-            for (int j = 0; j < LD_DQ - 1; ++j) {
-                if (j < nst) { load_desc(ic, dc); put_cells(load_cells(dc), j); }
-                ic = j + 1 < nst ? advance(ic) : ic;
-            }
-            load_desc(ic, dc);                                       // item LD_DQ - 1 (or the last one again)
-            ccur = load_cells(dc);
-        }
-        int tbm = im.tb;
-        Item im1 = nst > 1 ? advance(im) : im;                       // item st + 1 / its descriptor, fetched a stage ahead
-        Item ic1 = LD_DQ < nst ? advance(ic) : ic;                   // item st + LD_DQ
-        RawDesc rm = fetch_desc(im1), rc = fetch_desc(ic1);
-        lds_only_barrier();                                          // the loaders may start
-        const unsigned rowoff = lds0 + (unsigned)lane * LV_ROWB + (unsigned)lane * (unsigned)sizeof(T);
-        typedef const T __attribute__((address_space(3))) *lds_cptr;
-        for (int st = 0; st < nst; ++st) {
-            put_meta(dmeta, mcur, tbm, st & 1);
-            put_cells(ccur, st + LD_DQ - 1);
-            lds_only_barrier();                                      // barrier st
-            // fetch ahead (ordinary loads: these waves issue no DMA): item st + 1's metadata, item st + LD_DQ's cell table,
-            // and the descriptors of the items one further on
-            if (st + 1 < nst) {
-                decode(rm, dmeta);
-                load_meta(dmeta, mcur);
-                tbm = im1.tb;
-                if (st + 2 < nst) { im1 = advance(im1); rm = fetch_desc(im1); }
-            }
-            if (st + LD_DQ < nst) {
-                decode(rc, dc);
-                ccur = load_cells(dc);
-                if (st + LD_DQ + 1 < nst) { ic1 = advance(ic1); rc = fetch_desc(ic1); }
-            }
-            const char *ms = smem_raw + L::meta + (size_t)(st & 1) * L::m_size;
-            const T *sm_w = reinterpret_cast<const T *>(ms + L::m_seg_w);
-            const uint8_t *sm_u = reinterpret_cast<const uint8_t *>(ms + L::m_seg_u);
-            const int32_t *sm_er = reinterpret_cast<const int32_t *>(ms + L::m_ent_r);
-            const T *sm_ed = reinterpret_cast<const T *>(ms + L::m_ent_d);
-            const uint16_t *sm_es = reinterpret_cast<const uint16_t *>(ms + L::m_ent_s);
-            int32_t *hdr = reinterpret_cast<int32_t *>(const_cast<char *>(ms) + L::m_hdr);
-            const int ne = __builtin_amdgcn_readfirstlane(hdr[0]);
-            const int64_t t0 = (int64_t)__builtin_amdgcn_readfirstlane(hdr[2]) * TB;
-            const int nt = (int)((Ttot - t0) < TB ? (Ttot - t0) : TB);
-            const unsigned rb = rowoff + (unsigned)((st % NBUF) * TB) * LV_ROWB;
-            for (;;) {
-                int e = 0;
-                if (lane == 0) e = __hip_atomic_fetch_add(&hdr[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                e = __builtin_amdgcn_readfirstlane(e);
-                if (e >= ne) break;
-                const int s0 = __builtin_amdgcn_readfirstlane((int)sm_es[e]);
-                const int s1 = __builtin_amdgcn_readfirstlane((int)sm_es[e + 1]);
-                auto sum = [&](auto odd_tag) {
-                    constexpr bool ODD = decltype(odd_tag)::value;
-                    T acc = T(0);
-                    for (int base = (knob & 1) ? s1 : s0; base < s1; base += 64) {
-                        const int n = s1 - base < 64 ? s1 - base : 64;
-                        const int k = base + (lane < n ? lane : 0);
-                        int ul = (int)sm_u[k] * (int)sizeof(T);
-                        T wl = sm_w[k];
-                        if (lane >= n) { ul = 0; wl = T(0); }          // padding lanes add exactly 0 to finite data
-                        for (int j0 = 0; j0 < n; j0 += 8) {
-                            T xv[8], wv[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {             // 8 independent LDS reads in flight
-                                const unsigned u = (unsigned)__builtin_amdgcn_readlane(ul, j0 + j);
-                                if constexpr (sizeof(T) == 4) {
-                                    wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), j0 + j));
-                                } else {
-                                    const long long wb = __builtin_bit_cast(long long, wl);
-                                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(wb & 0xffffffffll), j0 + j);
-                                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(wb >> 32), j0 + j);
-                                    wv[j] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
-                                }
-                                xv[j] = *(lds_cptr)(uintptr_t)(rb ^ u);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                if constexpr (ODD) {
-                                    const T p = xv[j] * wv[j];                 // aggregations.py:78, skipna (S6)
-                                    acc += (p == p) ? p : T(0);
-                                } else if constexpr (sizeof(T) == 4) {
-                                    acc = __builtin_fmaf(xv[j], wv[j], acc);
-                                } else {
-                                    acc = __builtin_fma(xv[j], wv[j], acc);
-                                }
-                            }
-                        }
-                    }
-                    return acc;
-                };
-                T acc = sum(std::false_type{});
-                // a sum that is not finite (rows behind the last timestep repeat it; lanes behind TB read another buffer)
-                const bool bad = lane < nt && !(__builtin_fabs(acc) <= std::numeric_limits<T>::max());
-                if (__builtin_amdgcn_readfirstlane(__ballot(bad) != 0ull)) acc = sum(std::true_type{});
-                if (lane < nt) out[(int64_t)sm_er[e] * ldo + t0 + lane] = acc / sm_ed[e];          // :77-80
-            }
-        }
-    }
-}
-#endif  // WAGG_DIAG
-
 // (R x T) -> (T x R) through a padded 64x64 LDS tile: both sides coalesced.  The gather kernel
 // stores region-major (lane = timestep: 256 contiguous bytes per region) because a (T x R) store
 // from it would scatter single dwords over R-strided lines (7x write amplification measured).
@@ -2104,20 +1175,6 @@ template <typename T> static const LcvEntry<T> &lcv_pick(bool vec, bool edd, boo
     return table[vec ? 1 : 0][edd ? 1 : 0][gt ? 1 : 0][planes - 1];
 }
 
-// (diagnostic build, WAGG_SPARSE_STAMP) phase stamps of a loader/consumer launch: mean cycles per stage and phase, to stderr
-static int report_lc_stamps(unsigned long long *lc_stamps, long long nw, long long n_items, hipStream_t stream) {
-    std::vector<unsigned long long> h(8 * (size_t)nw);
-    WAGG_HIP(hipStreamSynchronize(stream));
-    WAGG_HIP(staged_d2h(h.data(), lc_stamps, sizeof(unsigned long long) * h.size()));
-    WAGG_HIP(hipFree(lc_stamps));
-    double sm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < h.size(); ++i) sm[i % 8] += (double)h[i];
-    const double stg = (double)n_items;
-    fprintf(stderr, "[wagg lc stamp] items=%lld nw=%lld cycles/stage  loader: issue=%.0f rotate=%.0f wait+park=%.0f barrier=%.0f | consumer: tile=%.0f mfma+store=%.0f unscatter=%.0f barrier=%.0f\n",
-            n_items, nw, sm[0] / stg, sm[1] / stg, sm[2] / stg, sm[3] / stg, sm[4] / stg, sm[5] / stg, sm[6] / stg, sm[7] / stg);
-    return WAGG_OK;
-}
-
 template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
@@ -2204,28 +1261,6 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     bool lc_done = false;
     // plain aggregation: loaders + vector-ALU consumers (sparse_lcv_kernel).  fp32 on either chunking, fp64 on its
     // whole-line chunking only (a region-shaped chunk of 64 quads is 2 KiB of a fp64 row: twice the image row)
-#ifdef WAGG_DIAG
-    // (diagnostic build, WAGG_LCD = 1: three image buffers of 48 rows, 2: two of 64) the LDS-DMA loader experiment
-    if (const int lcd_mode = diag_env("WAGG_LCD"); lcd_mode && stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) &&
-        !edd && xpow == 0 && nfuse == 1 && layout == WAGG_LAYOUT_TG && (sizeof(T) == 4 || lines) && plan->info.G < (int64_t)(1u << 28)) {
-        const int ncu = plan->ncu;
-        const int tb = lcd_mode == 2 ? 64 : 48;
-        const long long n_items = (long long)n_norm * ((Ttot + tb - 1) / tb);
-        long long nw = n_items < ncu ? n_items : ncu;
-        if (const int v = diag_env("WAGG_LCV_NW")) { if (v >= 1 && v < nw) nw = v; }
-        auto kern = sparse_lcd_kernel<T, 48, 3>;
-        size_t lds_bytes = LdLds<T, 48, 3>::total;
-        if (lcd_mode == 2) { kern = sparse_lcd_kernel<T, 64, 2>; lds_bytes = LdLds<T, 64, 2>::total; }
-        WAGG_HIP(allow_dynamic_lds((const void *)kern, lds_bytes));
-        profile_mark(stream, true);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LD_THREADS), lds_bytes, stream, pv, X, Ttot, ldx, plan->info.G, kout, kldo,
-                           n_norm, n_items, diag_env("WAGG_LCD_KNOB"));
-        profile_mark(stream, false);
-        WAGG_HIP(hipGetLastError());
-        pv.n_groups = d.g0_normal;
-        lc_done = true;
-    }
-#endif
     if (!lc_done && stream_path && n_norm > 0 && !(plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_LC_MFMA)) && (!edd || edd_lcv) && nfuse <= 4 &&
         (sizeof(T) == 4 || lines)) {
         const int ncu = plan->ncu;
@@ -2240,40 +1275,20 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         WAGG_HIP(allow_dynamic_lds((const void *)kern, lds_bytes));
         unsigned long long *lc_stamps = nullptr;
         if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
-        profile_mark(stream, true);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LV_THREADS), lds_bytes, stream, pv, X, Ttot, ldx,
-                           plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
-        profile_mark(stream, false);
+        launch_timed(true, kern, dim3((unsigned)nw), dim3(LV_THREADS), lds_bytes, stream, pv, X, Ttot, ldx,
+                     (int64_t)plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
         WAGG_HIP(hipGetLastError());
+#ifdef WAGG_DIAG
         if (lc_stamps) { if (int rc = report_lc_stamps(lc_stamps, nw, n_items, stream)) return rc; }
+#endif
         pv.n_groups = d.g0_normal;
         lc_done = true;
     }
 #ifdef WAGG_DIAG
     if constexpr (sizeof(T) == 4) {
+        // (diagnostic build, wagg_sparse_diag.hip) plans created with WAGG_PLAN_LC_MFMA: the MFMA-consumer kernel
         if (stream_path && n_norm > 0 && !lc_done && (plan->flags & WAGG_PLAN_LC_MFMA) && !(plan->flags & WAGG_PLAN_NO_LC)) {
-            // (diagnostic build) loader/consumer kernel with dense-tile MFMA consumers (8 + 4 waves) over the single-chunk groups,
-            // plans created with WAGG_PLAN_LC_MFMA; one workgroup per CU
-            const int ncu = plan->ncu;
-            const long long n_items = (long long)n_norm * ((Ttot + LC_TB - 1) / LC_TB);
-            const long long nw = n_items < ncu ? n_items : ncu;
-            auto kern = vec ? sparse_lc_kernel<true> : sparse_lc_kernel<false>;
-            if (edd) kern = vec ? sparse_lc_kernel<true, 1, true> : sparse_lc_kernel<false, 1, true>;
-            if (nfuse == 2) kern = vec ? sparse_lc_kernel<true, 2> : sparse_lc_kernel<false, 2>;
-            if (nfuse == 3) kern = vec ? sparse_lc_kernel<true, 3> : sparse_lc_kernel<false, 3>;
-            if (nfuse == 4) kern = vec ? sparse_lc_kernel<true, 4> : sparse_lc_kernel<false, 4>;
-            // |y| below this can be raised to the nfuse-th power (and summed 512 times) inside fp32
-            const float ylim = nfuse > 1 ? std::pow(3.0e38f / 1024.f, 1.0f / (float)(xpow + nfuse - 1)) : 0.f;
-            WAGG_HIP(allow_dynamic_lds((const void *)kern, LcLds::total));
-            unsigned long long *lc_stamps = nullptr;
-            if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
-            profile_mark(stream, true);
-            hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(LC_THREADS), LcLds::total, stream, pv, X, Ttot, ldx,
-                               plan->info.G, kout, kldo, n_norm, n_items, plan->timeout_dev, lc_stamps,
-                               diag_env("WAGG_LC_KNOB"), kpstride, ylim);
-            profile_mark(stream, false);
-            WAGG_HIP(hipGetLastError());
-            if (lc_stamps) { if (int rc = report_lc_stamps(lc_stamps, nw, n_items, stream)) return rc; }
+            if (int rc = launch_lc_mfma(plan, pv, X, Ttot, ldx, kout, kldo, n_norm, vec, edd, xpow, nfuse, kpstride, stream)) return rc;
             pv.n_groups = d.g0_normal;
             lc_done = true;
         }
@@ -2295,10 +1310,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         }
 #endif
         WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));
-        profile_mark(stream, true);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nw), dim3(STHREADS), shmem, stream, pv, X, Ttot, ldx, plan->info.G,
-                           kout, kldo, n_norm, n_items, stamps, diag_env("WAGG_SPARSE_STAMP"));
-        profile_mark(stream, false);
+        launch_timed(true, kern, dim3((unsigned)nw), dim3(STHREADS), shmem, stream, pv, X, Ttot, ldx, (int64_t)plan->info.G,
+                     kout, kldo, n_norm, n_items, stamps, diag_env("WAGG_SPARSE_STAMP"));
         WAGG_HIP(hipGetLastError());
         if (do_stamp) {           // diagnostic: print mean cycles per stage and phase
             std::vector<unsigned long long> h(10 * (size_t)nw);
@@ -2330,10 +1343,8 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
             if (xpow == XF_EDD && pv.n_thr > 1) kern = sparse_gather_kernel<T, TB, L, O, V, 0, 4>; \
             WAGG_DIAG_GATHER_VARIANTS(L, O, V)                                                   \
             WAGG_HIP(allow_dynamic_lds((const void *)kern, shmem));                              \
-            if (!main_done) profile_mark(stream, true);                                          \
-            hipLaunchKernelGGL(kern, grid, block, shmem, stream, pv, X, Ttot, ldx, plan->info.G, \
-                               kout + (int64_t)pz * kpstride, kldo);                             \
-            if (!main_done) profile_mark(stream, false);                                         \
+            launch_timed(!main_done, kern, grid, block, shmem, stream, pv, X, Ttot, ldx,         \
+                         (int64_t)plan->info.G, kout + (int64_t)pz * kpstride, kldo);            \
         } while (0)
         if (layout == WAGG_LAYOUT_TG) { if (vec) WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, true); else WAGG_LAUNCH(WAGG_LAYOUT_TG, WAGG_OUT_RT, false); }
         else WAGG_LAUNCH(WAGG_LAYOUT_GT, WAGG_OUT_RT, false);
@@ -2398,7 +1409,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
     using namespace wagg;
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
-    WAGG_REQUIRE((flags & ~(WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LINES | WAGG_PLAN_LC_MFMA)) == 0, "unknown plan flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_NO_LINES | WAGG_PLAN_LC_MFMA | WAGG_PLAN_SERIAL_BUILD)) == 0, "unknown plan flags 0x%x", flags);
 #ifndef WAGG_DIAG
     if (flags & WAGG_PLAN_LC_MFMA) {
         set_error("WAGG_PLAN_LC_MFMA: the MFMA-consumer kernel lives in the diagnostic build (libwagg_diag.so) only");
@@ -2863,22 +1874,47 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         int mult = diag_env("WAGG_LINE_MULT");
         const bool half_lines = mult == 16;
         if (mult != 2 && mult != 4 && mult != 8) mult = 1;
-        struct LineJob { int line_cells, lines_per_chunk, kind; SparsePlanDev *d; bool ok = false; hipError_t he = hipSuccess; bool oom = false; };
+        struct LineJob { int line_cells, lines_per_chunk, kind; SparsePlanDev *d; bool ok = false; hipError_t he = hipSuccess; bool oom = false, failed = false; };
         LineJob jobs[3] = {{half_lines ? 16 : 32 * mult, half_lines ? 16 : 8 / mult, 1, &plan->dl},
                            {half_lines ? 8 : 16 * mult, half_lines ? 16 : 8 / mult, 2, &plan->dl64},
                            {16, 4, 3, &plan->dl64e}};
-        std::vector<std::thread> workers;
-        if (want_line_plans)
-            for (LineJob &j : jobs)
-                workers.emplace_back([&build, &j, dev = plan->device]() {
-                    j.he = hipSetDevice(dev);                       // a new thread starts on device 0
-                    try { if (j.he == hipSuccess) j.ok = build(j.line_cells, j.lines_per_chunk, j.kind, *j.d, j.he); }
-                    catch (const std::bad_alloc &) { j.oom = true; }
-                });
-        bool oom = false;
-        try { build(0, 0, 0, plan->d, he); } catch (const std::bad_alloc &) { oom = true; }
-        for (std::thread &w : workers) w.join();
-        for (const LineJob &j : jobs) { if (he == hipSuccess) he = j.he; oom |= j.oom; }
+        // A job never lets an exception out of its thread (that would be std::terminate): bad_alloc and anything else it
+        // meets are noted in the job.  A thread that cannot be started (std::system_error: EAGAIN under a thread or process
+        // limit -- every plan build asks for three, concurrent drop-in calls multiply that) means the job runs here, on the
+        // calling thread, like all of them do under WAGG_PLAN_SERIAL_BUILD.  The joiner runs before anything leaves this
+        // scope, so no joinable thread is ever destroyed and `build` / `jobs` outlive every worker.
+        auto run_job = [&build](LineJob &j, int dev, bool set_device) noexcept {
+            try {
+                if (set_device) j.he = hipSetDevice(dev);            // a new thread starts on device 0
+                if (j.he == hipSuccess) j.ok = build(j.line_cells, j.lines_per_chunk, j.kind, *j.d, j.he);
+            } catch (const std::bad_alloc &) { j.oom = true; }
+            catch (...) { j.failed = true; }
+        };
+        struct Joiner {
+            std::vector<std::thread> t;
+            ~Joiner() { for (std::thread &w : t) if (w.joinable()) w.join(); }
+        } workers;
+        bool oom = false, failed = false;
+        if (want_line_plans) {
+            try { workers.t.reserve(3); } catch (...) { flags |= WAGG_PLAN_SERIAL_BUILD; }
+            for (LineJob &j : jobs) {
+                bool started = false;
+                if (!(flags & WAGG_PLAN_SERIAL_BUILD)) {
+                    try {
+                        workers.t.emplace_back(run_job, std::ref(j), plan->device, true);
+                        started = true;
+                    } catch (...) {}                                  // no thread to be had: the job runs below
+                }
+                if (!started) run_job(j, plan->device, false);
+            }
+        }
+        try { build(0, 0, 0, plan->d, he); } catch (const std::bad_alloc &) { oom = true; } catch (...) { failed = true; }
+        for (std::thread &w : workers.t) w.join();
+        for (const LineJob &j : jobs) { if (he == hipSuccess) he = j.he; oom |= j.oom; failed |= j.failed; }
+        if (failed) {
+            set_error("plan build failed: unexpected exception in a chunking builder");
+            return WAGG_EINTERNAL;                                    // (plan_guard deletes the plan)
+        }
         if (oom) throw std::bad_alloc();
         if (want_line_plans && he == hipSuccess) {
             plan->has_lines = jobs[0].ok; plan->has_lines64 = jobs[1].ok; plan->has_lines64e = jobs[2].ok;
@@ -2894,6 +1930,12 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
     } catch (const std::bad_alloc &) {
         set_error("host allocation failed while building the plan");
         return WAGG_ENOMEM;
+    } catch (const std::exception &e) {                               // nothing may cross the C boundary
+        set_error("plan build failed: %s", e.what());
+        return WAGG_EINTERNAL;
+    } catch (...) {
+        set_error("plan build failed: unknown exception");
+        return WAGG_EINTERNAL;
     }
 }
 

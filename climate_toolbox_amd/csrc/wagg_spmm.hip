@@ -6,31 +6,35 @@
 // compacted per 16-region block a 16x16x4 MFMA tile is only ~6.7 % full, so the matrix pipe cannot
 // beat ~10 TF here.  This kernel does exactly 2*T*nnz flops on the vector ALU instead:
 //
-//   * lanes = timesteps, two per lane.  A workgroup (16 waves, one per CU) owns 128 timesteps x (16 * rw)
-//     regions; every wave keeps rw <= 43 regions x 128 timesteps as ACCUMULATOR REGISTER PAIRS
-//     v[40:125] for the whole k loop (90k accumulators per CU: each byte of X that reaches the CU is
-//     used ~7 times).
+//   * lanes = timesteps: two fp32 per lane, one fp64.  A workgroup (16 waves, one per CU) owns 512 bytes of
+//     timesteps (128 fp32 / 64 fp64) x (16 * rw) regions; every wave keeps rw <= 43 regions as ACCUMULATOR
+//     REGISTER PAIRS v[40:125] for the whole k loop (90k accumulators per CU: each byte of X that reaches the
+//     CU is used ~7 times).
 //   * X is packed once per apply as Xp[time block][cell][128 timesteps] (transform, NaN -> 0 and
 //     zero padding fused, like the MFMA forms' pack); a chunk of 128 cells is one contiguous 64 KiB
 //     run that goes HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered, one
 //     workgroup barrier per chunk.
 //   * W is never a matrix: per (region block, chunk, wave) a list of entries (cell_in_chunk << 9 |
-//     accumulator: 16 bits; weight: 32 / 64 bits), padded to 8-entry groups stored as
-//     [4 x lo16 pairs][8 x weight]([8 x weight high words]) -- 48 bytes in fp32, 80 in fp64.
-//     A wave loads its whole list for the chunk with coalesced vector loads up front (the scalar cache
-//     was tried first and is latency/throughput-bound at ~870 cycles per 64-byte line: 104 ms per c5
-//     rank shard) and broadcasts entry after entry into SGPRs with v_readlane (one for the lo16 of TWO
-//     entries, one per weight word); one entry = 1.5 v_readlane + v_bfi (LDS address) + ds_read_b64
-//     (2 x 64 timesteps of the cell, conflict-free) + ONE v_pk_fma_f32 whose accumulator pair is picked
-//     by the entry itself through the VGPR index mode (s_set_gpr_idx_*: dst/src2 = v[40 + M0[7:0] ...]).
-//     fp64 (the reference's own arithmetic type, aggregations.py:73-80): one timestep per lane, the same
-//     512-byte cell rows, 2.5 v_readlane and one v_fma_f64 per entry.  The loop is generated
-//     (tools/gen_spmm_asm.py -> wagg_spmm_asm.inc); the next chunk's list is loaded into a second
-//     register set while this chunk's entries are processed.
-//   * bound: a wave64 vector instruction occupies its SIMD for 4 cycles (measured: SQ_ACTIVE_INST_VALU),
-//     so 4 vector instructions per entry = 16 cycles per 128 FMAs -> 32 lane-FMAs/clk/CU = 25 % of
-//     the fp32 vector/MFMA peak (157.3 TF) on the algorithmic flops; the LDS (one ds_read_b64 per
-//     entry) is at half of its rate there.
+//     accumulator register: 16 bits; weight: 32 / 64 bits), padded to 8-entry groups stored as
+//     [4 x lo16 pairs][8 x weight] -- 48 bytes in fp32, 80 in fp64.  While a wave works through this chunk's
+//     list, the NEXT chunk's list is already on its way: the lo16 halves two per dword by coalesced vector
+//     loads into a second register set (the scalar cache was tried first: ~870 cycles per 64-byte line, 104 ms
+//     per c5 rank shard), the WEIGHTS straight into the wave's own LDS slots by LDS-DMA (round 3: a v_readlane
+//     per weight word cost more vector-ALU issue time than the FMA it fed, profiles/r03_spmm_ablation_a.txt).
+//     Per entry: half a v_readlane (one brings the lo16 of TWO entries; the odd one is a scalar shift), v_bfi
+//     (LDS address of the cell), ds_read_b64 (2 x 64 fp32 timesteps of the cell, or 64 doubles: conflict-free),
+//     a quarter of a broadcast ds_read_b128 (four weights; two in fp64) and ONE v_pk_fma_f32 / v_fma_f64 whose
+//     accumulator pair is picked by the entry itself through the VGPR index mode (s_set_gpr_idx_idx: dst / src2
+//     = v[40 + M0[7:0] ...]) and whose weight operand is a VGPR selected by op_sel -- no dynamic-indexing
+//     moves, no scratch.  fp64 is the reference's own arithmetic type (aggregations.py:73-80): one timestep
+//     per lane, the same 512-byte cell rows.  The loop is generated (tools/gen_spmm_asm.py ->
+//     wagg_spmm_asm.inc); tools/check_spmm_codegen.py verifies in the Makefile that the compiler's glue code
+//     between the inline-asm statements leaves the live list registers v[3:35] alone.
+//   * bound (profiles/r04_pmc.csv): 2.85 vector + 1.42 LDS instructions per entry; three
+//     resources of a CU are each within 1.6x of the kernel's time -- the LDS array (the 512-byte cell row per
+//     entry plus the DMA writes), the LDS-DMA ingest of the X stream (36 region blocks re-stream X) and vector
+//     issue; the formulation tops out near 25 % of the fp32 vector peak, measured 15.8 % (fp64 13.9 %).  This is
+//     the worst-case structure (1 % non-zeros at random positions); frozen since round 4.
 //   * k is split into S slices so that every CU gets the same number of items; partial sums go to
 //     slabT[slice][region][time] (256-byte coalesced stores straight from the accumulators) and one
 //     reduce kernel adds the slices, divides by den[r] (aggregations.py:77-80) and transposes to
@@ -374,7 +378,7 @@ void spmm_geometry(int64_t G, int32_t R, SpmmPlan &sp) {
 
 // counts per (region block, chunk, wave) -> first 8-entry group of each list (+ total at the end)
 template <typename T>
-static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
+static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts, hipStream_t st = nullptr) {
     constexpr int GW = SpT<T>::GW;
     SpmmPlan &sp = d->sp;
     std::vector<int32_t> off(counts.size() + 1, 0);
@@ -388,10 +392,10 @@ static int spmm_offsets(wagg_dense *d, const std::vector<int32_t> &counts) {
     off[counts.size()] = (int32_t)groups;
     sp.n_groups = groups;
     sp.nnz = nnz;
-    WAGG_HIP(sp.grp_off.upload(off));
+    WAGG_HIP(sp.grp_off.upload(off, st));
     // padding groups at the end: a wave always loads 16 groups from its list start
     WAGG_HIP(sp.ent.alloc((size_t)(groups + SP_PAD_GROUPS) * GW));
-    WAGG_HIP(hipMemset(sp.ent.p + (size_t)groups * GW, 0, sizeof(uint32_t) * GW * SP_PAD_GROUPS));
+    WAGG_HIP(hipMemsetAsync(sp.ent.p + (size_t)groups * GW, 0, sizeof(uint32_t) * GW * SP_PAD_GROUPS, st));
     return WAGG_OK;
 }
 
@@ -431,17 +435,24 @@ template int spmm_build_synth<double>(wagg_dense *, uint32_t, double);
 // The distinct pairs arrive in key order = (bucket, cell in chunk, region in wave): every list is one run of them, already
 // in the order the synthetic builder produces (cell-major, regions ascending), so a table that holds the synthetic weights
 // gives the same lists -- and with them the same fp32 sums -- bit for bit.
+// first[b] = place of bucket b's first pair = lower bound of the bucket's smallest possible key: one binary search per
+// bucket (+ one for the end).  (Round 4 looked at every pair and its left neighbour: two 64-bit divisions per pair, 23 ms for
+// c5's 2.5e8 pairs -- the largest single kernel of that build; this one reads ~28 keys per bucket, 4.7e6 buckets.)
 __global__ __launch_bounds__(256) void spmm_bounds_kernel(const uint64_t *__restrict__ key, int64_t n, EntryKeyGeom geom,
-                                                          int32_t *__restrict__ first, int32_t *__restrict__ counts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t b = geom.bucket_of(key[i]);
-    if (i == 0 || geom.bucket_of(key[i - 1]) != b) {
-        int64_t e = i + 1;                              // a list is short (c5: ~55 entries): walk to its end
-        while (e < n && geom.bucket_of(key[e]) == b) ++e;
-        first[b] = (int32_t)i;
-        counts[b] = (int32_t)(e - i);
+                                                          int64_t n_buckets, int32_t *__restrict__ first) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    const uint64_t k0 = (uint64_t)b * 128u * (uint64_t)geom.rw;      // keys of bucket b lie in [k0, k0 + 128 rw)
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key[mid] < k0) lo = mid + 1; else hi = mid;
     }
+    first[b] = (int32_t)lo;
+}
+__global__ __launch_bounds__(256) void spmm_counts_kernel(const int32_t *__restrict__ first, int64_t n_buckets, int32_t *__restrict__ counts) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_buckets) counts[b] = first[b + 1] - first[b];
 }
 
 template <typename T>
@@ -470,41 +481,78 @@ __global__ __launch_bounds__(256) void spmm_pad_kernel(const int32_t *__restrict
     for (int e = c; e < padded; ++e) sp_store_entry<T>(ent, (int64_t)grp_off[b] * SP_GROUP + e, (unsigned)SP_TRASH, T(0));
 }
 
+// What the entry-list kernel would have to walk for this table: an item = (region block, chunk) is done when its LONGEST of
+// the 16 per-wave lists is, so the work is 16 x sum over items of the longest list (in whole 8-entry groups) -- equal to the
+// pair count for evenly spread weights, several times it when a chunk's regions sit in a few waves (block-local tables).
+// Integer sums only (order-free): the same table gives the same figure.
+__global__ __launch_bounds__(256) void spmm_cost_kernel(const int32_t *__restrict__ first, int64_t n_items,
+                                                        unsigned long long *__restrict__ total) {
+    const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long m = 0;
+    if (it < n_items) {
+        const int32_t *f = first + it * SP_WAVES;
+        for (int w = 0; w < SP_WAVES; ++w) {
+            const unsigned long long c = (unsigned long long)((f[w + 1] - f[w] + SP_GROUP - 1) / SP_GROUP * SP_GROUP);
+            m = c > m ? c : m;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, m);
+}
+
+int spmm_list_cost(BuildCtx &ctx, const SortedEntries &se, int64_t *walked_entries) {
+    const int64_t n_items = (int64_t)se.geom.n_rb * se.geom.n_chunks, n_buckets = n_items * SP_WAVES;
+    WAGG_REQUIRE(n_buckets < (int64_t)0x7fffffff, "grid too large");
+    const size_t mk = ctx.mark();
+    int32_t *first;
+    unsigned long long *total;
+    WAGG_TAKE(first, ctx, int32_t, n_buckets + 1);
+    WAGG_TAKE(total, ctx, unsigned long long, 1);
+    WAGG_HIP(hipMemsetAsync(total, 0, sizeof(unsigned long long), ctx.st));
+    hipLaunchKernelGGL(spmm_bounds_kernel, dim3((unsigned)((n_buckets + 256) / 256)), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, se.n_u,
+                       se.geom, n_buckets, first);
+    hipLaunchKernelGGL(spmm_cost_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ctx.st, (const int32_t *)first, n_items, total);
+    WAGG_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    WAGG_HIP(staged_d2h(&h, total, sizeof(h), ctx.st));
+    *walked_entries = (int64_t)h * SP_WAVES;
+    ctx.release_to(mk);
+    return WAGG_OK;
+}
+
 template <typename T>
-int spmm_build_from_sorted(wagg_dense *d, const SortedEntries &se) {
+int spmm_build_from_sorted(BuildCtx &ctx, wagg_dense *d, const SortedEntries &se) {
     spmm_geometry(d->G, d->R, d->sp);
     SpmmPlan &sp = d->sp;
     WAGG_REQUIRE(se.geom.rw == sp.rw && se.geom.n_rb == sp.n_rb && se.geom.n_chunks == sp.n_chunks, "sort key of another geometry");
     const int64_t n_buckets = (int64_t)sp.n_rb * sp.n_chunks * SP_WAVES;
     WAGG_REQUIRE(n_buckets < (int64_t)0x7fffffff, "grid too large");
-    DevBuf<int32_t> first, dcounts;
-    WAGG_HIP(first.alloc((size_t)n_buckets));
-    WAGG_HIP(dcounts.alloc((size_t)n_buckets));
-    WAGG_HIP(hipMemset(dcounts.p, 0, sizeof(int32_t) * (size_t)n_buckets));
-    const unsigned nblk = (unsigned)((se.n_u + 255) / 256);
-    if (se.n_u > 0) {
-        hipLaunchKernelGGL(spmm_bounds_kernel, dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, se.n_u, se.geom, first.p,
-                           dcounts.p);
-        WAGG_HIP(hipGetLastError());
-    }
+    const size_t mk = ctx.mark();
+    int32_t *first, *dcounts;
+    WAGG_TAKE(first, ctx, int32_t, n_buckets + 1);
+    WAGG_TAKE(dcounts, ctx, int32_t, n_buckets);
+    const unsigned bblk = (unsigned)((n_buckets + 256) / 256), nblk = (unsigned)((se.n_u + 255) / 256);
+    hipLaunchKernelGGL(spmm_bounds_kernel, dim3(bblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, se.n_u, se.geom, n_buckets, first);
+    hipLaunchKernelGGL(spmm_counts_kernel, dim3(bblk), dim3(256), 0, ctx.st, (const int32_t *)first, n_buckets, dcounts);
+    WAGG_HIP(hipGetLastError());
     std::vector<int32_t> counts;
     try { counts.resize((size_t)n_buckets); } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
-    WAGG_HIP(hipDeviceSynchronize());
-    WAGG_HIP(staged_d2h(counts.data(), dcounts.p, sizeof(int32_t) * counts.size()));
-    if (int rc = spmm_offsets<T>(d, counts)) return rc;
+    WAGG_HIP(staged_d2h(counts.data(), dcounts, sizeof(int32_t) * counts.size(), ctx.st));     // (the host lays the lists out)
+    if (int rc = spmm_offsets<T>(d, counts, ctx.st)) return rc;
     if (se.n_u > 0) {
-        hipLaunchKernelGGL((spmm_fill_kernel<T>), dim3(nblk), dim3(256), 0, nullptr, (const uint64_t *)se.key.p, (const double *)se.w.p,
-                           se.n_u, se.geom, (const int32_t *)first.p, (const int32_t *)sp.grp_off.p, sp.ent.p);
+        hipLaunchKernelGGL((spmm_fill_kernel<T>), dim3(nblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, (const double *)se.w.p,
+                           se.n_u, se.geom, (const int32_t *)first, (const int32_t *)sp.grp_off.p, sp.ent.p);
         WAGG_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL((spmm_pad_kernel<T>), dim3((unsigned)((n_buckets + 255) / 256)), dim3(256), 0, nullptr, (const int32_t *)dcounts.p,
+    hipLaunchKernelGGL((spmm_pad_kernel<T>), dim3((unsigned)((n_buckets + 255) / 256)), dim3(256), 0, ctx.st, (const int32_t *)dcounts,
                        (const int32_t *)sp.grp_off.p, n_buckets, sp.ent.p);
     WAGG_HIP(hipGetLastError());
-    WAGG_HIP(hipDeviceSynchronize());            // `first` / `dcounts` are freed on return
+    ctx.release_to(mk);                          // (the caller synchronises ctx.st before the arena goes)
     return WAGG_OK;
 }
-template int spmm_build_from_sorted<float>(wagg_dense *, const SortedEntries &);
-template int spmm_build_from_sorted<double>(wagg_dense *, const SortedEntries &);
+template int spmm_build_from_sorted<float>(BuildCtx &, wagg_dense *, const SortedEntries &);
+template int spmm_build_from_sorted<double>(BuildCtx &, wagg_dense *, const SortedEntries &);
 
 template <typename T>
 int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT<T> &xf, T *out, int64_t ldo,
@@ -546,11 +594,9 @@ int spmm_apply(wagg_dense *d, const T *X, int64_t Tn, int64_t ldx, const PackXfT
 #ifdef WAGG_DIAG
     if (const char *k = getenv("WAGG_SPMM_KNOB")) knob = atoi(k);
 #endif
-    profile_mark(st, true);
-    hipLaunchKernelGGL((spmm_kernel<T>), dim3((unsigned)nwg), dim3(SP_THREADS), sp_lds_bytes<T>(), st, (const T *)xp,
-                       (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, slabs, n_tb, sp.n_rb, sp.n_chunks, cps,
-                       sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups, knob);
-    profile_mark(st, false);
+    launch_timed(true, spmm_kernel<T>, dim3((unsigned)nwg), dim3(SP_THREADS), sp_lds_bytes<T>(), st, (const T *)xp,
+                 (const uint32_t *)sp.ent.p, (const int32_t *)sp.grp_off.p, slabs, n_tb, sp.n_rb, sp.n_chunks, cps,
+                 sp.rw, Gpad, Tpad, Rpad, (int)n_items, (int)sp.n_groups, knob);
     WAGG_HIP(hipGetLastError());
     const T *den;
     if constexpr (sizeof(T) == 4) den = d->den32.p; else den = d->den64.p;

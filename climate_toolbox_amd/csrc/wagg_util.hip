@@ -41,16 +41,12 @@ struct ProfRing {
 };
 static ProfRing g_prof;
 
-void profile_mark(hipStream_t stream, bool begin) {
-    if (!g_prof.on) return;
-    if (begin) {
-        if (g_prof.count >= WAGG_PROFILE_SLOTS) return;
-        (void)hipEventRecord(g_prof.a[g_prof.count], stream);
-    } else {
-        if (g_prof.count >= WAGG_PROFILE_SLOTS) return;
-        (void)hipEventRecord(g_prof.b[g_prof.count], stream);
-        ++g_prof.count;
-    }
+bool profile_slot(hipEvent_t *start, hipEvent_t *stop) {
+    if (!g_prof.on || g_prof.count >= WAGG_PROFILE_SLOTS) return false;
+    *start = g_prof.a[g_prof.count];
+    *stop = g_prof.b[g_prof.count];
+    ++g_prof.count;
+    return true;
 }
 
 // out[t, i] = X[t, cell_idx[i]]; one thread per (segment, timestep) with the contiguous axis of

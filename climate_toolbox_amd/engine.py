@@ -285,8 +285,17 @@ class DensePlan:
                            "wagg_dense_create_host")
         return cls(h, W.shape[0], W.shape[1], dev, (cls.from_host, (W,), {}))
 
+    # A plan built from a caller's table can be rebuilt on another device (``replica``) only from that table.  Holding on
+    # to the arrays pins the caller's memory -- 3 GB for a configs[4]-sized table -- to the lifetime of every cached plan,
+    # so they are kept only on request (``keep_recipe=True``: the drop-in asks for it when HOST_DEVICES opts into replicas)
+    # or when they are small.
+    _RECIPE_KEEP_BYTES = 64 << 20
+
     @classmethod
-    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32", device=None):
+    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32", device=None, form=None, keep_recipe=None):
+        """From the coded segment table (COO rows; ``wagg_dense_create_from_segments*``).  ``form``: None / "auto" lets the
+        library choose (the caller never needs to know the form, like the reference's single weights type,
+        aggregations.py:64-73); "full" / "tiles" / "entries" pin it (measurements, tests).  At most 2**31 - 1 rows."""
         require_gpu()
         ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
         rc = np.ascontiguousarray(region_code, dtype=np.int32)
@@ -297,15 +306,17 @@ class DensePlan:
         with _on_device(device):
             dev = _current_device()
             _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
-                          int(R), C.byref(h)), "wagg_dense_create_from_segments")
-        return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype)))
+                          int(R), _lib.FORCE_FORM[form], C.byref(h)), "wagg_dense_create_from_segments")
+        keep = keep_recipe if keep_recipe is not None else ci.nbytes + rc.nbytes + we.nbytes <= cls._RECIPE_KEEP_BYTES
+        return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype, form=form)) if keep else None)
 
     @classmethod
-    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None):
+    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None, form=None, keep_recipe=None):
         """From a caller's table in CSR form (``wagg_dense_create_from_csr*``; BASELINE configs[4] "sparse CSR weights"):
         ``rowptr`` (G + 1 offsets, rows = grid cells), ``col`` = region codes, ``val`` = fp64 weights -- the coded form of
         the reference's weights table (aggregations.py:64-73).  The arrays are uploaded as they are (no host copy when
-        they already have the dtypes int64 / int32 / float64); everything else happens on the device."""
+        they already have the dtypes int64 / int32 / float64); everything else happens on the device.  ``form`` as for
+        :meth:`from_segments`."""
         require_gpu()
         rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         co = np.ascontiguousarray(col, dtype=np.int32)
@@ -317,14 +328,20 @@ class DensePlan:
         fn = L.wagg_dense_create_from_csr_f64 if cls._is64(dtype) else L.wagg_dense_create_from_csr
         with _on_device(device):
             dev = _current_device()
-            _lib.check(fn(_np_ptr(rp, C.c_int64), _np_ptr(co, C.c_int32), _np_ptr(va, C.c_double), int(G), int(R), C.byref(h)),
-                       "wagg_dense_create_from_csr")
-        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype)))
+            _lib.check(fn(_np_ptr(rp, C.c_int64), _np_ptr(co, C.c_int32), _np_ptr(va, C.c_double), int(G), int(R),
+                          _lib.FORCE_FORM[form], C.byref(h)), "wagg_dense_create_from_csr")
+        keep = keep_recipe if keep_recipe is not None else rp.nbytes + co.nbytes + va.nbytes <= cls._RECIPE_KEEP_BYTES
+        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype, form=form)) if keep else None)
 
     def replica(self, device):
         """The same weights as a plan of its own on ``device`` (multi-device host streaming; a dense-family plan
         owns its workspaces, so every pipeline needs its own replica -- also two on one device)."""
+        if self._recipe is None:
+            raise WaggError("this plan was built from a large caller's table that it did not keep (keep_recipe=False): "
+                            "build the replica from the table yourself, DensePlan.from_csr(..., device=%r)" % (device,))
         fn, args, kw = self._recipe
+        if "keep_recipe" in fn.__code__.co_varnames:
+            kw = dict(kw, keep_recipe=True)
         return fn(*args, device=device, **kw)
 
     def close(self):
@@ -617,9 +634,12 @@ def profile_enable(on=True):
     _lib.check(_lib.load().wagg_profile_enable(1 if on else 0), "wagg_profile_enable")
 
 
+PROFILE_SLOTS = 1024      # wagg.h WAGG_PROFILE_SLOTS
+
+
 def profile_read():
     """Durations (ms) of the dominant kernels recorded since profile_enable(); blocks."""
-    buf = (C.c_float * 256)()
+    buf = (C.c_float * PROFILE_SLOTS)()
     n = C.c_int(0)
-    _lib.check(_lib.load().wagg_profile_read(buf, 256, C.byref(n)), "wagg_profile_read")
+    _lib.check(_lib.load().wagg_profile_read(buf, PROFILE_SLOTS, C.byref(n)), "wagg_profile_read")
     return [float(buf[i]) for i in range(n.value)]

@@ -34,6 +34,12 @@ class DataArray:
         return np.asarray(v)
 
     @property
+    def data(self):
+        """The buffer as it is held (xarray's ``.data``): a NumPy array, or a torch CUDA tensor for device-resident
+        variables and for results returned under ``results_on_device()`` -- no copy."""
+        return self._values
+
+    @property
     def shape(self):
         return tuple(self._values.shape)
 

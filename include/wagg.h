@@ -40,7 +40,8 @@ typedef enum wagg_status {
     WAGG_ENOMEM = -3,  /* host or device allocation failed */
     WAGG_ENODEV = -4,  /* no gfx950 device visible */
     WAGG_EUNSUPPORTED = -5,
-    WAGG_EKEY = -6     /* a segment label is absent from the grid (the reference's KeyError, S1) */
+    WAGG_EKEY = -6,    /* a segment label is absent from the grid (the reference's KeyError, S1) */
+    WAGG_EINTERNAL = -7 /* an exception other than bad_alloc inside the library (never crosses the C boundary) */
 } wagg_status;
 
 /* memory layout of the flattened data matrix X and of the result */
@@ -86,12 +87,13 @@ int wagg_shard_rows(int64_t T, int world, int rank, int64_t *start, int64_t *sto
 const char *wagg_last_error(void);      /* thread-local, never NULL                              */
 
 /* ---- in-library kernel timing (HIP events on the stream the kernel is launched on) ----------- */
-/* While enabled, every apply records an event pair around its DOMINANT kernel (sparse: the
- * gather kernel; dense: the MFMA kernel) into a ring of WAGG_PROFILE_SLOTS pairs, without any
- * synchronisation.  wagg_profile_read blocks until the recorded kernels have finished and
- * returns their durations in milliseconds, oldest first.  Process-global and not thread-safe:
- * enable/read from the thread that issues the applies.                                         */
-#define WAGG_PROFILE_SLOTS 256
+/* While enabled, every apply hands an event pair to the launch of its DOMINANT kernel (sparse: the
+ * gather kernel; dense-family: the MFMA / entry-list kernel) -- hipExtLaunchKernel's startEvent / stopEvent, which
+ * stamp the dispatch itself, so host time between two API calls is never booked as kernel time -- from a
+ * ring of WAGG_PROFILE_SLOTS pairs, without any synchronisation.  wagg_profile_read blocks until the recorded
+ * kernels have finished and returns their durations in milliseconds, oldest first.  Process-global and not
+ * thread-safe: enable/read from the thread that issues the applies.  Not for use under stream capture.   */
+#define WAGG_PROFILE_SLOTS 1024
 int wagg_profile_enable(int on);        /* also resets the ring */
 int wagg_profile_read(float *ms_out, int max_out, int *n_out);
 
@@ -130,6 +132,9 @@ int wagg_factorize_bytes(const char *buf, int64_t width, const uint8_t *isnull, 
 #define WAGG_PLAN_LC_MFMA 8   /* DIAGNOSTIC BUILD ONLY (libwagg_diag.so): fp32 loader/consumer kernel with dense-tile MFMA consumers
                                  (rounds 1-2) -- the one kernel with a bounded-spin barrier; libwagg.so refuses the flag with
                                  WAGG_EUNSUPPORTED */
+#define WAGG_PLAN_SERIAL_BUILD 16 /* build the chunkings one after the other on the calling thread (the library starts three
+                                 worker threads otherwise and falls back to exactly this when a thread cannot be started);
+                                 the plan is the same bit for bit */
 int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_code, const double *w_eff,
                      int64_t nseg, int64_t G, int32_t R, int64_t row_len, int flags,
                      wagg_plan **out);
@@ -295,25 +300,34 @@ int wagg_dense_create_synth_sparse(int64_t G, int32_t R, uint32_t seed, double f
  * full matrix is generated; the same holds for wagg_dense_create_synth_f64)                        */
 /* from a host row-major (G, R) fp32 matrix (small cases / tests) */
 int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense **out);
-/* from a sparse plan's coded table (weights whose regions are scattered over the grid).  The form
- * follows the structure: fewer than half of the (32-cell x 256-region) tiles occupied -> only those
- * are stored and contracted by the MFMA kernel (WAGG_FORM_TILES: c5's block-local weights); tiles
- * mostly occupied but under 10 % non-zeros -> entry lists and the vector-ALU kernel
- * (WAGG_FORM_ENTRIES: c5's uniformly random weights); else the full matrix (WAGG_FORM_FULL).     */
+/* from a sparse plan's coded table (weights whose regions are scattered over the grid).  The caller brings ONE kind of
+ * table, like the reference (aggregations.py:64-73); which of the three device forms it takes is the library's choice,
+ * made from the structure it finds (a census of the occupied (32-cell x 256-region) tiles and the number of distinct
+ * pairs) by the estimated time per row of X of each form at its measured rate (tools/form_crossover.py):
+ * only the non-empty tiles on the MFMA kernel (WAGG_FORM_TILES: c5's block-local weights), entry lists on the vector ALU
+ * (WAGG_FORM_ENTRIES: c5's uniformly random 1 %), or the full matrix (WAGG_FORM_FULL).
+ * flags: WAGG_DENSE_FORM_AUTO (0), or WAGG_DENSE_FORCE_* to pin the form -- for measurements and tests; results agree
+ * between the forms to rounding.  Up to 2^31 - 1 rows.                                              */
+#define WAGG_DENSE_FORM_AUTO 0
+#define WAGG_DENSE_FORCE_FULL 1
+#define WAGG_DENSE_FORCE_TILES 2
+#define WAGG_DENSE_FORCE_ENTRIES 3
 int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                     const double *w_eff, int64_t nseg, int64_t G, int32_t R,
-                                    wagg_dense **out);
+                                    int flags, wagg_dense **out);
 /* The same table in CSR form -- BASELINE configs[4] "sparse CSR weights (<= 1 % nnz)": rows = grid cells (rowptr[G + 1],
  * rowptr[0] = 0, non-decreasing), col = region codes (-1 = null label, dropped), val = fp64 weights (NaN: dropped);
  * columns of a row in any order, repeated (cell, region) pairs add in the order they are stored (S5).
  * Both constructors only UPLOAD the host arrays (page-locked in place for the copy when they are large, through the
  * library's staging pieces otherwise: no host copy of the table is made); sorting into the kernels' order, coalescing,
  * the denominators (aggregations.py:79), the tile census that picks the form, and the packing run on the device
- * (stable radix sort, fixed summation orders: the same table gives the same plan, bit for bit; csrc/wagg_build.hip).
- * Up to 2^31 - 1 entries; a configs[4]-sized table (2.53e8 entries, 3 GB) needs ~13 GB of device scratch while it is
- * built.  wagg_dense_info.build_s / build_upload_s report where the time went.                                        */
+ * (stable radix sort, fixed summation orders: the same table gives the same plan, bit for bit; csrc/wagg_build.hip) --
+ * on a stream of the build's own, out of one scratch arena: a build never waits for, nor stops, the streams other plans
+ * are applied on.  Up to 2^31 - 1 entries; a configs[4]-sized table (2.53e8 entries, 3 GB) needs ~12 GB of device scratch
+ * while it is built (48 bytes per entry) plus 16 bytes per distinct pair.  wagg_dense_info.build_s / build_upload_s
+ * report where the time went.                                                                                         */
 int wagg_dense_create_from_csr(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
-                               wagg_dense **out);
+                               int flags, wagg_dense **out);
 /* synthetic block-local weights (SURVEY 8d, c5 "each 64-cell run touches <= 256 regions"): run j of
  * 64 cells touches the 256 regions of column tile (97 j) mod ceil(R/256); inside, W[g,r] =
  * hash_u01(g*R + r, seed) where hash_u01(g*R + r, seed ^ 0x9e3779b9) < fill, else 0.  Generated on
@@ -322,7 +336,7 @@ int wagg_dense_create_synth_blocklocal(int64_t G, int32_t R, uint32_t seed, doub
 #define WAGG_FORM_FULL 0     /* every (32-cell x 256-region) tile of W stored, fp32 MFMA contraction            */
 #define WAGG_FORM_TILES 1    /* only the non-empty tiles ("tile-sparse": block-local weights), same MFMA kernel */
 #define WAGG_FORM_ENTRIES 2  /* no matrix: per-wave (cell, region, weight) lists, vector-ALU kernel (scattered,
-                                sparse weights: <= 10 % non-zeros spread over (almost) every tile), fp32 or fp64 */
+                                sparse weights: a few per cent of non-zeros spread over (almost) every tile), fp32 or fp64 */
 /* The *_f64 constructors build the same forms with fp64 weights for fp64 data (the reference's own
  * arithmetic type, aggregations.py:73-80): tiles are (16-cell x 256-region), the contraction runs on
  * v_mfma_f64_16x16x4_f64 (wagg_dense_apply_f64); the entry-list form keeps 64-bit weights (80 bytes per
@@ -332,9 +346,9 @@ int wagg_dense_create_synth_f64(int64_t G, int32_t R, uint32_t seed, double fill
 int wagg_dense_create_host_f64(const double *W_host, int64_t G, int32_t R, wagg_dense **out);
 int wagg_dense_create_from_segments_f64(const int32_t *cell_idx, const int32_t *region_code,
                                         const double *w_eff, int64_t nseg, int64_t G, int32_t R,
-                                        wagg_dense **out);
+                                        int flags, wagg_dense **out);
 int wagg_dense_create_from_csr_f64(const int64_t *rowptr, const int32_t *col, const double *val, int64_t G, int32_t R,
-                                   wagg_dense **out);
+                                   int flags, wagg_dense **out);
 int wagg_dense_create_synth_blocklocal_f64(int64_t G, int32_t R, uint32_t seed, double fill, wagg_dense **out);
 typedef struct wagg_dense_info {
     int64_t G, n_tiles, w_bytes;   /* stored (32 x 256) tiles; bytes of W (or of the entry lists) in HBM */
@@ -344,6 +358,10 @@ typedef struct wagg_dense_info {
                                       caller's table (from_segments / from_csr); else -1 */
     double build_s, build_upload_s; /* plans built from a caller's table: wall seconds of the constructor, and the part of
                                       them spent moving the table to the device (else 0) */
+    double est_row_s[3];           /* plans built from a caller's table: what the form choice went by -- estimated seconds per
+                                      row of X in the forms WAGG_FORM_FULL / _TILES / _ENTRIES (else 0) */
+    int64_t walked_entries;        /* ... and the entries the entry-list kernel would walk (16 x the longest per-wave list of
+                                      every (region block, chunk) item): = nnz for evenly spread weights */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);

@@ -54,9 +54,10 @@ def _p(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
 
 
-def segments(X, cell_idx, region_code, w_eff, R, layout="TG", threaded=False):
+def segments(X, cell_idx, region_code, w_eff, R, layout="TG", threaded=False, out=None):
     """fp64 (T, R) result of the faithful single-threaded C restatement (``threaded``: the same sums with the
-    timesteps dealt to OpenMP threads -- the best-effort CPU leg of bench.py; identical bits)."""
+    timesteps dealt to OpenMP threads -- the best-effort CPU leg of bench.py; identical bits).  ``out``: a (T, R) float64
+    array to write into (repeated timing calls reuse one touched buffer instead of faulting 70 MB of fresh pages in)."""
     L = lib()
     X = np.ascontiguousarray(X)
     assert X.ndim == 2 and X.dtype in (np.float32, np.float64)
@@ -70,7 +71,9 @@ def segments(X, cell_idx, region_code, w_eff, R, layout="TG", threaded=False):
     ci = np.ascontiguousarray(cell_idx, dtype=np.int32)
     rc = np.ascontiguousarray(region_code, dtype=np.int32)
     we = np.ascontiguousarray(w_eff, dtype=np.float64)
-    out = np.empty((T, R), dtype=np.float64)
+    if out is None:
+        out = np.empty((T, R), dtype=np.float64)
+    assert out.shape == (T, R) and out.dtype == np.float64 and out.flags.c_contiguous
     fn = getattr(L, "wagg_oracle_segments_%s%s" % ("omp_" if threaded else "", "f32" if X.dtype == np.float32 else "f64"))
     ct = C.c_float if X.dtype == np.float32 else C.c_double
     rcode = fn(_p(X, ct), T, ldx, lay, _p(ci, C.c_int32), _p(rc, C.c_int32), _p(we, C.c_double),

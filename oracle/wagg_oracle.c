@@ -33,6 +33,15 @@ int wagg_oracle_threads(void) {
 #endif
 }
 
+/* A fixed team for the threaded legs: no dynamic adjustment of the thread count between calls (bench.py also sets
+ * OMP_PROC_BIND=spread OMP_PLACES=cores before this library loads, and warms the team with untimed calls). */
+static void wagg_oracle_fixed_team(void) {
+#ifdef _OPENMP
+    static int done = 0;
+    if (!done) { omp_set_dynamic(0); done = 1; }
+#endif
+}
+
 /* Faithful, single-threaded like the reference: per timestep gather -> multiply -> group-sum.
  * out is (T, R) row-major double.  Returns 0, or -1 on a bad index. */
 #define DEFINE_SEGMENTS(NAME, TYPE)                                                              \
@@ -311,7 +320,8 @@ int64_t wagg_oracle_synth_csr(int64_t G, int64_t R, uint32_t seed, double fill, 
             if (r >= R || cell_idx[i] < 0 || cell_idx[i] >= G) { free(den); return -1; }          \
             if (!isnan(w_eff[i])) den[r] += w_eff[i];                                             \
         }                                                                                         \
-        _Pragma("omp parallel for schedule(static)")                                              \
+        wagg_oracle_fixed_team();                                                                 \
+        _Pragma("omp parallel for schedule(static) proc_bind(spread)")                            \
         for (int64_t t = 0; t < T; ++t) {                                                         \
             double *row = out + t * (int64_t)R;                                                   \
             for (int32_t r = 0; r < R; ++r) row[r] = 0.0;                                         \

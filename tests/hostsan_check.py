@@ -75,7 +75,7 @@ for nseg, giant in ((0, 0), (1, 0), (40000, 0), (30000, 3)):
         L.wagg_plan_destroy(h)
     h2 = C.c_void_p()
     rcode = L.wagg_dense_create_from_segments(p(ci, C.c_int32), p(rc, C.c_int32), p(ww, C.c_double), C.c_int64(nseg),
-                                              C.c_int64(G), C.c_int32(R), C.byref(h2))
+                                              C.c_int64(G), C.c_int32(R), 0, C.byref(h2))
     assert rcode in (0, -1, -2, -3, -4), (rcode, L.wagg_last_error())
     if rcode == 0:
         L.wagg_dense_destroy(h2)
@@ -84,13 +84,13 @@ for nseg, giant in ((0, 0), (1, 0), (40000, 0), (30000, 3)):
     rowptr = np.zeros(G + 1, np.int64); np.add.at(rowptr, ci.astype(np.int64) + 1, 1); rowptr = np.cumsum(rowptr)
     col, val = np.ascontiguousarray(rc[order]), np.ascontiguousarray(ww[order])
     h3 = C.c_void_p()
-    rcode = L.wagg_dense_create_from_csr(p(rowptr, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), C.byref(h3))
+    rcode = L.wagg_dense_create_from_csr(p(rowptr, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), 0, C.byref(h3))
     assert rcode in (0, -1, -2, -3, -4), (rcode, L.wagg_last_error())
     if rcode == 0:
         L.wagg_dense_destroy(h3)
     if nseg > 1:
         bad = rowptr.copy(); bad[G // 2] = bad[G // 2 + 1] + 1
-        assert L.wagg_dense_create_from_csr(p(bad, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), C.byref(h3)) == -1
+        assert L.wagg_dense_create_from_csr(p(bad, C.c_int64), p(col, C.c_int32), p(val, C.c_double), C.c_int64(G), C.c_int32(R), 0, C.byref(h3)) == -1
 # compact regions on a grid whose rows are not a whole number of 32-cell lines: the whole-line plan (chunks of eight
 # lines per column strip, partial rows) and, with WAGG_PLAN_NO_LINES = 4, the region-shaped chunks
 nlat, nlon = 61, 100
@@ -99,8 +99,8 @@ reg = ((cells // nlon) // 5 * 20 + (cells % nlon) // 5).astype(np.int32)
 dup = rng.integers(0, len(cells), 700)
 ci = np.concatenate([cells, cells[dup]]); rc = np.concatenate([reg, (reg[dup] + 1) % (reg.max() + 1)])
 ww = rng.uniform(0.1, 1, len(ci))
-for fl in (0, 4):
-    h = C.c_void_p()
+for fl in (0, 4, 16, 20):                  # 16 = WAGG_PLAN_SERIAL_BUILD: the chunkings one after the other on this thread (what the
+    h = C.c_void_p()                       # library falls back to when it cannot start its worker threads)
     rcode = L.wagg_plan_create(p(ci, C.c_int32), p(rc, C.c_int32), p(ww, C.c_double), C.c_int64(len(ci)), C.c_int64(nlat * nlon),
                                C.c_int32(int(reg.max()) + 1), C.c_int64(nlon), fl, C.byref(h))
     assert rcode in (0, -2, -4), (rcode, L.wagg_last_error())

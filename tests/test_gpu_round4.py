@@ -323,7 +323,12 @@ def test_bench_over_rccl_with_one_rank():
     assert len(lines) == 1, p.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["scaling_measured"] is False
-    assert rec["roofline"]["bound"] == "hbm" and rec["value"] > 0 and rec["min_ms"] <= rec["median_ms"]
+    assert rec["roofline"]["bound"] == "hbm" and rec["value"] > 0 and rec["min_ms"] <= rec["median_ms"] <= rec["max_ms"]
+    # the N > 1 fields, here over RCCL itself (one rank): the all-reduce proof, one blocking gather timed, per-rank medians
+    assert rec["rccl_ranks"] == 1 and rec["backend"] == "nccl" and rec["gather_ms"] > 0 and len(rec["per_rank_ms"]) == 1
+    rf = rec["roofline"]                   # kernel timings: hipExtLaunchKernel start / stop events, median-based fraction
+    assert rf["kernel_launches"] == 3 and rf["kernel_ms_min"] <= rf["kernel_ms_median"] <= rf["kernel_ms_max"] <= rec["max_ms"]
+    assert rf["frac_basis"] == "median kernel time" and rec["warmup_done"] >= rec["warmup"]
 
 
 _RCCL_CHILD = r"""
@@ -499,11 +504,25 @@ def test_bench_multi_rank_control_flow_rehearsal():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 3 and rec["scaling"] == "weak" and rec["scaling_measured"] is False and "rehearsal" in rec
     assert rec["gather_ok"] is True and rec["config"]["T_job"] == 3 * 365
+    # what the driver needs to check an N > 1 line: the all-reduce-of-ones proof that the collective
+    # backend saw every rank, one blocking gather of the real block timed (max over ranks), every rank's median step
+    assert rec["rccl_ranks"] == 3 and rec["backend"] == "gloo" and rec["gather_ms"] > 0 and len(rec["per_rank_ms"]) == 3
+    assert rec["gather_bytes"] == 3 * 365 * 600 * 4 and all(ms > 0 for ms in rec["per_rank_ms"])
+    assert rec["summary"]["rows"][0]["wl"] == "c2-dense" and [r["wl"] for r in rec["summary"]["rows"][1:]] == ["c4", "c5-uniform"]
     sec = {s["workload"]: s for s in rec["secondary"]}
     assert set(sec) == {"c4", "c5-uniform"}
     assert sec["c4"]["scaling"] == "strong" and sec["c4"]["T_job"] == 10950 and sec["c4"]["gather_ok"] is True
     assert sec["c5-uniform"]["scaling"] == "strong" and sec["c5-uniform"]["T_job"] == 18250 and sec["c5-uniform"]["gather_ok"] is True
     assert sec["c5-uniform"]["T"] == 6084                                # ragged: 6084 + 6083 + 6083 rows
+    for wl in ("c4", "c5-uniform"):
+        assert sec[wl]["rccl_ranks"] == 3 and sec[wl]["gather_ms"] > 0 and len(sec[wl]["per_rank_ms"]) == 3
+    # a spent wall-clock budget drops the secondaries instead of running into the driver's limit
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--nlat", "180", "--nlon", "360", "--R", "600",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--budget-s", "0"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert [(s_["workload"], s_["skipped"]) for s_ in rec["secondary"]] == [("c4", "budget"), ("c5-uniform", "budget")]
 
 
 def test_integration_md_csr_binding_runs_as_written(torch_cuda):

@@ -113,6 +113,7 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["config"]["T_job"] == 730
+    assert rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"       # the all-reduce-of-ones proof an N > 1 line carries
     if torch.cuda.device_count() < 2:
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                            capture_output=True, text=True, env=env, timeout=300)

@@ -85,7 +85,11 @@ if os.path.exists(tr):
                      ("c5 table -> plan: sort keys", "keygen_kernel"), ("c5 table -> plan: radix histogram (per pass)", "rs_hist_kernel"),
                      ("c5 table -> plan: radix scatter (per pass)", "rs_scatter_kernel"), ("c5 table -> plan: coalesce duplicates", "coalesce_kernel"),
                      ("c5 table -> plan: denominators", "den_kernel"), ("c5 table -> plan: tile census", "table_tiles_kernel"),
-                     ("c5 table -> plan: entry lists", "spmm_fill_kernel"), ("c5 table -> plan: packed tiles", "table_scatter_kernel"),
+                     ("c5 table -> plan: list bounds (binary search per bucket; also the form choice's cost census)", "spmm_bounds_kernel"),
+                     ("c5 table -> plan: list cost census", "spmm_cost_kernel"),
+                     ("c5 table -> plan: entry lists", "spmm_fill_kernel"), ("c5 table -> plan: list padding", "spmm_pad_kernel"),
+                     ("c5 table -> plan: packed tiles", "table_scatter_kernel"),
+                     ("c5 table -> plan: scan (per call)", "scan_apply_kernel"),
                      ("synthetic c5 table (CSR generator)", "synth_csr_kernel")):
         pick = None
         if "#" in ksub:
