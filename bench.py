@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launcher and the rank plumbing on CPU (gloo, no kernels, value 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-auto-steps", type=int, default=0,
+                    help="cap of the automatically sized timed regions of the secondaries (default 1000; profiler runs pass ~24: "
+                         "a counter pass serialises every launch)")
+    ap.add_argument("--warm-s", type=float, default=-1.0, help="seconds of warm-up before every timed region (default 0.3)")
     ap.add_argument("--budget-s", type=float, default=480.0,
                     help="wall-clock budget of the whole run: secondaries that would start beyond it are dropped with "
                          "\"skipped\": \"budget\" (the driver ends a run at 600 s)")
@@ -296,6 +300,48 @@ def cpu_baseline_dense(T, G, R, seed_w, fill=1.0, blocklocal=False):
                       % (fill, ", block-local" if blocklocal else "", Tw, Gw, Rw)}
 
 
+def usable_cpus():
+    """(threads worth starting, what limits them): the smallest of the logical CPUs, the affinity mask and the cgroup's CPU
+    quota (v2 cpu.max / v1 cpu.cfs_quota_us), the physical cores when nothing else binds (2 hardware threads per core)."""
+    n = os.cpu_count() or 1
+    why = "os.cpu_count"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, "affinity mask"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(quota)), "cgroup cpu quota (%.4g CPUs of %d visible)" % (quota, os.cpu_count() or 1)
+    else:
+        try:                                           # one thread per physical core (OMP_PLACES=cores)
+            cpus = sorted(os.sched_getaffinity(0))
+            cores = set()
+            for c in cpus:
+                base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+                with open(base + "physical_package_id") as f, open(base + "core_id") as g:
+                    cores.add((f.read().strip(), g.read().strip()))
+            if 0 < len(cores) < n:
+                n, why = len(cores), "physical cores"
+        except (AttributeError, OSError):
+            pass
+    return n, why
+
+
 def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
     """The oracle's faithful single-threaded restatement (gather -> fp64 multiply -> group-sum ->
     divide, like the reference) on the sample handed in (the FULL workload for the segment-table
@@ -343,7 +389,8 @@ def cpu_baseline_sparse(X_host, cell, codes, w_eff, R, G, what):
                       % ("f32" if X_host.dtype == np.float32 else "f64", what),
             "cpu_best": {"value": Ts * G * R / dto, "wall_s": round(dto, 5), "wall_s_min": round(domin, 5), "cores": c_oracle.threads(),
                          "repeats": repso, "warm_calls": 3, "kind": "port",
-                         "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_DYNAMIC")},
+                         "omp": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "OMP_DYNAMIC")},
+                         "threads_limited_by": usable_cpus()[1], "host_logical_cpus": os.cpu_count(),
                          "what": "the same C restatement with the timesteps dealt to every host core (OpenMP, one warm team, threads "
                                  "bound to cores, result buffer reused), same sample"},
             "cpu_scipy": {"value": Ts * G * R / dtb, "wall_s": round(dtb, 4), "wall_s_min": round(dbmin, 4), "cores": 1, "repeats": repsb,
@@ -355,11 +402,20 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)              # before anything that could initialise the GPU
+    global MAX_AUTO_STEPS, WARM_S
+    if a.max_auto_steps > 0:
+        MAX_AUTO_STEPS = a.max_auto_steps
+    if a.warm_s >= 0:
+        WARM_S = a.warm_s
     # the CPU legs' OpenMP team: one thread per core, bound, no dynamic adjustment -- set before ANY OpenMP runtime loads
     # (torch brings one; the oracle links another): a team placed by chance gave medians 6x their minimum in round 4
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
     os.environ.setdefault("OMP_DYNAMIC", "false")
+    # ... and no more threads than the CPU time this process may use: the GPU box shows 256 logical CPUs but its cgroup grants
+    # 16 CPUs' worth of time (cpu.max = "1600000 100000"); 128 threads on that are throttled by the scheduler -- the round-4
+    # line's all-cores leg had a median 6x its minimum for exactly that reason
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()[0]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -644,20 +644,44 @@ def _host_replicas(plan, n_rows, row_bytes):
     return tuple(out)
 
 
-DENSE_SWITCH = 16.0   # gathered cells per timestep / grid cells above which the dense form wins
+# Which FAMILY serves a table -- the segment-table gather or the dense family -- by estimated time per row of X, each at its
+# measured rate (tools/form_crossover.py, profiles/r05_form_crossover.txt):
+#   segment table   n_ucells cell slots gathered per row at _SPARSE_CELLS_PER_S (2.7e11 / s in fp32: 0.13 ms for 0.46 G
+#                   compact cells x 365 rows, 0.64 ms for 1.8 G scattered ones; fp64 moves twice the bytes per cell)
+#   dense family    at best its entry lists: never faster than the X stream that each block of 688 regions pulls through the
+#                   LDS-DMA path (b G n_rb bytes per row at 10.1e12 B/s), nor than 2 x 1.3 nseg flop at the entry-loop rate
+# The dense family takes over when the gather would cost _DENSE_MARGIN times as much (the estimate of the dense side is its
+# floor; building it costs more and holds more memory).  Round 4's rule -- n_ucells > 16 G whatever the region count -- sat
+# on the wrong side for small region counts (R = 600: the dense family wins from n_ucells ~ 0.2 G).
+DENSE_SWITCH = 16.0   # the old rule, kept for callers that do not know R (then: n_ucells > DENSE_SWITCH * G)
+_SPARSE_CELLS_PER_S = {True: 2.7e11, False: 1.8e11}      # is_f32 -> gathered cell slots per second
+_DENSE_MARGIN = 1.5
+ENTRY_LIST_MAX_FILL = 0.10   # (memory estimate only) below this share of pairs a table never becomes the full matrix
 _DENSE_BUILD_BYTES_PER_ROW = 64      # device scratch of wagg_dense_create_from_segments while it builds (48 + 16 per row)
 _ENOMEM = -3                         # wagg.h WAGG_ENOMEM
-ENTRY_LIST_MAX_FILL = 0.10   # wagg_dense.hip SPMM_MAX_FILL: below it a scattered table is stored as entry lists
 
 
-def _wants_dense(n_ucells, G, layout):
-    """Device-form choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
+def _dense_floor_s(G, R, nseg, is_f32):
+    """Seconds per row of X the dense family cannot beat for this table (its entry-list form)."""
+    b = 4 if is_f32 else 8
+    n_rb = -(-int(R) // (16 * 43))
+    loop = 2.0 * 1.3 * float(nseg) / (30e12 if is_f32 else 13e12)
+    pack = 2.0 * b * float(G) / 5.3e12                  # X is packed once per apply (read + write at the HBM rate)
+    return max(b * float(G) * n_rb / 10.1e12, loop) + pack
+
+
+def _wants_dense(n_ucells, G, layout, R=None, nseg=None, is_f32=True):
+    """Device-family choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
     per timestep; when regions are scattered all over the grid (e.g. <=1 % non-zeros at random
     columns: every region is a multi-chunk "giant") that is many times the grid itself and the
     dense-family forms (MFMA contraction of the stored tiles in fp32 or fp64, entry lists for very
     sparse tables), whose cost does not depend on where a region's cells lie, are faster -- for a
     (time, gridcell) problem."""
-    return layout == "TG" and n_ucells > DENSE_SWITCH * G
+    if layout != "TG":
+        return False
+    if R is None or nseg is None:
+        return n_ucells > DENSE_SWITCH * G
+    return n_ucells / _SPARSE_CELLS_PER_S[bool(is_f32)] > _DENSE_MARGIN * _dense_floor_s(G, R, nseg, is_f32)
 
 
 def _dense_bytes(G, R, is_f32=True, nseg=None):
@@ -672,8 +696,9 @@ def _dense_bytes(G, R, is_f32=True, nseg=None):
 
 
 def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes, nseg=None):
-    """The form choice as one predicate (tests, tools): scattered regions AND the dense-family plan fits."""
-    return _wants_dense(n_ucells, G, layout) and _dense_bytes(G, R, is_f32, nseg=nseg) < 0.6 * free_bytes
+    """The family choice as one predicate (tests, tools): the gather would cost more AND the dense-family plan fits."""
+    return (_wants_dense(n_ucells, G, layout, R=R, nseg=nseg if nseg is not None else n_ucells, is_f32=is_f32)
+            and _dense_bytes(G, R, is_f32, nseg=nseg) < 0.6 * free_bytes)
 
 
 def _plan_bytes(plan):
@@ -790,11 +815,13 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
                             _evict_plans(0, keep=0)
             return None
 
-        if len(cell_idx) > 4 * DENSE_SWITCH * G and _wants_dense(float("inf"), G, layout) and dense_fits():
+        # (n_ucells >= the table's distinct cells: a table with that many rows per cell needs no sparse plan to know)
+        sure = len(cell_idx) > 4 * DENSE_SWITCH * G and _wants_dense(len(cell_idx) / 4.0, G, layout, R=R, nseg=len(cell_idx), is_f32=is_f32)
+        if sure and dense_fits():
             plan = dense_plan()
         if plan is None:
             plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
-            if _wants_dense(plan.info["n_ucells"], G, layout) and len(cell_idx) <= 4 * DENSE_SWITCH * G and dense_fits():
+            if not sure and _wants_dense(plan.info["n_ucells"], G, layout, R=R, nseg=len(cell_idx), is_f32=is_f32) and dense_fits():
                 dense = dense_plan()
                 if dense is not None:
                     plan.close()

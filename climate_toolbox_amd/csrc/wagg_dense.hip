@@ -633,25 +633,40 @@ constexpr double SPMM_MAX_FILL = 0.10;
 // The reference knows one weights type (aggregations.py:64-73) and so does the caller here: the form is the library's
 // business.  It is chosen by the estimated time per row of X of the three forms, each priced at the rate its kernel was
 // MEASURED at on the c5 grid (tools/form_crossover.py -> profiles/r05_form_crossover.txt; DESIGN.md (b) has the table):
-//   full matrix     2 G R flop                          at the full-form MFMA rate
+//   full matrix     2 x (all tiles x BK x 256) flop     at the full-form MFMA rate (padding of G and R to whole tiles included)
 //   tile-sparse     2 x (stored tiles x BK x 256) flop  at the tile-sparse MFMA rate (a little lower: the tile list is walked)
-//   entry lists     2 nnz flop at the entry-loop rate, but never faster than the X stream that every one of the n_rb region
-//                   blocks pulls through the LDS-DMA path (b G n_rb bytes per row at its ingest rate)
+//   entry lists     2 x walked entries flop at the entry-loop rate of their mean list length, but never faster than the X
+//                   stream that every one of the n_rb region blocks pulls through the LDS-DMA path (b G n_rb bytes per row)
 // Rates in flop/s and byte/s; fp32 / fp64.
-struct FormRates { double full, tiled, entries, dma; };
-constexpr FormRates FORM_RATES_F32 = {145e12, 129e12, 24.8e12, 10.1e12};
-constexpr FormRates FORM_RATES_F64 = {67.7e12, 67.7e12, 10.9e12, 10.1e12};
+struct FormRates { double full, tiled, entries_scale, dma; };
+// fp32: full 204.3 ms / tiles 212.1 ms for 2,282 rows x 8,100 x 96 tiles (all stored); tile-sparse shares 5-75 %: 135-137 TF on
+// the stored tiles' flops; c5-block-f64 / c5-uniform-f64 of bench.py for the fp64 column
+constexpr FormRates FORM_RATES_F32 = {142e12, 136e12, 1.0, 10.1e12};
+constexpr FormRates FORM_RATES_F64 = {70e12, 71e12, 0.44, 10.1e12};
+// The entry loop slows down as the lists grow (the first 16 groups of a wave's list are preloaded across the previous chunk;
+// what follows is fetched inside the loop): flop/s on the WALKED entries against the mean list length per wave and chunk,
+// fp32, measured at uniform fills of 1, 3, 6, 10, 15 and 30 % (mean lengths 54 ... 1625)
+static double entry_loop_rate(double mean_list) {
+    static const double L[] = {170, 325, 541, 812, 1625}, Rt[] = {30e12, 23e12, 19.5e12, 17.3e12, 15.9e12};
+    if (mean_list <= L[0]) return Rt[0];
+    for (int i = 1; i < 5; ++i)
+        if (mean_list <= L[i]) return Rt[i - 1] + (Rt[i] - Rt[i - 1]) * (mean_list - L[i - 1]) / (L[i] - L[i - 1]);
+    return Rt[4];
+}
 
 struct FormCost { double t_full, t_tiled, t_entries; };
 // seconds per row of X.  The MFMA forms multiply whole (BK x 256) tiles, padding included; the entry-list kernel walks
-// `walked` entries (spmm_list_cost: 16 x the longest per-wave list of every item, in whole groups).
-static FormCost table_form_cost(int64_t G, int elem_bytes, int64_t n_tiles_stored, int64_t n_tiles_all, int64_t walked, int n_rb) {
+// `walked` entries (spmm_list_cost: 16 x the longest per-wave list of every item, in whole groups) spread over n_lists
+// (region block, chunk, wave) lists.
+static FormCost table_form_cost(int64_t G, int elem_bytes, int64_t n_tiles_stored, int64_t n_tiles_all, int64_t walked, int n_rb,
+                                int64_t n_lists) {
     const FormRates &rt = elem_bytes == 8 ? FORM_RATES_F64 : FORM_RATES_F32;
     const double tile_flop = 2.0 * (128.0 / elem_bytes) * 256.0;        // BK = 32 / 16 cells x 256 regions
     FormCost c;
     c.t_full = tile_flop * (double)n_tiles_all / rt.full;
     c.t_tiled = tile_flop * (double)n_tiles_stored / rt.tiled;
-    const double t_loop = 2.0 * (double)walked / rt.entries, t_stream = (double)elem_bytes * (double)G * (double)n_rb / rt.dma;
+    const double rate = rt.entries_scale * entry_loop_rate((double)walked / (double)(n_lists > 0 ? n_lists : 1));
+    const double t_loop = 2.0 * (double)walked / rate, t_stream = (double)elem_bytes * (double)G * (double)n_rb / rt.dma;
     c.t_entries = t_loop > t_stream ? t_loop : t_stream;
     return c;
 }
@@ -888,7 +903,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     const double fill_all = (double)se.n_u / ((double)G * (double)R);
     int64_t walked = 0;
     if (se.n_u > 0) { if (int rc = spmm_list_cost(ctx, se, &walked)) return rc; }
-    const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb);
+    const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb, n_buckets);
     bool tiled, entries;
     pick_table_form(cost, &tiled, &entries);
     if (flags == WAGG_DENSE_FORCE_FULL) { tiled = false; entries = false; }

@@ -80,9 +80,10 @@ def test_dense_family_takes_batches_longer_than_one_launch(torch_cuda, form, dty
     got = plan.apply(Xd).cpu().numpy()
     rows = np.r_[0:64, 65400:65600, T - 64:T]               # both sides of 65,504 (fp32) / 65,472 (fp64), first and last rows
     _rel_ok(got[rows], O.agg_coded(X[rows], cell, code, w, R), rtol)
-    # the whole batch: equal to the same rows applied in two halves (bit for bit: rows are independent)
+    # the whole batch against its first half applied alone (rows are independent; the k-split of a launch follows its row
+    # count, so the sums agree to rounding, S12)
     half = plan.apply(Xd[: T // 2]).cpu().numpy()
-    np.testing.assert_array_equal(got[: T // 2], half)
+    np.testing.assert_allclose(got[: T // 2], half, rtol=2e-6 if dtype == np.float32 else 1e-13)
     plan.close()
 
 

@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--sweeps", default="uniform,blocklocal,scatter")
     ap.add_argument("--fills", default="0.003,0.01,0.03,0.06,0.10,0.15,0.30")
     ap.add_argument("--shares", default="0.05,0.25,0.50,0.75")
-    ap.add_argument("--scatters", default="0,0.01,0.03,0.1,0.3,1.0")
+    ap.add_argument("--scatters", default="0,0.1,1.0")
     ap.add_argument("--fill-in", type=float, default=0.30)
     a = ap.parse_args()
     G, R, T = a.nlat * a.nlon, a.R, a.T
@@ -156,30 +156,38 @@ def main():
             recs.append(sweep_table("blocklocal", p, rowptr, col, val, G, R, X, a.dtype))
             del rowptr, col, val
     if "scatter" in sweeps:
-        # the real segment table, a share q of its rows re-labelled with a random region: segment-table plan vs dense family
+        # the real segment table, a share q of its rows re-labelled with a random region; then (q = 1) m rows per land cell,
+        # each with a random region, for the full region count and for a small one (the entry lists' X stream is paid once per
+        # block of 688 regions): segment-table plan vs dense family -- the drop-in's choice between the two families
         from climate_toolbox_amd import aggregations as A
         lat, lon, df = synth.realistic_segments(nlat=a.nlat, nlon=a.nlon, R=R, string_labels=False)
         cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
-        Rr = len(uniq)
         rng = np.random.default_rng(11)
         T2 = 365
         X2 = X[:T2]
-        for q in [float(x) for x in a.scatters.split(",")]:
-            c2 = code.copy()
-            m = rng.random(len(c2)) < q
-            c2[m] = rng.integers(0, Rr, int(m.sum()))
-            rec = {"sweep": "scatter", "param": q, "G": G, "R": Rr, "T": T2, "rows": int(len(cell))}
-            sp = SparsePlan(cell, c2, w, G, Rr, row_len=len(lon))
+        land = np.unique(cell)
+        points = [("q", float(x), len(uniq)) for x in a.scatters.split(",")]
+        points += [("m", m, Rm) for Rm in (len(uniq), 600) for m in (1, 2, 4, 8, 16, 32)]
+        for kind, v, Rr in points:
+            if kind == "q":
+                c1, c2, w2 = cell, code.copy(), w
+                mk = rng.random(len(c2)) < v
+                c2[mk] = rng.integers(0, Rr, int(mk.sum()))
+            else:
+                c1 = np.repeat(land, int(v)).astype(np.int32)
+                c2 = rng.integers(0, Rr, len(c1)).astype(np.int32)
+                w2 = rng.uniform(0.1, 1.0, len(c1))
+            rec = {"sweep": "scatter", "kind": kind, "param": v, "G": G, "R": Rr, "T": T2, "rows": int(len(c1))}
+            sp = SparsePlan(c1, c2, w2, G, Rr, row_len=len(lon))
             med, mn, out = time_apply(sp, X2)
             ref = out[:4].cpu().numpy()
             rec["n_ucells_over_G"] = round(sp.info["n_ucells"] / G, 3)
             rec["n_giant"] = int(sp.info["n_giant"])
             rec["segment_table"] = {"ms": round(med, 4), "min_ms": round(mn, 4)}
-            free, _ = torch.cuda.mem_get_info()
-            rec["dropin_wants_dense"] = bool(A._wants_dense(sp.info["n_ucells"], G, "TG"))
+            rec["dropin_wants_dense"] = bool(A._wants_dense(sp.info["n_ucells"], G, "TG", R=Rr, nseg=len(c1), is_f32=a.dtype == "float32"))
             sp.close()
             for form in ("auto", "tiles", "entries"):
-                dp = DensePlan.from_segments(cell, c2, w, G, Rr, dtype=a.dtype, form=None if form == "auto" else form, keep_recipe=False)
+                dp = DensePlan.from_segments(c1, c2, w2, G, Rr, dtype=a.dtype, form=None if form == "auto" else form, keep_recipe=False)
                 med, mn, out = time_apply(dp, X2)
                 got = out[:4].cpu().numpy()
                 rec["dense_" + form] = {"ms": round(med, 4), "min_ms": round(mn, 4), "form": FORM_NAME[dp.info["form"]],
@@ -205,9 +213,12 @@ def main():
     for r in recs:
         if r["sweep"] != "scatter":
             continue
-        print("scatter q=%-5g n_ucells/G=%-8.3f giants=%-6d segment-table %8.3f ms | dense tiles %8.3f  entries %8.3f  auto(%s) %8.3f | wants_dense=%s" % (
-            r["param"], r["n_ucells_over_G"], r["n_giant"], r["segment_table"]["ms"], r["dense_tiles"]["ms"], r["dense_entries"]["ms"],
-            r["dense_auto"]["form"], r["dense_auto"]["ms"], r["dropin_wants_dense"]))
+        chosen, other = ((r["dense_auto"]["ms"], r["segment_table"]["ms"]) if r["dropin_wants_dense"] else (r["segment_table"]["ms"], r["dense_auto"]["ms"]))
+        right = chosen <= 1.25 * other                      # (the family the drop-in takes is at most 25 % behind the other)
+        print("scatter %s=%-5g R=%-6d rows=%-9d n_ucells/G=%-8.3f giants=%-6d segment-table %9.3f ms | dense tiles %9.3f  entries %9.3f  auto(%s) %9.3f | "
+              "wants_dense=%-5s %s" % (r["kind"], r["param"], r["R"], r["rows"], r["n_ucells_over_G"], r["n_giant"], r["segment_table"]["ms"],
+                                       r["dense_tiles"]["ms"], r["dense_entries"]["ms"], r["dense_auto"]["form"], r["dense_auto"]["ms"],
+                                       r["dropin_wants_dense"], "ok" if right else "MORE THAN 25 % BEHIND"))
 
 
 if __name__ == "__main__":

@@ -7,7 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+# (timed regions capped: a counter pass serialises every launch; the kernels are the same ones)
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --max-auto-steps 24 --warm-s 0.05 $*"
 export WAGG_BENCH_TRACE=1
 echo "== kernel trace"; 
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $REPO/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err || { echo trace failed; tail -5 $OUT/trace.err; exit 1; }
