@@ -13,6 +13,7 @@ PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA, PLAN_SERIAL_BUILD = 1, 
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
 FORCE_FORM = {None: 0, "auto": 0, "full": 1, "tiles": 2, "entries": 3}      # WAGG_DENSE_FORCE_*
 HOST_PIN, HOST_WHOLE = 1, 2
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
 
@@ -37,6 +38,8 @@ EXPORTS = (
     "wagg_host_block_plan", "wagg_host_stats_read",
     "wagg_combine_planes_f32", "wagg_combine_planes_f64", "wagg_take_axis", "wagg_relayout_f32", "wagg_relayout_f64",
     "wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64", "wagg_synth_table_csr", "wagg_relayout_to_f64",
+    "wagg_shard_group_create", "wagg_shard_group_destroy", "wagg_shard_group_info",
+    "wagg_apply_sharded_f32", "wagg_apply_sharded_f64", "wagg_dense_apply_sharded_f32", "wagg_dense_apply_sharded_f64",
 )
 
 
@@ -179,6 +182,11 @@ def load():
                                        C.c_float, vp]
     L.wagg_synth_field_f64.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_double,
                                        C.c_double, vp]
+    L.wagg_shard_group_create.argtypes = [i32p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.wagg_shard_group_destroy.argtypes = [vp]
+    L.wagg_shard_group_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    for name in ("wagg_apply_sharded_f32", "wagg_apply_sharded_f64", "wagg_dense_apply_sharded_f32", "wagg_dense_apply_sharded_f64"):
+        getattr(L, name).argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, C.c_int64, vp, C.c_int64, C.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("wagg_last_error",):

@@ -430,6 +430,74 @@ class DensePlan:
         return bool(saw.value)
 
 
+class ShardGroup:
+    """Time-axis shards of ONE job on several devices driven by this process, device-resident data
+    (``wagg_shard_group_*`` / ``wagg_*apply_sharded_*``; SURVEY 8b ``n_devices``, 8e): shard i -- a (rows_i, G) tensor on
+    ``devices[i]`` -- goes through ``plans[i]`` (a replica of the table on that device) and its block lands directly in its
+    rows of the result on ``devices[root]``; the blocks travel by RCCL (grouped send / receive, every shard to the root on its
+    own link) or by peer copies (``transport``: "auto", "rccl", "peer"; a device may be listed twice with "peer").  Blocking.
+    The process-per-GPU form of the same job is :mod:`climate_toolbox_amd.timeshard` (``torch.distributed``)."""
+
+    _TRANSPORTS = {"auto": _lib.GATHER_AUTO, "rccl": _lib.GATHER_RCCL, "peer": _lib.GATHER_PEER}
+
+    def __init__(self, devices, transport="auto"):
+        require_gpu()
+        self.devices = [int(d) for d in devices]
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().wagg_shard_group_create(arr, len(self.devices), self._TRANSPORTS[transport], C.byref(self._h)),
+                   "wagg_shard_group_create")
+        n, tr = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().wagg_shard_group_info(self._h, C.byref(n), C.byref(tr)), "wagg_shard_group_info")
+        self.transport = {_lib.GATHER_RCCL: "rccl", _lib.GATHER_PEER: "peer"}[tr.value]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value and _lib._lib is not None:
+            _lib._lib.wagg_shard_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def apply(self, plans, shards, root=0, out=None):
+        """``plans[i]`` / ``shards[i]`` per device of the group; returns the (sum rows, R) tensor on ``devices[root]``."""
+        import torch
+        n = len(self.devices)
+        if len(plans) != n or len(shards) != n:
+            raise ValueError("the group has %d shards: need as many plans and tensors" % n)
+        dense = isinstance(plans[0], DensePlan)
+        if any(isinstance(p, DensePlan) != dense for p in plans):
+            raise TypeError("all plans of a call are of one family")
+        dtype = shards[0].dtype
+        rows, lds = [], set()
+        for i, x in enumerate(shards):
+            if not (x.is_cuda and x.dim() == 2 and x.dtype == dtype and x.device.index == self.devices[i] and x.shape[1] == plans[0].G):
+                raise ValueError("shard %d must be a (rows, %d) %s tensor on device %d" % (i, plans[0].G, dtype, self.devices[i]))
+            if x.shape[0] and x.shape[1] > 1 and x.stride(1) != 1:
+                raise ValueError("shard %d: rows must be contiguous" % i)
+            if x.shape[0] > 1:
+                lds.add(_ld(x))
+            rows.append(int(x.shape[0]))
+        if len(lds) > 1:
+            raise ValueError("the shards must share one row stride, got %r" % sorted(lds))
+        ldx = lds.pop() if lds else plans[0].G
+        R = plans[0].R
+        total = sum(rows)
+        if out is None:
+            out = torch.empty((total, R), dtype=dtype, device="cuda:%d" % self.devices[root])
+        elif tuple(out.shape) != (total, R) or out.dtype != dtype or out.device.index != self.devices[root] or (R > 1 and out.stride(1) != 1):
+            raise ValueError("out must be a (%d, %d) %s tensor on device %d" % (total, R, dtype, self.devices[root]))
+        L = _lib.load()
+        stem = "wagg_dense_apply_sharded" if dense else "wagg_apply_sharded"
+        fn = getattr(L, stem + ("_f32" if dtype == torch.float32 else "_f64"))
+        hp = (C.c_void_p * n)(*[p._h for p in plans])
+        xp = (C.c_void_p * n)(*[C.c_void_p(x.data_ptr()) for x in shards])
+        rw = (C.c_int64 * n)(*rows)
+        for d in set(self.devices):                      # the shards' producers ran on torch's streams: the group uses its own
+            torch.cuda.synchronize(d)
+        _lib.check(fn(self._h, hp, xp, rw, ldx, C.c_void_p(out.data_ptr()), _ld(out), int(root)), stem)
+        return out
+
+
 def gather(X, cell_idx_dev, layout="TG", out_layout="TR", stream=None):
     """Materialised pointwise gather (aggregations.py:27) on the device."""
     import torch

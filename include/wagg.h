@@ -425,6 +425,38 @@ int wagg_synth_field_f32(float *X_dev, int64_t T, int64_t G, int64_t ldx, uint32
 int wagg_synth_field_f64(double *X_dev, int64_t T, int64_t G, int64_t ldx, uint32_t seed,
                          double base, double amp, void *stream);
 
+/* ---- time-axis shards on several devices, ONE process, device-resident data (SURVEY 8b n_devices, 8e) ----------------
+ * Output row t depends on input row t only: shard i (rows_i rows of the job, resident on devices[i]) goes through plans[i]
+ * on devices[i]; its (rows_i x R) block lands directly in rows [sum_{j<i} rows_j, ...) of out_root on devices[root].  No
+ * exchange during compute; one at the end, by `transport`:
+ *   WAGG_GATHER_RCCL  grouped ncclSend / ncclRecv between the communicators of ncclCommInitAll: every shard -> root on its
+ *                     own xGMI link (a direct gather, not a ring).  librccl is looked up at run time, not linked: the copy
+ *                     the process already holds (torch's) if there is one.  Every device once; out_root rows contiguous.
+ *   WAGG_GATHER_PEER  peer copies (hipMemcpyPeerAsync / hipMemcpy2DAsync) on the shard's own stream: needs no library, takes
+ *                     pitched results, and allows a device to be listed twice (several shards on one GPU)
+ *   WAGG_GATHER_AUTO  RCCL when it can be loaded, the devices are distinct and n > 1; else peer copies
+ * A group owns one stream per shard and the shards' staging blocks; the apply calls are BLOCKING (the result is complete on
+ * return) and restore the caller's current device.  The plans are replicas of one table, one per shard (a dense-family plan
+ * owns its workspaces; a segment-table plan may serve several shards of its own device).  The process-per-GPU form of the
+ * same job is torch.distributed + RCCL (climate_toolbox_amd/timeshard.py); for host-resident fields see
+ * wagg_*_apply_host_multi_*.  Validated on hardware with several shards on ONE device (peer copies) and with RCCL at n = 1;
+ * unmeasured at n > 1 devices (gpurun exposes one GPU).                                                                  */
+typedef struct wagg_shard_group wagg_shard_group;
+#define WAGG_GATHER_AUTO 0
+#define WAGG_GATHER_RCCL 1
+#define WAGG_GATHER_PEER 2
+int wagg_shard_group_create(const int *devices, int n, int transport, wagg_shard_group **out);
+int wagg_shard_group_destroy(wagg_shard_group *g);
+int wagg_shard_group_info(const wagg_shard_group *g, int *n_shards, int *transport /* RCCL or PEER: what the group uses */);
+int wagg_apply_sharded_f32(wagg_shard_group *g, const wagg_plan *const *plans, const float *const *X_dev, const int64_t *rows,
+                           int64_t ldx, float *out_root, int64_t ldo, int root);
+int wagg_apply_sharded_f64(wagg_shard_group *g, const wagg_plan *const *plans, const double *const *X_dev, const int64_t *rows,
+                           int64_t ldx, double *out_root, int64_t ldo, int root);
+int wagg_dense_apply_sharded_f32(wagg_shard_group *g, wagg_dense *const *plans, const float *const *X_dev, const int64_t *rows,
+                                 int64_t ldx, float *out_root, int64_t ldo, int root);
+int wagg_dense_apply_sharded_f64(wagg_shard_group *g, wagg_dense *const *plans, const double *const *X_dev, const int64_t *rows,
+                                 int64_t ldx, double *out_root, int64_t ldo, int root);
+
 #ifdef __cplusplus
 }
 #endif

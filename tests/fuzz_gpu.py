@@ -104,10 +104,11 @@ def one_case(i, rng):
             g = ge[k] if out_layout == "TR" else ge[k].T
             b = rel_bad(g, O.agg_coded(O.snyder_edd_values(lo + ft(-273.15), hi + ft(-273.15), e), cell, code, w, R), rtol, 0.05)
             if b: fails.append("edd e=%.2f: %s" % (e, b))
-    elif dtype == np.float32 and layout == "TG" and not np.isinf(X).any():            # dense / tile-sparse form
-        dp = DensePlan.from_segments(cell, code, w, G, R)
-        b = rel_bad(dp.apply(Xd.contiguous()).cpu().numpy(), ref, rtol, 1.0)
-        if b: fails.append("dense(%s): %s" % ("tiled" if dp.info["tiled"] else "full", b))
+    elif layout == "TG" and not np.isinf(X).any():            # dense family: the library's choice of form, or one pinned
+        form = [None, "full", "tiles", "entries"][int(rng.integers(0, 4))]              # (round 5: the choice goes by estimated
+        dp = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype, form=form)       #  time, so small tables mostly take entry
+        b = rel_bad(dp.apply(Xd.contiguous()).cpu().numpy(), ref, rtol, 1.0)            #  lists by themselves: pin the others)
+        if b: fails.append("dense(%s, asked %s): %s" % (["full", "tiled", "entries"][dp.info["form"]], form, b))
         dp.close()
     plan.close()
     return tag, fails
