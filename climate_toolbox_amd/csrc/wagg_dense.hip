@@ -659,12 +659,14 @@ struct FormCost { double t_full, t_tiled, t_entries; };
 // `walked` entries (spmm_list_cost: 16 x the longest per-wave list of every item, in whole groups) spread over n_lists
 // (region block, chunk, wave) lists.
 static FormCost table_form_cost(int64_t G, int elem_bytes, int64_t n_tiles_stored, int64_t n_tiles_all, int64_t walked, int n_rb,
-                                int64_t n_lists) {
+                                int64_t n_lists, int n_nt) {
     const FormRates &rt = elem_bytes == 8 ? FORM_RATES_F64 : FORM_RATES_F32;
     const double tile_flop = 2.0 * (128.0 / elem_bytes) * 256.0;        // BK = 32 / 16 cells x 256 regions
     FormCost c;
-    c.t_full = tile_flop * (double)n_tiles_all / rt.full;
-    c.t_tiled = tile_flop * (double)n_tiles_stored / rt.tiled;
+    // (few column tiles: a launch has at most n_nt x 64 k-slices of workgroups per row block -- R = 600 fills 192 of 256 CUs)
+    const double util = n_nt * 64.0 < 256.0 ? n_nt * 64.0 / 256.0 : 1.0;
+    c.t_full = tile_flop * (double)n_tiles_all / (rt.full * util);
+    c.t_tiled = tile_flop * (double)n_tiles_stored / (rt.tiled * util);
     const double rate = rt.entries_scale * entry_loop_rate((double)walked / (double)(n_lists > 0 ? n_lists : 1));
     const double t_loop = 2.0 * (double)walked / rate, t_stream = (double)elem_bytes * (double)G * (double)n_rb / rt.dma;
     c.t_entries = t_loop > t_stream ? t_loop : t_stream;
@@ -903,7 +905,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     const double fill_all = (double)se.n_u / ((double)G * (double)R);
     int64_t walked = 0;
     if (se.n_u > 0) { if (int rc = spmm_list_cost(ctx, se, &walked)) return rc; }
-    const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb, n_buckets);
+    const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb, n_buckets, n_nt);
     bool tiled, entries;
     pick_table_form(cost, &tiled, &entries);
     if (flags == WAGG_DENSE_FORCE_FULL) { tiled = false; entries = false; }
@@ -1035,16 +1037,26 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
         // slices (1, 2, 4, 8): the count whose workgroups fill whole rounds of the CUs best, less the cost of the
         // slabs the reduce kernel then reads (measured on c5-block, 672 items: 2 slices = 5.25 rounds: kernel 9.65 /
         // step 9.95 ms; 4: 8.94 / 9.35; 8 = exactly 21 rounds: 8.77 / 9.43), and at least ~16 stored tiles per slice
+        // Estimated time of the launch + the reduce for s = 1, 2, 4, ... slices: rounds of workgroups over the CUs x stored tiles
+        // per workgroup x the time of one tile (MT row blocks x 256 columns x 128 bytes of k at the tile-sparse rate), plus the
+        // slabs the reduce kernel then reads (3.6 TB/s).  c5-block (672 items): 2 slices = 5.25 rounds: kernel 9.65 / step 9.95 ms;
+        // 4: 8.94 / 9.35; 8 = exactly 21 rounds: 8.77 / 9.43 -- the estimate says 9.85 / 9.23 / 9.17 and a further split must gain
+        // 3 % to be taken.  Round 5: up to 64 slices and no fixed penalty per slice -- with three column tiles (R = 600) the old
+        // rule (efficiency minus 0.012 per slice) kept ONE slice, i.e. three workgroups on 256 CUs: 64.5 ms where 1.3 suffice.
         S = 1;
-        double best = -1.0;
+        double best = 1e300;
+        const double rate_cu = (sizeof(T) == 8 ? FORM_RATES_F64.tiled : FORM_RATES_F32.tiled) / (double)d->ncu;
+        const double t_tile = 2.0 * (MT * 16.0) * 256.0 * (double)DT<T>::BK / rate_cu;
         for (int s = 1; s <= wagg_dense::TS; s *= 2) {
-            if (s > 1 && d->n_tiles / ((int64_t)n_nt * s) < 16) break;
+            const int64_t per_block = (d->n_tiles + (int64_t)n_nt * s - 1) / ((int64_t)n_nt * s);      // mean stored tiles per workgroup
+            if (s > 1 && per_block < 8) break;
             const double blocks = (double)n_nt * n_mb * s;
-            const double eff = blocks / (std::ceil(blocks / d->ncu) * d->ncu) - 0.012 * s;
-            if (eff > best + 1e-9) { best = eff; S = s; }
+            const double t_k = std::ceil(blocks / d->ncu) * (double)per_block * t_tile;
+            const double t_r = (double)s * n_mb * (MT * 16.0) * n_nt * 256.0 * sizeof(T) / 3.6e12;
+            if (t_k + t_r < 0.97 * best) { best = t_k + t_r; S = s; }
         }
 #ifdef WAGG_DIAG
-        if (const char *e = getenv("WAGG_TILED_S")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) S = v; }
+        if (const char *e = getenv("WAGG_TILED_S")) { const int v = atoi(e); if (v >= 1 && v <= wagg_dense::TS && (v & (v - 1)) == 0) S = v; }
 #endif
     }
     const int kt_per_slice = (n_kt + S - 1) / S;

@@ -79,7 +79,7 @@ struct wagg_dense {
     bool tiled = false;
     int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
     wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: one table per slice count 1, 2, 4, 8
-    static constexpr int TS = 8;
+    static constexpr int TS = 64;                // most k-slices of a tile-sparse launch (tables for 1, 2, 4, ..., TS)
     static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
         int64_t at = 0;
         for (int t = 1; t < ts; t *= 2) at += (int64_t)n_nt * (t + 1);

@@ -203,8 +203,9 @@ def test_dropin_routes_inf_around_the_mfma_forms(torch_cuda):
     from climate_toolbox_amd.engine import DensePlan
     from oracle import ref_numpy as O
     rng = np.random.default_rng(3)
-    nlat, nlon, R, T = 48, 96, 256, 30                          # (a full column tile of regions: with 40 the form choice of
-    lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0    #  round 5 rightly prefers entry lists to a tile 84 % padding)
+    nlat, nlon, R, T = 24, 48, 1024, 30                         # (four full column tiles of regions: with 40 regions the form
+    lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0    #  choice of round 5 rightly prefers entry lists to one tile that is
+                                                                #  84 % padding and fills a quarter of the CUs)
     n = int(0.3 * nlat * nlon * R)                              # dense-ish random table -> full MFMA form
     flat = rng.choice(nlat * nlon * R, size=n, replace=False)
     cell, lab = flat // R, flat % R

@@ -239,7 +239,8 @@ def test_inf_in_a_block_dealt_to_a_replica_is_not_lost(torch_cuda):
     assert not plan.saw_inf()                            # ... and reading clears it
     plan.close(); rep.close()
     # drop-in level: a scattered, dense-ish table takes the full MFMA form; HOST_DEVICES = [0, 0]
-    nlat, nlon, R, T = 48, 96, 256, 2200                 # (a whole column tile of regions: the form choice goes by padded work)
+    nlat, nlon, R, T = 24, 48, 1024, 2200                # (four whole column tiles of regions: the form choice goes by padded work
+                                                         #  and by how many CUs a launch can fill)
     lat, lon = np.arange(nlat) * 1.0, np.arange(nlon) * 1.0
     n = int(0.3 * nlat * nlon * R)
     flat = rng.choice(nlat * nlon * R, size=n, replace=False)
