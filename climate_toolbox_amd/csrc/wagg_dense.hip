@@ -639,9 +639,10 @@ constexpr double SPMM_MAX_FILL = 0.10;
 //                   stream that every one of the n_rb region blocks pulls through the LDS-DMA path (b G n_rb bytes per row)
 // Rates in flop/s and byte/s; fp32 / fp64.
 struct FormRates { double full, tiled, entries_scale, dma; };
-// fp32: full 204.3 ms / tiles 212.1 ms for 2,282 rows x 8,100 x 96 tiles (all stored); tile-sparse shares 5-75 %: 135-137 TF on
-// the stored tiles' flops; c5-block-f64 / c5-uniform-f64 of bench.py for the fp64 column
-constexpr FormRates FORM_RATES_F32 = {142e12, 136e12, 1.0, 10.1e12};
+// fp32: full 204.3 ms / tiles 203.0 ms for 2,282 rows x 8,100 x 96 tiles (all stored); tile-sparse shares 5-75 %: 141-143 TF on
+// the stored tiles' flops (with the slice count chosen by estimate, below); c5-block-f64 / c5-uniform-f64 of bench.py for the
+// fp64 column
+constexpr FormRates FORM_RATES_F32 = {142e12, 142e12, 1.0, 10.1e12};
 constexpr FormRates FORM_RATES_F64 = {70e12, 71e12, 0.44, 10.1e12};
 // The entry loop slows down as the lists grow (the first 16 groups of a wave's list are preloaded across the previous chunk;
 // what follows is fetched inside the loop): flop/s on the WALKED entries against the mean list length per wave and chunk,
