@@ -207,8 +207,9 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=N
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     est = el / max(1, n_warm)                       # seconds per step (an over-estimate while things are cold)
-    if n_warm and el < WARM_S:
-        extra = _agree_max(torch, dist, min(4000, int(math.ceil((WARM_S - el) / max(est, 1e-6)))))
+    if n_warm:
+        # (every rank asks -- also one that has warmed up long enough by its own clock: the agreement is a collective)
+        extra = _agree_max(torch, dist, min(4000, int(math.ceil(max(0.0, WARM_S - el) / max(est, 1e-6)))))
         t1 = time.perf_counter()
         for _ in range(extra):
             step()
