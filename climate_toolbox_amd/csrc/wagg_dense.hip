@@ -95,9 +95,14 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 //
 // TILED (tile-sparse W, e.g. c5 "block-local" weights): only the non-empty (32-cell x 256-region)
 // tiles of W are stored, compacted per column tile; tile_kt[i] is the k-tile (= X tile) of stored
-// tile i and tile_off[nt][ks] .. tile_off[nt][ks+1] the run of stored tiles that block (nt, ks)
-// contracts.  The k index of tile t+2 is fetched by a plain vector load at the start of tile t
-// (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
+// tile i.  A workgroup walks PIECES (round 5): the stored tiles of all (row block, column tile) pairs,
+// laid end to end, are cut into one equal share per workgroup -- a piece is the part of one pair's run
+// that falls into a share: (column tile, row block, first stored tile, tile count, slab, -, -, -) -- so every CU
+// gets the same number of tiles whatever the pair count (rounds 2-4: n_nt x n_mb x S blocks of equal
+// k-slices, 10.5 rounds of 256 on c5-block: the last half round ran half empty).  `tile_off` points to
+// the piece table of this launch ([n_wg + 1] first piece of every workgroup, then 8 ints per piece), S
+// and kt_per_slice are unused.  The k index of tile t+2 is fetched by a plain vector load at the start of
+// tile t (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
 //
 // RM (tile-sparse only, "pack-free"): Xp is the caller's ROW-MAJOR X (row stride ldxB bytes, 16-byte aligned,
 // no NaN -> 0 pass): the LDS-DMA builds the same tile image straight from it -- lane l of 1-KiB piece q
@@ -110,212 +115,27 @@ __global__ __launch_bounds__(D_THREADS, 2) void dense_mfma_kernel(
     const T *__restrict__ Xp, const T *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
     int kt_per_slice, T *__restrict__ slabs, const int32_t *__restrict__ tile_kt = nullptr,
     const int32_t *__restrict__ tile_off = nullptr, int64_t ldxB = 0, int Tn = 0, const int *__restrict__ gate = nullptr) {
-    static_assert(MT <= DT<T>::MT_MAX, "accumulators of MT row blocks must fit the register file");
-    // the gated second pass: every tile-sparse packed kernel, and the DBG = 256 instantiations of the full form (the
-    // plain <T, 0, false, MT> kernels stay as they are: their tile loop is sensitive to code placement)
-    if constexpr (!RM && (TILED || DBG == 256)) { if (gate != nullptr && *gate == 0) return; }
-    typedef typename DT<T>::vec vec_t;
-    typedef typename DT<T>::acc acc_t;
-    constexpr int KS = DT<T>::EPP;                   // MFMA k-steps fed by one 16-byte fragment read
-    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2][BUF_BYTES]
-    constexpr int XT4 = d_xt_bytes(MT);              // bytes of the packed X tile (MT x 16 rows x 128 B)
-    constexpr int BUF_BYTES = d_buf_bytes(MT);
-    constexpr int XPIECES = XT4 / 1024;              // 2 MT one-KiB pieces
-    constexpr int NXP = (XPIECES + 7) / 8;           // X pieces per wave (the last round may be partial)
-    constexpr int NP = 4 + NXP;                      // DMA pieces per wave and tile: 4 W + NXP X
-    constexpr int DPB = (NP + MT - 1) / MT;          // pieces issued per row block (1 when MT >= NP)
+#define WAGG_PIECES 0
+#include "wagg_dense_kernel.inc"
+#undef WAGG_PIECES
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, kq = lane >> 4;
-
-    // work item: blocks with equal (blockIdx % 8) share a k-slice (XCD L2 affinity, speed only)
-    int j = TILED ? (int)(blockIdx.x / (unsigned)S) : (int)(blockIdx.x >> 3);
-    const int nt = j % n_nt; j /= n_nt;
-    const int mb = j % n_mb;
-    const int ks = TILED ? (int)(blockIdx.x % (unsigned)S) : (int)(blockIdx.x & 7) + 8 * (j / n_mb);
-    int kt0 = ks * kt_per_slice;
-    const int kt1 = kt0 + kt_per_slice < n_kt ? kt0 + kt_per_slice : n_kt;
-    int ntiles = kt1 > kt0 ? kt1 - kt0 : 0;
-    int64_t w_first = (int64_t)nt * n_kt + kt0;            // first W tile of this block
-    int kt_next = 0;                                         // TILED: X tile of the tile after the current one
-    int x_first = 0;
-    if (TILED) {
-        const int t_begin = tile_off[nt * (S + 1) + ks];
-        ntiles = tile_off[nt * (S + 1) + ks + 1] - t_begin;
-        w_first = t_begin;
-        kt0 = 0;
-        tile_kt += t_begin;                                  // (padded by two entries at the end)
-        x_first = tile_kt[0];
-        kt_next = tile_kt[ntiles > 1 ? 1 : 0];
-    }
-
-    // LDS-DMA sources: piece q of tile t is the contiguous KiB at tile base + 1024 q; this wave
-    // moves W pieces wave + 8 i (i < 4) and X pieces wave + 8 i (i < NXP, those below XPIECES)
-    const char *xsrc = RM ? reinterpret_cast<const char *>(Xp) + (int64_t)mb * (MT * 16) * ldxB + (int64_t)kt0 * D_ROWB +
-                                ((((lane & 7) ^ (lane >> 4)) ^ ((wave & 1) << 2)) << 4)
-                          : reinterpret_cast<const char *>(Xp) + ((int64_t)mb * n_kt + kt0) * XT4 + lane * 16;
-    const int rm_row = lane >> 3, rm_rmax = RM ? Tn - 1 - mb * (MT * 16) : 0;
-    const char *wsrc = reinterpret_cast<const char *>(Wp) + w_first * D_WTB + lane * 16;
-#define WAGG_DMA_X(q, tile, buf)                                                                  \
-    do {                                                                                          \
-        if constexpr (RM) {                                                                       \
-            int r_ = 8 * (q) + rm_row;                                                            \
-            r_ = r_ < rm_rmax ? r_ : rm_rmax;                                                     \
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)r_ * ldxB + (int64_t)(tile) * D_ROWB), \
-                                             (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0); \
-        } else {                                                                                  \
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc + (int64_t)(tile) * XT4 + (q) * 1024),  \
-                                             (lptr_t)(lds + (buf) * BUF_BYTES + (q) * 1024), 16, 0, 0); \
-        }                                                                                         \
-    } while (0)
-#define WAGG_DMA_W(q, tile, buf)                                                                  \
-    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (int64_t)(tile) * D_WTB + (q) * 1024),   \
-                                     (lptr_t)(lds + (buf) * BUF_BYTES + XT4 + (q) * 1024), 16, 0, 0)
-    // piece i of this wave: W pieces (HBM, longest latency) first, then the X pieces (served by the
-    // XCD's L2); DBG bit4 = X first
-#define WAGG_DMA_PIECE(i, xt, wt, buf)                                                            \
-    do {                                                                                          \
-        constexpr int i_ = (DBG & 16) ? ((i) + 4) % NP : (i);                                     \
-        if constexpr (i_ < 4) WAGG_DMA_W(wave + 8 * i_, wt, buf);                                 \
-        else if constexpr (8 * (i_ - 4) + 7 < XPIECES) WAGG_DMA_X(wave + 8 * (i_ - 4), xt, buf);  \
-        else { if (wave + 8 * (i_ - 4) < XPIECES) WAGG_DMA_X(wave + 8 * (i_ - 4), xt, buf); }     \
-    } while (0)
-#define WAGG_DMA_BLOCK(RB, xt, wt, buf)                                                           \
-    do {                                                                                          \
-        if constexpr (DPB * (RB) + 0 < NP && 0 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 0 < NP ? DPB * (RB) + 0 : 0, xt, wt, buf); \
-        if constexpr (DPB * (RB) + 1 < NP && 1 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 1 < NP ? DPB * (RB) + 1 : 0, xt, wt, buf); \
-        if constexpr (DPB * (RB) + 2 < NP && 2 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 2 < NP ? DPB * (RB) + 2 : 0, xt, wt, buf); \
-        if constexpr (DPB * (RB) + 3 < NP && 3 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 3 < NP ? DPB * (RB) + 3 : 0, xt, wt, buf); \
-        if constexpr (DPB * (RB) + 4 < NP && 4 < DPB) WAGG_DMA_PIECE(DPB * (RB) + 4 < NP ? DPB * (RB) + 4 : 0, xt, wt, buf); \
-    } while (0)
-    static_assert(DPB <= 5, "at most five DMA pieces per row block (MT = 1: 4 W + 1 X)");
-
-    acc_t acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = acc_t{0, 0, 0, 0};
-
-    if (ntiles > 0) {
-        WAGG_DMA_PIECE(0, x_first, 0, 0); WAGG_DMA_PIECE(1, x_first, 0, 0);
-        WAGG_DMA_PIECE(2, x_first, 0, 0); WAGG_DMA_PIECE(3, x_first, 0, 0);
-        WAGG_DMA_PIECE(4, x_first, 0, 0);
-        if constexpr (NP > 5) WAGG_DMA_PIECE(NP > 5 ? 5 : 0, x_first, 0, 0);
-        if constexpr (NP > 6) WAGG_DMA_PIECE(NP > 6 ? 6 : 0, x_first, 0, 0);
-        if constexpr (NP > 7) WAGG_DMA_PIECE(NP > 7 ? 7 : 0, x_first, 0, 0);
-        if constexpr (NP > 8) WAGG_DMA_PIECE(NP > 8 ? 8 : 0, x_first, 0, 0);
-        if constexpr (NP > 9) WAGG_DMA_PIECE(NP > 9 ? 9 : 0, x_first, 0, 0);
-    }
-    static_assert(NP <= 10, "prologue issues at most ten pieces");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // per-lane fragment offsets (bytes inside a tile image); + 2048 per 16-row block (immediate)
-    const int f = lr >> 1;
-    const int frag0 = (lr * 8 + (kq ^ f)) * 16;            // h = 0: piece kq
-    const int frag1 = (lr * 8 + ((kq ^ f) ^ 4)) * 16;      // h = 1: piece kq + 4
-    const int boff = XT4 + wave * (32 * 128);              // this wave's 32 columns of the W image
-
-    // One 16-row block = 16 MFMAs: k-steps 0..7 x the wave's two 16-column blocks.  k-steps 0..3
-    // come from the first fragment read (h = 0), 4..7 from the second.
-#define WAGG_MFMA(RB, CB, A, B, c) \
-    acc[RB][CB] = DT<T>::mfma(A[c], B[c], acc[RB][CB])
-#define WAGG_MFMA_REST7(RB, A, B0, B1)                                                            \
-    do {                                                                                          \
-        WAGG_MFMA(RB, 1, A, B1, 0);                                                               \
-        _Pragma("unroll") for (int c = 1; c < KS; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
-    } while (0)
-#define WAGG_MFMA8(RB, A, B0, B1)                                                                 \
-    do {                                                                                          \
-        _Pragma("unroll") for (int c = 0; c < KS; ++c) { WAGG_MFMA(RB, 0, A, B0, c); WAGG_MFMA(RB, 1, A, B1, c); } \
-    } while (0)
-#define WAGG_READ_A(D0, D1, RB)                                                                   \
-    do {                                                                                          \
-        D0 = *reinterpret_cast<const vec_t *>(img + frag0 + (RB) * 2048);                         \
-        D1 = *reinterpret_cast<const vec_t *>(img + frag1 + (RB) * 2048);                         \
-    } while (0)
-    // Row block RB.  The fragment reads of the NEXT block are issued right behind the first MFMA
-    // of the current one: hipcc's s_waitcnt for the current fragments (always a full lgkmcnt(0)
-    // once an LDS-DMA is in the stream) then finds only reads that were issued 15 MFMAs earlier.
-    // The next tile's DMA pieces go in the middle of the first row blocks, one per block when
-    // MT >= NP (so the end-of-tile vmcnt(0) never waits).
-#define WAGG_BLOCK_(RB, A0, A1, N0, N1)                                                           \
-    do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WAGG_MFMA(RB, 0, A0, b00, 0);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if constexpr ((RB) + 1 < MT) WAGG_READ_A(N0, N1, (RB) + 1 < MT ? (RB) + 1 : 0);           \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WAGG_MFMA_REST7(RB, A0, b00, b10);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if constexpr (!(DBG & 1)) { if ((DBG & 8) || early_dma) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf); } \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        WAGG_MFMA8(RB, A1, b01, b11);                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if constexpr (!(DBG & 1) && !(DBG & 8)) { if (!early_dma) WAGG_DMA_BLOCK(RB, xnext, tnext, nbuf); } \
-    } while (0)
-    // even blocks use register set A and prefetch into B, odd blocks the other way round
-#define WAGG_BLOCK(RB)                                                                            \
-    do {                                                                                          \
-        if constexpr ((RB) < MT) {                                                                \
-            constexpr int rb_ = (RB) < MT ? (RB) : 0;                                             \
-            if constexpr ((RB) & 1) WAGG_BLOCK_(rb_, aB0, aB1, aA0, aA1);                         \
-            else WAGG_BLOCK_(rb_, aA0, aA1, aB0, aB1);                                            \
-        }                                                                                         \
-    } while (0)
-
-    // waves w and w + 4 share a SIMD and run in step after every barrier: they issue their DMA
-    // pieces half a row block apart so that one of them always has MFMAs to issue (DBG bit3: off)
-    const bool early_dma = wave < 4;
-    // Code placement of the tile loop: the MFMA-paced loop is sensitive to it at the percent level
-    // (tools/ab_dense.py on one MI355X, c2-dense: 0 pads 127.9 ms, 2: 127.0, 6: 126.85, 7: 127.0).  Six
-    // 4-byte pads in front of the loop; the diagnostic build selects another count with DBG bits 5-7.
-    constexpr int PADS = (DBG >> 5) & 7 ? (DBG >> 5) & 7 : 6;
-    if constexpr (PADS >= 1) asm volatile("s_nop 0");
-    if constexpr (PADS >= 2) asm volatile("s_nop 0");
-    if constexpr (PADS >= 3) asm volatile("s_nop 0");
-    if constexpr (PADS >= 4) asm volatile("s_nop 0");
-    if constexpr (PADS >= 5) asm volatile("s_nop 0");
-    if constexpr (PADS >= 6) asm volatile("s_nop 0");
-    if constexpr (PADS >= 7) asm volatile("s_nop 0");
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const char *img = lds + (tile & 1) * BUF_BYTES;
-        const int nbuf = (tile & 1) ^ 1;
-        const int tnext = tile + 1 < ntiles ? tile + 1 : tile;     // last tile: harmless re-load
-        const int xnext = TILED ? kt_next : tnext;
-        int ktn_v = 0;
-        if (TILED) {                                               // k index of tile + 2 (clamped)
-            const int32_t *pa = tile_kt + (tile + 2 < ntiles ? tile + 2 : ntiles - 1);
-            const int zero = 0;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(ktn_v) : "v"(zero), "s"(pa) : "memory");
-        }
-        vec_t b00, b01, b10, b11, aA0, aA1, aB0, aB1;
-        b00 = *reinterpret_cast<const vec_t *>(img + boff + frag0);
-        b01 = *reinterpret_cast<const vec_t *>(img + boff + frag1);
-        b10 = *reinterpret_cast<const vec_t *>(img + boff + 2048 + frag0);
-        b11 = *reinterpret_cast<const vec_t *>(img + boff + 2048 + frag1);
-        WAGG_READ_A(aA0, aA1, 0);
-        WAGG_BLOCK(0); WAGG_BLOCK(1); WAGG_BLOCK(2); WAGG_BLOCK(3); WAGG_BLOCK(4); WAGG_BLOCK(5);
-        WAGG_BLOCK(6); WAGG_BLOCK(7); WAGG_BLOCK(8); WAGG_BLOCK(9); WAGG_BLOCK(10); WAGG_BLOCK(11);
-        WAGG_BLOCK(12); WAGG_BLOCK(13); WAGG_BLOCK(14); WAGG_BLOCK(15); WAGG_BLOCK(16); WAGG_BLOCK(17);
-        WAGG_BLOCK(18); WAGG_BLOCK(19); WAGG_BLOCK(20); WAGG_BLOCK(21); WAGG_BLOCK(22);
-        static_assert(MT <= 23, "row blocks are written out up to 22");
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's DMA pieces of tile+1 have landed; every wave is done reading this buffer
-        if (TILED) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(kt_next) : "v"(ktn_v) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (!(DBG & 4)) __builtin_amdgcn_s_barrier();
-    }
-
-    // C/D map: col = lane & 15, row = DT<T>::crow(lane >> 4, reg) (it differs between the f32 and f64 forms)
-    T *slab = slabs + ((((int64_t)mb * n_nt + nt) * S + ks) * (MT * 16)) * D_BN;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                slab[(m * 16 + DT<T>::crow(kq, r)) * D_BN + wave * 32 + cb * 16 + lr] = acc[m][cb][r];
+// The tile-sparse form's kernel (round 5): the same body, a workgroup walks PIECES.  The stored tiles of all (row block,
+// column tile) pairs, laid end to end, are cut into one equal share per workgroup -- a piece is the part of one pair's run
+// that falls into a share -- so every CU gets the same number of tiles whatever the pair count (rounds 2-4: n_nt x n_mb x S
+// blocks of equal k-slices; 10.5 rounds of 256 on c5-block, the last one half empty).  `tile_off` is the piece table of the
+// launch (csrc/wagg_dense.hip: tile_pieces_for); n_kt / n_mb / S / kt_per_slice are unused.
+template <typename T, int MT, bool RM>
+__global__ __launch_bounds__(D_THREADS, 2) void dense_pieces_kernel(
+    const T *__restrict__ Xp, const T *__restrict__ Wp, int n_kt, int n_nt, int n_mb, int S,
+    int kt_per_slice, T *__restrict__ slabs, const int32_t *__restrict__ tile_kt, const int32_t *__restrict__ tile_off,
+    int64_t ldxB, int Tn, const int *__restrict__ gate) {
+    constexpr bool TILED = true;
+    constexpr int DBG = 0;
+    (void)n_kt; (void)n_mb; (void)S; (void)kt_per_slice;
+#define WAGG_PIECES 1
+#include "wagg_dense_kernel.inc"
+#undef WAGG_PIECES
 }
 
 // X (T x G, row stride ldx) -> packed tiles Xp[mb][kt][slot] (one 16-byte piece per slot; a row block has
@@ -377,14 +197,18 @@ template <typename T>
 __global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S, int bm, int64_t Ttot,
                                     int32_t R, const T *__restrict__ den, T *__restrict__ out, int64_t ldo,
                                     int *__restrict__ nonfinite = nullptr, const int *__restrict__ gate = nullptr,
-                                    int *__restrict__ sticky = nullptr) {
+                                    int *__restrict__ sticky = nullptr, const int32_t *__restrict__ slab_first = nullptr) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t t = blockIdx.y;
     if (gate != nullptr && *gate == 0) return;
     if (r >= R) return;
     const int mb = (int)(t / bm), tl = (int)(t % bm);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    const T *p = slabs + ((((int64_t)mb * n_nt + nt) * S) * bm + tl) * D_BN + c;
+    // slabs of the pair (row block, column tile): S of them in a row, or (tile-sparse launches) slab_first[pair] ..
+    // slab_first[pair + 1] - 1 -- as many as pieces of the pair's run, added in that (fixed) order
+    int64_t first = ((int64_t)mb * n_nt + nt) * S;
+    if (slab_first != nullptr) { first = slab_first[mb * n_nt + nt]; S = slab_first[mb * n_nt + nt + 1] - (int)first; }
+    const T *p = slabs + (first * bm + tl) * D_BN + c;
     T s = T(0);
     for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
     if (nonfinite != nullptr && !(fabs(s) <= std::numeric_limits<T>::max())) {
@@ -620,10 +444,63 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
             for (int k = 0; k <= ts; ++k) tab[(size_t)nt * (ts + 1) + k] = (int32_t)(b + len * k / ts);
         }
     }
+    d->nt_first.assign(first.size(), 0);
+    for (size_t i = 0; i < first.size(); ++i) d->nt_first[i] = (int32_t)first[i];
     hipError_t e = d->tile_kt.upload(kt, st);
     if (e == hipSuccess) e = d->tile_off.upload(off, st);
     if (nt_out) *nt_out = ntv;
     return e;
+}
+
+// The piece table of a tile-sparse launch over n_mb row blocks (see dense_mfma_kernel).  Pairs in (row block, column tile)
+// order; workgroup w takes the tiles [w total / n_wg, (w + 1) total / n_wg) of their concatenation; a pair's pieces get
+// consecutive slabs, in run order (the reduce kernel adds them in that order: fixed, hence reproducible).  Built once per
+// row-block count and kept with the plan.
+static int tile_pieces_for(wagg_dense *d, int n_mb, hipStream_t st, const wagg_dense::TilePieces **out) {
+    for (const auto &tp : d->pieces)
+        if (tp->n_mb == n_mb) { *out = tp.get(); return WAGG_OK; }
+    try {
+        std::unique_ptr<wagg_dense::TilePieces> tp(new wagg_dense::TilePieces());
+        const int n_nt = d->n_nt;
+        const int64_t per_mb = d->n_tiles, total = per_mb * n_mb;
+        // at least ~8 tiles per workgroup (a piece costs a pipeline fill and a slab), at most one workgroup per CU
+        int64_t n_wg = total / 8;
+        if (n_wg > d->ncu) n_wg = d->ncu;
+        if (n_wg < 1) n_wg = 1;
+        std::vector<int32_t> first_piece((size_t)n_wg + 1, 0), rec, slab_first((size_t)n_mb * n_nt + 1, 0);
+        int64_t pos = 0;                               // position in the concatenation
+        int slab = 0, w = 0;
+        int64_t w_end = total * 1 / n_wg;              // end of workgroup 0's share
+        for (int mb = 0; mb < n_mb; ++mb)
+            for (int nt = 0; nt < n_nt; ++nt) {
+                slab_first[(size_t)mb * n_nt + nt] = slab;
+                int64_t t0 = d->nt_first[(size_t)nt];
+                const int64_t t1 = d->nt_first[(size_t)nt + 1];
+                while (t0 < t1) {
+                    while (pos >= w_end && w + 1 < n_wg) { ++w; first_piece[(size_t)w] = (int32_t)(rec.size() / 8); w_end = total * (w + 1) / n_wg; }
+                    const int64_t room = w + 1 < n_wg ? w_end - pos : t1 - t0;
+                    const int64_t take = room < t1 - t0 ? room : t1 - t0;
+                    const int32_t r8[8] = {nt, mb, (int32_t)t0, (int32_t)take, slab, 0, 0, 0};
+                    rec.insert(rec.end(), r8, r8 + 8);
+                    ++slab;
+                    t0 += take;
+                    pos += take;
+                }
+            }
+        slab_first[(size_t)n_mb * n_nt] = slab;
+        for (int64_t k = w + 1; k <= n_wg; ++k) first_piece[(size_t)k] = (int32_t)(rec.size() / 8);      // (workgroups without a share: none)
+        tp->n_mb = n_mb; tp->n_wg = (int)n_wg; tp->n_slabs = slab;
+        std::vector<int32_t> all;
+        all.reserve(first_piece.size() + rec.size() + slab_first.size());
+        all.insert(all.end(), first_piece.begin(), first_piece.end());
+        all.insert(all.end(), rec.begin(), rec.end());
+        tp->slab_first_at = (int64_t)all.size();
+        all.insert(all.end(), slab_first.begin(), slab_first.end());
+        WAGG_HIP(tp->tab.upload(all, st));
+        *out = tp.get();
+        d->pieces.push_back(std::move(tp));
+        return WAGG_OK;
+    } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
 }
 
 // Generated tables (wagg_dense_create_synth*): below this share of non-zeros a scattered W goes to the entry-list form.
@@ -957,7 +834,10 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
 }
 
 template <typename T, bool TILED, int MT, bool RM = false>
-static const void *mfma_kernel_ptr() { return (const void *)dense_mfma_kernel<T, 0, TILED, MT, RM>; }
+static const void *mfma_kernel_ptr() {
+    if constexpr (TILED) return (const void *)dense_pieces_kernel<T, MT, RM>;        // tile-sparse form: a workgroup walks pieces
+    else return (const void *)dense_mfma_kernel<T, 0, false, MT, RM>;
+}
 // full form, pack-free: instantiated for the tall row blocks only (fp32 MT >= 20, fp64 MT >= 10), where the packing
 // pass is worth skipping; rm = first pass reading X in place, !rm = its gated packed second pass (DBG = 256)
 template <typename T>
@@ -1034,36 +914,17 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     else { for (int m : mts64) if (m * 16 >= rows) { MT = m; break; } }
     const int bm = MT * 16;
     int S = ksplit ? ksplit : pick_ksplit((int64_t)n_nt * n_mb, n_kt);
+    // tile-sparse form: no k-slices -- the launch walks PIECES, an equal share of all stored tiles per workgroup (see the kernel)
+    const wagg_dense::TilePieces *tp = nullptr;
     if (d->tiled) {
-        // slices (1, 2, 4, 8): the count whose workgroups fill whole rounds of the CUs best, less the cost of the
-        // slabs the reduce kernel then reads (measured on c5-block, 672 items: 2 slices = 5.25 rounds: kernel 9.65 /
-        // step 9.95 ms; 4: 8.94 / 9.35; 8 = exactly 21 rounds: 8.77 / 9.43), and at least ~16 stored tiles per slice
-        // Estimated time of the launch + the reduce for s = 1, 2, 4, ... slices: rounds of workgroups over the CUs x stored tiles
-        // per workgroup x the time of one tile (MT row blocks x 256 columns x 128 bytes of k at the tile-sparse rate), plus the
-        // slabs the reduce kernel then reads (3.6 TB/s).  c5-block (672 items): 2 slices = 5.25 rounds: kernel 9.65 / step 9.95 ms;
-        // 4: 8.94 / 9.35; 8 = exactly 21 rounds: 8.77 / 9.43 -- the estimate says 9.85 / 9.23 / 9.17 and a further split must gain
-        // 3 % to be taken.  Round 5: up to 64 slices and no fixed penalty per slice -- with three column tiles (R = 600) the old
-        // rule (efficiency minus 0.012 per slice) kept ONE slice, i.e. three workgroups on 256 CUs: 64.5 ms where 1.3 suffice.
+        if (int rc = tile_pieces_for(d, n_mb, (hipStream_t)stream, &tp)) return rc;
         S = 1;
-        double best = 1e300;
-        const double rate_cu = (sizeof(T) == 8 ? FORM_RATES_F64.tiled : FORM_RATES_F32.tiled) / (double)d->ncu;
-        const double t_tile = 2.0 * (MT * 16.0) * 256.0 * (double)DT<T>::BK / rate_cu;
-        for (int s = 1; s <= wagg_dense::TS; s *= 2) {
-            const int64_t per_block = (d->n_tiles + (int64_t)n_nt * s - 1) / ((int64_t)n_nt * s);      // mean stored tiles per workgroup
-            if (s > 1 && per_block < 8) break;
-            const double blocks = (double)n_nt * n_mb * s;
-            const double t_k = std::ceil(blocks / d->ncu) * (double)per_block * t_tile;
-            const double t_r = (double)s * n_mb * (MT * 16.0) * n_nt * 256.0 * sizeof(T) / 3.6e12;
-            if (t_k + t_r < 0.97 * best) { best = t_k + t_r; S = s; }
-        }
-#ifdef WAGG_DIAG
-        if (const char *e = getenv("WAGG_TILED_S")) { const int v = atoi(e); if (v >= 1 && v <= wagg_dense::TS && (v & (v - 1)) == 0) S = v; }
-#endif
     }
     const int kt_per_slice = (n_kt + S - 1) / S;
-    const int64_t nblk = (int64_t)n_nt * n_mb * S;
+    const int64_t nblk = tp ? (int64_t)tp->n_wg : (int64_t)n_nt * n_mb * S;
     WAGG_REQUIRE(nblk < (int64_t)0x7fffffff, "grid too large");
-    const size_t need = (size_t)n_nt * n_mb * S * bm * D_BN * (sizeof(T) / 4);     // DevBuf<float>: 4-byte units
+    const size_t n_slabs = tp ? (size_t)tp->n_slabs : (size_t)n_nt * n_mb * S;
+    const size_t need = (n_slabs ? n_slabs : 1) * bm * D_BN * (sizeof(T) / 4);      // DevBuf<float>: 4-byte units
     if (d->slabs.n < need) WAGG_HIP(d->slabs.alloc(need));   // first call (or larger T) only
     const int64_t x_slots = (int64_t)n_mb * n_kt * bm * 8;
     if (d->xp.n < (size_t)x_slots * 4) WAGG_HIP(d->xp.alloc((size_t)x_slots * 4));
@@ -1120,7 +981,8 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     T *slabs = reinterpret_cast<T *>(d->slabs.p);
     int n_kt_a = n_kt, n_nt_a = n_nt, n_mb_a = n_mb, S_a = S, kps = kt_per_slice;
     const int32_t *tkt = d->tile_kt.p;
-    const int32_t *toff = d->tiled ? d->tile_off.p + wagg_dense::off_table(S, n_nt) : nullptr;
+    const int32_t *toff = tp ? tp->tab.p : nullptr;                       // tile-sparse: the launch's piece table
+    const int32_t *slab_first = tp ? tp->tab.p + tp->slab_first_at : nullptr;
     int64_t ldxB = ldx * (int64_t)sizeof(T);
     int Tn_a = (int)Tn;
     const T *den;
@@ -1134,7 +996,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
         void *args_rm[] = {&X_dev, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &no_gate};
         WAGG_HIP(launch_timed_ptr(true, kern_rm, dim3((unsigned)nblk), dim3(D_THREADS), args_rm, shmem, st));
         hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
-                           out_dev, ldo, d->nonfinite.p, (const int *)nullptr, d->inf_dev + 1);
+                           out_dev, ldo, d->nonfinite.p, (const int *)nullptr, d->inf_dev + 1, slab_first);
         WAGG_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((dense_pack_x_kernel<T>), dim3(256 * 16), dim3(256), 0, st, X_dev, Tn, ldx, d->G, n_kt, bm, x_slots,
@@ -1143,7 +1005,7 @@ static int dense_apply(wagg_dense *d, const T *X_dev, int64_t Tn, int64_t ldx, c
     void *args[] = {&xp, &wp, &n_kt_a, &n_nt_a, &n_mb_a, &S_a, &kps, &slabs, &tkt, &toff, &ldxB, &Tn_a, &gate};
     WAGG_HIP(launch_timed_ptr(!rm, kern, dim3((unsigned)nblk), dim3(D_THREADS), args, shmem, st));
     hipLaunchKernelGGL((dense_reduce_kernel<T>), rgrid, dim3(256), 0, st, (const T *)slabs, n_nt, S, bm, Tn, d->R, den,
-                       out_dev, ldo, (int *)nullptr, gate, (int *)nullptr);
+                       out_dev, ldo, (int *)nullptr, gate, (int *)nullptr, slab_first);
     WAGG_HIP(hipGetLastError());
     return WAGG_OK;
 }

@@ -1,6 +1,8 @@
 // Internal layout of a dense-family plan (wagg_dense) shared by wagg_dense.hip (full / tile-sparse
 // MFMA forms) and wagg_spmm.hip (entry-list form for scattered weights).
 #pragma once
+#include <memory>
+
 #include "wagg_build.h"
 #include "wagg_host.h"
 
@@ -78,7 +80,17 @@ struct wagg_dense {
     // the column tile's run split into TS slices of equal length
     bool tiled = false;
     int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
-    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: one table per slice count 1, 2, 4, 8
+    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: per-column-tile slice offsets (rounds 2-4; the kernels walk pieces now)
+    std::vector<int32_t> nt_first;               // host: first stored tile of every column tile (+ the total): [n_nt + 1]
+    // piece table of a tile-sparse launch with n_mb row blocks (wagg_dense.hip: tile_pieces_for): the stored tiles of all
+    // (row block, column tile) pairs, end to end, cut into one equal share per workgroup.  One table per row-block count the
+    // plan has met, kept until the plan goes (an apply queued on a stream may still be reading one).
+    struct TilePieces {
+        int n_mb = 0, n_wg = 0, n_slabs = 0;
+        wagg::DevBuf<int32_t> tab;               // [n_wg + 1] first piece of a workgroup | [n_pieces][8] | [n_mb * n_nt + 1] first slab of a pair
+        int64_t slab_first_at = 0;               // offset of the last part inside tab
+    };
+    std::vector<std::unique_ptr<TilePieces>> pieces;
     static constexpr int TS = 64;                // most k-slices of a tile-sparse launch (tables for 1, 2, 4, ..., TS)
     static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
         int64_t at = 0;
