@@ -794,9 +794,9 @@ def main():
             nnz = G * R
         flops = 2.0 * T * nnz                                   # algorithmic: 2 T nnz (dense: nnz = G R)
         traffic, tsrc = load_traffic(wl)
-        kname = {0: "dense_mfma_kernel", 1: "dense_mfma_kernel<tiled>", 2: "spmm_kernel (vector ALU, entry lists)"}[form]
+        kname = {0: "dense_mfma_kernel", 1: "dense_pieces_kernel", 2: "spmm_kernel (vector ALU, entry lists)"}[form]
         if f64:
-            kname = kname.replace("dense_mfma_kernel", "dense_mfma_kernel<double>").replace("spmm_kernel", "spmm_kernel<double>")
+            kname = kname.replace("dense_mfma_kernel", "dense_mfma_kernel<double>").replace("dense_pieces_kernel", "dense_pieces_kernel<double>").replace("spmm_kernel", "spmm_kernel<double>")
         # entry lists run on the vector ALU: fp32 FMA peak = the fp32 MFMA peak (157.3), fp64 FMA = 78.6
         peak = PEAK_F64_MFMA_TFLOPS if f64 else PEAK_F32_MFMA_TFLOPS
         res = {"workload": wl, "dtype": "f64" if f64 else "f32", "T": T, "T_job": T_job, "G": G, "R": R, "nnz": nnz,

@@ -95,14 +95,11 @@ __host__ __device__ __forceinline__ int tile_slot(int row, int p) { return row *
 //
 // TILED (tile-sparse W, e.g. c5 "block-local" weights): only the non-empty (32-cell x 256-region)
 // tiles of W are stored, compacted per column tile; tile_kt[i] is the k-tile (= X tile) of stored
-// tile i.  A workgroup walks PIECES (round 5): the stored tiles of all (row block, column tile) pairs,
-// laid end to end, are cut into one equal share per workgroup -- a piece is the part of one pair's run
-// that falls into a share: (column tile, row block, first stored tile, tile count, slab, -, -, -) -- so every CU
-// gets the same number of tiles whatever the pair count (rounds 2-4: n_nt x n_mb x S blocks of equal
-// k-slices, 10.5 rounds of 256 on c5-block: the last half round ran half empty).  `tile_off` points to
-// the piece table of this launch ([n_wg + 1] first piece of every workgroup, then 8 ints per piece), S
-// and kt_per_slice are unused.  The k index of tile t+2 is fetched by a plain vector load at the start of
-// tile t (it retires in order ahead of the DMA pieces) and moved to an SGPR after the end-of-tile wait.
+// tile i.  Since round 5 tile-sparse plans run dense_pieces_kernel (below: the same body, a workgroup
+// walks pieces of the stored-tile runs); the TILED branch of dense_mfma_kernel is what rounds 2-4 ran
+// (blocks of equal k-slices) and is no longer instantiated.  The k index of tile t+2 is fetched by a plain
+// vector load at the start of tile t (it retires in order ahead of the DMA pieces) and moved to an SGPR
+// after the end-of-tile wait.
 //
 // RM (tile-sparse only, "pack-free"): Xp is the caller's ROW-MAJOR X (row stride ldxB bytes, 16-byte aligned,
 // no NaN -> 0 pass): the LDS-DMA builds the same tile image straight from it -- lane l of 1-KiB piece q
@@ -427,9 +424,7 @@ static int dense_finish_den(wagg_dense *d) {
 // stored-tile lists of the tile-sparse form from the sorted keys nt * n_kt + kt
 static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &tiles, std::vector<int32_t> *nt_out = nullptr,
                                   hipStream_t st = nullptr) {
-    constexpr int TS = wagg_dense::TS;
     std::vector<int32_t> kt(tiles.size() + 2, 0), ntv(tiles.size() + 1, 0);
-    std::vector<int32_t> off((size_t)wagg_dense::off_table(2 * TS, d->n_nt), 0);
     std::vector<int64_t> first((size_t)d->n_nt + 1, 0);
     for (size_t i = 0; i < tiles.size(); ++i) {
         kt[i] = (int32_t)(tiles[i] % d->n_kt);
@@ -437,17 +432,9 @@ static hipError_t dense_set_tiles(wagg_dense *d, const std::vector<int64_t> &til
         first[(size_t)ntv[i] + 1]++;
     }
     for (int nt = 0; nt < d->n_nt; ++nt) first[(size_t)nt + 1] += first[(size_t)nt];
-    for (int ts = 1; ts <= TS; ts *= 2) {
-        int32_t *tab = off.data() + wagg_dense::off_table(ts, d->n_nt);
-        for (int nt = 0; nt < d->n_nt; ++nt) {
-            const int64_t b = first[(size_t)nt], len = first[(size_t)nt + 1] - b;
-            for (int k = 0; k <= ts; ++k) tab[(size_t)nt * (ts + 1) + k] = (int32_t)(b + len * k / ts);
-        }
-    }
     d->nt_first.assign(first.size(), 0);
     for (size_t i = 0; i < first.size(); ++i) d->nt_first[i] = (int32_t)first[i];
     hipError_t e = d->tile_kt.upload(kt, st);
-    if (e == hipSuccess) e = d->tile_off.upload(off, st);
     if (nt_out) *nt_out = ntv;
     return e;
 }
@@ -516,11 +503,11 @@ constexpr double SPMM_MAX_FILL = 0.10;
 //                   stream that every one of the n_rb region blocks pulls through the LDS-DMA path (b G n_rb bytes per row)
 // Rates in flop/s and byte/s; fp32 / fp64.
 struct FormRates { double full, tiled, entries_scale, dma; };
-// fp32: full 204.3 ms / tiles 203.0 ms for 2,282 rows x 8,100 x 96 tiles (all stored); tile-sparse shares 5-75 %: 141-143 TF on
-// the stored tiles' flops (with the slice count chosen by estimate, below); c5-block-f64 / c5-uniform-f64 of bench.py for the
-// fp64 column
-constexpr FormRates FORM_RATES_F32 = {142e12, 142e12, 1.0, 10.1e12};
-constexpr FormRates FORM_RATES_F64 = {70e12, 71e12, 0.44, 10.1e12};
+// fp32: full 204.3 ms for 2,282 rows x 8,100 x 96 tiles; tile-sparse (a workgroup walks an equal share of the stored tiles:
+// dense_pieces_kernel) 144 TF on the stored tiles' flops (c5-block: 8.39 ms), fp64 73 TF (16.58 ms); c5-uniform-f64 of
+// bench.py for the fp64 entry-list scale
+constexpr FormRates FORM_RATES_F32 = {142e12, 144e12, 1.0, 10.1e12};
+constexpr FormRates FORM_RATES_F64 = {70e12, 73e12, 0.44, 10.1e12};
 // The entry loop slows down as the lists grow (the first 16 groups of a wave's list are preloaded across the previous chunk;
 // what follows is fetched inside the loop): flop/s on the WALKED entries against the mean list length per wave and chunk,
 // fp32, measured at uniform fills of 1, 3, 6, 10, 15 and 30 % (mean lengths 54 ... 1625)
@@ -541,10 +528,11 @@ static FormCost table_form_cost(int64_t G, int elem_bytes, int64_t n_tiles_store
     const FormRates &rt = elem_bytes == 8 ? FORM_RATES_F64 : FORM_RATES_F32;
     const double tile_flop = 2.0 * (128.0 / elem_bytes) * 256.0;        // BK = 32 / 16 cells x 256 regions
     FormCost c;
-    // (few column tiles: a launch has at most n_nt x 64 k-slices of workgroups per row block -- R = 600 fills 192 of 256 CUs)
+    // (full form with few column tiles: a launch has at most n_nt x 64 k-slices of workgroups per row block -- R = 600 fills
+    //  192 of 256 CUs; the tile-sparse form hands every CU an equal share of the stored tiles whatever their layout)
     const double util = n_nt * 64.0 < 256.0 ? n_nt * 64.0 / 256.0 : 1.0;
     c.t_full = tile_flop * (double)n_tiles_all / (rt.full * util);
-    c.t_tiled = tile_flop * (double)n_tiles_stored / (rt.tiled * util);
+    c.t_tiled = tile_flop * (double)n_tiles_stored / rt.tiled;
     const double rate = rt.entries_scale * entry_loop_rate((double)walked / (double)(n_lists > 0 ? n_lists : 1));
     const double t_loop = 2.0 * (double)walked / rate, t_stream = (double)elem_bytes * (double)G * (double)n_rb / rt.dma;
     c.t_entries = t_loop > t_stream ? t_loop : t_stream;

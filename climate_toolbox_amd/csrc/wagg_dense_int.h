@@ -76,11 +76,10 @@ struct wagg_dense {
     wagg::DevBuf<double> den64;
     std::vector<double> den_host;
     // tile-sparse form: only the non-empty (32-cell x 256-region) tiles of W are stored, grouped by
-    // column tile; tile_kt[i] = k tile of stored tile i (+2 padding entries), tile_off[nt][0..TS] =
-    // the column tile's run split into TS slices of equal length
+    // column tile; tile_kt[i] = k tile of stored tile i (+2 padding entries)
     bool tiled = false;
     int64_t n_tiles = 0;                // stored tiles (n_nt * n_kt when dense)
-    wagg::DevBuf<int32_t> tile_kt, tile_off;     // tile_off: per-column-tile slice offsets (rounds 2-4; the kernels walk pieces now)
+    wagg::DevBuf<int32_t> tile_kt;
     std::vector<int32_t> nt_first;               // host: first stored tile of every column tile (+ the total): [n_nt + 1]
     // piece table of a tile-sparse launch with n_mb row blocks (wagg_dense.hip: tile_pieces_for): the stored tiles of all
     // (row block, column tile) pairs, end to end, cut into one equal share per workgroup.  One table per row-block count the
@@ -91,12 +90,6 @@ struct wagg_dense {
         int64_t slab_first_at = 0;               // offset of the last part inside tab
     };
     std::vector<std::unique_ptr<TilePieces>> pieces;
-    static constexpr int TS = 64;                // most k-slices of a tile-sparse launch (tables for 1, 2, 4, ..., TS)
-    static int64_t off_table(int ts, int n_nt) {  // start of the table for `ts` slices inside tile_off
-        int64_t at = 0;
-        for (int t = 1; t < ts; t *= 2) at += (int64_t)n_nt * (t + 1);
-        return at;
-    }
     int64_t w_slots() const { return n_tiles * (8192 / 4); }   // 16-byte slots (one tile = 256 x 32 floats)
     // entry-list form (scattered weights, e.g. <= 1 % non-zeros at random positions; fp32 or fp64): no W matrix at all
     bool spmm = false;

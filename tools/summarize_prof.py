@@ -72,8 +72,8 @@ if os.path.exists(tr):
                      # (round 4: the default line's host-resident / drop-in / country-level legs launch the c2-real instantiation on row blocks
                      #  and on another table as well: "#big" keeps the full-field launches of the c2-real table)
                      ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
-                     ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block", "dense_mfma_kernel<float, 0, true"),
-                     ("c5-block-f64", "dense_mfma_kernel<double, 0, true"), ("c5-uniform", "spmm_kernel<float>"),
+                     ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block", "dense_pieces_kernel<float"),
+                     ("c5-block-f64", "dense_pieces_kernel<double"), ("c5-uniform", "spmm_kernel<float>"),
                      ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>"),
                      ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
                      ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true, false>"),
@@ -122,7 +122,7 @@ LINES = ("whole-line chunks: every load instruction reads eight whole 128-B line
          "the bench line's plan), x1 if it matches them: see `calibration`; WRITE_SIZE exact")
 for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
                        ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big", "lines64"),
-                       ("c5-block", "dense_mfma_kernel<float, 0, true", "wide"), ("c5-block-f64", "dense_mfma_kernel<double, 0, true", "wide"),
+                       ("c5-block", "dense_pieces_kernel<float", "wide"), ("c5-block-f64", "dense_pieces_kernel<double", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
     fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
     if fs is None or ws is None:
