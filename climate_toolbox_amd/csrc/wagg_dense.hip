@@ -201,10 +201,10 @@ __global__ void dense_reduce_kernel(const T *__restrict__ slabs, int n_nt, int S
     if (r >= R) return;
     const int mb = (int)(t / bm), tl = (int)(t % bm);
     const int nt = (int)(r / D_BN), c = (int)(r % D_BN);
-    // slabs of the pair (row block, column tile): S of them in a row, or (tile-sparse launches) slab_first[pair] ..
-    // slab_first[pair + 1] - 1 -- as many as pieces of the pair's run, added in that (fixed) order
+    // slabs of the pair (row block, column tile): S of them in a row, or (tile-sparse launches) slab_first[2 pair + 1] of them
+    // from slab_first[2 pair] on -- as many as pieces of the pair's run, added in that (fixed) order
     int64_t first = ((int64_t)mb * n_nt + nt) * S;
-    if (slab_first != nullptr) { first = slab_first[mb * n_nt + nt]; S = slab_first[mb * n_nt + nt + 1] - (int)first; }
+    if (slab_first != nullptr) { first = slab_first[2 * (mb * n_nt + nt)]; S = slab_first[2 * (mb * n_nt + nt) + 1]; }
     const T *p = slabs + (first * bm + tl) * D_BN + c;
     T s = T(0);
     for (int k = 0; k < S; ++k) s += p[(int64_t)k * bm * D_BN];
@@ -454,13 +454,21 @@ static int tile_pieces_for(wagg_dense *d, int n_mb, hipStream_t st, const wagg_d
         int64_t n_wg = total / 8;
         if (n_wg > d->ncu) n_wg = d->ncu;
         if (n_wg < 1) n_wg = 1;
-        std::vector<int32_t> first_piece((size_t)n_wg + 1, 0), rec, slab_first((size_t)n_mb * n_nt + 1, 0);
+        std::vector<int32_t> first_piece((size_t)n_wg + 1, 0), rec, slab_first(2 * (size_t)n_mb * n_nt, 0);
         int64_t pos = 0;                               // position in the concatenation
         int slab = 0, w = 0;
         int64_t w_end = total * 1 / n_wg;              // end of workgroup 0's share
-        for (int mb = 0; mb < n_mb; ++mb)
-            for (int nt = 0; nt < n_nt; ++nt) {
-                slab_first[(size_t)mb * n_nt + nt] = slab;
+        // pair order: row block by row block (diagnostic build, WAGG_PIECES_ORDER=nt: column tile by column tile, so that the
+        // row blocks of one column tile -- which contract the same W tiles -- run side by side)
+        bool nt_major = false;
+#ifdef WAGG_DIAG
+        if (const char *e = getenv("WAGG_PIECES_ORDER")) nt_major = e[0] == 'n';
+#endif
+        for (int64_t pair = 0; pair < (int64_t)n_mb * n_nt; ++pair) {
+            const int mb = nt_major ? (int)(pair % n_mb) : (int)(pair / n_nt), nt = nt_major ? (int)(pair / n_mb) : (int)(pair % n_nt);
+            {
+                const int slab0 = slab;
+                slab_first[2 * ((size_t)mb * n_nt + nt)] = slab;
                 int64_t t0 = d->nt_first[(size_t)nt];
                 const int64_t t1 = d->nt_first[(size_t)nt + 1];
                 while (t0 < t1) {
@@ -473,8 +481,9 @@ static int tile_pieces_for(wagg_dense *d, int n_mb, hipStream_t st, const wagg_d
                     t0 += take;
                     pos += take;
                 }
+                slab_first[2 * ((size_t)mb * n_nt + nt) + 1] = slab - slab0;
             }
-        slab_first[(size_t)n_mb * n_nt] = slab;
+        }
         for (int64_t k = w + 1; k <= n_wg; ++k) first_piece[(size_t)k] = (int32_t)(rec.size() / 8);      // (workgroups without a share: none)
         tp->n_mb = n_mb; tp->n_wg = (int)n_wg; tp->n_slabs = slab;
         std::vector<int32_t> all;

@@ -86,7 +86,7 @@ struct wagg_dense {
     // plan has met, kept until the plan goes (an apply queued on a stream may still be reading one).
     struct TilePieces {
         int n_mb = 0, n_wg = 0, n_slabs = 0;
-        wagg::DevBuf<int32_t> tab;               // [n_wg + 1] first piece of a workgroup | [n_pieces][8] | [n_mb * n_nt + 1] first slab of a pair
+        wagg::DevBuf<int32_t> tab;               // [n_wg + 1] first piece of a workgroup | [n_pieces][8] | [n_mb * n_nt][2] first slab and slab count of a pair
         int64_t slab_first_at = 0;               // offset of the last part inside tab
     };
     std::vector<std::unique_ptr<TilePieces>> pieces;
