@@ -656,7 +656,6 @@ def _host_replicas(plan, n_rows, row_bytes):
 DENSE_SWITCH = 16.0   # the old rule, kept for callers that do not know R (then: n_ucells > DENSE_SWITCH * G)
 _SPARSE_CELLS_PER_S = {True: 2.7e11, False: 1.8e11}      # is_f32 -> gathered cell slots per second
 _DENSE_MARGIN = 1.5
-ENTRY_LIST_MAX_FILL = 0.10   # (memory estimate only) below this share of pairs a table never becomes the full matrix
 _DENSE_BUILD_BYTES_PER_ROW = 64      # device scratch of wagg_dense_create_from_segments while it builds (48 + 16 per row)
 _ENOMEM = -3                         # wagg.h WAGG_ENOMEM
 
@@ -685,13 +684,14 @@ def _wants_dense(n_ucells, G, layout, R=None, nseg=None, is_f32=True):
 
 
 def _dense_bytes(G, R, is_f32=True, nseg=None):
-    """Upper bound of what a dense-family plan of this table holds in HBM.  A table filled below
-    ENTRY_LIST_MAX_FILL never becomes the full matrix: it is stored either tile-sparse (fewer than half of
-    the tiles, by the library's own rule) or as entry lists (8 B per pair in fp32, 16 B in fp64)."""
+    """Upper bound of what a dense-family plan of this table holds in HBM: the full matrix, or -- knowing the number of rows --
+    what the library's form choice can store for that many pairs: entry lists (8 B per pair in fp32, 16 B in fp64), or the
+    tile-sparse form, which it only takes while the stored tiles' flops beat the entry loop, i.e. up to ~1.1e-3 (fp32) /
+    2.5e-3 (fp64) tiles of 32 KB per walked entry (csrc/wagg_dense.hip: table_form_cost) -- 64 / 160 bytes per row."""
     eb = 4 if is_f32 else 8
     full = eb * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
-    if nseg is not None and nseg < ENTRY_LIST_MAX_FILL * float(G) * float(R):
-        return min(full, max(full // 2, 4 * eb * int(nseg)))
+    if nseg is not None:
+        return min(full, (64 if is_f32 else 160) * int(nseg))
     return full
 
 
