@@ -226,17 +226,25 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=N
     if profile_reset is not None:
         profile_reset()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for a_, b_ in ev:
-        a_.record()
-        step()
-        b_.record()
-    finish()                               # every queued gather has completed
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # (no cyclic-garbage collection inside the timed region: a full collection walks every object of the process -- the
+    #  c2-real table alone holds 800,000 label strings -- and takes tens of milliseconds wherever an allocation triggers it)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for a_, b_ in ev:
+            a_.record()
+            step()
+            b_.record()
+        finish()                               # every queued gather has completed
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
