@@ -198,4 +198,6 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().wagg_last_error().decode("utf-8", "replace")
-        raise WaggError("%s failed (%d): %s" % (what, rc, msg))
+        err = WaggError("%s failed (%d): %s" % (what, rc, msg))
+        err.code = int(rc)                 # the wagg_status of the call (include/wagg.h)
+        raise err

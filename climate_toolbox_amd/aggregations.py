@@ -801,14 +801,13 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
         def dense_plan():
             # a build that runs out of device memory after all (another process took it meanwhile; the estimate was short)
             # is not the caller's problem: cached plans go and it is tried once more, then the segment-table form serves
-            nonlocal free_bytes
             if len(cell_idx) >= 2 ** 31:           # wagg_dense_create_from_segments: at most 2^31 - 1 rows
                 return None
             for attempt in (0, 1):
                 try:
                     return DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt, keep_recipe=keep)
                 except WaggError as e:
-                    if "(%d)" % _ENOMEM not in str(e):
+                    if getattr(e, "code", None) != _ENOMEM:
                         raise
                     if attempt == 0:
                         with _CACHE_LOCK:
