@@ -937,9 +937,10 @@ def main():
             return {"wl": r["workload"], "steps": r["steps"], "step_ms": [round(r["median_ms"], 4), round(r["min_ms"], 4), round(r["max_ms"], 4)],
                     "kernel_ms": [round(rf["kernel_ms_median"], 4), round(rf["kernel_ms_min"], 4), round(rf["kernel_ms_max"], 4)],
                     "frac": round(rf["frac"], 4), "frac_on_traffic": (round(rf["frac_on_traffic"], 4) if "frac_on_traffic" in rf else None),
-                    "bound": rf["bound"], "outlier": bool(rf.get("kernel_ms_outlier") or r.get("step_outlier")),
+                    "bound": rf["bound"], "outlier": bool(rf.get("kernel_ms_outlier")), "step_outlier": bool(r.get("step_outlier")),
                     **({"plan_build_s": r["plan_build_s"]} if "plan_build_s" in r else {})}
-        line["summary"] = {"columns": "step_ms / kernel_ms = [median, min, max]; frac = roofline fraction on the median kernel time",
+        line["summary"] = {"columns": "step_ms / kernel_ms = [median, min, max]; frac = roofline fraction on the median kernel time; outlier / "
+                                      "step_outlier = the slowest launch / step took more than 1.5 x the median (of up to 1,000 samples)",
                            "rows": [brief(main_res)] + [brief(r) for r in secondary]}
         text = json.dumps(line)
         try:                                        # the whole line also as a file (gpurun merges gpurun_out/ back)
