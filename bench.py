@@ -277,13 +277,20 @@ def step_stats(per_step_ms):
             **({"step_ms_sorted": d["step_ms_sorted"]} if "step_ms_sorted" in d else {"step_ms_quantiles": d.get("step_ms_quantiles")})}
 
 
-def kernel_stats(kms):
+def kernel_stats(kms, steps=0):
     """The dominant kernel's own durations over the timed steps (hipExtLaunchKernel start / stop events: the dispatch
     itself, no host time): the roofline is priced on the MEDIAN; mean, min, max and the sorted list ride along, and
     `outlier` says when the slowest launch took more than 1.5 x the median.  (step_ms_max >> kernel_ms_max = a gap between
     launches, i.e. the host; kernel_ms_max >> kernel_ms_median = the device itself ran a launch slowly.)"""
+    per_apply = 1
+    if steps and len(kms) > steps and len(kms) % steps == 0:
+        # an apply that launches its dominant kernel more than once (a ragged batch: full row blocks, then the remainder): the
+        # launches of one step are added up
+        per_apply = len(kms) // steps
+        kms = [sum(kms[i * per_apply:(i + 1) * per_apply]) for i in range(steps)]
     ks = sorted(kms)
     d = _spread(ks, "kernel_ms_")
+    d["kernel_launches_per_apply"] = per_apply
     d["kernel_ms_avg"] = sum(ks) / max(1, len(ks))
     d["kernel_launches"] = len(ks)
     return d
@@ -662,7 +669,7 @@ def main():
         Rr = len(uniq)
         st = stepper(lambda out: plan.apply(Xs, out=out), T, rows_all, Rr, Xs.dtype)
         dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto)
-        kst = kernel_stats(engine.profile_read())
+        kst = kernel_stats(engine.profile_read(), steps)
         engine.profile_enable(False)
         kmed = kst["kernel_ms_median"] * 1e-3          # the roofline is priced on the MEDIAN launch
         gok = gather_check(st, T)
@@ -786,7 +793,7 @@ def main():
         st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), T, rows_all, R, X.dtype)
         dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto,
                                                      min_steps=min_steps)
-        kst = kernel_stats(engine.profile_read())
+        kst = kernel_stats(engine.profile_read(), steps)
         engine.profile_enable(False)
         gok = gather_check(st, T)
         gt = gather_timing(st, T, per_step)
