@@ -13,6 +13,7 @@ PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA, PLAN_SERIAL_BUILD = 1, 
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
 FORCE_FORM = {None: 0, "auto": 0, "full": 1, "tiles": 2, "entries": 3}      # WAGG_DENSE_FORCE_*
 HOST_PIN, HOST_WHOLE = 1, 2
+DENSE_GENERAL_SORT = 16        # WAGG_DENSE_GENERAL_SORT
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1
 OUT_TR, OUT_RT = 0, 1
@@ -69,7 +70,8 @@ class DenseInfo(C.Structure):
                 ("R", C.c_int32), ("n_kt", C.c_int32), ("n_nt", C.c_int32), ("tiled", C.c_int32),
                 ("form", C.c_int32), ("elem_bytes", C.c_int32), ("nnz", C.c_int64),
                 ("build_s", C.c_double), ("build_upload_s", C.c_double),
-                ("est_full_s", C.c_double), ("est_tiles_s", C.c_double), ("est_entries_s", C.c_double), ("walked_entries", C.c_int64)]
+                ("est_full_s", C.c_double), ("est_tiles_s", C.c_double), ("est_entries_s", C.c_double), ("walked_entries", C.c_int64),
+                ("one_pass_sort", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class WaggError(RuntimeError):

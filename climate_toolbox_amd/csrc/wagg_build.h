@@ -69,6 +69,13 @@ struct BuildCtx {
     hipError_t sync() const { return hipStreamSynchronize(st); }
     ~BuildCtx();
 };
+// diagnostic build only (WAGG_BUILD_TRACE=1): wall time between milestones of a build, the stream drained at each
+#ifdef WAGG_DIAG
+void build_stamp(const BuildCtx &ctx, const char *what);
+#define WAGG_BUILD_STAMP(ctx, what) wagg::build_stamp((ctx), (what))
+#else
+#define WAGG_BUILD_STAMP(ctx, what) ((void)0)
+#endif
 #define WAGG_TAKE(ptr, ctx, T, count)                                                                        \
     do {                                                                                                     \
         (ptr) = (ctx).template take<T>((size_t)(count));                                                     \
@@ -88,6 +95,7 @@ size_t build_arena_bytes(int64_t n, int64_t G, int32_t R, bool csr);
 struct SortedEntries {
     EntryKeyGeom geom;
     int64_t n_in = 0, n_valid = 0, n_u = 0;           // rows handed in; with a label and a weight that is not NaN; distinct pairs
+    bool chunkwise = false;                           // sorted by the one-pass chunk partition (CSR with ascending columns)
     DevBuf<uint64_t> key;                             // [n_u] ascending
     DevBuf<double> w;                                 // [n_u] fp64 sum of the pair's rows, in input order
     DevBuf<double> den;                               // [R]   sum of the weights of a region's pairs (aggregations.py:79)
@@ -99,7 +107,10 @@ struct SortedEntries {
 // host's clock: the caller keeps working on ctx.st or synchronises it).  Scratch comes from ctx's arena above its current mark
 // and is released before returning; the arena's input side (where the caller put the table) is dropped once the keys exist.
 int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev,
-                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out);
+                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out,
+                         bool general_sort = false);
+// what the one-pass partition of a CSR table adds to build_arena_bytes (the chunk bounds and the bucket counts)
+size_t chunk_sort_scratch_bytes(const EntryKeyGeom &geom);
 
 // primitives (also used by the synthetic-table generator); scratch from the arena, released before returning
 int scan_u32_exclusive(BuildCtx &ctx, uint32_t *data_dev, int64_t n, uint32_t *total_dev /* may be NULL */);

@@ -9,6 +9,8 @@
 #include <utility>
 
 #include "wagg_build.h"
+#include <chrono>
+#include <cstdlib>
 #include "wagg_host.h"
 
 namespace wagg {
@@ -246,6 +248,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t *
     }
 }
 
+#ifdef WAGG_DIAG
+void build_stamp(const BuildCtx &ctx, const char *what) {
+    static const bool on = getenv("WAGG_BUILD_TRACE") != nullptr;
+    static thread_local double last = 0.0;
+    if (!on) return;
+    (void)ctx.sync();
+    const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (what[0] == '^') last = now;
+    std::fprintf(stderr, "[build] %-28s %8.3f ms\n", what, (now - last) * 1e3);
+    last = now;
+}
+#endif
+
 int radix_sort_pairs(BuildCtx &ctx, uint64_t *keys, uint64_t *vals, uint64_t *keys_alt, uint64_t *vals_alt, int64_t n, int passes) {
     if (n <= 1 || passes <= 0) return WAGG_OK;
     WAGG_REQUIRE(n < (int64_t)0x7fffffff, "too many entries to sort (%lld)", (long long)n);
@@ -289,20 +304,35 @@ __global__ __launch_bounds__(256) void keygen_kernel(const int32_t *__restrict__
                                                      uint64_t *__restrict__ vals, unsigned long long *__restrict__ note) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool dropped = false;
+    // CSR: the row that holds entry i = the last g with rowptr[g] <= i.  The block's 256 consecutive entries lie in the rows
+    // between those of its first and its last entry: two threads search all of rowptr for these, the rest search between them
+    // (a step or two for tables with hundreds of entries per row, where a search of its own per entry was most of this kernel)
+    __shared__ int64_t row_span[2];
+    auto row_of = [&](int64_t e, int64_t lo, int64_t hi) {      // rowptr[lo] <= e < rowptr[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rowptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    if (rowptr) {
+        if (threadIdx.x < 2) {
+            const int64_t first = (int64_t)blockIdx.x * blockDim.x, last = first + blockDim.x - 1 < n ? first + blockDim.x - 1 : n - 1;
+            row_span[threadIdx.x] = row_of(threadIdx.x ? last : first, 0, G);
+        }
+        __syncthreads();
+    }
     if (i < n) {
         int64_t c;
-        if (rowptr) {                              // CSR: the row that holds entry i = the last g with rowptr[g] <= i
-            int64_t lo = 0, hi = G;
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (rowptr[mid] <= i) lo = mid; else hi = mid;
-            }
-            c = lo;
+        if (rowptr) {
+            c = row_of(i, row_span[0], row_span[1] + 1);
         } else {
             c = cell[i];
         }
         const int32_t r = region[i];
         const double wv = w[i];
+        // CSR rows whose columns ascend are already in (cell, region) order: the one-pass partition below relies on it
+        if (rowptr && i > rowptr[c] && region[i - 1] > r) note[2] = 1ull;
         uint64_t key = KEY_DROPPED;
         if (r >= R || c < 0 || c >= G) atomicMin(&note[0], (unsigned long long)i);           // first bad row
         else if (r >= 0 && wv == wv) key = geom.key(c, r);
@@ -339,6 +369,114 @@ __global__ __launch_bounds__(256) void coalesce_kernel(const uint64_t *__restric
     rkey[u] = (uint64_t)regionv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CSR tables with ascending columns: the sort in ONE stable pass
+// ---------------------------------------------------------------------------------------------
+// Key order is (region block, chunk, wave, cell in chunk, region in wave); such a table arrives in (chunk, cell in chunk,
+// region block, wave, region in wave) order.  Inside one chunk the pairs of one (region block, wave) bin are therefore
+// already in key order, and the whole sort is a stable partition of every chunk's run into its n_rb x 16 bins whose places
+// come from one exclusive scan over the counts laid out [region block][chunk][wave] -- the buckets of the key.  One
+// workgroup per chunk (its pairs are the contiguous run rowptr[128 c] .. rowptr[128 (c + 1)]), tiles of 8,192 pairs walked
+// in order with the running place of every bin in LDS; inside a tile the rounds of rs_scatter_kernel.
+constexpr int CP_BINS_MAX = 1024;
+
+__global__ __launch_bounds__(256) void chunk_first_kernel(const int64_t *__restrict__ rowptr, int64_t G, int n_chunks,
+                                                          uint32_t *__restrict__ cf, unsigned long long *__restrict__ note) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_chunks) return;
+    const int64_t g0 = c * 128 < G ? c * 128 : G, g1 = (c + 1) * 128 < G ? (c + 1) * 128 : G;
+    cf[c] = (uint32_t)rowptr[g0];
+    if (c < n_chunks) atomicMax(&note[3], (unsigned long long)(rowptr[g1] - rowptr[g0]));
+}
+
+__device__ __forceinline__ unsigned chunk_bin(uint64_t key, const EntryKeyGeom &geom, int64_t chunk) {
+    const uint64_t b = (uint64_t)geom.bucket_of(key);            // (rb n_chunks + chunk) 16 + wave
+    return (unsigned)((((b >> 4) - (uint64_t)chunk) / (uint64_t)geom.n_chunks) * 16u + (b & 15u));
+}
+
+__global__ __launch_bounds__(RS_THREADS) void chunk_hist_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ cf,
+                                                                EntryKeyGeom geom, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[CP_BINS_MAX];
+    const int nbins = geom.n_rb * 16;
+    const int64_t c = blockIdx.x;
+    for (int b = threadIdx.x; b < nbins; b += RS_THREADS) h[b] = 0;
+    __syncthreads();
+    const int64_t end = cf[c + 1];
+    for (int64_t i = (int64_t)cf[c] + threadIdx.x; i < end; i += RS_THREADS) atomicAdd(&h[chunk_bin(keys[i], geom, c)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += RS_THREADS)
+        hist[((int64_t)(b >> 4) * geom.n_chunks + c) * 16 + (b & 15)] = h[b];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void chunk_scatter_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ vals,
+                                                                   const uint32_t *__restrict__ cf, EntryKeyGeom geom,
+                                                                   const uint32_t *__restrict__ offs, uint64_t *__restrict__ keys_out,
+                                                                   uint64_t *__restrict__ vals_out) {
+    __shared__ uint32_t cnt[RS_WAVES][CP_BINS_MAX];
+    __shared__ uint32_t run[CP_BINS_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nbins = geom.n_rb * 16;
+    const int64_t c = blockIdx.x, end = cf[c + 1];
+    for (int b = threadIdx.x; b < nbins; b += RS_THREADS) run[b] = offs[((int64_t)(b >> 4) * geom.n_chunks + c) * 16 + (b & 15)];
+    const uint64_t below_mask = (1ull << lane) - 1ull;
+    for (int64_t tile = cf[c]; tile < end; tile += RS_TILE) {
+        for (int w = 0; w < RS_WAVES; ++w)
+            for (int b = threadIdx.x; b < nbins; b += RS_THREADS) cnt[w][b] = 0;
+        __syncthreads();                           // (also: run[] of the tile before is complete)
+        const int64_t wbase = tile + (int64_t)wave * (64 * RS_ROUNDS) + lane;
+        uint64_t k[RS_ROUNDS], v[RS_ROUNDS];
+        uint16_t d[RS_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const int64_t i = wbase + 64 * r;
+            const bool ok = i < end;
+            k[r] = ok ? keys[i] : 0ull;
+            v[r] = ok ? vals[i] : 0ull;
+            d[r] = ok ? (uint16_t)chunk_bin(k[r], geom, c) : (uint16_t)0;
+            if (ok) atomicAdd(&cnt[wave][d[r]], 1u);
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nbins; b += RS_THREADS) {      // counts -> first place of (wave, bin) in this tile
+            uint32_t at = run[b];
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                const uint32_t n_w = cnt[w][b];
+                cnt[w][b] = at;
+                at += n_w;
+            }
+            run[b] = at;
+        }
+        __syncthreads();
+        // the rounds of rs_scatter_kernel (see there for the hand-over of cnt[wave][bin] between rounds), ten bin bits
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; ++r) {
+            const bool ok = wbase + 64 * r < end;
+            const unsigned bin = d[r];
+            uint64_t peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+                const bool bit = (bin >> b) & 1u;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+            uint32_t first = 0;
+            if (ok) first = __hip_atomic_load(&cnt[wave][bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+            if (ok) {
+                const uint32_t at = first + (uint32_t)__popcll(peers & below_mask);
+                keys_out[at] = k[r];
+                vals_out[at] = v[r];
+                if ((peers & below_mask) == 0)
+                    __hip_atomic_store(&cnt[wave][bin], first + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();                           // every wave is through with cnt[] before the next tile clears it
+    }
+}
+
 // den[r] = sum of the weights of region r's pairs (aggregations.py:79), pairs in (region, key) order: one wave per
 // region, lane-strided partial sums, then the fixed shuffle tree
 __global__ __launch_bounds__(256) void den_kernel(const uint64_t *__restrict__ rkey, const uint64_t *__restrict__ w, int64_t n,
@@ -362,8 +500,14 @@ __global__ __launch_bounds__(256) void den_kernel(const uint64_t *__restrict__ r
     if (lane == 0) den[r] = s;
 }
 
+size_t chunk_sort_scratch_bytes(const EntryKeyGeom &geom) {
+    const size_t nb = (size_t)geom.n_rb * 16 * (size_t)geom.n_chunks;
+    return sizeof(uint32_t) * (nb + (size_t)geom.n_chunks + 1) + scan_scratch_bytes((int64_t)nb) + 2048;
+}
+
 int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *rowptr_dev, const int32_t *region_dev,
-                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out) {
+                         const double *w_dev, int64_t n, int64_t G, int32_t R, const EntryKeyGeom &geom, SortedEntries *out,
+                         bool general_sort) {
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     WAGG_REQUIRE(n >= 0 && n < (int64_t)0x7fffffff, "table of %lld rows: at most 2^31 - 1", (long long)n);
     WAGG_REQUIRE((cell_dev != nullptr) != (rowptr_dev != nullptr) || n == 0, "exactly one of cell / rowptr");
@@ -382,21 +526,50 @@ int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *
     WAGG_TAKE(va, ctx, uint64_t, n);
     WAGG_TAKE(kb, ctx, uint64_t, n);
     WAGG_TAKE(vb, ctx, uint64_t, n);
-    WAGG_TAKE(note, ctx, unsigned long long, 2);
+    WAGG_TAKE(note, ctx, unsigned long long, 4);
     {
-        const unsigned long long init[2] = {~0ull, 0ull};
+        // first row out of range | rows dropped | CSR columns out of order somewhere | longest chunk of a CSR table
+        const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
         WAGG_HIP(staged_h2d(note, init, sizeof(init), ctx.st));
+    }
+    const int nbins = geom.n_rb * 16;
+    const int64_t n_buckets = (int64_t)nbins * geom.n_chunks;
+    const bool chunkwise_possible = rowptr_dev != nullptr && nbins <= CP_BINS_MAX && !general_sort;
+    uint32_t *cf = nullptr, *chist = nullptr;
+    if (chunkwise_possible) {
+        WAGG_TAKE(cf, ctx, uint32_t, geom.n_chunks + 1);
+        WAGG_TAKE(chist, ctx, uint32_t, n_buckets);
+        hipLaunchKernelGGL(chunk_first_kernel, dim3((unsigned)(geom.n_chunks / 256 + 1)), dim3(256), 0, ctx.st, rowptr_dev, G,
+                           geom.n_chunks, cf, note);
     }
     hipLaunchKernelGGL(keygen_kernel, dim3(nblk), dim3(256), 0, ctx.st, cell_dev, rowptr_dev, region_dev, w_dev, n, G, R, geom,
                        ka, va, note);
     WAGG_HIP(hipGetLastError());
     ctx.drop_inputs();                           // the table has been read once this kernel is through (stream order)
-    unsigned long long noted[2];
+    unsigned long long noted[4];
     WAGG_HIP(staged_d2h(noted, note, sizeof(noted), ctx.st));      // (waits for the copy, hence for the kernel: the host reads here)
     WAGG_REQUIRE(noted[0] == ~0ull, "segment %llu out of range", noted[0]);
     const int64_t n_valid = n - (int64_t)noted[1];
     out->n_valid = n_valid;
-    if (int rc = radix_sort_pairs(ctx, ka, va, kb, vb, n, passes_for(geom.range()))) return rc;
+    WAGG_BUILD_STAMP(ctx, "keygen");
+    // one pass when the table is CSR with ascending columns, drops nothing and no chunk holds so much of it that its one
+    // workgroup would be the build (a chunk walks its tiles in order); the general sort otherwise
+    const int64_t longest_ok = std::max<int64_t>(64 * (int64_t)RS_TILE, 8 * (n / geom.n_chunks + 1));
+    out->chunkwise = chunkwise_possible && noted[1] == 0 && noted[2] == 0 && (int64_t)noted[3] <= longest_ok;
+    if (out->chunkwise) {
+        hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)geom.n_chunks), dim3(RS_THREADS), 0, ctx.st, (const uint64_t *)ka,
+                           (const uint32_t *)cf, geom, chist);
+        WAGG_HIP(hipGetLastError());
+        if (int rc = scan_u32_exclusive(ctx, chist, n_buckets, nullptr)) return rc;
+        hipLaunchKernelGGL(chunk_scatter_kernel, dim3((unsigned)geom.n_chunks), dim3(RS_THREADS), 0, ctx.st, (const uint64_t *)ka,
+                           (const uint64_t *)va, (const uint32_t *)cf, geom, (const uint32_t *)chist, kb, vb);
+        WAGG_HIP(hipGetLastError());
+        std::swap(ka, kb);
+        std::swap(va, vb);
+    } else if (int rc = radix_sort_pairs(ctx, ka, va, kb, vb, n, passes_for(geom.range()))) {
+        return rc;
+    }
+    WAGG_BUILD_STAMP(ctx, "sort by key");
     if (n_valid == 0) { ctx.release_to(mk); return WAGG_OK; }
     // distinct pairs: rank of every run's head, then one sum per run
     uint32_t *rank, *total;
@@ -410,6 +583,7 @@ int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *
     WAGG_HIP(staged_d2h(&n_u32, total, sizeof(n_u32), ctx.st));    // (the host sizes the output from it)
     const int64_t n_u = n_u32;
     out->n_u = n_u;
+    WAGG_BUILD_STAMP(ctx, "heads + scan");
     WAGG_HIP(out->key.alloc((size_t)n_u));
     WAGG_HIP(out->w.alloc((size_t)n_u));
     // kb <- region of every distinct pair (the key of the denominator sort), vb <- a copy of the sums to sort along
@@ -417,7 +591,9 @@ int build_sorted_entries(BuildCtx &ctx, const int32_t *cell_dev, const int64_t *
                        (const uint32_t *)rank, out->key.p, out->w.p, kb, geom);
     WAGG_HIP(hipGetLastError());
     WAGG_HIP(hipMemcpyAsync(vb, out->w.p, sizeof(double) * (size_t)n_u, hipMemcpyDeviceToDevice, ctx.st));
+    WAGG_BUILD_STAMP(ctx, "alloc + coalesce");
     if (int rc = radix_sort_pairs(ctx, kb, vb, ka, va, n_u, passes_for((uint64_t)R))) return rc;
+    WAGG_BUILD_STAMP(ctx, "sort by region");
     hipLaunchKernelGGL(den_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, ctx.st, (const uint64_t *)kb, (const uint64_t *)vb,
                        n_u, R, out->den.p);
     WAGG_HIP(hipGetLastError());

@@ -653,21 +653,28 @@ static int create_host(const T *W_host, int64_t G, int32_t R, wagg_dense **out) 
 }
 
 // ---- plans from a caller's table (COO segment rows or CSR), built on the device ---------------------------------------
-// which (BK-cell x 256-region) tiles of W hold a pair: one bit per tile.  Neighbouring pairs mostly share their tile
-// (key order walks a chunk's cells inside one wave's regions), so only the first of such a run touches the bitmap.
+// which (BK-cell x 256-region) tiles of W hold a pair: one bit per tile.  Key order walks a chunk's cells inside one wave's
+// regions, so the 64 pairs of a wavefront lie in a handful of tiles: one lane per distinct tile of the wave sets its bit
+// (evenly spread weights ask for every bit some eight hundred times -- the atomics on 24,300 words were most of this
+// kernel while every head of a run of equal tiles issued one).
 template <typename T>
 __global__ __launch_bounds__(256) void table_tiles_kernel(const uint64_t *__restrict__ key, int64_t n, EntryKeyGeom geom, int n_kt,
                                                           uint32_t *__restrict__ bitmap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    auto tile_of = [&](uint64_t k) {
+    const int lane = threadIdx.x & 63;
+    int64_t t = -1;
+    if (i < n) {
         int64_t cell; int32_t region; int cic, j;
-        geom.decode(k, cell, region, cic, j);
-        return (int64_t)(region / D_BN) * n_kt + cell / DT<T>::BK;
-    };
-    const int64_t t = tile_of(key[i]);
-    if (i > 0 && tile_of(key[i - 1]) == t) return;
-    atomicOr(&bitmap[t >> 5], 1u << (t & 31));          // idempotent: the bitmap is the same on every build
+        geom.decode(key[i], cell, region, cic, j);
+        t = (int64_t)(region / D_BN) * n_kt + cell / DT<T>::BK;
+    }
+    uint64_t todo = __ballot(i < n);
+    while (todo) {                                     // (wave-uniform)
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const int64_t tl = __shfl(t, leader, 64);
+        if (lane == leader) atomicOr(&bitmap[tl >> 5], 1u << (tl & 31));      // idempotent: the same bitmap on every build
+        todo &= ~__ballot(t == tl);
+    }
 }
 
 // distinct pairs -> packed W (full form: word_rank == NULL; tile-sparse: stored tile = rank of the pair's tile among the set bits)
@@ -705,6 +712,8 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     WAGG_REQUIRE(out != nullptr, "out is NULL");
     *out = nullptr;
     WAGG_REQUIRE(G > 0 && R > 0, "bad sizes G=%lld R=%d", (long long)G, R);
+    const bool general_sort = (flags & WAGG_DENSE_GENERAL_SORT) != 0;
+    flags &= ~WAGG_DENSE_GENERAL_SORT;
     WAGG_REQUIRE(flags >= WAGG_DENSE_FORM_AUTO && flags <= WAGG_DENSE_FORCE_ENTRIES, "unknown form flag %d", flags);
     if (rowptr) {
         WAGG_REQUIRE(rowptr[0] == 0, "rowptr[0] must be 0");
@@ -723,10 +732,13 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     const int64_t n_buckets = (int64_t)geo.n_rb * geo.n_chunks * SP_WAVES;
     // one stream and one arena for the whole build (wagg_build.h): the sort's scratch first, and once that is released the
     // tile bitmap with its ranks or the list bounds of the entry-list packing
-    const size_t after_sort = 2 * (sizeof(uint32_t) * (size_t)n_words + 512) + 2 * (sizeof(int32_t) * ((size_t)n_buckets + 1) + 512) + 4096;
+    const size_t after_sort = 2 * (sizeof(uint32_t) * (size_t)n_words + 512) + 2 * (sizeof(int32_t) * ((size_t)n_buckets + 1) + 512) +
+                              sizeof(uint32_t) * ((size_t)n_buckets / 2048 + 2) + 8192;
     size_t arena = build_arena_bytes(n, G, R, rowptr != nullptr);
+    if (rowptr) arena += chunk_sort_scratch_bytes(kg);
     if (arena < after_sort) arena = after_sort;
     BuildCtx ctx;
+    WAGG_BUILD_STAMP(ctx, "^start");
     {
         const hipError_t e = ctx.init(arena);
         if (e != hipSuccess) {
@@ -734,6 +746,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
             return e == hipErrorOutOfMemory ? WAGG_ENOMEM : WAGG_EHIP;
         }
     }
+    WAGG_BUILD_STAMP(ctx, "arena");
     SortedEntries se;
     double t_up = 0.0;
     {
@@ -753,7 +766,8 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
             if (rc != WAGG_OK) return rc;
         }
         t_up = wall_s() - t0;
-        if (int rc = build_sorted_entries(ctx, dcell, drow, dreg, dw, n, G, R, kg, &se)) return rc;
+        WAGG_BUILD_STAMP(ctx, "upload");
+        if (int rc = build_sorted_entries(ctx, dcell, drow, dreg, dw, n, G, R, kg, &se, general_sort)) return rc;
     }
     // which tiles of W hold anything?  Few -> tile-sparse form; (almost) all but few pairs in them -> entry lists
     uint32_t *bitmap, *word_rank = nullptr;
@@ -764,6 +778,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
         hipLaunchKernelGGL((table_tiles_kernel<T>), dim3(nblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, se.n_u, kg, n_kt, bitmap);
         WAGG_HIP(hipGetLastError());
     }
+    WAGG_BUILD_STAMP(ctx, "den + tile census");
     std::vector<uint32_t> hbits, hrank;
     std::vector<int64_t> tiles;
     try {
@@ -780,6 +795,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     const double fill_all = (double)se.n_u / ((double)G * (double)R);
     int64_t walked = 0;
     if (se.n_u > 0) { if (int rc = spmm_list_cost(ctx, se, &walked)) return rc; }
+    WAGG_BUILD_STAMP(ctx, "bitmap to host + list cost");
     const FormCost cost = table_form_cost(G, (int)sizeof(T), (int64_t)tiles.size(), n_tiles_all, walked, geo.n_rb, n_buckets, n_nt);
     bool tiled, entries;
     pick_table_form(cost, &tiled, &entries);
@@ -794,6 +810,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     int rc = dense_alloc<T>(G, R, out, tiled ? (int64_t)tiles.size() : -1, entries);
     if (rc != WAGG_OK) return rc;
     wagg_dense *d = *out;
+    WAGG_BUILD_STAMP(ctx, "plan alloc");
     auto fail = [&](int code) { (void)ctx.sync(); delete d; *out = nullptr; return code; };
     if (entries) {
         ctx.release_to(0);                            // (the bitmap has been read; the list bounds take its place, in stream order)
@@ -820,10 +837,12 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
     if (rc != WAGG_OK) return fail(rc);
     e = ctx.sync();                                   // the plan is complete before anyone applies it on another stream
     if (e != hipSuccess) { set_error("plan build: %s", hipGetErrorString(e)); return fail(WAGG_EHIP); }
+    WAGG_BUILD_STAMP(ctx, "pack + den to host");
     if (entries) d->sp.nnz = se.n_u;
     d->nnz_table = se.n_u;
     d->est_row_s[0] = cost.t_full; d->est_row_s[1] = cost.t_tiled; d->est_row_s[2] = cost.t_entries;
     d->walked_entries = walked;
+    d->one_pass_sort = se.chunkwise;
     d->build.upload_s = t_up;
     d->build.total_s = wall_s() - t0;
     d->build.device_s = d->build.total_s - t_up;
@@ -1102,6 +1121,8 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     info->build_upload_s = d->build.upload_s;
     for (int k = 0; k < 3; ++k) info->est_row_s[k] = d->est_row_s[k];
     info->walked_entries = d->walked_entries;
+    info->one_pass_sort = d->one_pass_sort ? 1 : 0;
+    info->reserved0 = 0;
     return WAGG_OK;
 }
 

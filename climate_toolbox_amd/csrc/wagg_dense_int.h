@@ -105,6 +105,7 @@ struct wagg_dense {
     wagg::BuildTimes build;            // constructors that take a caller's table: where the seconds went
     double est_row_s[3] = {0, 0, 0};   // ... and what the form choice went by (seconds per row of X: full, tiles, entries)
     int64_t walked_entries = 0;
+    bool one_pass_sort = false;              // the table was put in key order by the one-pass chunk partition
     ~wagg_dense() { if (inf_host) wagg::note_cleanup(hipHostFree(inf_host), "hipHostFree(inf note)"); }
 };
 

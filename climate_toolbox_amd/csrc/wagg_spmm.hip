@@ -450,9 +450,18 @@ __global__ __launch_bounds__(256) void spmm_bounds_kernel(const uint64_t *__rest
     }
     first[b] = (int32_t)lo;
 }
-__global__ __launch_bounds__(256) void spmm_counts_kernel(const int32_t *__restrict__ first, int64_t n_buckets, int32_t *__restrict__ counts) {
+// counts[b] = pairs of list b, groups[b] = its 8-entry groups (groups[n_buckets] = 0: the exclusive scan over n_buckets + 1
+// values then leaves the total in the last place -- the table of first groups the kernel reads, built without the host)
+__global__ __launch_bounds__(256) void spmm_counts_kernel(const int32_t *__restrict__ first, int64_t n_buckets, int32_t *__restrict__ counts,
+                                                          uint32_t *__restrict__ groups) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_buckets) counts[b] = first[b + 1] - first[b];
+    if (b < n_buckets) {
+        const int32_t c = first[b + 1] - first[b];
+        counts[b] = c;
+        groups[b] = (uint32_t)((c + SP_GROUP - 1) / SP_GROUP);
+    } else if (b == n_buckets) {
+        groups[b] = 0u;
+    }
 }
 
 template <typename T>
@@ -534,12 +543,27 @@ int spmm_build_from_sorted(BuildCtx &ctx, wagg_dense *d, const SortedEntries &se
     WAGG_TAKE(dcounts, ctx, int32_t, n_buckets);
     const unsigned bblk = (unsigned)((n_buckets + 256) / 256), nblk = (unsigned)((se.n_u + 255) / 256);
     hipLaunchKernelGGL(spmm_bounds_kernel, dim3(bblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, se.n_u, se.geom, n_buckets, first);
-    hipLaunchKernelGGL(spmm_counts_kernel, dim3(bblk), dim3(256), 0, ctx.st, (const int32_t *)first, n_buckets, dcounts);
+    // the lists are laid out on the device: first group of every list = exclusive scan of the group counts, straight into
+    // the plan's table; the host only learns the total (it sizes the entry array).  (Round 4 and the first half of round 5
+    // brought 19 MB of counts to the host, added them up there and sent 19 MB of offsets back: 6 ms of a c5 build.)
+    WAGG_HIP(sp.grp_off.alloc((size_t)n_buckets + 1));
+    uint32_t *goff = reinterpret_cast<uint32_t *>(sp.grp_off.p), *gtotal;
+    WAGG_TAKE(gtotal, ctx, uint32_t, 1);
+    hipLaunchKernelGGL(spmm_counts_kernel, dim3(bblk), dim3(256), 0, ctx.st, (const int32_t *)first, n_buckets, dcounts, goff);
     WAGG_HIP(hipGetLastError());
-    std::vector<int32_t> counts;
-    try { counts.resize((size_t)n_buckets); } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
-    WAGG_HIP(staged_d2h(counts.data(), dcounts, sizeof(int32_t) * counts.size(), ctx.st));     // (the host lays the lists out)
-    if (int rc = spmm_offsets<T>(d, counts, ctx.st)) return rc;
+    if (int rc = scan_u32_exclusive(ctx, goff, n_buckets + 1, gtotal)) return rc;
+    uint32_t groups32 = 0;
+    WAGG_HIP(staged_d2h(&groups32, gtotal, sizeof(groups32), ctx.st));
+    // (a 32-bit sum cannot wrap: at most 2^31 - 1 pairs and as many lists, a list of c pairs has at most c groups or one)
+    WAGG_REQUIRE(groups32 < 0x7fffffffu, "entry list too long");
+    {
+        constexpr int GW = SpT<T>::GW;
+        sp.n_groups = (int64_t)groups32;
+        sp.nnz = se.n_u;
+        WAGG_HIP(sp.ent.alloc((size_t)(sp.n_groups + SP_PAD_GROUPS) * GW));
+        // padding groups at the end: a wave always loads 16 groups from its list start
+        WAGG_HIP(hipMemsetAsync(sp.ent.p + (size_t)sp.n_groups * GW, 0, sizeof(uint32_t) * GW * SP_PAD_GROUPS, ctx.st));
+    }
     if (se.n_u > 0) {
         hipLaunchKernelGGL((spmm_fill_kernel<T>), dim3(nblk), dim3(256), 0, ctx.st, (const uint64_t *)se.key.p, (const double *)se.w.p,
                            se.n_u, se.geom, (const int32_t *)first, (const int32_t *)sp.grp_off.p, sp.ent.p);

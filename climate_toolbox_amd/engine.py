@@ -311,12 +311,15 @@ class DensePlan:
         return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype, form=form)) if keep else None)
 
     @classmethod
-    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None, form=None, keep_recipe=None):
+    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None, form=None, keep_recipe=None, general_sort=False):
         """From a caller's table in CSR form (``wagg_dense_create_from_csr*``; BASELINE configs[4] "sparse CSR weights"):
         ``rowptr`` (G + 1 offsets, rows = grid cells), ``col`` = region codes, ``val`` = fp64 weights -- the coded form of
         the reference's weights table (aggregations.py:64-73).  The arrays are uploaded as they are (no host copy when
         they already have the dtypes int64 / int32 / float64); everything else happens on the device.  ``form`` as for
-        :meth:`from_segments`."""
+        :meth:`from_segments`.  A table whose columns ascend inside every row (scipy's ``has_sorted_indices``) is put in
+        the plan's order by one stable pass per chunk of 128 cells instead of the general radix sort
+        (``info["one_pass_sort"]``); ``general_sort=True`` takes the general sort regardless -- same plan, for tests
+        and timings."""
         require_gpu()
         rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         co = np.ascontiguousarray(col, dtype=np.int32)
@@ -329,9 +332,10 @@ class DensePlan:
         with _on_device(device):
             dev = _current_device()
             _lib.check(fn(_np_ptr(rp, C.c_int64), _np_ptr(co, C.c_int32), _np_ptr(va, C.c_double), int(G), int(R),
-                          _lib.FORCE_FORM[form], C.byref(h)), "wagg_dense_create_from_csr")
+                          _lib.FORCE_FORM[form] | (_lib.DENSE_GENERAL_SORT if general_sort else 0), C.byref(h)),
+                       "wagg_dense_create_from_csr")
         keep = keep_recipe if keep_recipe is not None else rp.nbytes + co.nbytes + va.nbytes <= cls._RECIPE_KEEP_BYTES
-        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype, form=form)) if keep else None)
+        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype, form=form, general_sort=general_sort)) if keep else None)
 
     def replica(self, device):
         """The same weights as a plan of its own on ``device`` (multi-device host streaming; a dense-family plan

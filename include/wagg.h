@@ -312,6 +312,10 @@ int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense
 #define WAGG_DENSE_FORCE_FULL 1
 #define WAGG_DENSE_FORCE_TILES 2
 #define WAGG_DENSE_FORCE_ENTRIES 3
+/* ... or-ed with WAGG_DENSE_GENERAL_SORT: sort the table with the general radix sort even when it is a CSR table with
+ * ascending columns, which the builder otherwise puts in order with one stable pass per chunk of 128 cells (the plans
+ * are bit-identical; for tests and timings) */
+#define WAGG_DENSE_GENERAL_SORT 16
 int wagg_dense_create_from_segments(const int32_t *cell_idx, const int32_t *region_code,
                                     const double *w_eff, int64_t nseg, int64_t G, int32_t R,
                                     int flags, wagg_dense **out);
@@ -362,6 +366,8 @@ typedef struct wagg_dense_info {
                                       row of X in the forms WAGG_FORM_FULL / _TILES / _ENTRIES (else 0) */
     int64_t walked_entries;        /* ... and the entries the entry-list kernel would walk (16 x the longest per-wave list of
                                       every (region block, chunk) item): = nnz for evenly spread weights */
+    int32_t one_pass_sort, reserved0; /* 1 = the table was put in key order by the one-pass chunk partition (CSR, ascending
+                                      columns, nothing dropped), 0 = by the general radix sort */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
 int wagg_dense_destroy(wagg_dense *d);

@@ -256,6 +256,77 @@ def test_radix_sort_keeps_table_order_among_equal_keys(torch_cuda):
     np.testing.assert_array_equal(outs[0][1][:, [0, 299]], outs[1][1][:, [0, 299]])
 
 
+def _csr_table(rng, G, R, fill, dup=0.0, sort_cols=True, dense_chunks=()):
+    """rows = cells; `dup` of the entries are repeated right behind themselves with the weight pattern that shows a reordering"""
+    rowptr = [0]; col = []; val = []
+    for g in range(G):
+        k = R if (g // 128) in dense_chunks else rng.binomial(R, fill)
+        c = np.sort(rng.choice(R, k, replace=False)) if k else np.zeros(0, np.int64)
+        if dup and k:
+            c = np.sort(np.concatenate([c, rng.choice(c, max(1, int(dup * k)))]))
+        if not sort_cols and len(c) > 1:
+            c = rng.permutation(c)
+        col.append(c.astype(np.int32))
+        rowptr.append(rowptr[-1] + len(c))
+    col = np.concatenate(col) if col else np.zeros(0, np.int32)
+    val = rng.uniform(0.5, 1.5, len(col)) * np.tile(np.array([1e16, 1.0, -1e16, 1.0]), len(col) // 4 + 1)[:len(col)] if dup else rng.uniform(0.1, 1.0, len(col))
+    return np.asarray(rowptr, np.int64), col, np.asarray(val, np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["plain", "duplicates", "unsorted columns", "a dropped row", "one chunk holds the table", "many region blocks"])
+def test_one_pass_chunk_sort_gives_the_general_sort_plan(torch_cuda, case):
+    """A CSR table with ascending columns is put in the plan's order by ONE stable pass per chunk of 128 cells
+    (csrc/wagg_build.hip, chunk_scatter_kernel) instead of five radix passes.  Same plan, bit for bit -- denominators and
+    results of all three forms in both types -- as with WAGG_DENSE_GENERAL_SORT, duplicates added in table order (S5,
+    aggregations.py:78); tables the pass does not take (columns out of order, a dropped row, a chunk that holds most of
+    the table, more than 64 region blocks) go through the general sort by themselves.  Each also against the oracle."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(5 + len(case))
+    G, R, fill, kw, one_pass = 5000, 700, 0.03, {}, 1
+    if case == "duplicates": kw = dict(dup=0.2)
+    if case == "unsorted columns": kw, one_pass = dict(sort_cols=False), 0
+    if case == "one chunk holds the table": G, R, fill, kw, one_pass = 1300, 5000, 0.001, dict(dense_chunks=(3,)), 0
+    if case == "many region blocks": G, R, fill, one_pass = 600, 50000, 0.02, 0
+    rowptr, col, val = _csr_table(rng, G, R, fill, **kw)
+    if case == "a dropped row":
+        val[len(val) // 2] = np.nan
+        one_pass = 0
+    cell = np.repeat(np.arange(G, dtype=np.int32), np.diff(rowptr))
+    T = 37
+    X = rng.normal(280.0, 20.0, (T, G))
+    X[3, 17] = np.nan
+    keep = ~np.isnan(val)
+    want = O.agg_coded(X, cell[keep], col[keep], val[keep], R)
+    for dtype, rtol in (("float32", RTOL32), ("float64", RTOL64)):
+        Xd = torch.from_numpy(X.astype(dtype)).cuda()
+        for form in ("full", "tiles", "entries"):
+            a = DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype, form=form)
+            b = DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype, form=form, general_sort=True)
+            assert a.info["one_pass_sort"] == one_pass and b.info["one_pass_sort"] == 0, (case, a.info["one_pass_sort"])
+            assert a.info["nnz"] == b.info["nnz"]
+            np.testing.assert_array_equal(a.den, b.den)
+            ga, gb = a.apply(Xd).cpu().numpy(), b.apply(Xd).cpu().numpy()
+            np.testing.assert_array_equal(ga, gb)
+            if case != "duplicates":                    # (those weights cancel to 1 part in 1e16: the sums are the test)
+                _rel_ok(ga, want, rtol)
+            a.close(); b.close()
+    if case == "duplicates":
+        # row t of X picks out one cell: its row of W x den must be the pair sums added in table order
+        a = DensePlan.from_csr(rowptr, col, val, G, R, dtype="float64", form="full")
+        for g in (0, 129, G - 1):
+            e = np.zeros((1, G)); e[0, g] = 1.0
+            got = a.apply(torch.from_numpy(e).cuda()).cpu().numpy()[0] * a.den
+            lo, hi = rowptr[g], rowptr[g + 1]
+            exp = np.zeros(R)
+            for c_, v_ in zip(col[lo:hi], val[lo:hi]):
+                exp[c_] += v_                           # (numpy float64 adds in this order)
+            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+        a.close()
+
+
 def test_plan_build_beside_applies_on_another_stream(torch_cuda):
     """A table is built into a plan (its own stream, its own arena: csrc/wagg_build.h) on one thread while another thread
     keeps applying a different plan on a stream of its own: both come out right, and the build finishes although the other
