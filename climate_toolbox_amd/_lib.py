@@ -30,7 +30,7 @@ EXPORTS = (
     "wagg_transform_poly_f32", "wagg_transform_poly_f64", "wagg_transform_edd_f32", "wagg_transform_edd_f64",
     "wagg_any_less_f32", "wagg_any_less_f64",
     "wagg_dense_create_synth", "wagg_dense_create_host", "wagg_dense_create_from_segments", "wagg_dense_create_synth_blocklocal", "wagg_dense_create_synth_sparse", "wagg_dense_get_info",
-    "wagg_dense_destroy", "wagg_dense_get_den", "wagg_dense_apply_f32", "wagg_dense_apply_poly_f32",
+    "wagg_dense_destroy", "wagg_dense_clone", "wagg_release_scratch", "wagg_scratch_bytes", "wagg_dense_get_den", "wagg_dense_apply_f32", "wagg_dense_apply_poly_f32",
     "wagg_dense_apply_edd_f32", "wagg_dense_saw_inf",
     "wagg_dense_create_synth_f64", "wagg_dense_create_host_f64", "wagg_dense_create_from_segments_f64",
     "wagg_dense_create_synth_blocklocal_f64", "wagg_dense_apply_f64", "wagg_dense_apply_poly_f64", "wagg_dense_apply_edd_f64",
@@ -163,6 +163,10 @@ def load():
     L.wagg_dense_create_synth_sparse.argtypes = [C.c_int64, C.c_int32, C.c_uint32, C.c_double, C.POINTER(vp)]
     L.wagg_dense_get_info.argtypes = [vp, C.POINTER(DenseInfo)]
     L.wagg_dense_destroy.argtypes = [vp]
+    L.wagg_dense_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.wagg_release_scratch.argtypes = []
+    L.wagg_scratch_bytes.argtypes = []
+    L.wagg_scratch_bytes.restype = C.c_int64
     L.wagg_dense_get_den.argtypes = [vp, f64p]
     L.wagg_dense_apply_f32.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, C.c_int64, C.c_int, vp]
     L.wagg_dense_apply_poly_f32.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, vp, C.c_int64, C.c_int, vp]

@@ -24,7 +24,7 @@ from collections import OrderedDict
 import numpy as np
 import pandas as pd
 
-from . import engine as _engine, minixr
+from . import _lib as _libmod, engine as _engine, minixr
 from ._lib import FORM_ENTRIES, WaggError
 from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
 
@@ -504,8 +504,9 @@ def _device_results_wanted():
 
 def clear_caches():
     """Give back what the module keeps between calls: cached plans that no call is using (device memory), the table memos,
-    the coded tables of the CSV route and the FREE blocks of the page-locked result pool (blocks behind results the caller
-    still holds return to the pool when those are dropped, and go with the next call of this function)."""
+    the coded tables of the CSV route, the FREE blocks of the page-locked result pool (blocks behind results the caller
+    still holds return to the pool when those are dropped, and go with the next call of this function) and the device
+    scratch the library keeps from one plan build to the next (``wagg_release_scratch``)."""
     with _CACHE_LOCK:
         for key in list(_PLAN_CACHE):
             plan = _PLAN_CACHE[key]
@@ -524,6 +525,8 @@ def clear_caches():
             _PINNED_POOL["bytes"] -= size * len(blocks)
             blocks.clear()
         _PINNED_POOL["lru"].clear()
+    if _libmod._lib is not None:
+        _libmod._lib.wagg_release_scratch()
 
 
 def _is_device_tensor(values):
@@ -796,7 +799,6 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
         # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
         # form: go to the dense-family form directly instead of building the sparse plan first just to
         # read its statistics
-        keep = bool(_host_devices())               # replicas on other devices are rebuilt from the table: keep it only then
 
         def dense_plan():
             # a build that runs out of device memory after all (another process took it meanwhile; the estimate was short)
@@ -805,7 +807,7 @@ def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", 
                 return None
             for attempt in (0, 1):
                 try:
-                    return DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt, keep_recipe=keep)
+                    return DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
                 except WaggError as e:
                     if getattr(e, "code", None) != _ENOMEM:
                         raise

@@ -172,6 +172,8 @@ inline hipError_t staged_d2h(void *dst_host, const void *src_dev, size_t bytes, 
 }
 void clear_error();
 
+void release_build_scratch();          // wagg_build.hip: frees the arena and stream kept between plan builds
+
 template <typename T>
 struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime)
     T *p = nullptr;
@@ -183,7 +185,13 @@ struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime
     hipError_t alloc(size_t count) {
         if (p) { (void)hipFree(p); p = nullptr; }
         n = count;
-        return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipErrorOutOfMemory) {          // the arena a plan build left for the next one (wagg_build.hip) goes first
+            (void)hipGetLastError();
+            release_build_scratch();
+            e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+        }
+        return e;
     }
     hipError_t upload(const std::vector<T> &h, hipStream_t st = nullptr) {
         hipError_t e = alloc(h.size());

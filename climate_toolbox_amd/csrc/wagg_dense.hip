@@ -1126,6 +1126,68 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     return WAGG_OK;
 }
 
+namespace wagg {
+template <typename E>
+static hipError_t clone_buf(DevBuf<E> &dst, int dst_dev, const DevBuf<E> &src, int src_dev) {
+    if (!src.p) return hipSuccess;
+    hipError_t e = dst.alloc(src.n);
+    if (e == hipSuccess && src.n) e = hipMemcpyPeer(dst.p, dst_dev, src.p, src_dev, src.n * sizeof(E));
+    return e;
+}
+}  // namespace wagg
+
+extern "C" int wagg_dense_clone(const wagg_dense *src, int device, wagg_dense **out) {
+    using namespace wagg;
+    clear_error();
+    WAGG_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    WAGG_REQUIRE(src != nullptr, "dense plan is NULL");
+    int n_dev = 0, cur = 0;
+    WAGG_HIP(hipGetDeviceCount(&n_dev));
+    WAGG_REQUIRE(device >= 0 && device < n_dev, "no device %d (%d visible)", device, n_dev);
+    WAGG_HIP(hipGetDevice(&cur));
+    wagg_dense *d = new (std::nothrow) wagg_dense();
+    if (!d) { set_error("host allocation failed"); return WAGG_ENOMEM; }
+    hipError_t e = hipSetDevice(device);
+    try {
+        d->G = src->G; d->R = src->R; d->n_kt = src->n_kt; d->n_nt = src->n_nt; d->f64 = src->f64;
+        d->tiled = src->tiled; d->n_tiles = src->n_tiles; d->spmm = src->spmm;
+        d->sp.rw = src->sp.rw; d->sp.n_rb = src->sp.n_rb; d->sp.n_chunks = src->sp.n_chunks;
+        d->sp.nnz = src->sp.nnz; d->sp.n_groups = src->sp.n_groups;
+        d->nnz_table = src->nnz_table; d->walked_entries = src->walked_entries; d->one_pass_sort = src->one_pass_sort;
+        for (int k = 0; k < 3; ++k) d->est_row_s[k] = src->est_row_s[k];
+        d->den_host = src->den_host;
+        d->nt_first = src->nt_first;
+        d->device = device;
+        const double t0 = wall_s();
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&d->ncu, hipDeviceAttributeMultiprocessorCount, device);
+        if (e == hipSuccess) e = d->nonfinite.alloc(1);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&d->inf_host, 2 * sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) { d->inf_host[0] = d->inf_host[1] = 0; e = hipHostGetDevicePointer((void **)&d->inf_dev, d->inf_host, 0); }
+        if (e == hipSuccess) e = clone_buf(d->W, device, src->W, src->device);
+        if (e == hipSuccess) e = clone_buf(d->den32, device, src->den32, src->device);
+        if (e == hipSuccess) e = clone_buf(d->den64, device, src->den64, src->device);
+        if (e == hipSuccess) e = clone_buf(d->tile_kt, device, src->tile_kt, src->device);
+        if (e == hipSuccess) e = clone_buf(d->sp.ent, device, src->sp.ent, src->device);
+        if (e == hipSuccess) e = clone_buf(d->sp.grp_off, device, src->sp.grp_off, src->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);   // (the copies are complete before anyone applies the clone)
+        d->build.total_s = d->build.device_s = wall_s() - t0;
+    } catch (const std::bad_alloc &) {
+        (void)hipSetDevice(cur);
+        delete d;
+        set_error("host allocation failed");
+        return WAGG_ENOMEM;
+    }
+    const hipError_t back = hipSetDevice(cur);
+    if (e != hipSuccess || back != hipSuccess) {
+        set_error("clone of a dense plan onto device %d: %s", device, hipGetErrorString(e != hipSuccess ? e : back));
+        delete d;
+        return e == hipErrorOutOfMemory ? WAGG_ENOMEM : WAGG_EHIP;
+    }
+    *out = d;
+    return WAGG_OK;
+}
+
 extern "C" int wagg_dense_destroy(wagg_dense *d) {
     delete d;
     return WAGG_OK;

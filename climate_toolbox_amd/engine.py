@@ -228,7 +228,7 @@ class DensePlan:
     def __init__(self, handle, G, R, device=None, recipe=None):
         self._h, self.G, self.R = handle, int(G), int(R)
         self.device = _current_device() if device is None else int(device)
-        self._recipe = recipe                # (constructor, args, kwargs): what a replica on another device is built from
+        self._recipe = recipe                # synthetic plans: (constructor, args, kwargs) a replica is generated from
         self._lease = threading.Lock()
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
@@ -283,16 +283,10 @@ class DensePlan:
                 W = np.ascontiguousarray(W, dtype=np.float32)
                 _lib.check(_lib.load().wagg_dense_create_host(_np_ptr(W, C.c_float), W.shape[0], W.shape[1], C.byref(h)),
                            "wagg_dense_create_host")
-        return cls(h, W.shape[0], W.shape[1], dev, (cls.from_host, (W,), {}))
-
-    # A plan built from a caller's table can be rebuilt on another device (``replica``) only from that table.  Holding on
-    # to the arrays pins the caller's memory -- 3 GB for a configs[4]-sized table -- to the lifetime of every cached plan,
-    # so they are kept only on request (``keep_recipe=True``: the drop-in asks for it when HOST_DEVICES opts into replicas)
-    # or when they are small.
-    _RECIPE_KEEP_BYTES = 64 << 20
+        return cls(h, W.shape[0], W.shape[1], dev)
 
     @classmethod
-    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32", device=None, form=None, keep_recipe=None):
+    def from_segments(cls, cell_idx, region_code, w_eff, G, R, dtype="float32", device=None, form=None):
         """From the coded segment table (COO rows; ``wagg_dense_create_from_segments*``).  ``form``: None / "auto" lets the
         library choose (the caller never needs to know the form, like the reference's single weights type,
         aggregations.py:64-73); "full" / "tiles" / "entries" pin it (measurements, tests).  At most 2**31 - 1 rows."""
@@ -307,11 +301,10 @@ class DensePlan:
             dev = _current_device()
             _lib.check(fn(_np_ptr(ci, C.c_int32), _np_ptr(rc, C.c_int32), _np_ptr(we, C.c_double), len(ci), int(G),
                           int(R), _lib.FORCE_FORM[form], C.byref(h)), "wagg_dense_create_from_segments")
-        keep = keep_recipe if keep_recipe is not None else ci.nbytes + rc.nbytes + we.nbytes <= cls._RECIPE_KEEP_BYTES
-        return cls(h, G, R, dev, (cls.from_segments, (ci, rc, we, G, R), dict(dtype=dtype, form=form)) if keep else None)
+        return cls(h, G, R, dev)
 
     @classmethod
-    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None, form=None, keep_recipe=None, general_sort=False):
+    def from_csr(cls, rowptr, col, val, G, R, dtype="float32", device=None, form=None, general_sort=False):
         """From a caller's table in CSR form (``wagg_dense_create_from_csr*``; BASELINE configs[4] "sparse CSR weights"):
         ``rowptr`` (G + 1 offsets, rows = grid cells), ``col`` = region codes, ``val`` = fp64 weights -- the coded form of
         the reference's weights table (aggregations.py:64-73).  The arrays are uploaded as they are (no host copy when
@@ -334,19 +327,21 @@ class DensePlan:
             _lib.check(fn(_np_ptr(rp, C.c_int64), _np_ptr(co, C.c_int32), _np_ptr(va, C.c_double), int(G), int(R),
                           _lib.FORCE_FORM[form] | (_lib.DENSE_GENERAL_SORT if general_sort else 0), C.byref(h)),
                        "wagg_dense_create_from_csr")
-        keep = keep_recipe if keep_recipe is not None else rp.nbytes + co.nbytes + va.nbytes <= cls._RECIPE_KEEP_BYTES
-        return cls(h, G, R, dev, (cls.from_csr, (rp, co, va, G, R), dict(dtype=dtype, form=form, general_sort=general_sort)) if keep else None)
+        return cls(h, G, R, dev)
 
     def replica(self, device):
         """The same weights as a plan of its own on ``device`` (multi-device host streaming; a dense-family plan
-        owns its workspaces, so every pipeline needs its own replica -- also two on one device)."""
-        if self._recipe is None:
-            raise WaggError("this plan was built from a large caller's table that it did not keep (keep_recipe=False): "
-                            "build the replica from the table yourself, DensePlan.from_csr(..., device=%r)" % (device,))
-        fn, args, kw = self._recipe
-        if "keep_recipe" in fn.__code__.co_varnames:
-            kw = dict(kw, keep_recipe=True)
-        return fn(*args, device=device, **kw)
+        owns its workspaces, so every pipeline needs its own replica -- also two on one device).  Plans built from a
+        table or a host matrix are cloned device to device (``wagg_dense_clone``: the packed plan travels, over xGMI
+        between two GPUs -- nothing is uploaded or sorted again and no copy of the caller's arrays is kept for it);
+        the synthetic generators run again on the target (a 101 GB operand is quicker made than moved)."""
+        if self._recipe is not None:
+            fn, args, kw = self._recipe
+            return fn(*args, device=device, **kw)
+        require_gpu()
+        h = C.c_void_p()
+        _lib.check(_lib.load().wagg_dense_clone(self._h, int(device), C.byref(h)), "wagg_dense_clone")
+        return type(self)(h, self.G, self.R, int(device))
 
     def close(self):
         for r in getattr(self, "_replicas", {}).values():

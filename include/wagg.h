@@ -370,6 +370,18 @@ typedef struct wagg_dense_info {
                                       columns, nothing dropped), 0 = by the general radix sort */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
+/* Plan builds from a caller's table keep their device scratch (one arena per device, at most 1/16 of the device's memory:
+ * 11 GB after a 2.5e8-row table) and stream for the next build -- giving 11 GB back to the driver and asking again costs
+ * a wait of seconds every dozen builds.  This frees it (the package's clear_caches() calls it); an allocation of the
+ * library that runs out of device memory does so by itself before it tries once more. */
+int wagg_release_scratch(void);
+int64_t wagg_scratch_bytes(void);  /* device bytes kept right now, all devices */
+/* A second plan with the same weights on `device` (may be the device `src` lives on): the finished plan's device arrays --
+ * packed W with its tile tables, or the entry lists, and the denominators -- are copied device to device (hipMemcpyPeer:
+ * xGMI between two GPUs), nothing is uploaded or sorted again and no host copy of the caller's table is needed.  The
+ * clone owns its workspaces, so the two plans apply independently (wagg_apply_host_multi_* wants one plan per pipeline).
+ * `src` is only read: applies on it may be in flight.  The calling thread's current device is left as it was. */
+int wagg_dense_clone(const wagg_dense *src, int device, wagg_dense **out);
 int wagg_dense_destroy(wagg_dense *d);
 int wagg_dense_get_den(const wagg_dense *d, double *den_host /* R values */);
 /* out[t, r] = sum_g nan0(X[t,g]) * W[g,r] / den[r], fp32 MFMA (v_mfma_f32_16x16x4_f32).

@@ -150,7 +150,7 @@ def test_default_form_is_within_10_percent_of_the_fastest_forced_form(torch_cuda
 
     times = {}
     for form in (None, "full", "tiles", "entries"):
-        plan = DensePlan.from_csr(rowptr, col, val, G, R, form=form, keep_recipe=False)
+        plan = DensePlan.from_csr(rowptr, col, val, G, R, form=form)
         ms, got = timed(plan)
         _rel_ok(got, ref, RTOL32)
         times[form or "auto"] = ms
@@ -271,6 +271,78 @@ def _csr_table(rng, G, R, fill, dup=0.0, sort_cols=True, dense_chunks=()):
     col = np.concatenate(col) if col else np.zeros(0, np.int32)
     val = rng.uniform(0.5, 1.5, len(col)) * np.tile(np.array([1e16, 1.0, -1e16, 1.0]), len(col) // 4 + 1)[:len(col)] if dup else rng.uniform(0.1, 1.0, len(col))
     return np.asarray(rowptr, np.int64), col, np.asarray(val, np.float64)
+
+
+@pytest.mark.gpu
+def test_build_scratch_stays_for_the_next_build_and_goes_on_request(torch_cuda):
+    """The device arena of a table -> plan build is kept for the next build (returning 11 GB to the driver and asking
+    again costs a wait of seconds every dozen c5 builds: csrc/wagg_build.hip, tools/diag/malloc_stall.cpp) and freed by
+    `clear_caches()` / `wagg_release_scratch`: kept after a build and its plan are gone, the same arena after a second
+    build (reused, not added to), a larger one after a larger table, nothing after the release -- and the plans do not
+    depend on whether their build found an arena waiting."""
+    from climate_toolbox_amd import _lib, clear_caches
+    from climate_toolbox_amd.engine import DensePlan
+    L = _lib.load()
+    clear_caches()
+    assert L.wagg_scratch_bytes() == 0
+    rng = np.random.default_rng(3)
+    G, R = 20000, 2000
+    n = 3_000_000
+    cell = rng.integers(0, G, 2 * n).astype(np.int32)
+    code = rng.integers(0, R, 2 * n).astype(np.int32)
+    w = rng.uniform(0.1, 1.0, 2 * n)
+    den, kept = [], []
+    for rows in (n, n, 2 * n, n):
+        p = DensePlan.from_segments(cell[:rows], code[:rows], w[:rows], G, R, form="entries")
+        den.append(p.den.copy())
+        p.close()
+        kept.append(L.wagg_scratch_bytes())
+    assert kept[0] >= 48 * n and kept[1] == kept[0], kept          # 48 bytes of arena per table row (DESIGN (d))
+    assert kept[2] >= 96 * n and kept[3] == kept[2], kept          # the larger arena replaced the smaller one, and stays
+    np.testing.assert_array_equal(den[0], den[1])
+    np.testing.assert_array_equal(den[0], den[3])
+    clear_caches()
+    assert L.wagg_scratch_bytes() == 0
+
+
+@pytest.mark.gpu
+def test_replica_of_a_table_plan_is_a_device_copy(torch_cuda):
+    """`DensePlan.replica` of a plan built from a caller's table (or host matrix) clones the finished plan device to device
+    (`wagg_dense_clone`): no host copy of the table is kept for it, nothing is sorted again.  The clone is its own plan:
+    same denominators and info, bit-equal results in all three forms and both types, also after the original is gone,
+    and the two serve as the two pipelines of a host-resident apply."""
+    from climate_toolbox_amd import _lib
+    from climate_toolbox_amd.engine import DensePlan
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    G, R, T = 5000, 700, 150
+    rowptr, col, val = _csr_table(rng, G, R, 0.03)
+    X = rng.normal(280.0, 20.0, (T, G))
+    for dtype in ("float32", "float64"):
+        Xd = torch.from_numpy(X.astype(dtype)).cuda()
+        for form in ("full", "tiles", "entries"):
+            a = DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype, form=form)
+            assert a._recipe is None                     # (nothing of the caller's arrays is held)
+            b = a.replica(0)
+            assert b.info["form"] == a.info["form"] and b.info["nnz"] == a.info["nnz"] and b.dtype == a.dtype
+            np.testing.assert_array_equal(a.den, b.den)
+            want = a.apply(Xd).cpu().numpy()
+            np.testing.assert_array_equal(b.apply(Xd).cpu().numpy(), want)
+            Xh = np.ascontiguousarray(X.astype(dtype))
+            # (two pipelines deal the row blocks differently from one: other k slices, hence rounding, not bits)
+            np.testing.assert_allclose(a.apply_host(Xh, flags=_lib.HOST_PIN, replicas=[b]), a.apply_host(Xh, flags=_lib.HOST_PIN),
+                                       rtol=2e-6 if dtype == "float32" else 1e-12)
+            a.close()
+            np.testing.assert_array_equal(b.apply(Xd).cpu().numpy(), want)
+            b.close()
+    W = rng.uniform(0.0, 1.0, (300, 520)).astype(np.float32)
+    a = DensePlan.from_host(W)
+    b = a.replica(0)
+    Xd = torch.from_numpy(rng.normal(0, 1, (40, 300)).astype(np.float32)).cuda()
+    np.testing.assert_array_equal(a.apply(Xd).cpu().numpy(), b.apply(Xd).cpu().numpy())
+    with pytest.raises(Exception, match="no device"):
+        a.replica(99)
+    a.close(); b.close()
 
 
 @pytest.mark.gpu

@@ -94,7 +94,7 @@ def sweep_table(name, param, rowptr, col, val, G, R, X, dtype, forms=FORMS, max_
             continue
         try:
             t0 = time.perf_counter()
-            plan = DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype, form=None if form == "auto" else form, keep_recipe=False)
+            plan = DensePlan.from_csr(rowptr, col, val, G, R, dtype=dtype, form=None if form == "auto" else form)
             tb = time.perf_counter() - t0
         except _lib.WaggError as e:
             rec[form] = "failed: %s" % str(e)[:120]
@@ -187,7 +187,7 @@ def main():
             rec["dropin_wants_dense"] = bool(A._wants_dense(sp.info["n_ucells"], G, "TG", R=Rr, nseg=len(c1), is_f32=a.dtype == "float32"))
             sp.close()
             for form in ("auto", "tiles", "entries"):
-                dp = DensePlan.from_segments(c1, c2, w2, G, Rr, dtype=a.dtype, form=None if form == "auto" else form, keep_recipe=False)
+                dp = DensePlan.from_segments(c1, c2, w2, G, Rr, dtype=a.dtype, form=None if form == "auto" else form)
                 med, mn, out = time_apply(dp, X2)
                 got = out[:4].cpu().numpy()
                 rec["dense_" + form] = {"ms": round(med, 4), "min_ms": round(mn, 4), "form": FORM_NAME[dp.info["form"]],

@@ -36,7 +36,7 @@ for bl in (False, True):
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()
-            p = DensePlan.from_csr(*tables[bl], G, R, dtype=dt, keep_recipe=False)
+            p = DensePlan.from_csr(*tables[bl], G, R, dtype=dt)
             ts.append((time.perf_counter() - t0, p.info["build_s"], p.info["build_upload_s"], p.info["form"]))
             p.close()
         best = min(ts)
@@ -81,7 +81,7 @@ time.sleep(0.3)
 builds = []
 for _ in range(3):
     t0 = time.perf_counter()
-    p = DensePlan.from_csr(*tables[False], G, R, keep_recipe=False)
+    p = DensePlan.from_csr(*tables[False], G, R)
     builds.append(round(time.perf_counter() - t0, 4))
     p.close()
     time.sleep(0.1)
