@@ -46,13 +46,12 @@ struct BuildTimes { double upload_s = 0, device_s = 0, total_s = 0; };
 //     every scan and sort pass -- each one a stop for every stream of the process.)  The host waits exactly where it reads
 //     something back (hipStreamSynchronize on this stream): the dropped-row note, the number of distinct pairs, the tile
 //     bitmap, the list lengths.
-//   * The arena is sized from the table (build_arena_bytes) and allocated once -- or taken over from the build before (one
-//     arena and stream per device stay with the process, see BuildCtx::init); scratch is taken from it with stack
+//   * The arena is sized from the table (build_arena_bytes) and taken once, from the scratch pool (wagg_scratch.hip: the
+//     arena and stream of the build before, when it fits); scratch is taken from it with stack
 //     discipline (mark / release_to).  Reuse is safe without any wait because every kernel of the build runs on the one
 //     stream, in order.  Per-pass hipMalloc / hipFree pairs are gone: hipFree waits for the whole device.
 struct BuildCtx {
     hipStream_t st = nullptr;
-    int device = 0;
     char *base = nullptr;
     size_t cap = 0, top = 0, high = 0, peak = 0;      // scratch grows up from 0 to `top`; inputs sit at the far end, from `high` to `cap`
     BuildCtx() = default;

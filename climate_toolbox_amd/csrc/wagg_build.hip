@@ -18,67 +18,16 @@
 
 namespace wagg {
 
-// ---- the arena and the stream of the last build stay with the process -------------------------------------------------
-// A build of a configs[4]-sized table takes an 11 GB arena.  Handing that back with hipFree and asking for it again on the
-// next build is what the driver punishes: freed VRAM is reclaimed lazily, and once ~128 GB of it have gone through
-// hipMalloc / hipFree the next hipMalloc waits for the reclaim -- 0.7 to 4 s, measured on every twelfth c5 build
-// (tools/diag/malloc_stall.cpp shows it with nothing but hipMalloc / hipFree; the same policy is why torch caches its blocks).
-// So one arena (and its stream: create + destroy are 2.5 ms) per device is kept between builds: a build takes it when it
-// is large enough, gives back whichever of (its own, the kept one) is larger, and frees the other.  Arenas above 1/16 of
-// the device's memory are never kept; wagg_release_scratch() (the package's clear_caches()) frees what is kept, and so
-// does any allocation of the library that runs out of device memory, before it tries once more (DevBuf::alloc).
-namespace {
-struct KeptArena { int device; hipStream_t st; char *base; size_t cap; };
-std::mutex g_arena_mu;
-std::vector<KeptArena> g_arenas;                 // at most one per device
-
-size_t keep_limit_bytes(int device) {
-    size_t total = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) total = prop.totalGlobalMem;
-    return total / 16;
-}
-}  // namespace
-
-void release_build_scratch() {
-    std::vector<KeptArena> gone;
-    {
-        std::lock_guard<std::mutex> lock(g_arena_mu);
-        gone.swap(g_arenas);
-    }
-    for (const KeptArena &a : gone) {
-        note_cleanup(hipFree(a.base), "hipFree(kept build arena)");
-        note_cleanup(hipStreamDestroy(a.st), "hipStreamDestroy(kept build stream)");
-    }
-}
-
+// The arena and the stream come from the scratch pool (wagg_scratch.hip): a build of a configs[4]-sized table takes 11 GB,
+// and handing that back to the driver after every build made every twelfth build wait seconds in hipMalloc.
 hipError_t BuildCtx::init(size_t arena_bytes) {
-    size_t want = (arena_bytes + 255) / 256 * 256;
-    if (want == 0) want = 256;
-    hipError_t e = hipGetDevice(&device);
-    if (e != hipSuccess) return e;
+    cap = (arena_bytes + 255) / 256 * 256;
+    if (cap == 0) cap = 256;
     top = peak = 0;
-    {
-        std::lock_guard<std::mutex> lock(g_arena_mu);
-        for (size_t i = 0; i < g_arenas.size(); ++i) {
-            if (g_arenas[i].device != device || g_arenas[i].cap < want) continue;
-            st = g_arenas[i].st; base = g_arenas[i].base; cap = g_arenas[i].cap;      // (idle: its last build synchronised it)
-            g_arenas.erase(g_arenas.begin() + (long)i);
-            high = cap;
-            return hipSuccess;
-        }
-    }
-    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    if (e != hipSuccess) return e;
-    cap = want;
     high = cap;
-    e = hipMalloc((void **)&base, cap);
-    if (e == hipErrorOutOfMemory) {              // what is kept for later builds must not be what this one lacks
-        (void)hipGetLastError();
-        release_build_scratch();
-        e = hipMalloc((void **)&base, cap);
-    }
-    return e;
+    hipError_t e = scratch_stream(&st);
+    if (e != hipSuccess) return e;
+    return scratch_alloc(reinterpret_cast<void **>(&base), cap);
 }
 
 void *BuildCtx::take_bytes(size_t bytes) {
@@ -101,25 +50,8 @@ void *BuildCtx::take_input_bytes(size_t bytes) {
 BuildCtx::~BuildCtx() {
     // nothing of the build may still be running on the arena (error paths return without having waited)
     if (st) note_cleanup(hipStreamSynchronize(st), "hipStreamSynchronize(build stream)");
-    KeptArena mine{device, st, base, cap}, drop{-1, nullptr, nullptr, 0};
-    bool keep = st && base && cap <= keep_limit_bytes(device);
-    if (keep) {
-        std::lock_guard<std::mutex> lock(g_arena_mu);
-        size_t at = g_arenas.size();
-        for (size_t i = 0; i < g_arenas.size(); ++i)
-            if (g_arenas[i].device == device) at = i;
-        if (at == g_arenas.size()) {
-            try { g_arenas.push_back(mine); } catch (const std::bad_alloc &) { keep = false; }
-        } else if (g_arenas[at].cap < cap) {
-            drop = g_arenas[at];
-            g_arenas[at] = mine;
-        } else {
-            keep = false;
-        }
-    }
-    if (!keep) drop = mine;
-    if (drop.base) note_cleanup(hipFree(drop.base), "hipFree(build arena)");
-    if (drop.st) note_cleanup(hipStreamDestroy(drop.st), "hipStreamDestroy(build stream)");
+    scratch_free(base);
+    scratch_stream_done(st);
 }
 
 constexpr int RS_TILE_ = 512 * 16;
@@ -720,19 +652,6 @@ __global__ void widen_rowptr_kernel(const uint32_t *__restrict__ first, int64_t 
 }  // namespace wagg
 
 using namespace wagg;
-
-extern "C" int64_t wagg_scratch_bytes(void) {
-    std::lock_guard<std::mutex> lock(g_arena_mu);
-    int64_t total = 0;
-    for (const auto &a : g_arenas) total += (int64_t)a.cap;
-    return total;
-}
-
-extern "C" int wagg_release_scratch(void) {
-    clear_error();
-    release_build_scratch();
-    return WAGG_OK;
-}
 
 extern "C" int wagg_synth_table_csr(int64_t G, int32_t R, uint32_t seed, double fill, int blocklocal, int64_t *rowptr_host,
                                     int32_t *col_host, double *val_host, int64_t capacity, int64_t *nnz_out) {

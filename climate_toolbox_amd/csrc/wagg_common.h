@@ -172,7 +172,25 @@ inline hipError_t staged_d2h(void *dst_host, const void *src_dev, size_t bytes, 
 }
 void clear_error();
 
-void release_build_scratch();          // wagg_build.hip: frees the arena and stream kept between plan builds
+// wagg_scratch.hip: device blocks and streams needed for the length of one call come from (and return to) a small pool --
+// see there for why hipMalloc / hipFree per call is not an option.  A block / stream is returned only when nothing on the
+// device can still be using it.
+hipError_t scratch_alloc(void **p, size_t bytes);        // on the current device
+void scratch_free(void *p, bool keep = true);             // keep = false: hipFree now (with its implicit wait for the device)
+hipError_t scratch_stream(hipStream_t *st);              // an idle non-blocking stream of the current device
+void scratch_stream_done(hipStream_t st);
+void release_scratch();                                  // everything kept goes back to the driver
+template <typename T>
+struct ScratchBuf {                                      // RAII over scratch_alloc (call-lifetime buffers)
+    T *p = nullptr;
+    ScratchBuf() = default;
+    ScratchBuf(const ScratchBuf &) = delete;
+    ScratchBuf &operator=(const ScratchBuf &) = delete;
+    hipError_t alloc(size_t count) { return scratch_alloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)); }
+    // (the block may reach its next taker at once, so whatever was queued on it -- also on an error path that returned
+    //  without waiting -- is drained first; hipFree used to do that implicitly)
+    ~ScratchBuf() { if (p) { (void)hipDeviceSynchronize(); scratch_free(p); } }
+};
 
 template <typename T>
 struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime)
@@ -186,9 +204,9 @@ struct DevBuf {  // owning device buffer, freed in the destructor (plan lifetime
         if (p) { (void)hipFree(p); p = nullptr; }
         n = count;
         hipError_t e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
-        if (e == hipErrorOutOfMemory) {          // the arena a plan build left for the next one (wagg_build.hip) goes first
+        if (e == hipErrorOutOfMemory) {          // what the scratch pool keeps for later calls (wagg_scratch.hip) goes first
             (void)hipGetLastError();
-            release_build_scratch();
+            release_scratch();
             e = hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
         }
         return e;

@@ -1246,7 +1246,7 @@ static int dense_apply_host(wagg_dense *d, const T *X_host, int64_t Tn, int64_t 
     WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
     if (int rc = check_dense_device(d)) return rc;
     if (flags & WAGG_HOST_WHOLE) {
-        DevBuf<T> dx, dout;
+        ScratchBuf<T> dx, dout;                  // (call-lifetime blocks: from the pool, wagg_scratch.hip; the device is drained below)
         WAGG_HIP(dx.alloc((size_t)(Tn * ldx)));
         WAGG_HIP(dout.alloc((size_t)(Tn * ldo)));
         const bool pin = (flags & WAGG_HOST_PIN) != 0;

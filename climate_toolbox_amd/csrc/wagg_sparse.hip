@@ -2027,7 +2027,7 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     }
     const int64_t xrows = layout == WAGG_LAYOUT_TG ? Tn : plan->info.G;
     const int64_t orows = out_layout == WAGG_OUT_TR ? Tn : plan->info.R;
-    DevBuf<T> dx, dout;
+    ScratchBuf<T> dx, dout;                      // (call-lifetime blocks: from the pool, wagg_scratch.hip; the device is drained below)
     WAGG_HIP(dx.alloc((size_t)(xrows * ldx)));
     WAGG_HIP(dout.alloc((size_t)(orows * ldo)));
     const int64_t xcols = layout == WAGG_LAYOUT_TG ? plan->info.G : Tn, ocols = out_layout == WAGG_OUT_TR ? plan->info.R : Tn;

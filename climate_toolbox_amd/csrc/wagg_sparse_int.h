@@ -74,7 +74,7 @@ struct wagg_plan {
     // without touching the stream); checked by the next apply, wagg_plan_status and the *_host_ forms
     int *timeout_host = nullptr, *timeout_dev = nullptr;
     // Region-major staging buffers of the (time, region) output form, one per stream that has applied
-    // this plan (kept until the plan is destroyed).  A stream-ordered hipMallocAsync / hipFreeAsync pair
+    // this plan (kept until the plan is destroyed; blocks of the scratch pool, wagg_scratch.hip).  A stream-ordered hipMallocAsync / hipFreeAsync pair
     // per apply made every call block for the whole kernel (0.28 ms enqueue against 0.01 ms without).
     struct Staging { hipStream_t stream; void *p; size_t bytes; };
     mutable std::mutex ws_mu;
@@ -85,14 +85,14 @@ struct wagg_plan {
             if (w.stream == st) {
                 if (w.bytes >= bytes) return w.p;
                 if (hipStreamSynchronize(st) != hipSuccess) return nullptr;      // the old buffer may still be in use on this stream
-                if (hipFree(w.p) != hipSuccess) return nullptr;
+                wagg::scratch_free(w.p);
                 w.p = nullptr; w.bytes = 0;
-                if (hipMalloc(&w.p, bytes) != hipSuccess) return nullptr;
+                if (wagg::scratch_alloc(&w.p, bytes) != hipSuccess) return nullptr;
                 w.bytes = bytes;
                 return w.p;
             }
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (wagg::scratch_alloc(&p, bytes) != hipSuccess) return nullptr;
         ws.push_back({st, p, bytes});
         return p;
     }
@@ -102,14 +102,16 @@ struct wagg_plan {
         std::lock_guard<std::mutex> lock(ws_mu);
         for (size_t i = 0; i < ws.size(); ++i)
             if (ws[i].stream == st) {
-                if (ws[i].p) wagg::note_cleanup(hipFree(ws[i].p), "hipFree(staging)");
+                wagg::scratch_free(ws[i].p);         // (the caller has synchronised the stream)
                 ws.erase(ws.begin() + (long)i);
                 return;
             }
     }
     ~wagg_plan() {
         if (timeout_host) wagg::note_cleanup(hipHostFree(timeout_host), "hipHostFree(status word)");
-        for (Staging &w : ws) if (w.p) wagg::note_cleanup(hipFree(w.p), "hipFree(staging)");
+        // (straight back to the driver: hipFree waits for whatever the last apply on that stream left running, which a
+        //  block handed to the pool's next taker would not)
+        for (Staging &w : ws) wagg::scratch_free(w.p, false);
     }
 };
 

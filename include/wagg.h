@@ -370,10 +370,12 @@ typedef struct wagg_dense_info {
                                       columns, nothing dropped), 0 = by the general radix sort */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
-/* Plan builds from a caller's table keep their device scratch (one arena per device, at most 1/16 of the device's memory:
- * 11 GB after a 2.5e8-row table) and stream for the next build -- giving 11 GB back to the driver and asking again costs
- * a wait of seconds every dozen builds.  This frees it (the package's clear_caches() calls it); an allocation of the
- * library that runs out of device memory does so by itself before it tries once more. */
+/* Device blocks and streams the library needs for the length of one call -- the arena of a table -> plan build (11 GB for
+ * a 2.5e8-row table), the block buffers and streams of a host-resident apply, a plan's per-stream staging -- come from a
+ * per-device pool and return to it (csrc/wagg_scratch.hip: giving 11 GB back to the driver and asking again costs a wait
+ * of seconds every dozen builds).  At most 1/16 of a device's memory is kept.  This frees it (the package's
+ * clear_caches() calls it); an allocation of the library that runs out of device memory does so by itself before it
+ * tries once more. */
 int wagg_release_scratch(void);
 int64_t wagg_scratch_bytes(void);  /* device bytes kept right now, all devices */
 /* A second plan with the same weights on `device` (may be the device `src` lives on): the finished plan's device arrays --

@@ -303,6 +303,21 @@ def test_build_scratch_stays_for_the_next_build_and_goes_on_request(torch_cuda):
     np.testing.assert_array_equal(den[0], den[3])
     clear_caches()
     assert L.wagg_scratch_bytes() == 0
+    # the block buffers (and streams) of a host-resident apply come from the same pool: taken and returned, not added to
+    from climate_toolbox_amd.engine import SparsePlan
+    ucell = rng.choice(G, 6000, replace=False).astype(np.int32)
+    sp = SparsePlan(ucell, rng.integers(0, R, 6000).astype(np.int32), rng.uniform(0.1, 1.0, 6000), G, R)
+    X = rng.normal(280.0, 20.0, (500, G)).astype(np.float32)
+    outs, kept = [], []
+    for _ in range(4):
+        outs.append(sp.apply_host(X, flags=_lib.HOST_PIN))
+        kept.append(L.wagg_scratch_bytes())
+    assert kept[0] >= X.nbytes // 4 and kept[1:] == kept[:1] * 3, kept
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+    sp.close()
+    clear_caches()
+    assert L.wagg_scratch_bytes() == 0
 
 
 @pytest.mark.gpu
