@@ -274,6 +274,40 @@ def _csr_table(rng, G, R, fill, dup=0.0, sort_cols=True, dense_chunks=()):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,rtol", [("float32", RTOL32), ("float64", RTOL64)])
+def test_ragged_batches_split_into_full_row_blocks_and_a_remainder(torch_cuda, dtype, rtol):
+    """A batch whose last row block would be mostly padding runs as two launches -- the full row blocks, then the
+    remainder with a smaller row-block count (csrc/wagg_dense.hip, dense_apply) -- here 1,369 rows, the c4 rank share
+    (fp32: 3 x 352 + 313 rows; fp64: 7 x 176 + 137).  The second launch starts `head` rows into X, into the second field
+    of a degree-day pair and into the result: plain, powers and degree days against the oracle in the full and the
+    tile-sparse form, and the plain result bit-equal to the two halves applied by hand."""
+    from climate_toolbox_amd.engine import DensePlan
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    T, G, R = 1369, 64 * 30 + 7, 300
+    np_t = np.dtype(dtype).type
+    Wf = rng.uniform(0, 1, (G, R)).astype(np.float32)
+    Wb = O.blocklocal_weights_oracle(G, R, 5)
+    X = (285 + 12 * rng.standard_normal((T, G))).astype(dtype)
+    X[1200, 4] = np.nan
+    Xhi = X + rng.uniform(0, 9, X.shape).astype(dtype)
+    Xd, Hd = torch.from_numpy(X).cuda(), torch.from_numpy(Xhi).cuda()
+    plans = ((Wf, DensePlan.from_host(Wf.astype(dtype))), (Wb, DensePlan.synth_blocklocal(G, R, 5, dtype=dtype)))
+    for W, plan in plans:
+        got = plan.apply(Xd).cpu().numpy()
+        _rel_ok(got, O.agg_dense(X, W), rtol)
+        _rel_ok(plan.apply_poly(Xd, -273.15, 3).cpu().numpy(), O.agg_dense(O.tas_poly_values(X, 3), W), rtol, scale=1.0)
+        edd = O.snyder_edd_values(X + np_t(-273.15), Xhi + np_t(-273.15), 14.0)
+        _rel_ok(plan.apply_edd(Xd, Hd, 14.0, offset=-273.15).cpu().numpy(), O.agg_dense(edd, W), rtol, scale=0.05)
+        head = 1056 if dtype == "float32" else 1232
+        if plan.info["tiled"] == 0:
+            by_hand = np.concatenate([plan.apply(Xd[:head]).cpu().numpy(), plan.apply(Xd[head:]).cpu().numpy()])
+            np.testing.assert_array_equal(got, by_hand)
+        plan.close()
+
+
+@pytest.mark.gpu
 def test_build_scratch_stays_for_the_next_build_and_goes_on_request(torch_cuda):
     """The device arena of a table -> plan build is kept for the next build (returning 11 GB to the driver and asking
     again costs a wait of seconds every dozen c5 builds: csrc/wagg_build.hip, tools/diag/malloc_stall.cpp) and freed by

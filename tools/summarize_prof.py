@@ -68,11 +68,12 @@ if os.path.exists(tr):
     for r in csv.DictReader(open(tr)):
         dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     rows = []
-    for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share)", "dense_mfma_kernel<float, 0, false, 22, true"),
+    for wl, ksub in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23"), ("c4 (rank share): 3 full row blocks", "dense_mfma_kernel<float, 0, false, 22, true"),
+                     ("c4 (rank share): the remainder (313 rows)", "dense_mfma_kernel<float, 0, false, 20, false"),
                      # (round 4: the default line's host-resident / drop-in / country-level legs launch the c2-real instantiation on row blocks
                      #  and on another table as well: "#big" keeps the full-field launches of the c2-real table)
                      ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
-                     ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block", "dense_pieces_kernel<float"),
+                     ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block: 6 full row blocks", "dense_pieces_kernel<float, 21"), ("c5-block: the remainder (266 rows)", "dense_pieces_kernel<float, 18"),
                      ("c5-block-f64", "dense_pieces_kernel<double"), ("c5-uniform", "spmm_kernel<float>"),
                      ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>"),
                      ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
@@ -82,8 +83,11 @@ if os.path.exists(tr):
                      ("c3-real combine + transpose, one plane", "combine_parts_kernel<double, true>#band:0.035:0.07"),
                      ("c3-real combine + transpose, 3-4 planes (fused transforms)", "combine_parts_kernel<double, true>#big"),
                      # round 4: plans built on the device from the caller's CSR table (c5: 2.5e8 entries; four plans per run)
-                     ("c5 table -> plan: sort keys", "keygen_kernel"), ("c5 table -> plan: radix histogram (per pass)", "rs_hist_kernel"),
-                     ("c5 table -> plan: radix scatter (per pass)", "rs_scatter_kernel"), ("c5 table -> plan: coalesce duplicates", "coalesce_kernel"),
+                     ("c5 table -> plan: sort keys", "keygen_kernel"), ("c5 table -> plan: chunk bounds", "chunk_first_kernel"),
+                     ("c5 table -> plan: one-pass sort, bin counts per chunk", "chunk_hist_kernel"),
+                     ("c5 table -> plan: one-pass sort, stable partition per chunk", "chunk_scatter_kernel"),
+                     ("c5 table -> plan: radix histogram (per pass; the denominators' sort by region, and the general sort)", "rs_hist_kernel"),
+                     ("c5 table -> plan: radix scatter (per pass; as above)", "rs_scatter_kernel"), ("c5 table -> plan: coalesce duplicates", "coalesce_kernel"),
                      ("c5 table -> plan: denominators", "den_kernel"), ("c5 table -> plan: tile census", "table_tiles_kernel"),
                      ("c5 table -> plan: list bounds (binary search per bucket; also the form choice's cost census)", "spmm_bounds_kernel"),
                      ("c5 table -> plan: list cost census", "spmm_cost_kernel"),
@@ -120,13 +124,15 @@ GATHER = ("FETCH_SIZE x1: calibrated on the segment-table gather in round 1 with
 LINES = ("whole-line chunks: every load instruction reads eight whole 128-B lines, i.e. the wide coalesced case: FETCH_SIZE x2 if "
          "the raw figure is about half of the lines' bytes (lines_ucells x 4 B x T for fp32, lines64_ucells x 8 B x T for fp64, in "
          "the bench line's plan), x1 if it matches them: see `calibration`; WRITE_SIZE exact")
-for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true", "wide"),
+for wl, ksub, mode in (("c2-dense", "dense_mfma_kernel<float, 0, false, 23", "wide"), ("c4", "dense_mfma_kernel<float, 0, false, 22, true+dense_mfma_kernel<float, 0, false, 20, false", "wide"),
                        ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big", "lines"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big", "lines64"),
-                       ("c5-block", "dense_pieces_kernel<float", "wide"), ("c5-block-f64", "dense_pieces_kernel<double", "wide"),
+                       ("c5-block", "dense_pieces_kernel<float, 21+dense_pieces_kernel<float, 18", "wide"), ("c5-block-f64", "dense_pieces_kernel<double", "wide"),
                        ("c5-uniform", "spmm_kernel<float>", "wide"), ("c5-uniform-f64", "spmm_kernel<double>", "wide")):
-    fs, ws = mean(ksub, "FETCH_SIZE"), mean(ksub, "WRITE_SIZE")
-    if fs is None or ws is None:
+    # "a+b": an apply that launches its dominant kernel twice (full row blocks, then the remainder): the sum of the two means
+    parts = [(mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")) for k in ksub.split("+")]
+    if any(f is None or w_ is None for f, w_ in parts):
         continue
+    fs, ws = sum(f for f, _ in parts), sum(w_ for _, w_ in parts)
     factor = 1.0 if mode == "gather" else 2.0      # gather64: see below
     entry = {"fetch_size_kib_raw": fs, "write_size_kib_raw": ws, "source": "profiles/%s_pmc.csv" % tag,
              "measured": "round %d" % int(tag.lstrip("r"))}
