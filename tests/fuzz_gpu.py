@@ -108,8 +108,31 @@ def one_case(i, rng):
         form = [None, "full", "tiles", "entries"][int(rng.integers(0, 4))]              # (round 5: the choice goes by estimated
         dp = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype, form=form)       #  time, so small tables mostly take entry
         b = rel_bad(dp.apply(Xd.contiguous()).cpu().numpy(), ref, rtol, 1.0)            #  lists by themselves: pin the others)
-        if b: fails.append("dense(%s, asked %s): %s" % (["full", "tiled", "entries"][dp.info["form"]], form, b))
+        fname = ["full", "tiled", "entries"][dp.info["form"]]
+        if b: fails.append("dense(%s, asked %s): %s" % (fname, form, b))
+        # a tall ragged batch of the same rows (full row blocks + a shorter remainder: two launches), and a cloned plan
+        T2 = int(rng.choice([500, 700, 1369, 1500]))
+        idx = rng.integers(0, T, T2)
+        Xt = Xd.contiguous()[torch.from_numpy(idx).cuda()]
+        gt = dp.apply(Xt).cpu().numpy()
+        b = rel_bad(gt, ref[idx], rtol, 1.0)
+        if b: fails.append("dense(%s) tall batch T=%d: %s" % (fname, T2, b))
+        if rng.random() < 0.4:
+            rep = dp.replica(0)
+            if not np.array_equal(rep.apply(Xt).cpu().numpy(), gt, equal_nan=True): fails.append("dense(%s): the clone's result differs" % fname)
+            rep.close()
         dp.close()
+        if rng.random() < 0.5 and len(cell):
+            # the same table as CSR (rows = cells, columns ascending): the one-pass sort when nothing is dropped
+            order = np.lexsort((code, cell))
+            rowptr = np.zeros(G + 1, np.int64)
+            np.add.at(rowptr, cell[order].astype(np.int64) + 1, 1)
+            dc = DensePlan.from_csr(np.cumsum(rowptr), code[order], w[order], G, R, dtype=dtype, form=form)
+            want_one_pass = int(not ((code < 0).any() or np.isnan(w).any()) and dc.info["one_pass_sort"] == 1)
+            b = rel_bad(dc.apply(Xt).cpu().numpy(), ref[idx], rtol, 1.0)
+            if b: fails.append("dense from CSR (one pass: %d): %s" % (dc.info["one_pass_sort"], b))
+            if dc.info["one_pass_sort"] and ((code < 0).any() or np.isnan(w).any()): fails.append("one-pass sort taken with dropped rows")
+            dc.close()
     plan.close()
     return tag, fails
 
