@@ -189,7 +189,10 @@ def _agree_max(torch, dist, n):
     return int(t.item())
 
 
-def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=None, auto_steps=False, min_steps=10):
+LAUNCHES_PER_APPLY = 0      # of the last timed_steps() run with a profile: dominant-kernel launches of one apply
+
+
+def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=None, auto_steps=False, min_steps=10, profile_read=None):
     """(wall seconds of exactly `steps` steps between barrier + synchronize on both sides, max over ranks;
     per-step milliseconds from event pairs on the compute stream -- recorded without any synchronisation;
     the number of timed steps; the number of warm-up steps actually run).
@@ -223,7 +226,20 @@ def timed_steps(torch, dist, step, finish, steps, warmup, world, profile_reset=N
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    global LAUNCHES_PER_APPLY
+    LAUNCHES_PER_APPLY = 0
     if profile_reset is not None:
+        if profile_read is not None:
+            # one more untimed step under the profile alone: how many launches of its dominant kernel does one apply make?
+            # (a ragged batch makes two; the library's ring holds the first 1,024 launches of the timed region, so the
+            #  count cannot always be had from len(ring) / steps afterwards)
+            profile_reset()
+            step()
+            finish()
+            torch.cuda.synchronize()
+            LAUNCHES_PER_APPLY = len(profile_read())
+            if world > 1:
+                dist.barrier()
         profile_reset()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     # (no cyclic-garbage collection inside the timed region: a full collection walks every object of the process -- the
@@ -277,17 +293,20 @@ def step_stats(per_step_ms):
             **({"step_ms_sorted": d["step_ms_sorted"]} if "step_ms_sorted" in d else {"step_ms_quantiles": d.get("step_ms_quantiles")})}
 
 
-def kernel_stats(kms, steps=0):
+def kernel_stats(kms, steps=0, per_apply_known=0):
     """The dominant kernel's own durations over the timed steps (hipExtLaunchKernel start / stop events: the dispatch
     itself, no host time): the roofline is priced on the MEDIAN; mean, min, max and the sorted list ride along, and
     `outlier` says when the slowest launch took more than 1.5 x the median.  (step_ms_max >> kernel_ms_max = a gap between
     launches, i.e. the host; kernel_ms_max >> kernel_ms_median = the device itself ran a launch slowly.)"""
     per_apply = 1
-    if steps and len(kms) > steps and len(kms) % steps == 0:
-        # an apply that launches its dominant kernel more than once (a ragged batch: full row blocks, then the remainder): the
-        # launches of one step are added up
+    if per_apply_known and per_apply_known > 1:
+        per_apply = per_apply_known
+    elif steps and len(kms) > steps and len(kms) % steps == 0:
         per_apply = len(kms) // steps
-        kms = [sum(kms[i * per_apply:(i + 1) * per_apply]) for i in range(steps)]
+    if per_apply > 1:
+        # an apply that launches its dominant kernel more than once (a ragged batch: full row blocks, then the remainder): the
+        # launches of one step are added up (whole applies only: the ring may have filled up in the middle of one)
+        kms = [sum(kms[i * per_apply:(i + 1) * per_apply]) for i in range(len(kms) // per_apply)]
     ks = sorted(kms)
     d = _spread(ks, "kernel_ms_")
     d["kernel_launches_per_apply"] = per_apply
@@ -668,8 +687,9 @@ def main():
         plan_build_s = time.perf_counter() - t0
         Rr = len(uniq)
         st = stepper(lambda out: plan.apply(Xs, out=out), T, rows_all, Rr, Xs.dtype)
-        dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto)
-        kst = kernel_stats(engine.profile_read(), steps)
+        dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto,
+                                                     profile_read=engine.profile_read)
+        kst = kernel_stats(engine.profile_read(), steps, LAUNCHES_PER_APPLY)
         engine.profile_enable(False)
         kmed = kst["kernel_ms_median"] * 1e-3          # the roofline is priced on the MEDIAN launch
         gok = gather_check(st, T)
@@ -785,15 +805,16 @@ def main():
                 build = {"plan_build_s": round(time.perf_counter() - t0, 4), "library_s": round(plan.info["build_s"], 4),
                          "upload_s": round(plan.info["build_upload_s"], 4), "table_entries": int(len(col)),
                          "table_bytes": int(rowptr.nbytes + col.nbytes + val.nbytes),
-                         "what": "wagg_dense_create_from_csr%s on host CSR arrays: upload, device radix sort + coalesce + "
-                                 "denominators + form choice + packing" % ("_f64" if f64 else "")}
+                         "one_pass_sort": int(plan.info["one_pass_sort"]),
+                         "what": "wagg_dense_create_from_csr%s on host CSR arrays: upload, device sort (one stable pass per chunk of 128 "
+                                 "cells for a table with ascending columns) + coalesce + denominators + form choice + packing" % ("_f64" if f64 else "")}
         else:
             fill, bl = 1.0, False
             plan = plan or engine.DensePlan.synth(G, R, seed=2)
         st = stepper(lambda out: plan.apply(X, out=out, ksplit=a.ksplit), T, rows_all, R, X.dtype)
         dt, per_step, steps, warm_done = timed_steps(torch, dist, st.step, st.finish, steps, warmup, world, profile_reset, auto_steps=auto,
-                                                     min_steps=min_steps)
-        kst = kernel_stats(engine.profile_read(), steps)
+                                                     min_steps=min_steps, profile_read=engine.profile_read)
+        kst = kernel_stats(engine.profile_read(), steps, LAUNCHES_PER_APPLY)
         engine.profile_enable(False)
         gok = gather_check(st, T)
         gt = gather_timing(st, T, per_step)
