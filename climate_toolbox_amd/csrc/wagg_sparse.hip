@@ -1437,9 +1437,36 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             den[(size_t)r] += w_eff[i];                           // aggregations.py:79
             segs.push_back({r, cell_idx[i], w_eff[i]});
         }
-        std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
-            return a.region != b.region ? a.region < b.region : a.cell < b.cell;
-        });
+        // by (region, cell), rows of one pair in table order (S5: they are added in that order below).  std::stable_sort on
+        // the 16-byte rows was half of a c2-real plan build (42 of ~80 ms for 4e5 rows); stable counting passes -- by cell,
+        // then by region -- do it in a third of that, and a table that already comes by cell (rows = grid order, the usual
+        // export) or by (region, cell) skips the passes it does not need
+        {
+            bool by_cell = true, by_region_cell = true;
+            for (size_t i = 1; i < segs.size(); ++i) {
+                by_cell = by_cell && segs[i - 1].cell <= segs[i].cell;
+                by_region_cell = by_region_cell && (segs[i - 1].region < segs[i].region ||
+                                                    (segs[i - 1].region == segs[i].region && segs[i - 1].cell <= segs[i].cell));
+            }
+            auto counting_pass = [&](int64_t n_keys, auto key_of) {
+                std::vector<int64_t> first((size_t)n_keys + 1, 0);
+                for (const Seg &sg : segs) ++first[(size_t)key_of(sg) + 1];
+                for (int64_t k = 0; k < n_keys; ++k) first[(size_t)k + 1] += first[(size_t)k];
+                std::vector<Seg> sorted(segs.size());
+                for (const Seg &sg : segs) sorted[(size_t)first[(size_t)key_of(sg)]++] = sg;
+                segs.swap(sorted);
+            };
+            if (by_region_cell) {
+                // nothing to do
+            } else if (G > 8 * (int64_t)segs.size() + (1 << 22)) {          // a counter per cell would dwarf the table
+                std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
+                    return a.region != b.region ? a.region < b.region : a.cell < b.cell;
+                });
+            } else {
+                if (!by_cell) counting_pass(G, [](const Seg &sg) { return (int64_t)sg.cell; });
+                counting_pass(R, [](const Seg &sg) { return (int64_t)sg.region; });
+            }
+        }
         // coalesce duplicate (cell, region) rows (S5)
         size_t m = 0;
         for (size_t i = 0; i < segs.size(); ++i) {
