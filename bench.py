@@ -604,8 +604,23 @@ def main():
         ts.sort()
         mid = ts[len(ts) // 2]
         out["host_resident"] = {"ms_per_step": mid * 1e3, "min_ms": ts[0] * 1e3, "max_ms": ts[-1] * 1e3, "calls": len(ts), "h2d_gbs": Xh.nbytes / mid / 1e9,
-                                "what": "wagg_apply_host_f32 (row-block pipeline, arrays page-locked in place): X from host memory, result "
-                                        "back to host memory; PCIe-bound, never the headline value"}
+                                "what": "wagg_apply_host_ex_f32(WAGG_HOST_PIN) (row-block pipeline, arrays page-locked in place): every byte of X "
+                                        "from host memory over PCIe, result back to host memory; PCIe-bound, never the headline value"}
+        # the same with WAGG_HOST_LINES (what wagg_apply_host_f32 and the drop-in do by default): host threads pack the 128-byte
+        # lines the table references into page-locked pieces, only those cross PCIe
+        L_.host_stats(reset=True)
+        tl = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            plan.apply_host(Xh, flags=L_.HOST_PIN | L_.HOST_LINES)
+            tl.append(time.perf_counter() - t0)
+        st = L_.host_stats()
+        tl = sorted(tl[2:])
+        out["host_resident"]["lines_only"] = {"ms_per_step": tl[len(tl) // 2] * 1e3, "min_ms": tl[0] * 1e3, "max_ms": tl[-1] * 1e3, "calls": len(tl),
+                                              "packed_fraction_of_x": st["lines_h2d_bytes"] / 9 / Xh.nbytes,
+                                              "x_equivalent_gbs": Xh.nbytes / tl[len(tl) // 2] / 1e9,
+                                              "wait_for_copy_engine_ms": st["lines_wait_copy_us"] / 9e3, "wait_for_packing_threads_ms": st["lines_wait_pack_us"] / 9e3,
+                                              "packing_threads": min(8, max(1, usable_cpus()[0] // 2))}
 
         def calls(ds, n=30, warm=15):
             # (15 warm-up calls: the first dozen calls after an idle spell run 2-3x slower on this platform whatever they do --
@@ -767,10 +782,14 @@ def main():
             if "cpu_baseline" in res and "host_resident" in res:
                 cb = res["cpu_baseline"]["cpu_best"]
                 res["host_memory_comparison"] = {
-                    "host_resident_gpu_ms": round(res["host_resident"]["ms_per_step"], 3), "cpu_best_ms": round(cb["wall_s"] * 1e3, 3),
+                    "host_resident_gpu_ms": round(res["host_resident"]["ms_per_step"], 3),
+                    "host_resident_gpu_lines_only_ms": round(res["host_resident"]["lines_only"]["ms_per_step"], 3),
+                    "cpu_best_ms": round(cb["wall_s"] * 1e3, 3),
                     "cpu_best_min_ms": round(cb["wall_s_min"] * 1e3, 3), "cpu_threads": cb["cores"],
                     "device_resident_step_ms": round(res["median_ms"], 4),
-                    "what": "for data that STARTS in host memory the GPU path is bound by PCIe (X crosses it once per call); "
+                    "what": "for data that STARTS in host memory the GPU path is bound by PCIe (X crosses it once per call -- with "
+                            "WAGG_HOST_LINES, the default of wagg_apply_host_* and the drop-in, only the 128-byte lines the table references, "
+                            "packed by up to 8 host threads); "
                             "the all-cores CPU restatement reads X from DRAM.  The device-resident step beside them is what a "
                             "pipeline that keeps the field in HBM pays"}
         plan.close()

@@ -1079,9 +1079,9 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             # wagg_dense_apply_host_*): the H2D of block i+1 overlaps the kernels of block i and the device
             # never holds the whole field.  PCIe-bound for the segment-table form (49 GB/s of X, ~100x the
             # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
-            from ._lib import HOST_PIN
+            from ._lib import HOST_LINES, HOST_PIN
             X2c = np.ascontiguousarray(X2)
-            host_out = plan.apply_host(X2c, flags=HOST_PIN, replicas=_host_replicas(plan, X2c.shape[0], X2c.strides[0]))
+            host_out = plan.apply_host(X2c, flags=HOST_PIN | HOST_LINES, replicas=_host_replicas(plan, X2c.shape[0], X2c.strides[0]))
             if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
                 exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
                 try:

@@ -24,7 +24,7 @@ namespace wagg {
 struct HostStats {
     std::atomic<int64_t> calls{0}, registered{0}, register_failed{0}, unregistered{0}, unregister_failed{0},
         cleanup_failed{0}, staged_h2d_bytes{0}, staged_d2h_bytes{0}, direct_h2d_bytes{0}, direct_d2h_bytes{0},
-        blocks{0};
+        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0};
 };
 extern HostStats g_host_stats;
 
@@ -85,6 +85,13 @@ struct HostRowsArgs {
     const int *devices;                                         // nullptr: the current device, n_dev == 1
     std::function<int(int, const void *, int64_t, void *, hipStream_t)> apply;
     std::function<void(int, hipStream_t)> release;
+    // "lines only" (WAGG_HOST_LINES; one device): n_runs > 0 makes the copy-in stage a GATHER -- host threads pack runs
+    // [run_src[k], run_src[k] + run_len[k]) (bytes of a row of X) of every row side by side into page-locked ring pieces,
+    // crow_bytes per row, and only those cross PCIe; `apply` then receives blocks of rows x crow_bytes (its own business
+    // to read them with a matching cell table).  The caller's X is read by the CPU only and is never page-locked.
+    const int64_t *run_src = nullptr;
+    const int32_t *run_len = nullptr;
+    int64_t n_runs = 0, crow_bytes = 0;
 };
 int stream_host_rows_any(const HostRowsArgs &a);
 
@@ -104,6 +111,14 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, int64_t G, T *out
     a.release = [&](int slot, hipStream_t st) { release(slot, st); };
     return stream_host_rows_any(a);
 }
+
+// CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one
+int granted_cpus();
+// the page-locked ring of the gather (process lifetime, one call at a time; a second concurrent call does without and
+// takes the plain path): nullptr when it is in use or cannot be had.  release_host_ring(): free it (wagg_release_scratch)
+char *acquire_host_ring(size_t bytes);
+void return_host_ring(char *p);
+void release_host_ring();
 
 // blocking host -> device copy of a whole buffer (plan uploads, the whole-field forms): staged, or in place under a
 // page-lock of its own for large buffers.  `st`: the stream the copy is queued on and waited for (the null stream by default;

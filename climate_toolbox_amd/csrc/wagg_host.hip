@@ -1,7 +1,16 @@
 // Host-resident data: page-locks, staging and the row-block pipeline (wagg_host.h).  Host code only.
+#include <sched.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
+#include <system_error>
 
 #include "wagg_host.h"
 
@@ -192,6 +201,181 @@ int copy_rows_to_host(void *dst_host, const void *src_dev, int64_t rows, size_t 
     return WAGG_OK;
 }
 
+// ---- "lines only": the gather of the referenced runs of every row (WAGG_HOST_LINES) -----------------------------------
+int granted_cpus() {
+    static const int n = []() {
+        int cpus = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus < 1) cpus = (int)std::thread::hardware_concurrency();
+        if (cpus < 1) cpus = 1;
+        // cgroup v2: "<quota> <period>" or "max <period>"; v1: cfs_quota_us (-1 = none) / cfs_period_us
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE *f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (fscanf(f2, "%lld", &period) != 1) period = 0;
+                fclose(f2);
+            }
+        }
+        if (quota > 0 && period > 0) {
+            const int by_quota = (int)((quota + period - 1) / period);
+            if (by_quota >= 1 && by_quota < cpus) cpus = by_quota;
+        }
+        return cpus;
+    }();
+    return n;
+}
+
+namespace {
+struct HostRing { std::mutex mu; char *p = nullptr; size_t cap = 0; bool busy = false; } g_ring;
+}  // namespace
+
+char *acquire_host_ring(size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_ring.mu);
+    if (g_ring.busy) return nullptr;
+    if (g_ring.cap < bytes) {
+        if (g_ring.p) { note_cleanup(hipHostFree(g_ring.p), "hipHostFree(gather ring)"); g_ring.p = nullptr; g_ring.cap = 0; }
+        void *q = nullptr;
+        if (hipHostMalloc(&q, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_ring.p = static_cast<char *>(q); g_ring.cap = bytes;
+    }
+    g_ring.busy = true;
+    return g_ring.p;
+}
+
+void return_host_ring(char *p) {
+    std::lock_guard<std::mutex> lock(g_ring.mu);
+    if (p && p == g_ring.p) g_ring.busy = false;
+}
+
+void release_host_ring() {
+    std::lock_guard<std::mutex> lock(g_ring.mu);
+    if (g_ring.busy || !g_ring.p) return;
+    note_cleanup(hipHostFree(g_ring.p), "hipHostFree(gather ring)");
+    g_ring.p = nullptr; g_ring.cap = 0;
+}
+
+namespace {
+// One run of a row into the ring: streaming stores (the packed bytes are read next by the copy engine, not by a CPU: no
+// write-allocate read of the destination, no dirty lines for the DMA to snoop out of the caches -- tools/micro/host_gather.cpp:
+// 20.1 -> 18.0 ms for the c2-real field).  dst and n are multiples of 16 (whole quads of a compact row in page-locked memory).
+static inline void copy_run(char *dst, const char *src, size_t n) {
+#if defined(__x86_64__)
+    for (size_t i = 0; i < n; i += 16)
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i)));
+#else
+    std::memcpy(dst, src, n);
+#endif
+}
+static inline void runs_done() {
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+}
+static inline int64_t now_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Host threads that pack the rows of the field, in order, into ring pieces of RPP rows; the pipeline's thread sends a
+// piece off as soon as all its rows are there and hands its slot back once the copy engine has read it.  Rows are
+// claimed in ascending order from one counter, so the piece everybody may be waiting for is always being worked on.
+struct GatherTeam {
+    static constexpr int RPP = 8, SLOTS = 4;
+    const HostRowsArgs &a;
+    char *ring = nullptr;
+    size_t piece_bytes = 0;
+    int64_t n_pieces = 0;
+    std::vector<int64_t> doff;                           // byte position of run k in the compact row
+    std::unique_ptr<std::atomic<int>[]> done;            // rows packed, per piece
+    std::atomic<int64_t> next_row{0}, free_upto{SLOTS};  // pieces below free_upto own a free slot
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> th;
+    hipEvent_t pev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+
+    explicit GatherTeam(const HostRowsArgs &args) : a(args) {}
+    GatherTeam(const GatherTeam &) = delete;
+    GatherTeam &operator=(const GatherTeam &) = delete;
+    // false: the team cannot work (no ring, no thread) -- the caller takes the plain path; nothing has been touched
+    bool start() {
+        try {
+            piece_bytes = (size_t)(RPP * a.crow_bytes);
+            n_pieces = (a.Tn + RPP - 1) / RPP;
+            doff.resize((size_t)a.n_runs);
+            int64_t off = 0;
+            for (int64_t k = 0; k < a.n_runs; ++k) { doff[(size_t)k] = off; off += a.run_len[k]; }
+            if (off != a.crow_bytes) return false;
+            done.reset(new std::atomic<int>[(size_t)n_pieces]);
+            for (int64_t p = 0; p < n_pieces; ++p) done[(size_t)p].store(0, std::memory_order_relaxed);
+            for (int s = 0; s < SLOTS; ++s)
+                if (hipEventCreateWithFlags(&pev[s], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+            ring = acquire_host_ring(piece_bytes * SLOTS);
+            if (!ring) return false;
+            int want = granted_cpus() / 2;
+            want = want < 1 ? 1 : (want > 8 ? 8 : want);
+            if ((int64_t)want > a.Tn) want = (int)a.Tn;
+            th.reserve((size_t)want);
+            for (int w = 0; w < want; ++w) {
+                try { th.emplace_back([this]() { work(); }); } catch (const std::system_error &) { break; }
+            }
+            return !th.empty();
+        } catch (const std::bad_alloc &) { return false; }
+    }
+    void work() {
+        for (;;) {
+            const int64_t r = next_row.fetch_add(1, std::memory_order_relaxed);
+            if (r >= a.Tn) return;
+            const int64_t p = r / RPP;
+            while (p >= free_upto.load(std::memory_order_acquire)) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
+            }
+            const char *src = a.X_host + r * a.ldx_bytes;
+            char *dst = ring + (size_t)(p % SLOTS) * piece_bytes + (size_t)((r % RPP) * a.crow_bytes);
+            for (int64_t k = 0; k < a.n_runs; ++k) copy_run(dst + doff[(size_t)k], src + a.run_src[k], (size_t)a.run_len[k]);
+            runs_done();
+            done[(size_t)p].fetch_add(1, std::memory_order_release);
+        }
+    }
+    // rows [r0, r0 + rows) of the field -> dst_dev (rows x crow_bytes), queued on `sc` piece by piece
+    hipError_t send_block(char *dst_dev, int64_t r0, int64_t rows, hipStream_t sc) {
+        hipError_t e;
+        for (int64_t p = r0 / RPP; p * RPP < r0 + rows; ++p) {
+            const int64_t pr0 = p * RPP, prow = (pr0 + RPP <= a.Tn ? RPP : a.Tn - pr0);
+            const int64_t w0 = now_us();
+            while (done[(size_t)p].load(std::memory_order_acquire) < (int)prow) std::this_thread::yield();
+            g_host_stats.lines_wait_pack_us += now_us() - w0;
+            if ((e = hipMemcpyAsync(dst_dev + (size_t)((pr0 - r0) * a.crow_bytes), ring + (size_t)(p % SLOTS) * piece_bytes,
+                                    (size_t)(prow * a.crow_bytes), hipMemcpyHostToDevice, sc)) != hipSuccess) return e;
+            if ((e = hipEventRecord(pev[p % SLOTS], sc)) != hipSuccess) return e;
+            g_host_stats.lines_h2d_bytes += prow * a.crow_bytes;
+            if (p >= 1) {       // the copy of piece p - 1 is over (p stays queued behind it): its slot goes to piece p - 1 + SLOTS
+                const int64_t w1 = now_us();
+                if ((e = hipEventSynchronize(pev[(p - 1) % SLOTS])) != hipSuccess) return e;
+                g_host_stats.lines_wait_copy_us += now_us() - w1;
+                free_upto.store(p + SLOTS, std::memory_order_release);
+            }
+        }
+        return hipSuccess;
+    }
+    ~GatherTeam() {
+        stop.store(true);
+        next_row.store(a.Tn);
+        for (std::thread &t : th) if (t.joinable()) t.join();
+        // (the ring returns only once nothing can still be reading it: run_device_ has drained its streams, or is about to
+        //  fail the call -- the events below are waited for either way)
+        for (int s = 0; s < SLOTS; ++s)
+            if (pev[s]) { note_cleanup(hipEventSynchronize(pev[s]), "hipEventSynchronize(gather piece)"); note_cleanup(hipEventDestroy(pev[s]), "hipEventDestroy"); }
+        if (ring) return_host_ring(ring);
+    }
+};
+}  // namespace
+
 // ---- one device's streams, events and block buffers ---------------------------------------------------------------
 hipError_t DevicePipe::init(int dev, bool set_device, size_t x_bytes, size_t o_bytes, int nbuf) {
     // streams and block buffers from the scratch pool (wagg_scratch.hip): 0.6 GB of hipMalloc / hipFree and three stream
@@ -250,11 +434,18 @@ static int run_device(const HostRowsArgs &a, int slot, bool set_device, int64_t 
 static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t B, int64_t nb, bool pin_x, bool pin_o) {
     const int64_t my_blocks = nb > slot ? (nb - slot + a.n_dev - 1) / a.n_dev : 0;
     if (my_blocks == 0) return WAGG_OK;
+    // (declared before the pipe: the pipe's destructor drains the streams, then the team waits for its pieces and goes)
+    std::unique_ptr<GatherTeam> team;
+    const bool gather = a.n_runs > 0;
     DevicePipe P;
     const int dev = a.devices ? a.devices[slot] : -1;
     int cur = 0;
     if (!set_device) WAGG_HIP(hipGetDevice(&cur));
-    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * a.ldx_bytes), (size_t)(B * a.ldo_bytes), my_blocks >= 2 ? 2 : 1));
+    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * (gather ? a.crow_bytes : a.ldx_bytes)), (size_t)(B * a.ldo_bytes), my_blocks >= 2 ? 2 : 1));
+    if (gather) {
+        team.reset(new (std::nothrow) GatherTeam(a));
+        if (!team || !team->start()) return WAGG_EUNSUPPORTED;       // (nothing queued yet: the caller takes the plain path)
+    }
     struct Releaser {                                   // per-stream plan state keyed by P.sk goes before the stream does --
         const HostRowsArgs &a; int slot; hipStream_t s; // and, on every path (also the early returns), only once nothing on
         ~Releaser() {                                   // that stream can still be using it (this runs BEFORE ~DevicePipe)
@@ -280,7 +471,9 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
         const char *src = a.X_host + r0 * a.ldx_bytes;
         const size_t xspan = span(rows, a.ldx_bytes, a.xrow_bytes);
         if (j >= 2) WAGG_HIP(hipStreamWaitEvent(P.sc, P.kdone[b], 0));            // the kernels of block j-2 have read dx[b]
-        if (pin_x) {
+        if (gather) {
+            WAGG_HIP(team->send_block(static_cast<char *>(P.dx[b]), r0, rows, P.sc));
+        } else if (pin_x) {
             WAGG_HIP(hipMemcpyAsync(P.dx[b], src, xspan, hipMemcpyHostToDevice, P.sc));      // page-locked source: truly asynchronous
             g_host_stats.direct_h2d_bytes += (int64_t)xspan;
         } else {
@@ -323,12 +516,16 @@ int stream_host_rows_any(const HostRowsArgs &a) {
     const int64_t fail0 = tl_release_failures;
     int64_t B, nb;
     host_block_plan(a.Tn, a.ldx_bytes, a.quantum, a.n_dev, &B, &nb);
+    if (a.n_runs > 0) {
+        WAGG_REQUIRE(a.n_dev == 1 && a.devices == nullptr, "the lines-only host path drives one device");
+        WAGG_REQUIRE(nb == 1 || B % GatherTeam::RPP == 0, "row blocks of %lld rows do not hold whole gather pieces", (long long)B);
+    }
     const size_t xbytes = (size_t)((a.Tn - 1) * a.ldx_bytes + a.xrow_bytes), obytes = (size_t)((a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
     int rc = WAGG_OK;
     {
         HostPin px, po;
         const bool want = (a.flags & WAGG_HOST_PIN) != 0;
-        const bool pin_x = want && px.acquire(a.X_host, xbytes, a.n_dev > 1);
+        const bool pin_x = want && a.n_runs == 0 && px.acquire(a.X_host, xbytes, a.n_dev > 1);      // (gathered rows: the CPU reads X)
         const bool pin_o = want && po.acquire(a.out_host, obytes, a.n_dev > 1);
         if (a.n_dev == 1 && a.devices == nullptr) {
             int64_t f = 0;
@@ -392,9 +589,11 @@ extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
     out->cleanup_failed = s.cleanup_failed;
     out->staged_h2d_bytes = s.staged_h2d_bytes; out->staged_d2h_bytes = s.staged_d2h_bytes;
     out->direct_h2d_bytes = s.direct_h2d_bytes; out->direct_d2h_bytes = s.direct_d2h_bytes;
+    out->lines_h2d_bytes = s.lines_h2d_bytes; out->lines_wait_pack_us = s.lines_wait_pack_us; out->lines_wait_copy_us = s.lines_wait_copy_us;
     if (reset) {
         s.calls = 0; s.blocks = 0; s.registered = 0; s.register_failed = 0; s.unregistered = 0; s.unregister_failed = 0;
         s.cleanup_failed = 0; s.staged_h2d_bytes = 0; s.staged_d2h_bytes = 0; s.direct_h2d_bytes = 0; s.direct_d2h_bytes = 0;
+        s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0;
     }
     return WAGG_OK;
 }

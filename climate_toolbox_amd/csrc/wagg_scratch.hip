@@ -64,6 +64,7 @@ void release_scratch() {
     }
     give_back(blocks);
     for (const IdleStream &s : streams) note_cleanup(hipStreamDestroy(s.st), "hipStreamDestroy(kept stream)");
+    release_host_ring();                         // (the page-locked ring of the lines-only host path, wagg_host.hip)
 }
 
 int64_t scratch_bytes_kept() {

@@ -1179,7 +1179,9 @@ template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
                          int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, const double *thr = nullptr,
-                         int n_thr = 0) {
+                         int n_thr = 0, bool compact = false) {
+    // compact: X holds COMPACT rows (ldx >= Gc cells: the distinct quads of the whole-line chunking side by side, the
+    // lines-only host path) -- the plain aggregation of (time, gridcell) data on that chunking, read through ucell_c
     // nfuse > 1: powers xpow .. xpow + nfuse - 1 of (x + xoff) in one pass over X (fused tas_poly); the i-th goes to
     // out + i * pstride.  sparse_lcv_kernel fuses up to four planes (powers or degree-day thresholds) in both element types and
     // both layouts on the chunkings of the table above; everything it does not serve (giant groups, plans whose flags or
@@ -1198,6 +1200,9 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const auto &d = edd_lcv ? d_edd
                             : (gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64) : (use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d));
     if (int rc = check_timeout(plan)) return rc;
+    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse == 1 && xpow == 0 && d.Gc > 0 && ldx >= d.Gc),
+                 "compact rows need the whole-line chunking of this plan and data type");
+    const int64_t Gk = compact ? d.Gc : (int64_t)plan->info.G;        // cells of a row as the kernels see it
     if (nfuse > 1) {
         // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
         const bool lc_ok = ((layout == WAGG_LAYOUT_TG && (sizeof(T) == 4 || (use_lines && !lcv_off))) || gt_lcv) &&
@@ -1219,7 +1224,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const int nplanes = xpow == XF_EDD ? pv.n_thr : nfuse;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
-    pv.ucell = d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
+    pv.ucell = compact ? d.ucell_c.p : d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
     pv.seg_u = d.seg_u.p;
     if constexpr (sizeof(T) == 4) { pv.seg_w = d.seg_w32.p; pv.den = d.den32.p; pv.ent_den = d.ent_den32.p; }
     else { pv.seg_w = d.seg_w64.p; pv.den = d.den64.p; pv.ent_den = d.ent_den64.p; }
@@ -1276,7 +1281,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         unsigned long long *lc_stamps = nullptr;
         if (diag_set("WAGG_SPARSE_STAMP")) WAGG_HIP(hipMalloc((void **)&lc_stamps, sizeof(unsigned long long) * 8 * (size_t)nw));
         launch_timed(true, kern, dim3((unsigned)nw), dim3(LV_THREADS), lds_bytes, stream, pv, X, Ttot, ldx,
-                     (int64_t)plan->info.G, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
+                     Gk, kout, kldo, n_norm, n_items, lc_stamps, diag_env("WAGG_LC_KNOB"), kpstride, ylim);
         WAGG_HIP(hipGetLastError());
 #ifdef WAGG_DIAG
         if (lc_stamps) { if (int rc = report_lc_stamps(lc_stamps, nw, n_items, stream)) return rc; }
@@ -1329,6 +1334,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         lc_done = true;                     // (a dominant kernel has been launched and timed)
     }
     const bool main_done = lc_done;
+    WAGG_REQUIRE(!compact || (lc_done && pv.n_groups == 0), "compact rows: the whole-line kernel did not take the whole plan");
     pv.thr_pstride = kpstride;
     for (int pz = 0; pz < nfuse; ++pz) {      // per power: the groups the kernels above left over (giant ones)
     if (nfuse > 1) pv.xpow = xpow + pz;
@@ -1885,6 +1891,22 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             up(d.ent_den64, ed64); up(d.ent_den32, ed32);
         }
         if (lines_plan) { up(d.part_begin, part_begin); d.n_part = n_part_rows; }
+        if (lines_plan && (kind == 1 || kind == 2)) {
+            // the compact row of the lines-only host path: the distinct quads of this chunking in grid order, side by side
+            std::vector<int32_t> uq(ucell);
+            std::sort(uq.begin(), uq.end());
+            uq.erase(std::unique(uq.begin(), uq.end()), uq.end());
+            std::vector<int32_t> ucell_c(ucell.size());
+            for (size_t i = 0; i < ucell.size(); ++i)
+                ucell_c[i] = (int32_t)(4 * (std::lower_bound(uq.begin(), uq.end(), ucell[i]) - uq.begin()));
+            d.run_src.clear(); d.run_len.clear();
+            for (size_t i = 0; i < uq.size(); ++i) {
+                if (i > 0 && uq[i] == uq[i - 1] + 4) d.run_len.back() += 4;
+                else { d.run_src.push_back((int64_t)uq[i]); d.run_len.push_back(4); }
+            }
+            up(d.ucell_c, ucell_c);
+            d.Gc = 4 * (int64_t)uq.size();
+        }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         d.n_groups = (int64_t)grp_giant.size(); d.n_empty = (int64_t)empty.size();
         return true;
@@ -2041,9 +2063,38 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     clear_error();
     int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
     if (rc != WAGG_OK || Tn == 0) return rc;
-    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE)) == 0, "unknown host flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
     if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
+        // lines only: host threads pack the quads the whole-line chunking fetches into page-locked pieces and only those
+        // cross PCIe (c2-real: 64 % of a fp32 row, 47 % of a fp64 row).  Taken when asked for, when the plan has that
+        // chunking for T, when the row shrinks to <= 80 % and the field is large enough to be worth a thread team; a team
+        // that cannot start (ring in use by a concurrent call, no thread to be had) means the plain pipeline below
+        const SparsePlanDev &dc = sizeof(T) == 4 ? plan->dl : plan->dl64;
+        const bool has_c = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && dc.Gc > 0 && !dc.run_len.empty();
+        if ((flags & WAGG_HOST_LINES) && has_c && 5 * dc.Gc <= 4 * (int64_t)plan->info.G &&
+            Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
+            std::vector<int64_t> src(dc.run_src.size());
+            std::vector<int32_t> len(dc.run_len.size());
+            for (size_t k = 0; k < src.size(); ++k) { src[k] = dc.run_src[k] * (int64_t)sizeof(T); len[k] = dc.run_len[k] * (int32_t)sizeof(T); }
+            HostRowsArgs a;
+            a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
+            a.Tn = Tn;
+            a.ldx_bytes = ldx * (int64_t)sizeof(T); a.xrow_bytes = plan->info.G * (int64_t)sizeof(T);
+            a.ldo_bytes = ldo * (int64_t)sizeof(T); a.orow_bytes = (int64_t)plan->info.R * (int64_t)sizeof(T);
+            a.quantum = 64; a.flags = flags; a.n_dev = 1; a.devices = nullptr;
+            a.run_src = src.data(); a.run_len = len.data(); a.n_runs = (int64_t)src.size(); a.crow_bytes = dc.Gc * (int64_t)sizeof(T);
+            const int64_t Gc = dc.Gc;
+            a.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
+                return launch_sparse<T, (sizeof(T) == 4 ? 64 : 32)>(plan, static_cast<const T *>(xd), rows, Gc, WAGG_LAYOUT_TG, static_cast<T *>(od), ldo,
+                                                                    WAGG_OUT_TR, st, T(0), 0, 1, 0, nullptr, nullptr, 0, true);
+            };
+            a.release = [&](int, hipStream_t st) { plan->drop_staging(st); };
+            rc = stream_host_rows_any(a);
+            if (rc == WAGG_OK) return check_timeout(plan);
+            if (rc != WAGG_EUNSUPPORTED) return rc;
+            clear_error();
+        }
         rc = stream_host_rows<T>(X, Tn, ldx, plan->info.G, out, ldo, plan->info.R, flags, 64, 1, nullptr,
                                  [&](int, const T *xd, int64_t rows, T *od, hipStream_t st) {
                                      return fn(plan, xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
@@ -2100,7 +2151,7 @@ static int apply_host_multi(const wagg_plan *const *plans, const int *devices, i
 
 extern "C" int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                                    int layout, float *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN, wagg_apply_f32);
+    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, wagg_apply_f32);
 }
 extern "C" int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                                       int layout, float *out_host, int64_t ldo, int out_layout, int flags) {
@@ -2108,7 +2159,7 @@ extern "C" int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host
 }
 extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                    int layout, double *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN, wagg_apply_f64);
+    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, wagg_apply_f64);
 }
 extern "C" int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                       int layout, double *out_host, int64_t ldo, int out_layout, int flags) {

@@ -53,6 +53,14 @@ struct SparsePlanDev {
     DevBuf<int32_t> part_begin;
     int64_t n_part = 0;
     int64_t n_groups = 0, n_empty = 0;          // groups of this chunking; regions without any kept row
+    // whole-line chunkings of (time, gridcell) data only -- the COMPACT row of the "lines only" host path (wagg_host.h,
+    // WAGG_HOST_LINES): the distinct quads the chunks fetch, in grid order, packed side by side.  ucell_c[i] = position of
+    // quad ucell[i] in that row; run k of the row = cells run_src[k] .. run_src[k] + run_len[k] - 1 of the grid row (maximal
+    // runs of adjacent quads); Gc = cells of the compact row (0: no compact row)
+    DevBuf<int32_t> ucell_c;
+    std::vector<int64_t> run_src;
+    std::vector<int32_t> run_len;
+    int64_t Gc = 0;
 };
 
 }  // namespace wagg

@@ -192,7 +192,8 @@ class SparsePlan:
         """Blocking host-buffer form (wagg_apply_host_ex_*): numpy in, numpy out.  (time, gridcell) data
         is streamed through the device in row blocks (H2D of block i+1, the kernels of block i and the
         return of block i-1 at once); ``flags``: ``_lib.HOST_PIN`` page-locks the arrays for the call,
-        ``_lib.HOST_WHOLE`` copies the whole field at once.  ``replicas``: further plans of the same table
+        ``_lib.HOST_WHOLE`` copies the whole field at once, ``_lib.HOST_LINES`` lets host threads pack the 128-byte
+        lines the table references so that only those cross PCIe (one device; ignored with ``replicas``).  ``replicas``: further plans of the same table
         on other devices (``replica(d)``): the row blocks are then dealt over all of them
         (``wagg_apply_host_multi_*``), each device on its own PCIe link."""
         X = np.ascontiguousarray(X)
@@ -210,7 +211,7 @@ class SparsePlan:
             devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
             fn = L.wagg_apply_host_multi_f32 if X.dtype == np.float32 else L.wagg_apply_host_multi_f64
             _lib.check(fn(hs, devs, len(plans), C.c_void_p(X.ctypes.data), T, X.shape[1], C.c_void_p(out.ctypes.data),
-                          max(1, self.R), int(flags)), "wagg_apply_host_multi")
+                          max(1, self.R), int(flags) & ~_lib.HOST_LINES), "wagg_apply_host_multi")
             return out
         fn = L.wagg_apply_host_ex_f32 if X.dtype == np.float32 else L.wagg_apply_host_ex_f64
         with _on_device(self.device):

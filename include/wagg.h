@@ -170,12 +170,26 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  * while resources are released are counted (wagg_host_stats) and fail the call.
  * Pitched arrays (ldx > G, ldo > R) are honoured: nothing behind the used cells of the last row is read and the
  * padding between result rows is not written.  The plan must live on the current device.
- * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN.  Measured on one MI355X (tools/host_path_timing.py):
- * the segment-table form is PCIe-bound either way (1.5 GB field: 31 ms = 49 GB/s whole, 31 ms pinned blocks);
+ * wagg_apply_host_* = the _ex form with WAGG_HOST_PIN | WAGG_HOST_LINES.  Measured on one MI355X (tools/host_path_timing.py):
+ * the segment-table form is PCIe-bound either way (1.5 GB field: 51 ms whole from pageable memory, 29.8 ms pinned blocks =
+ * 51 GB/s of X, 21.3 ms lines only; the 3 GB fp64 field: 59.2 / 33.5 ms);
  * a dense 1,369-row shard takes 602 ms whole and 523 ms in pinned blocks (the copies hide behind the 490 ms of
  * MFMA work).                                                                                         */
 #define WAGG_HOST_PIN 1
 #define WAGG_HOST_WHOLE 2
+/*   WAGG_HOST_LINES  "lines only" (round 5; segment-table plans, (time, gridcell) data, (time, region) result, one device):
+ *                    the table references a fraction of the grid -- the whole 128-byte lines its cells lie in are 64 % of a
+ *                    c2-real fp32 row, 47 % of a fp64 row -- so up to eight host threads (half the CPUs the process is
+ *                    granted: affinity mask and cgroup quota) pack exactly those runs of every row side by side into a ring of
+ *                    page-locked pieces, only the packed rows cross PCIe, and the kernel reads them through a second cell
+ *                    table of the same plan.  X is read by the CPU and never page-locked; the result returns as WAGG_HOST_PIN
+ *                    says.  Taken when the packed row is <= 80 % of the row and the field >= 64 MiB, otherwise (and when the
+ *                    ring is busy with a concurrent call, or no thread can be started) the call runs as without the flag:
+ *                    the flag permits, it never fails a call.  Same bits as every other form (the kernel sees the same cells
+ *                    in the same order).  wagg_host_stats.lines_h2d_bytes counts the packed bytes sent.
+ *                    Measured (tools/host_path_timing.py, c2-real T = 365): fp32 29.8 -> 21.3 ms per call (the C call alone
+ *                    18.5 ms, of which 16.7 ms are the copy engine's), fp64 59.2 -> 33.5 ms; DESIGN.md (f).              */
+#define WAGG_HOST_LINES 4
 int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                         int layout, float *out_host, int64_t ldo, int out_layout);
 int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
@@ -203,6 +217,9 @@ int wagg_host_block_plan(int64_t T, int64_t row_bytes, int64_t quantum, int n_de
 typedef struct wagg_host_stats {
     int64_t calls, blocks, registered, register_failed, unregistered, unregister_failed, cleanup_failed;
     int64_t staged_h2d_bytes, staged_d2h_bytes, direct_h2d_bytes, direct_d2h_bytes;
+    int64_t lines_h2d_bytes;      /* packed rows of the lines-only path (WAGG_HOST_LINES) ...                              */
+    int64_t lines_wait_pack_us;   /* ... time its pipeline thread waited for the packing threads (they are the bottleneck) */
+    int64_t lines_wait_copy_us;   /* ... and for the copy engine to hand a ring piece back (PCIe is the bottleneck)        */
 } wagg_host_stats;
 int wagg_host_stats_read(wagg_host_stats *out, int reset);
 

@@ -667,3 +667,60 @@ def test_xarray_branches_meet_a_stand_in_for_the_package(torch_cuda):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "stubs"), ROOT, os.environ.get("PYTHONPATH", "")]))
     p = subprocess.run([sys.executable, "-c", _XARRAY_CHILD], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode == 0 and "xarray stand-in: ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+# ---------------------------------------------------------------------------------------------
+# "lines only": host threads pack the referenced lines of every row, only those cross PCIe (WAGG_HOST_LINES)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,T", [(np.float32, 301), (np.float64, 150), (np.float32, 1000)])
+def test_lines_only_host_path_gives_the_bits_of_the_whole_rows(torch_cuda, dtype, T):
+    """wagg_apply_host_ex_* with WAGG_HOST_LINES against the same call without it and against the device apply: the kernel
+    reads the same cells in the same order through the plan's second cell table, so the results are bit-equal -- NaN and
+    +-inf cells included; pitched host arrays (ldx > G, ldo > R) are honoured and the caller's padding stays untouched;
+    the packed bytes that crossed PCIe are counted and are less than the field.  Where the path does not apply -- a plan
+    without the whole-line chunkings, a small field, the (gridcell, time) layout -- the flag changes nothing and no packed
+    byte is sent."""
+    import ctypes as C
+    from climate_toolbox_amd import _lib, engine, synth
+    torch = torch_cuda
+    L = _lib.load()
+    lat, lon, df = synth.realistic_segments(nlat=192, nlon=384, R=600, n_iso=20, seed=5, land_frac=0.15, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "popwt", "hierid")           # lines: 73 % (fp32) / 53 % (fp64) of a row
+    G, R = len(lat) * len(lon), len(uniq)
+    plan = engine.SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    assert plan.info["lines"] & (1 if dtype == np.float32 else 2)
+    rng = np.random.default_rng(3)
+    X = (280 + 20 * rng.standard_normal((T, G))).astype(dtype)
+    X[rng.random((T, G)) < 0.01] = np.nan
+    X[5, cell[:7]] = np.inf
+    X[T - 1, cell[-3:]] = -np.inf
+    ref = plan.apply(torch.from_numpy(X).cuda()).cpu().numpy()
+    _lib.host_stats(reset=True)
+    got = plan.apply_host(X, flags=_lib.HOST_LINES | _lib.HOST_PIN)
+    st = _lib.host_stats()
+    np.testing.assert_array_equal(got, ref)
+    assert 0 < st["lines_h2d_bytes"] <= 0.8 * X.nbytes and st["lines_h2d_bytes"] % (T * 16) == 0
+    assert st["direct_h2d_bytes"] == 0 and st["staged_h2d_bytes"] == 0 and st["registered"] <= 1      # X: read by the CPU only
+    np.testing.assert_array_equal(plan.apply_host(X, flags=_lib.HOST_LINES), ref)                       # result staged
+    # pitched arrays through the C-ABI
+    ldx, ldo = G + 40, R + 12
+    Xp = np.full((T, ldx), -1e30, dtype=dtype)
+    Xp[:, :G] = X
+    out = np.full((T, ldo), 777.0, dtype=dtype)
+    sfx = "f32" if dtype == np.float32 else "f64"
+    rc = getattr(L, "wagg_apply_host_ex_" + sfx)(plan._h, C.c_void_p(Xp.ctypes.data), T, ldx, 0, C.c_void_p(out.ctypes.data), ldo, 0,
+                                                 _lib.HOST_LINES | _lib.HOST_PIN)
+    assert rc == 0, L.wagg_last_error()
+    np.testing.assert_array_equal(out[:, :R], ref)
+    assert (out[:, R:] == 777.0).all()
+    # where it does not apply, the flag is a no-op
+    _lib.host_stats(reset=True)
+    np.testing.assert_array_equal(plan.apply_host(X[:40], flags=_lib.HOST_LINES | _lib.HOST_PIN), ref[:40])       # < 64 MiB
+    np.testing.assert_allclose(plan.apply_host(np.ascontiguousarray(X[:64].T), layout="GT", out_layout="RT", flags=_lib.HOST_LINES),
+                               np.ascontiguousarray(ref[:64].T), rtol=1e-5 if dtype == np.float32 else 1e-12)    # (another chunking: another order)
+    quads = engine.SparsePlan(cell, code, w, G, R, row_len=len(lon), flags=_lib.PLAN_NO_LINES)
+    np.testing.assert_allclose(quads.apply_host(X, flags=_lib.HOST_LINES | _lib.HOST_PIN), ref, rtol=1e-5 if dtype == np.float32 else 1e-12,
+                               equal_nan=True)
+    assert _lib.host_stats()["lines_h2d_bytes"] == 0
+    quads.close()
+    plan.close()
