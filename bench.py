@@ -335,6 +335,12 @@ def cpu_baseline_dense(T, G, R, seed_w, fill=1.0, blocklocal=False):
                       % (fill, ", block-local" if blocklocal else "", Tw, Gw, Rw)}
 
 
+try:
+    AFFINITY_AT_START = os.sched_getaffinity(0)
+except (AttributeError, OSError):
+    AFFINITY_AT_START = None
+
+
 def usable_cpus():
     """(threads worth starting, what limits them): the smallest of the logical CPUs, the affinity mask and the cgroup's CPU
     quota (v2 cpu.max / v1 cpu.cfs_quota_us), the physical cores when nothing else binds (2 hardware threads per core)."""
@@ -590,6 +596,13 @@ def main():
         level of the same table (agglev = "ISO": the other level the reference's docstring names, aggregations.py:104-106)."""
         from climate_toolbox_amd import _lib as L_, aggregations as A, minixr, weighted_aggregate_grid_to_regions
         out = {}
+        # (the CPU legs ran OpenMP with OMP_PROC_BIND: the runtime bound THIS thread to one core when it entered its first
+        #  parallel region, and threads started from here would inherit that mask -- the packing threads of the lines-only
+        #  host path among them.  Back to the mask the process started with.)
+        try:
+            os.sched_setaffinity(0, AFFINITY_AT_START)
+        except (AttributeError, OSError, TypeError):
+            pass
         Xh = Xs.cpu().numpy()
         # (warm-up by time: staging pieces, the registration path, and -- measured -- host cores and copy engines that take
         #  several calls to leave their idle states: 25 GB/s for the first four calls of a run, 49 GB/s from then on)

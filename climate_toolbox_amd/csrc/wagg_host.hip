@@ -203,13 +203,15 @@ int copy_rows_to_host(void *dst_host, const void *src_dev, int64_t rows, size_t 
 
 // ---- "lines only": the gather of the referenced runs of every row (WAGG_HOST_LINES) -----------------------------------
 int granted_cpus() {
-    static const int n = []() {
-        int cpus = 0;
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
-        if (cpus < 1) cpus = (int)std::thread::hardware_concurrency();
-        if (cpus < 1) cpus = 1;
-        // cgroup v2: "<quota> <period>" or "max <period>"; v1: cfs_quota_us (-1 = none) / cfs_period_us
+    // the calling thread's affinity mask, read per call: threads started from here inherit it, and it can be narrower than
+    // the process's (an OpenMP runtime with OMP_PROC_BIND binds the thread that entered its first parallel region)
+    int cpus = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+    if (cpus < 1) cpus = (int)std::thread::hardware_concurrency();
+    if (cpus < 1) cpus = 1;
+    // cgroup v2: "<quota> <period>" or "max <period>"; v1: cfs_quota_us (-1 = none) / cfs_period_us -- read once
+    static const int by_quota = []() {
         long long quota = -1, period = 0;
         if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
             char q[32] = {0};
@@ -223,13 +225,10 @@ int granted_cpus() {
                 fclose(f2);
             }
         }
-        if (quota > 0 && period > 0) {
-            const int by_quota = (int)((quota + period - 1) / period);
-            if (by_quota >= 1 && by_quota < cpus) cpus = by_quota;
-        }
-        return cpus;
+        return quota > 0 && period > 0 ? (int)((quota + period - 1) / period) : 0;
     }();
-    return n;
+    if (by_quota >= 1 && by_quota < cpus) cpus = by_quota;
+    return cpus;
 }
 
 namespace {
@@ -304,6 +303,13 @@ struct GatherTeam {
     // false: the team cannot work (no ring, no thread) -- the caller takes the plain path; nothing has been touched
     bool start() {
         try {
+            // half the CPUs this thread may use, eight at most -- and not fewer than it takes to pack faster than the copy
+            // engine would move the WHOLE rows (one thread packs ~10 GB/s, PCIe moves ~56: 6 x the packed fraction of a
+            // row; measured, tools/micro/host_gather.cpp: 4 threads 24-26 ms, 8 threads 18 ms, whole rows 26.3 ms)
+            int want = granted_cpus() / 2;
+            want = want > 8 ? 8 : want;
+            const int need = (int)((6 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes);
+            if (want < 1 || want < need || (int64_t)want > a.Tn) return false;
             piece_bytes = (size_t)(RPP * a.crow_bytes);
             n_pieces = (a.Tn + RPP - 1) / RPP;
             doff.resize((size_t)a.n_runs);
@@ -316,14 +322,11 @@ struct GatherTeam {
                 if (hipEventCreateWithFlags(&pev[s], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
             ring = acquire_host_ring(piece_bytes * SLOTS);
             if (!ring) return false;
-            int want = granted_cpus() / 2;
-            want = want < 1 ? 1 : (want > 8 ? 8 : want);
-            if ((int64_t)want > a.Tn) want = (int)a.Tn;
             th.reserve((size_t)want);
             for (int w = 0; w < want; ++w) {
                 try { th.emplace_back([this]() { work(); }); } catch (const std::system_error &) { break; }
             }
-            return !th.empty();
+            return (int)th.size() >= need;               // (fewer than that could be started: the destructor joins them)
         } catch (const std::bad_alloc &) { return false; }
     }
     void work() {

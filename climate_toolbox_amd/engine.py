@@ -402,7 +402,9 @@ class DensePlan:
 
     def apply_host(self, X, flags=0, replicas=()):
         """Host-resident (time, gridcell) array through the plan in row blocks (``wagg_dense_apply_host_*``):
-        numpy in, numpy out; flags and ``replicas`` as for :meth:`SparsePlan.apply_host`."""
+        numpy in, numpy out; flags and ``replicas`` as for :meth:`SparsePlan.apply_host` (``_lib.HOST_LINES`` means nothing
+        to a dense-family plan -- every cell of a row is an operand -- and is dropped)."""
+        flags = int(flags) & ~_lib.HOST_LINES
         want = np.float64 if self.dtype == "float64" else np.float32
         X = np.ascontiguousarray(X)
         if X.dtype != want or X.ndim != 2 or X.shape[1] != self.G:

@@ -183,8 +183,10 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *                    granted: affinity mask and cgroup quota) pack exactly those runs of every row side by side into a ring of
  *                    page-locked pieces, only the packed rows cross PCIe, and the kernel reads them through a second cell
  *                    table of the same plan.  X is read by the CPU and never page-locked; the result returns as WAGG_HOST_PIN
- *                    says.  Taken when the packed row is <= 80 % of the row and the field >= 64 MiB, otherwise (and when the
- *                    ring is busy with a concurrent call, or no thread can be started) the call runs as without the flag:
+ *                    says.  Taken when the packed row is <= 80 % of the row, the field >= 64 MiB and the calling thread's
+ *                    affinity mask and quota leave enough threads to pack faster than PCIe would move the whole rows (6 x the
+ *                    packed fraction, e.g. 4 for c2-real fp32: >= 8 usable CPUs); otherwise (and when the ring is busy with
+ *                    a concurrent call, or the threads cannot be started) the call runs as without the flag:
  *                    the flag permits, it never fails a call.  Same bits as every other form (the kernel sees the same cells
  *                    in the same order).  wagg_host_stats.lines_h2d_bytes counts the packed bytes sent.
  *                    Measured (tools/host_path_timing.py, c2-real T = 365): fp32 29.8 -> 21.3 ms per call (the C call alone
