@@ -334,9 +334,10 @@ struct GatherTeam {
             const int64_t r = next_row.fetch_add(1, std::memory_order_relaxed);
             if (r >= a.Tn) return;
             const int64_t p = r / RPP;
-            while (p >= free_upto.load(std::memory_order_acquire)) {
+            for (int spins = 0; p >= free_upto.load(std::memory_order_acquire); ++spins) {      // (the ring is full: PCIe sets the pace)
                 if (stop.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
+                if (spins < 64) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
             const char *src = a.X_host + r * a.ldx_bytes;
             char *dst = ring + (size_t)(p % SLOTS) * piece_bytes + (size_t)((r % RPP) * a.crow_bytes);
