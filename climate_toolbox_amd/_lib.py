@@ -26,6 +26,7 @@ EXPORTS = (
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
     "wagg_apply_host_ex_f32", "wagg_apply_host_ex_f64", "wagg_dense_apply_host_f32", "wagg_dense_apply_host_f64",
     "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
+    "wagg_apply_poly_host_f32", "wagg_apply_poly_host_f64",
     "wagg_gather_f32", "wagg_gather_f64",
     "wagg_transform_poly_f32", "wagg_transform_poly_f64", "wagg_transform_edd_f32", "wagg_transform_edd_f64",
     "wagg_any_less_f32", "wagg_any_less_f64",
@@ -47,7 +48,7 @@ EXPORTS = (
 class HostStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("calls", "blocks", "registered", "register_failed", "unregistered", "unregister_failed",
                                          "cleanup_failed", "staged_h2d_bytes", "staged_d2h_bytes", "direct_h2d_bytes",
-                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us")]
+                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us", "blocks_retired")]
 
 
 def host_stats(reset=False):
@@ -126,6 +127,8 @@ def load():
     for name in ("wagg_apply_poly_f32", "wagg_apply_poly_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, vp,
                                      C.c_int64, C.c_int64, C.c_int, vp]
+    for name in ("wagg_apply_poly_host_f32", "wagg_apply_poly_host_f64"):
+        getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int, vp, C.c_int64, C.c_int64, C.c_int]
     for name in ("wagg_apply_edd_f32", "wagg_apply_edd_f64"):
         getattr(L, name).argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, f64p, C.c_int, vp,
                                      C.c_int64, C.c_int64, C.c_int, vp]

@@ -1096,6 +1096,24 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                     coords[d] = np.asarray(carried[d].values)
             coords[agglev] = uniq
             return res0, rdims, coords, was_xr
+        if ((not _is_device_tensor(X2)) and layout == "TG" and powers is not None and edd is None and isinstance(plan, SparsePlan)
+                and max(powers) <= 16 and min(powers) >= 1 and len(_host_devices()) < 2):
+            # Host-resident (time, gridcell) field raised to powers (tas_poly, transformations.py:188, then the aggregation):
+            # the same row-block pipeline (wagg_apply_poly_host_*) -- the field crosses PCIe once, lines only, and every
+            # block is raised to its powers on the device, four per pass.  (Before round 5: one pageable copy of the whole
+            # field, ~28 GB/s, then the kernels.)
+            from ._lib import HOST_LINES, HOST_PIN
+            X2c = np.ascontiguousarray(X2)
+            lo, hi = int(min(powers)), int(max(powers))
+            stack = plan.apply_poly_host(X2c, offset, hi - lo + 1, pow_first=lo, flags=HOST_PIN | HOST_LINES)
+            res = [unflatten(stack[int(p) - lo], len(uniq)) for p in powers]
+            rdims = _result_dims(dims, agglev)
+            coords = {}
+            for d in rdims:
+                if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+                    coords[d] = np.asarray(carried[d].values)
+            coords[agglev] = uniq
+            return (res[0] if single else res), rdims, coords, was_xr
         # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
         # kernels, one D2H copy of the result
         Xd = _to_device(X2)

@@ -177,9 +177,12 @@ void clear_error();
 // device can still be using it.
 hipError_t scratch_alloc(void **p, size_t bytes);        // on the current device
 void scratch_free(void *p, bool keep = true);             // keep = false: hipFree now (with its implicit wait for the device)
-hipError_t scratch_stream(hipStream_t *st);              // an idle non-blocking stream of the current device
-void scratch_stream_done(hipStream_t st);
-void release_scratch();                                  // everything kept goes back to the driver
+// an idle non-blocking stream of the current device.  `role`: what the taker will use it for -- 0 kernels / anything, 1 host ->
+// device copies, 2 device -> host copies: a stream comes back with the role it had, and a taker gets a stream of its own role
+// (so a copy-in stream never carries kernels or copies out in another call)
+hipError_t scratch_stream(hipStream_t *st, int role = 0);
+void scratch_stream_done(hipStream_t st, int role = 0, bool keep = true);    // keep = false: destroy it
+void release_scratch(int what = 7);                                  // everything kept goes back to the driver
 template <typename T>
 struct ScratchBuf {                                      // RAII over scratch_alloc (call-lifetime buffers)
     T *p = nullptr;

@@ -24,7 +24,7 @@ namespace wagg {
 struct HostStats {
     std::atomic<int64_t> calls{0}, registered{0}, register_failed{0}, unregistered{0}, unregister_failed{0},
         cleanup_failed{0}, staged_h2d_bytes{0}, staged_d2h_bytes{0}, direct_h2d_bytes{0}, direct_d2h_bytes{0},
-        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0};
+        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0}, blocks_retired{0};
 };
 extern HostStats g_host_stats;
 
@@ -71,6 +71,7 @@ struct DevicePipe {
     hipStream_t sc = nullptr, sk = nullptr, sd = nullptr;      // H2D, kernels, D2H
     hipEvent_t ready[2] = {nullptr, nullptr}, kdone[2] = {nullptr, nullptr}, ddone[2] = {nullptr, nullptr};
     void *dx[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+    bool retire = false;                                        // the device blocks go back to the driver instead of the pool
     hipError_t init(int dev, bool set_device, size_t x_bytes, size_t o_bytes, int nbuf);
     hipError_t drain();                                         // synchronise the three streams
     ~DevicePipe();
@@ -92,6 +93,10 @@ struct HostRowsArgs {
     const int64_t *run_src = nullptr;
     const int32_t *run_len = nullptr;
     int64_t n_runs = 0, crow_bytes = 0;
+    // several result planes per block (the fused powers): `apply` writes plane k of a block of `rows` rows at
+    // out_dev + k * rows * ldo_bytes; plane k of the whole result starts at out_host + k * opstride_bytes
+    int n_planes = 1;
+    int64_t opstride_bytes = 0;
 };
 int stream_host_rows_any(const HostRowsArgs &a);
 

@@ -296,6 +296,7 @@ struct GatherTeam {
     std::atomic<bool> stop{false};
     std::vector<std::thread> th;
     hipEvent_t pev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t sent_bytes = 0, copy_wait_us = 0;            // of this call: packed bytes queued, time spent waiting for their copies
 
     explicit GatherTeam(const HostRowsArgs &args) : a(args) {}
     GatherTeam(const GatherTeam &) = delete;
@@ -358,10 +359,13 @@ struct GatherTeam {
                                     (size_t)(prow * a.crow_bytes), hipMemcpyHostToDevice, sc)) != hipSuccess) return e;
             if ((e = hipEventRecord(pev[p % SLOTS], sc)) != hipSuccess) return e;
             g_host_stats.lines_h2d_bytes += prow * a.crow_bytes;
+            sent_bytes += prow * a.crow_bytes;
             if (p >= 1) {       // the copy of piece p - 1 is over (p stays queued behind it): its slot goes to piece p - 1 + SLOTS
                 const int64_t w1 = now_us();
                 if ((e = hipEventSynchronize(pev[(p - 1) % SLOTS])) != hipSuccess) return e;
-                g_host_stats.lines_wait_copy_us += now_us() - w1;
+                const int64_t dw = now_us() - w1;
+                g_host_stats.lines_wait_copy_us += dw;
+                copy_wait_us += dw;
                 free_upto.store(p + SLOTS, std::memory_order_release);
             }
         }
@@ -387,9 +391,9 @@ hipError_t DevicePipe::init(int dev, bool set_device, size_t x_bytes, size_t o_b
     hipError_t e = hipSuccess;
     if (set_device) { if ((e = hipSetDevice(dev)) != hipSuccess) return e; }
     device = dev;
-    if ((e = scratch_stream(&sc)) != hipSuccess) return e;
+    if ((e = scratch_stream(&sc, 1)) != hipSuccess) return e;
     if ((e = scratch_stream(&sk)) != hipSuccess) return e;
-    if ((e = scratch_stream(&sd)) != hipSuccess) return e;
+    if ((e = scratch_stream(&sd, 2)) != hipSuccess) return e;
     for (int b = 0; b < nbuf && b < 2; ++b) {
         if ((e = hipEventCreateWithFlags(&ready[b], hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&kdone[b], hipEventDisableTiming)) != hipSuccess) return e;
@@ -417,12 +421,13 @@ DevicePipe::~DevicePipe() {
         if (ready[b]) note_cleanup(hipEventDestroy(ready[b]), "hipEventDestroy");
         if (kdone[b]) note_cleanup(hipEventDestroy(kdone[b]), "hipEventDestroy");
         if (ddone[b]) note_cleanup(hipEventDestroy(ddone[b]), "hipEventDestroy");
-        scratch_free(dx[b]);
-        scratch_free(dout[b]);
+        scratch_free(dx[b], !retire);
+        scratch_free(dout[b], !retire);
     }
-    scratch_stream_done(sc);
-    scratch_stream_done(sk);
-    scratch_stream_done(sd);
+    scratch_stream_done(sc, 1);
+    scratch_stream_done(sk, 0);
+    scratch_stream_done(sd, 2);
+    if (retire) release_scratch(1);              // (and what idles in the pool: fresh blocks for the next call)
 }
 
 // ---- the pipeline of one device: blocks slot, slot + n_dev, ... ---------------------------------------------------------
@@ -445,7 +450,7 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     const int dev = a.devices ? a.devices[slot] : -1;
     int cur = 0;
     if (!set_device) WAGG_HIP(hipGetDevice(&cur));
-    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * (gather ? a.crow_bytes : a.ldx_bytes)), (size_t)(B * a.ldo_bytes), my_blocks >= 2 ? 2 : 1));
+    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * (gather ? a.crow_bytes : a.ldx_bytes)), (size_t)(B * a.ldo_bytes * a.n_planes), my_blocks >= 2 ? 2 : 1));
     if (gather) {
         team.reset(new (std::nothrow) GatherTeam(a));
         if (!team || !team->start()) return WAGG_EUNSUPPORTED;       // (nothing queued yet: the caller takes the plain path)
@@ -458,12 +463,17 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
         }
     } rel{a, slot, P.sk};
     auto span = [](int64_t rows, int64_t ld, int64_t row) { return (size_t)((rows - 1) * ld + row); };
+    const int64_t t_begin_us = now_us();
+    int64_t moved_plain = 0;
     int64_t prev_r0 = -1, prev_rows = 0;
     int prev_b = 0;
     auto drain_prev = [&]() -> int {                    // staged return of the previous block (blocks the host)
         if (prev_r0 < 0) return WAGG_OK;
         WAGG_HIP(hipStreamWaitEvent(P.sd, P.kdone[prev_b], 0));
-        WAGG_HIP(staged_d2h_rows(a.out_host + prev_r0 * a.ldo_bytes, P.dout[prev_b], prev_rows, (size_t)a.ldo_bytes, (size_t)a.orow_bytes, P.sd));
+        for (int k = 0; k < a.n_planes; ++k)
+            WAGG_HIP(staged_d2h_rows(a.out_host + k * a.opstride_bytes + prev_r0 * a.ldo_bytes,
+                                     static_cast<const char *>(P.dout[prev_b]) + (size_t)(k * prev_rows * a.ldo_bytes), prev_rows,
+                                     (size_t)a.ldo_bytes, (size_t)a.orow_bytes, P.sd));
         WAGG_HIP(hipEventRecord(P.ddone[prev_b], P.sd));
         prev_r0 = -1;
         return WAGG_OK;
@@ -480,6 +490,7 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
         } else if (pin_x) {
             WAGG_HIP(hipMemcpyAsync(P.dx[b], src, xspan, hipMemcpyHostToDevice, P.sc));      // page-locked source: truly asynchronous
             g_host_stats.direct_h2d_bytes += (int64_t)xspan;
+            moved_plain += (int64_t)xspan;
         } else {
             WAGG_HIP(staged_h2d(P.dx[b], src, xspan, P.sc));
         }
@@ -491,15 +502,18 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
         WAGG_HIP(hipEventRecord(P.kdone[b], P.sk));
         g_host_stats.blocks++;
         if (pin_o) {                                                               // page-locked destination: asynchronous
-            char *dst = a.out_host + r0 * a.ldo_bytes;
             WAGG_HIP(hipStreamWaitEvent(P.sd, P.kdone[b], 0));
-            if (a.ldo_bytes == a.orow_bytes)
-                WAGG_HIP(hipMemcpyAsync(dst, P.dout[b], (size_t)(rows * a.orow_bytes), hipMemcpyDeviceToHost, P.sd));
-            else
-                WAGG_HIP(hipMemcpy2DAsync(dst, (size_t)a.ldo_bytes, P.dout[b], (size_t)a.ldo_bytes, (size_t)a.orow_bytes, (size_t)rows,
-                                          hipMemcpyDeviceToHost, P.sd));
+            for (int k = 0; k < a.n_planes; ++k) {
+                char *dst = a.out_host + k * a.opstride_bytes + r0 * a.ldo_bytes;
+                const char *srcd = static_cast<const char *>(P.dout[b]) + (size_t)(k * rows * a.ldo_bytes);
+                if (a.ldo_bytes == a.orow_bytes)
+                    WAGG_HIP(hipMemcpyAsync(dst, srcd, (size_t)(rows * a.orow_bytes), hipMemcpyDeviceToHost, P.sd));
+                else
+                    WAGG_HIP(hipMemcpy2DAsync(dst, (size_t)a.ldo_bytes, srcd, (size_t)a.ldo_bytes, (size_t)a.orow_bytes, (size_t)rows,
+                                              hipMemcpyDeviceToHost, P.sd));
+            }
             WAGG_HIP(hipEventRecord(P.ddone[b], P.sd));
-            g_host_stats.direct_d2h_bytes += (int64_t)(rows * a.orow_bytes);
+            g_host_stats.direct_d2h_bytes += (int64_t)(rows * a.orow_bytes) * a.n_planes;
         } else {
             // the previous block's result returns through the staging pieces WHILE this block's kernels run (they are
             // queued already); this block's own result follows in the next round (or behind the loop)
@@ -509,6 +523,27 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     }
     if (int rc2 = drain_prev()) return rc2;
     WAGG_HIP(P.drain());
+    // Copy-rate watch.  The pipeline can get into a state in which the copies into its pooled device blocks run at half the
+    // rate (seen on MI355X / ROCm 7.2 in one call sequence -- plain lines-only calls after wagg_apply_poly_host_* calls with
+    // page-locked whole rows, tools/host_poly_timing.py: 21.3 -> 47 ms per call, wait for the copy engine 16.6 -> 31 ms; it
+    // stays until the pool's device blocks go back to the driver -- fresh streams or a fresh ring do not help -- and a
+    // different call order does not show it; cause inside the runtime not established).  A call that moved >= 256 MiB at
+    // < 70 % of the best rate this process has seen on the device for the same kind of call therefore hands its device
+    // blocks, and the idle ones of the pool, back to the driver: the next call allocates its own (~1 ms).
+    {
+        const int64_t moved = gather ? team->sent_bytes : moved_plain;
+        const int64_t us = gather ? team->copy_wait_us : now_us() - t_begin_us;
+        if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x)) {
+            static std::mutex mu;
+            static double best[MAX_DEV][2] = {};
+            const double rate = (double)moved / (double)us;
+            const int di = P.device >= 0 && P.device < MAX_DEV ? P.device : 0;
+            std::lock_guard<std::mutex> lock(mu);
+            double &b = best[di][gather ? 1 : 0];
+            if (rate > b) b = rate;
+            else if (rate < 0.7 * b) { P.retire = true; g_host_stats.blocks_retired++; }
+        }
+    }
     return WAGG_OK;
 }
 
@@ -524,7 +559,9 @@ int stream_host_rows_any(const HostRowsArgs &a) {
         WAGG_REQUIRE(a.n_dev == 1 && a.devices == nullptr, "the lines-only host path drives one device");
         WAGG_REQUIRE(nb == 1 || B % GatherTeam::RPP == 0, "row blocks of %lld rows do not hold whole gather pieces", (long long)B);
     }
-    const size_t xbytes = (size_t)((a.Tn - 1) * a.ldx_bytes + a.xrow_bytes), obytes = (size_t)((a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
+    WAGG_REQUIRE(a.n_planes >= 1 && (a.n_planes == 1 || a.opstride_bytes >= a.Tn * a.ldo_bytes), "bad result planes");
+    const size_t xbytes = (size_t)((a.Tn - 1) * a.ldx_bytes + a.xrow_bytes),
+                 obytes = (size_t)((a.n_planes - 1) * a.opstride_bytes + (a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
     int rc = WAGG_OK;
     {
         HostPin px, po;
@@ -593,11 +630,12 @@ extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
     out->cleanup_failed = s.cleanup_failed;
     out->staged_h2d_bytes = s.staged_h2d_bytes; out->staged_d2h_bytes = s.staged_d2h_bytes;
     out->direct_h2d_bytes = s.direct_h2d_bytes; out->direct_d2h_bytes = s.direct_d2h_bytes;
+    out->blocks_retired = s.blocks_retired;
     out->lines_h2d_bytes = s.lines_h2d_bytes; out->lines_wait_pack_us = s.lines_wait_pack_us; out->lines_wait_copy_us = s.lines_wait_copy_us;
     if (reset) {
         s.calls = 0; s.blocks = 0; s.registered = 0; s.register_failed = 0; s.unregistered = 0; s.unregister_failed = 0;
         s.cleanup_failed = 0; s.staged_h2d_bytes = 0; s.staged_d2h_bytes = 0; s.direct_h2d_bytes = 0; s.direct_d2h_bytes = 0;
-        s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0;
+        s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0; s.blocks_retired = 0;
     }
     return WAGG_OK;
 }

@@ -13,7 +13,7 @@
 //
 // Policy: a freed block is kept unless it is larger than 1/16 of the device's memory; when the blocks kept for a device
 // exceed that same budget the least recently returned go back to the driver.  A request takes the smallest kept block that
-// is large enough and at most a quarter (at least 32 MiB) larger than asked.  Streams: up to eight idle ones per device.
+// is large enough and at most a quarter (at least 32 MiB) larger than asked.  Streams: up to four idle ones per device and role (kernels, copies in, copies out).
 // wagg_release_scratch() frees everything kept (the package's clear_caches() calls it), and an allocation of the library
 // that runs out of device memory does so before it tries once more.
 //
@@ -29,7 +29,7 @@
 namespace wagg {
 namespace {
 struct Block { int device; void *p; size_t cap; uint64_t tick; };
-struct IdleStream { int device; hipStream_t st; };
+struct IdleStream { int device; hipStream_t st; int role; };
 std::mutex g_mu;
 std::vector<Block> g_free, g_live;               // kept blocks; blocks handed out (their size is needed when they return)
 std::vector<IdleStream> g_streams;
@@ -54,17 +54,17 @@ void give_back(const std::vector<Block> &gone) {
 }
 }  // namespace
 
-void release_scratch() {
+void release_scratch(int what) {                 // 1 device blocks, 2 idle streams, 4 the host ring
     std::vector<Block> blocks;
     std::vector<IdleStream> streams;
     {
         std::lock_guard<std::mutex> lock(g_mu);
-        blocks.swap(g_free);
-        streams.swap(g_streams);
+        if (what & 1) blocks.swap(g_free);
+        if (what & 2) streams.swap(g_streams);
     }
     give_back(blocks);
     for (const IdleStream &s : streams) note_cleanup(hipStreamDestroy(s.st), "hipStreamDestroy(kept stream)");
-    release_host_ring();                         // (the page-locked ring of the lines-only host path, wagg_host.hip)
+    if (what & 4) release_host_ring();           // (the page-locked ring of the lines-only host path, wagg_host.hip)
 }
 
 int64_t scratch_bytes_kept() {
@@ -151,7 +151,7 @@ void scratch_free(void *p, bool keep) {
     give_back(gone);
 }
 
-hipError_t scratch_stream(hipStream_t *st) {
+hipError_t scratch_stream(hipStream_t *st, int role) {
     *st = nullptr;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
@@ -159,7 +159,7 @@ hipError_t scratch_stream(hipStream_t *st) {
     {
         std::lock_guard<std::mutex> lock(g_mu);
         for (size_t i = 0; i < g_streams.size(); ++i)
-            if (g_streams[i].device == device) {
+            if (g_streams[i].device == device && g_streams[i].role == role) {
                 *st = g_streams[i].st;
                 g_streams.erase(g_streams.begin() + (long)i);
                 return hipSuccess;
@@ -168,16 +168,16 @@ hipError_t scratch_stream(hipStream_t *st) {
     return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
 }
 
-void scratch_stream_done(hipStream_t st) {
+void scratch_stream_done(hipStream_t st, int role, bool keep) {
     if (!st) return;
     int device = -1;
-    bool keep = hipStreamGetDevice(st, &device) == hipSuccess;
+    keep = keep && hipStreamGetDevice(st, &device) == hipSuccess;
     if (keep) {
         std::lock_guard<std::mutex> lock(g_mu);
         size_t idle = 0;
-        for (const IdleStream &s : g_streams) if (s.device == device) ++idle;
-        keep = idle < MAX_IDLE_STREAMS;
-        if (keep) { try { g_streams.push_back(IdleStream{device, st}); } catch (const std::bad_alloc &) { keep = false; } }
+        for (const IdleStream &s : g_streams) if (s.device == device && s.role == role) ++idle;
+        keep = idle < MAX_IDLE_STREAMS / 2;
+        if (keep) { try { g_streams.push_back(IdleStream{device, st, role}); } catch (const std::bad_alloc &) { keep = false; } }
     }
     if (!keep) note_cleanup(hipStreamDestroy(st), "hipStreamDestroy(scratch stream)");
 }
@@ -191,3 +191,4 @@ extern "C" int wagg_release_scratch(void) {
     wagg::release_scratch();
     return WAGG_OK;
 }
+

@@ -1200,7 +1200,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const auto &d = edd_lcv ? d_edd
                             : (gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64) : (use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d));
     if (int rc = check_timeout(plan)) return rc;
-    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse == 1 && xpow == 0 && d.Gc > 0 && ldx >= d.Gc),
+    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse <= 4 && xpow != XF_EDD && d.Gc > 0 && ldx >= d.Gc),
                  "compact rows need the whole-line chunking of this plan and data type");
     const int64_t Gk = compact ? d.Gc : (int64_t)plan->info.G;        // cells of a row as the kernels see it
     if (nfuse > 1) {
@@ -1210,7 +1210,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
         if (!lc_ok || nfuse > 4) {
             for (int i = 0; i < nfuse; ++i) {
                 const int rc = launch_sparse<T, TB>(plan, X, Ttot, ldx, layout, out + (int64_t)i * pstride, ldo,
-                                                    out_layout, stream, xoff, xpow + i);
+                                                    out_layout, stream, xoff, xpow + i, 1, 0, nullptr, nullptr, 0, compact);
                 if (rc != WAGG_OK) return rc;
             }
             return WAGG_OK;
@@ -2057,6 +2057,47 @@ static int check_plan_device(const wagg_plan *plan) {
     return WAGG_OK;
 }
 
+// The row-block pipeline of a host-resident (time, gridcell) field with a (time, region) result (wagg_host.h), for the plain
+// aggregation and for the fused powers: `launch(xd, rows, ldx_dev, od, st, compact)` queues the device work of one block
+// -- rows x ldx_dev cells in, n_planes planes of rows x ldo out (plane k at od + k * rows * ldo) -- on `st`.
+template <typename T, typename LaunchFn>
+static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, T *out, int64_t ldo, int flags,
+                              int n_planes, int64_t opstride, LaunchFn launch) {
+    HostRowsArgs a;
+    a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
+    a.Tn = Tn;
+    a.ldx_bytes = ldx * (int64_t)sizeof(T); a.xrow_bytes = plan->info.G * (int64_t)sizeof(T);
+    a.ldo_bytes = ldo * (int64_t)sizeof(T); a.orow_bytes = (int64_t)plan->info.R * (int64_t)sizeof(T);
+    a.quantum = 64; a.flags = flags; a.n_dev = 1; a.devices = nullptr;
+    a.n_planes = n_planes; a.opstride_bytes = opstride * (int64_t)sizeof(T);
+    a.release = [&](int, hipStream_t st) { plan->drop_staging(st); };
+    // lines only: host threads pack the quads the whole-line chunking fetches into page-locked pieces and only those
+    // cross PCIe (c2-real: 64 % of a fp32 row, 47 % of a fp64 row).  Taken when asked for, when the plan has that
+    // chunking for T, when the row shrinks to <= 80 % and the field is large enough to be worth a thread team; a team
+    // that cannot start (ring in use by a concurrent call, too few usable CPUs) means the plain pipeline below
+    const SparsePlanDev &dc = sizeof(T) == 4 ? plan->dl : plan->dl64;
+    const bool has_c = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && dc.Gc > 0 && !dc.run_len.empty();
+    if ((flags & WAGG_HOST_LINES) && has_c && 5 * dc.Gc <= 4 * (int64_t)plan->info.G &&
+        Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
+        std::vector<int64_t> src(dc.run_src.size());
+        std::vector<int32_t> len(dc.run_len.size());
+        for (size_t k = 0; k < src.size(); ++k) { src[k] = dc.run_src[k] * (int64_t)sizeof(T); len[k] = dc.run_len[k] * (int32_t)sizeof(T); }
+        HostRowsArgs c = a;
+        c.run_src = src.data(); c.run_len = len.data(); c.n_runs = (int64_t)src.size(); c.crow_bytes = dc.Gc * (int64_t)sizeof(T);
+        const int64_t Gc = dc.Gc;
+        c.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
+            return launch(static_cast<const T *>(xd), rows, Gc, static_cast<T *>(od), st, true);
+        };
+        const int rc = stream_host_rows_any(c);
+        if (rc != WAGG_EUNSUPPORTED) return rc;
+        clear_error();
+    }
+    a.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
+        return launch(static_cast<const T *>(xd), rows, ldx, static_cast<T *>(od), st, false);
+    };
+    return stream_host_rows_any(a);
+}
+
 template <typename T, typename F>
 static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, int layout, T *out,
                       int64_t ldo, int out_layout, int flags, F fn) {
@@ -2066,40 +2107,12 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
     if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
-        // lines only: host threads pack the quads the whole-line chunking fetches into page-locked pieces and only those
-        // cross PCIe (c2-real: 64 % of a fp32 row, 47 % of a fp64 row).  Taken when asked for, when the plan has that
-        // chunking for T, when the row shrinks to <= 80 % and the field is large enough to be worth a thread team; a team
-        // that cannot start (ring in use by a concurrent call, no thread to be had) means the plain pipeline below
-        const SparsePlanDev &dc = sizeof(T) == 4 ? plan->dl : plan->dl64;
-        const bool has_c = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && dc.Gc > 0 && !dc.run_len.empty();
-        if ((flags & WAGG_HOST_LINES) && has_c && 5 * dc.Gc <= 4 * (int64_t)plan->info.G &&
-            Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
-            std::vector<int64_t> src(dc.run_src.size());
-            std::vector<int32_t> len(dc.run_len.size());
-            for (size_t k = 0; k < src.size(); ++k) { src[k] = dc.run_src[k] * (int64_t)sizeof(T); len[k] = dc.run_len[k] * (int32_t)sizeof(T); }
-            HostRowsArgs a;
-            a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
-            a.Tn = Tn;
-            a.ldx_bytes = ldx * (int64_t)sizeof(T); a.xrow_bytes = plan->info.G * (int64_t)sizeof(T);
-            a.ldo_bytes = ldo * (int64_t)sizeof(T); a.orow_bytes = (int64_t)plan->info.R * (int64_t)sizeof(T);
-            a.quantum = 64; a.flags = flags; a.n_dev = 1; a.devices = nullptr;
-            a.run_src = src.data(); a.run_len = len.data(); a.n_runs = (int64_t)src.size(); a.crow_bytes = dc.Gc * (int64_t)sizeof(T);
-            const int64_t Gc = dc.Gc;
-            a.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
-                return launch_sparse<T, (sizeof(T) == 4 ? 64 : 32)>(plan, static_cast<const T *>(xd), rows, Gc, WAGG_LAYOUT_TG, static_cast<T *>(od), ldo,
-                                                                    WAGG_OUT_TR, st, T(0), 0, 1, 0, nullptr, nullptr, 0, true);
-            };
-            a.release = [&](int, hipStream_t st) { plan->drop_staging(st); };
-            rc = stream_host_rows_any(a);
-            if (rc == WAGG_OK) return check_timeout(plan);
-            if (rc != WAGG_EUNSUPPORTED) return rc;
-            clear_error();
-        }
-        rc = stream_host_rows<T>(X, Tn, ldx, plan->info.G, out, ldo, plan->info.R, flags, 64, 1, nullptr,
-                                 [&](int, const T *xd, int64_t rows, T *od, hipStream_t st) {
-                                     return fn(plan, xd, rows, ldx, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
-                                 },
-                                 [&](int, hipStream_t st) { plan->drop_staging(st); });
+        rc = host_rows_pipeline<T>(plan, X, Tn, ldx, out, ldo, flags, 1, 0,
+                                   [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                                       if (!compact) return fn(plan, xd, rows, ldx_dev, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
+                                       return launch_sparse<T, (sizeof(T) == 4 ? 64 : 32)>(plan, xd, rows, ldx_dev, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, st,
+                                                                                           T(0), 0, 1, 0, nullptr, nullptr, 0, true);
+                                   });
         if (rc != WAGG_OK) return rc;
         return check_timeout(plan);
     }
@@ -2117,6 +2130,33 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     WAGG_HIP(hipDeviceSynchronize());
     if (int rc2 = check_timeout(plan)) return rc2;
     return copy_rows_to_host(out, dout.p, orows, sizeof(T) * (size_t)ldo, sizeof(T) * (size_t)ocols, pin);
+}
+
+// The fused powers of a host-resident field (wagg_apply_poly_host_*): the same pipeline, n_pow result planes per block.
+template <typename T>
+static int apply_poly_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, double offset, int pow_first, int n_pow,
+                           T *out, int64_t ldo, int64_t out_pstride, int flags) {
+    clear_error();
+    int rc = check_apply_args(plan, X, Tn, ldx, WAGG_LAYOUT_TG, out, ldo, WAGG_OUT_TR);
+    if (rc != WAGG_OK) return rc;
+    WAGG_REQUIRE(pow_first >= 1 && n_pow >= 1 && pow_first + n_pow - 1 <= 16, "powers must lie in [1, 16], got %d..%d", pow_first,
+                 pow_first + n_pow - 1);
+    WAGG_REQUIRE(n_pow == 1 || out_pstride >= Tn * ldo, "out_pstride %lld overlaps the previous power", (long long)out_pstride);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
+    if (Tn == 0) return WAGG_OK;
+    if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
+    constexpr int TB = sizeof(T) == 4 ? 64 : 32;
+    rc = host_rows_pipeline<T>(plan, X, Tn, ldx, out, ldo, flags, n_pow, out_pstride,
+                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                                   int r2 = WAGG_OK;
+                                   const int64_t ps = rows * ldo;                 // planes of one block lie side by side
+                                   for (int i = 0; i < n_pow && r2 == WAGG_OK; i += 4)      // one pass over the block per four powers
+                                       r2 = launch_sparse<T, TB>(plan, xd, rows, ldx_dev, WAGG_LAYOUT_TG, od + (int64_t)i * ps, ldo, WAGG_OUT_TR, st,
+                                                                 (T)offset, pow_first + i, n_pow - i < 4 ? n_pow - i : 4, ps, nullptr, nullptr, 0, compact);
+                                   return r2;
+                               });
+    if (rc != WAGG_OK) return rc;
+    return check_timeout(plan);
 }
 
 // Multi-device form (SURVEY 8b `n_devices`, 8e "one process driving all devices"): plan replica s lives on device
@@ -2172,6 +2212,15 @@ extern "C" int wagg_apply_host_multi_f32(const wagg_plan *const *plans, const in
 extern "C" int wagg_apply_host_multi_f64(const wagg_plan *const *plans, const int *devices, int n_devices, const double *X_host,
                                          int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags) {
     return wagg::apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, wagg_apply_f64);
+}
+
+extern "C" int wagg_apply_poly_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+                                        int n_pow, float *out_host, int64_t ldo, int64_t out_pstride, int flags) {
+    return wagg::apply_poly_host<float>(plan, X_host, T, ldx, offset, pow_first, n_pow, out_host, ldo, out_pstride, flags);
+}
+extern "C" int wagg_apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+                                        int n_pow, double *out_host, int64_t ldo, int64_t out_pstride, int flags) {
+    return wagg::apply_poly_host<double>(plan, X_host, T, ldx, offset, pow_first, n_pow, out_host, ldo, out_pstride, flags);
 }
 
 extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,

@@ -220,6 +220,25 @@ class SparsePlan:
         return out
 
 
+    def apply_poly_host(self, X, offset, n_pow, pow_first=1, flags=0):
+        """The fused powers of a host-resident (time, gridcell) field (``wagg_apply_poly_host_*``): numpy in, a
+        (n_pow, T, R) numpy array out; the field crosses PCIe once (``_lib.HOST_LINES``: only the lines the table
+        references), every row block is raised to its powers on the device."""
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64) or X.ndim != 2:
+            raise TypeError("X must be a 2-D float32/float64 array")
+        if X.shape[1] != self.G:
+            raise ValueError("X has %d grid cells, plan expects %d" % (X.shape[1], self.G))
+        T = X.shape[0]
+        out = np.empty((int(n_pow), T, self.R), dtype=X.dtype)
+        L = _lib.load()
+        fn = L.wagg_apply_poly_host_f32 if X.dtype == np.float32 else L.wagg_apply_poly_host_f64
+        with _on_device(self.device):
+            _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], float(offset), int(pow_first), int(n_pow),
+                          C.c_void_p(out.ctypes.data), max(1, self.R), max(1, T * self.R), int(flags)), "wagg_apply_poly_host")
+        return out
+
+
 class DensePlan:
     """Dense-family plan: W as a (gridcell x region) matrix resident in HBM contracted on the matrix
     cores (full or tile-sparse form; fp32 or fp64 weights), or per-wave entry lists for scattered,

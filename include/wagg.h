@@ -222,6 +222,7 @@ typedef struct wagg_host_stats {
     int64_t lines_h2d_bytes;      /* packed rows of the lines-only path (WAGG_HOST_LINES) ...                              */
     int64_t lines_wait_pack_us;   /* ... time its pipeline thread waited for the packing threads (they are the bottleneck) */
     int64_t lines_wait_copy_us;   /* ... and for the copy engine to hand a ring piece back (PCIe is the bottleneck)        */
+    int64_t blocks_retired;       /* calls whose copies ran < 70 % of the best rate seen: their device blocks left the pool  */
 } wagg_host_stats;
 int wagg_host_stats_read(wagg_host_stats *out, int reset);
 
@@ -241,6 +242,16 @@ int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, in
 int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
                         double offset, int pow_first, int n_pow, double *out_dev, int64_t ldo,
                         int64_t out_pstride, int out_layout, void *stream);
+/* The same for a HOST-resident (time, gridcell) field, (time, region) results in host memory (round 5): the field goes
+ * through the row-block pipeline of wagg_apply_host_ex_* once -- every block is raised to its powers on the device, four
+ * per pass -- and plane i of the result (power pow_first + i) lands at out_host + i * out_pstride (elements, >= T * ldo)
+ * with leading dimension ldo.  flags: WAGG_HOST_PIN, WAGG_HOST_LINES (as there; WAGG_HOST_LINES sends only the 128-byte
+ * lines the table references).  This is the reference's tas_poly-then-aggregate on the arrays its callers hold
+ * (transformations.py:188 + aggregations.py:87): c2-real, four powers, 1.5 GB field: DESIGN.md (f).  Blocking. */
+int wagg_apply_poly_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+                             int n_pow, float *out_host, int64_t ldo, int64_t out_pstride, int flags);
+int wagg_apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+                             int n_pow, double *out_host, int64_t ldo, int64_t out_pstride, int flags);
 
 /* Replaces  snyder_edd  (transformations.py:7-93: Snyder exceedance degree days of the daily
  * (tasmin, tasmax) pair at a threshold e, the nested xr.where of :75-87) followed by the

@@ -724,3 +724,45 @@ def test_lines_only_host_path_gives_the_bits_of_the_whole_rows(torch_cuda, dtype
     assert _lib.host_stats()["lines_h2d_bytes"] == 0
     quads.close()
     plan.close()
+
+
+@pytest.mark.parametrize("dtype,T,rtol", [(np.float32, 301, RTOL32), (np.float64, 150, RTOL64)])
+def test_fused_powers_of_a_host_resident_field(torch_cuda, dtype, T, rtol):
+    """wagg_apply_poly_host_*: tas_poly-then-aggregate (transformations.py:188 + aggregations.py:87) on a HOST array -- the
+    row-block pipeline with n_pow result planes per block, with and without WAGG_HOST_LINES -- bit-equal to the device form
+    of the same fused kernel (wagg_apply_poly_*), within tolerance of the oracle (transform the grid, then aggregate), five
+    powers (two passes per block), and through the reference-named functions on a host-resident Dataset."""
+    from climate_toolbox_amd import _lib, engine, minixr, synth, tas_poly, weighted_aggregate_grid_to_regions
+    from climate_toolbox_amd import aggregations as A
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(nlat=192, nlon=384, R=600, n_iso=20, seed=5, land_frac=0.15, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R = len(lat) * len(lon), len(uniq)
+    plan = engine.SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    rng = np.random.default_rng(11)
+    X = (273.15 + 25 * rng.random((T, G))).astype(dtype)
+    X[rng.random((T, G)) < 0.005] = np.nan
+    dev = plan.apply_poly(torch.from_numpy(X).cuda(), -273.15, 5).cpu().numpy()
+    for flags in (_lib.HOST_PIN, _lib.HOST_PIN | _lib.HOST_LINES, _lib.HOST_LINES):
+        _lib.host_stats(reset=True)
+        got = plan.apply_poly_host(X, -273.15, 5, flags=flags)
+        np.testing.assert_array_equal(got, dev)
+        assert (_lib.host_stats()["lines_h2d_bytes"] > 0) == bool(flags & _lib.HOST_LINES)
+    for p in (1, 3, 5):
+        ref = O.agg_coded(O.tas_poly_values(X.astype(np.float64), p), cell, code, w, R)
+        _rel_ok(dev[p - 1], ref, rtol * (4 if p > 3 else 1), scale=1.0)       # (x - 273.15 in the data type: absolute near 0)
+    np.testing.assert_array_equal(plan.apply_poly_host(X[:40], -273.15, 2, pow_first=2), dev[1:3, :40])       # small field, other powers
+    with pytest.raises(_lib.WaggError):
+        plan.apply_poly_host(X[:8], 0.0, 3, pow_first=15)
+    plan.close()
+    # the drop-in: a host-resident Dataset through tas_poly, then the aggregation
+    A._PLAN_CACHE.clear()
+    time_ = np.datetime64("2001-01-01") + np.arange(T)                               # (no leap day: nothing is dropped)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), X.reshape(T, len(lat), len(lon)))},
+                        coords={"time": time_, "lat": lat, "lon": lon})
+    _lib.host_stats(reset=True)
+    out = weighted_aggregate_grid_to_regions(tas_poly(ds, 3, "tas-poly-3"), "tas-poly-3", "areawt", "hierid", df)
+    assert _lib.host_stats()["lines_h2d_bytes"] > 0
+    # (one power by itself and the same power inside a fused pass multiply in another order: last-bit differences)
+    np.testing.assert_allclose(np.asarray(out["tas-poly-3"].values), dev[2], rtol=5e-6 if dtype == np.float32 else 1e-13)
