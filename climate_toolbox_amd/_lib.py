@@ -39,7 +39,7 @@ EXPORTS = (
     "wagg_apply_host_multi_f32", "wagg_apply_host_multi_f64", "wagg_dense_apply_host_multi_f32", "wagg_dense_apply_host_multi_f64",
     "wagg_host_block_plan", "wagg_host_stats_read",
     "wagg_combine_planes_f32", "wagg_combine_planes_f64", "wagg_take_axis", "wagg_relayout_f32", "wagg_relayout_f64",
-    "wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64", "wagg_synth_table_csr", "wagg_relayout_to_f64",
+    "wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64", "wagg_synth_table_csr", "wagg_relayout_to_f64", "wagg_upload",
     "wagg_shard_group_create", "wagg_shard_group_destroy", "wagg_shard_group_info",
     "wagg_apply_sharded_f32", "wagg_apply_sharded_f64", "wagg_dense_apply_sharded_f32", "wagg_dense_apply_sharded_f64",
 )
@@ -147,6 +147,7 @@ def load():
     for name in ("wagg_relayout_f32", "wagg_relayout_f64"):
         getattr(L, name).argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]
     L.wagg_relayout_to_f64.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp, vp]
+    L.wagg_upload.argtypes = [vp, vp, C.c_int64]
     L.wagg_host_block_plan.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wagg_host_stats_read.argtypes = [C.POINTER(HostStats), C.c_int]
     for name in ("wagg_gather_f32", "wagg_gather_f64"):

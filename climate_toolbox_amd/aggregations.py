@@ -535,11 +535,11 @@ def _is_device_tensor(values):
 
 
 def _to_device(X2):
-    """2-D host array -> device tensor (one pageable H2D copy); device tensors pass through."""
+    """2-D host array -> device tensor (``wagg_upload``: one DMA from the array page-locked in place for the call -- no
+    pageable pointer goes to a runtime copy, no pin is left behind); device tensors pass through."""
     if _is_device_tensor(X2):
         return X2
-    import torch
-    return torch.from_numpy(X2).cuda()
+    return _engine.upload(X2)
 
 
 def _flatten_for_device(values, dims):

@@ -5,6 +5,7 @@
 #include <utility>
 
 #include "wagg_common.h"
+#include "wagg_host.h"
 
 namespace wagg {
 
@@ -336,6 +337,13 @@ static int relayout_to_f64(const void *src, int src_type, int nd, const int64_t 
     return WAGG_OK;
 }
 }  // namespace wagg
+
+extern "C" int wagg_upload(void *dst_dev, const void *src_host, int64_t bytes) {
+    using namespace wagg;
+    clear_error();
+    WAGG_REQUIRE(bytes >= 0 && (bytes == 0 || (dst_dev && src_host)), "bad upload request");
+    return copy_to_device(dst_dev, src_host, (size_t)bytes, true);
+}
 
 extern "C" int wagg_relayout_to_f64(const void *src_dev, int src_type, int ndim, const int64_t *shape, const int64_t *src_strides,
                                     double *dst_dev, void *stream) {

@@ -620,6 +620,20 @@ def take_axis(t, axis, index, stream=None):
     return out
 
 
+def upload(a):
+    """A C-contiguous float32 / float64 NumPy array as a CUDA tensor of the current device (``wagg_upload``: page-locked in
+    place for one DMA when it is large, through the library's staging pieces otherwise; blocking)."""
+    torch = require_gpu()
+    a = np.ascontiguousarray(a)
+    dt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(a.dtype)
+    if dt is None:
+        raise TypeError("float32 or float64 arrays only, got %s" % a.dtype)
+    out = torch.empty(a.shape, dtype=dt, device="cuda")
+    torch.cuda.current_stream().synchronize()          # (the caching allocator may hand out memory the stream still writes)
+    _lib.check(_lib.load().wagg_upload(C.c_void_p(out.data_ptr()), C.c_void_p(a.ctypes.data), a.nbytes), "wagg_upload")
+    return out
+
+
 def relayout(t, order=None, stream=None):
     """A contiguous copy of ``t`` (float32/float64 CUDA tensor, any strides), its dims in ``order`` if given
     (``wagg_relayout_*``): what ``permute(order).contiguous()`` would do, in the library's own kernel."""

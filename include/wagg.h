@@ -306,6 +306,14 @@ int wagg_relayout_f64(const double *src_dev, int ndim, const int64_t *shape, con
 #define WAGG_T_F64 8
 int wagg_relayout_to_f64(const void *src_dev, int src_type, int ndim, const int64_t *shape, const int64_t *src_strides,
                          double *dst_dev, void *stream);
+/* One blocking copy of a contiguous host buffer to the device, the way the library uploads its own operands: buffers of
+ * >= 32 MiB are page-locked in place for the copy (one DMA; the lock goes before the call returns), smaller ones pass through
+ * the library's page-locked staging pieces -- a pageable pointer is never handed to a runtime copy, which pins the range on
+ * the fly and keeps that pin, keyed by address, beyond the call.  Measured (tools/host_edd_timing.py, 1.5 GB): 32.4 ms =
+ * 47 GB/s lock + copy + unlock, the same as a runtime copy of an array the runtime has pinned in an earlier call (32.8 ms;
+ * its first copy of a new array is slower).  The drop-in uploads the host-resident fields the row-block pipelines do not
+ * serve (degree days, (gridcell, time) data, dense-family plans with transforms) through it.                                */
+int wagg_upload(void *dst_dev, const void *src_host, int64_t bytes);
 int wagg_any_less_f32(const float *a_dev, const float *b_dev, int64_t n, int *result, void *stream);
 int wagg_any_less_f64(const double *a_dev, const double *b_dev, int64_t n, int *result, void *stream);
 

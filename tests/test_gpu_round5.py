@@ -766,3 +766,22 @@ def test_fused_powers_of_a_host_resident_field(torch_cuda, dtype, T, rtol):
     assert _lib.host_stats()["lines_h2d_bytes"] > 0
     # (one power by itself and the same power inside a fused pass multiply in another order: last-bit differences)
     np.testing.assert_allclose(np.asarray(out["tas-poly-3"].values), dev[2], rtol=5e-6 if dtype == np.float32 else 1e-13)
+
+
+def test_upload_is_the_array_on_the_device(torch_cuda):
+    """wagg_upload (what the drop-in moves host-resident fields with when no row-block pipeline serves them): small arrays
+    through the staging pieces, large ones page-locked in place for one DMA and unlocked again; values bit for bit."""
+    from climate_toolbox_amd import _lib, engine
+    rng = np.random.default_rng(0)
+    for shape, dt in (((7, 13), np.float32), ((3000, 3000), np.float32), ((2100, 2048), np.float64), ((0, 5), np.float64)):
+        a = rng.standard_normal(shape).astype(dt)
+        _lib.host_stats(reset=True)
+        t = engine.upload(a)
+        assert tuple(t.shape) == shape and str(t.dtype).endswith(np.dtype(dt).name)
+        np.testing.assert_array_equal(t.cpu().numpy(), a)
+        st = _lib.host_stats()
+        assert st["registered"] == st["unregistered"] == (1 if a.nbytes >= (32 << 20) else 0) and st["register_failed"] == 0
+    v = rng.standard_normal((50, 64)).astype(np.float32)[:, ::2]             # a strided view is made contiguous first
+    np.testing.assert_array_equal(engine.upload(v).cpu().numpy(), v)
+    with pytest.raises(TypeError):
+        engine.upload(np.zeros(4, dtype=np.int32))
