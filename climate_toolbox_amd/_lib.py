@@ -26,7 +26,7 @@ EXPORTS = (
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
     "wagg_apply_host_ex_f32", "wagg_apply_host_ex_f64", "wagg_dense_apply_host_f32", "wagg_dense_apply_host_f64",
     "wagg_apply_poly_f32", "wagg_apply_poly_f64", "wagg_apply_edd_f32", "wagg_apply_edd_f64",
-    "wagg_apply_poly_host_f32", "wagg_apply_poly_host_f64",
+    "wagg_apply_poly_host_f32", "wagg_apply_poly_host_f64", "wagg_apply_edd_host_f32", "wagg_apply_edd_host_f64",
     "wagg_gather_f32", "wagg_gather_f64",
     "wagg_transform_poly_f32", "wagg_transform_poly_f64", "wagg_transform_edd_f32", "wagg_transform_edd_f64",
     "wagg_any_less_f32", "wagg_any_less_f64",
@@ -129,6 +129,8 @@ def load():
                                      C.c_int64, C.c_int64, C.c_int, vp]
     for name in ("wagg_apply_poly_host_f32", "wagg_apply_poly_host_f64"):
         getattr(L, name).argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_double, C.c_int, C.c_int, vp, C.c_int64, C.c_int64, C.c_int]
+    for name in ("wagg_apply_edd_host_f32", "wagg_apply_edd_host_f64"):
+        getattr(L, name).argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_double, f64p, C.c_int, vp, C.c_int64, C.c_int64, C.c_int]
     for name in ("wagg_apply_edd_f32", "wagg_apply_edd_f64"):
         getattr(L, name).argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int, C.c_double, f64p, C.c_int, vp,
                                      C.c_int64, C.c_int64, C.c_int, vp]

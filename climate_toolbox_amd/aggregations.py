@@ -1114,6 +1114,25 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                     coords[d] = np.asarray(carried[d].values)
             coords[agglev] = uniq
             return (res[0] if single else res), rdims, coords, was_xr
+        if ((not _is_device_tensor(X2)) and layout == "TG" and edd is not None and isinstance(plan, SparsePlan)
+                and len(edd[2]) == 1 and edd[2][0][0] == 1.0 and len(_host_devices()) < 2):
+            # Host-resident tasmin / tasmax, one set of degree days (snyder_edd, transformations.py:7-93, then the aggregation):
+            # both fields through the row-block pipeline together (wagg_apply_edd_host_*), lines only.  (A combination of
+            # several degree-day planes -- snyder_gdd -- is summed on the device: the upload-then-kernels way below.)
+            H2 = _flatten_for_device(edd[0], dims)[0]
+            if not _is_device_tensor(H2):
+                if H2.shape != X2.shape or H2.dtype != X2.dtype:
+                    raise ValueError("tasmin and tasmax must have the same shape and dtype")
+                from ._lib import HOST_LINES, HOST_PIN
+                stack = plan.apply_edd_host(np.ascontiguousarray(X2), np.ascontiguousarray(H2), [edd[2][0][1]], offset=edd[1],
+                                            flags=HOST_PIN | HOST_LINES)
+                rdims = _result_dims(dims, agglev)
+                coords = {}
+                for d in rdims:
+                    if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
+                        coords[d] = np.asarray(carried[d].values)
+                coords[agglev] = uniq
+                return unflatten(stack[0], len(uniq)), rdims, coords, was_xr
         # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
         # kernels, one D2H copy of the result
         Xd = _to_device(X2)

@@ -93,6 +93,9 @@ struct HostRowsArgs {
     const int64_t *run_src = nullptr;
     const int32_t *run_len = nullptr;
     int64_t n_runs = 0, crow_bytes = 0;
+    // a second field of the same shape and pitch (the degree days' tasmax beside tasmin in X_host): whole rows: block f of a
+    // device block at X_dev + f * rows * ldx_bytes; gathered rows: a compact row holds field 0 then field 1 (2 * crow_bytes)
+    const char *X2_host = nullptr;
     // several result planes per block (the fused powers): `apply` writes plane k of a block of `rows` rows at
     // out_dev + k * rows * ldo_bytes; plane k of the whole result starts at out_host + k * opstride_bytes
     int n_planes = 1;

@@ -297,6 +297,7 @@ struct GatherTeam {
     std::vector<std::thread> th;
     hipEvent_t pev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     int64_t sent_bytes = 0, copy_wait_us = 0;            // of this call: packed bytes queued, time spent waiting for their copies
+    int64_t crow_all = 0;                                // bytes of a packed row: every field's compact row side by side
 
     explicit GatherTeam(const HostRowsArgs &args) : a(args) {}
     GatherTeam(const GatherTeam &) = delete;
@@ -309,9 +310,10 @@ struct GatherTeam {
             // row; measured, tools/micro/host_gather.cpp: 4 threads 24-26 ms, 8 threads 18 ms, whole rows 26.3 ms)
             int want = granted_cpus() / 2;
             want = want > 8 ? 8 : want;
-            const int need = (int)((6 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes);
+            const int need = (int)((6 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes);       // (per field: two fields, twice the bytes on both sides)
             if (want < 1 || want < need || (int64_t)want > a.Tn) return false;
-            piece_bytes = (size_t)(RPP * a.crow_bytes);
+            crow_all = a.crow_bytes * (a.X2_host ? 2 : 1);
+            piece_bytes = (size_t)(RPP * crow_all);
             n_pieces = (a.Tn + RPP - 1) / RPP;
             doff.resize((size_t)a.n_runs);
             int64_t off = 0;
@@ -340,14 +342,17 @@ struct GatherTeam {
                 if (spins < 64) std::this_thread::yield();
                 else std::this_thread::sleep_for(std::chrono::microseconds(50));
             }
-            const char *src = a.X_host + r * a.ldx_bytes;
-            char *dst = ring + (size_t)(p % SLOTS) * piece_bytes + (size_t)((r % RPP) * a.crow_bytes);
-            for (int64_t k = 0; k < a.n_runs; ++k) copy_run(dst + doff[(size_t)k], src + a.run_src[k], (size_t)a.run_len[k]);
+            char *dst = ring + (size_t)(p % SLOTS) * piece_bytes + (size_t)((r % RPP) * crow_all);
+            for (int f = 0; f < (a.X2_host ? 2 : 1); ++f) {
+                const char *src = (f ? a.X2_host : a.X_host) + r * a.ldx_bytes;
+                char *df = dst + (size_t)f * (size_t)a.crow_bytes;
+                for (int64_t k = 0; k < a.n_runs; ++k) copy_run(df + doff[(size_t)k], src + a.run_src[k], (size_t)a.run_len[k]);
+            }
             runs_done();
             done[(size_t)p].fetch_add(1, std::memory_order_release);
         }
     }
-    // rows [r0, r0 + rows) of the field -> dst_dev (rows x crow_bytes), queued on `sc` piece by piece
+    // rows [r0, r0 + rows) of the field(s) -> dst_dev (rows x crow_all), queued on `sc` piece by piece
     hipError_t send_block(char *dst_dev, int64_t r0, int64_t rows, hipStream_t sc) {
         hipError_t e;
         for (int64_t p = r0 / RPP; p * RPP < r0 + rows; ++p) {
@@ -355,11 +360,11 @@ struct GatherTeam {
             const int64_t w0 = now_us();
             while (done[(size_t)p].load(std::memory_order_acquire) < (int)prow) std::this_thread::yield();
             g_host_stats.lines_wait_pack_us += now_us() - w0;
-            if ((e = hipMemcpyAsync(dst_dev + (size_t)((pr0 - r0) * a.crow_bytes), ring + (size_t)(p % SLOTS) * piece_bytes,
-                                    (size_t)(prow * a.crow_bytes), hipMemcpyHostToDevice, sc)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(dst_dev + (size_t)((pr0 - r0) * crow_all), ring + (size_t)(p % SLOTS) * piece_bytes,
+                                    (size_t)(prow * crow_all), hipMemcpyHostToDevice, sc)) != hipSuccess) return e;
             if ((e = hipEventRecord(pev[p % SLOTS], sc)) != hipSuccess) return e;
-            g_host_stats.lines_h2d_bytes += prow * a.crow_bytes;
-            sent_bytes += prow * a.crow_bytes;
+            g_host_stats.lines_h2d_bytes += prow * crow_all;
+            sent_bytes += prow * crow_all;
             if (p >= 1) {       // the copy of piece p - 1 is over (p stays queued behind it): its slot goes to piece p - 1 + SLOTS
                 const int64_t w1 = now_us();
                 if ((e = hipEventSynchronize(pev[(p - 1) % SLOTS])) != hipSuccess) return e;
@@ -450,7 +455,7 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     const int dev = a.devices ? a.devices[slot] : -1;
     int cur = 0;
     if (!set_device) WAGG_HIP(hipGetDevice(&cur));
-    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * (gather ? a.crow_bytes : a.ldx_bytes)), (size_t)(B * a.ldo_bytes * a.n_planes), my_blocks >= 2 ? 2 : 1));
+    WAGG_HIP(P.init(set_device ? dev : cur, set_device, (size_t)(B * (gather ? a.crow_bytes : a.ldx_bytes) * (a.X2_host ? 2 : 1)), (size_t)(B * a.ldo_bytes * a.n_planes), my_blocks >= 2 ? 2 : 1));
     if (gather) {
         team.reset(new (std::nothrow) GatherTeam(a));
         if (!team || !team->start()) return WAGG_EUNSUPPORTED;       // (nothing queued yet: the caller takes the plain path)
@@ -487,12 +492,18 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
         if (j >= 2) WAGG_HIP(hipStreamWaitEvent(P.sc, P.kdone[b], 0));            // the kernels of block j-2 have read dx[b]
         if (gather) {
             WAGG_HIP(team->send_block(static_cast<char *>(P.dx[b]), r0, rows, P.sc));
-        } else if (pin_x) {
-            WAGG_HIP(hipMemcpyAsync(P.dx[b], src, xspan, hipMemcpyHostToDevice, P.sc));      // page-locked source: truly asynchronous
-            g_host_stats.direct_h2d_bytes += (int64_t)xspan;
-            moved_plain += (int64_t)xspan;
         } else {
-            WAGG_HIP(staged_h2d(P.dx[b], src, xspan, P.sc));
+            for (int f = 0; f < (a.X2_host ? 2 : 1); ++f) {
+                const char *sf = f ? a.X2_host + r0 * a.ldx_bytes : src;
+                char *df = static_cast<char *>(P.dx[b]) + (size_t)f * (size_t)(rows * a.ldx_bytes);
+                if (pin_x) {
+                    WAGG_HIP(hipMemcpyAsync(df, sf, xspan, hipMemcpyHostToDevice, P.sc));        // page-locked source: truly asynchronous
+                    g_host_stats.direct_h2d_bytes += (int64_t)xspan;
+                    moved_plain += (int64_t)xspan;
+                } else {
+                    WAGG_HIP(staged_h2d(df, sf, xspan, P.sc));
+                }
+            }
         }
         WAGG_HIP(hipEventRecord(P.ready[b], P.sc));
         WAGG_HIP(hipStreamWaitEvent(P.sk, P.ready[b], 0));
@@ -532,7 +543,7 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     // blocks, and the idle ones of the pool, back to the driver: the next call allocates its own (~1 ms).
     {
         const int64_t moved = gather ? team->sent_bytes : moved_plain;
-        const int64_t us = gather ? team->copy_wait_us : now_us() - t_begin_us;
+        const int64_t us = now_us() - t_begin_us;         // (the whole pipeline: a PCIe-bound call's wall time is its copy time)
         if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x)) {
             static std::mutex mu;
             static double best[MAX_DEV][2] = {};
@@ -564,9 +575,10 @@ int stream_host_rows_any(const HostRowsArgs &a) {
                  obytes = (size_t)((a.n_planes - 1) * a.opstride_bytes + (a.Tn - 1) * a.ldo_bytes + a.orow_bytes);
     int rc = WAGG_OK;
     {
-        HostPin px, po;
+        HostPin px, px2, po;
         const bool want = (a.flags & WAGG_HOST_PIN) != 0;
-        const bool pin_x = want && a.n_runs == 0 && px.acquire(a.X_host, xbytes, a.n_dev > 1);      // (gathered rows: the CPU reads X)
+        bool pin_x = want && a.n_runs == 0 && px.acquire(a.X_host, xbytes, a.n_dev > 1);            // (gathered rows: the CPU reads X)
+        if (pin_x && a.X2_host && !px2.acquire(a.X2_host, xbytes, a.n_dev > 1)) pin_x = false;      // (both fields, or both staged)
         const bool pin_o = want && po.acquire(a.out_host, obytes, a.n_dev > 1);
         if (a.n_dev == 1 && a.devices == nullptr) {
             int64_t f = 0;
@@ -595,7 +607,8 @@ int stream_host_rows_any(const HostRowsArgs &a) {
             (void)home;                                  // (the calling thread's current device was never changed)
         }
         // the page-locks go only now: every stream that touched the arrays has been drained and destroyed
-        const hipError_t ex = px.release(), eo = po.release();
+        const hipError_t ex1 = px.release(), ex2 = px2.release(), eo = po.release();
+        const hipError_t ex = ex1 != hipSuccess ? ex1 : ex2;
         if (rc == WAGG_OK && (ex != hipSuccess || eo != hipSuccess)) {
             set_error("hipHostUnregister -> %s", hipGetErrorString(ex != hipSuccess ? ex : eo));
             rc = WAGG_EHIP;

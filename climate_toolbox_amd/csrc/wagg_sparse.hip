@@ -1200,7 +1200,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const auto &d = edd_lcv ? d_edd
                             : (gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64) : (use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d));
     if (int rc = check_timeout(plan)) return rc;
-    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse <= 4 && xpow != XF_EDD && d.Gc > 0 && ldx >= d.Gc),
+    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse <= 4 && (xpow != XF_EDD || edd_lcv) && d.Gc > 0 && ldx >= d.Gc),
                  "compact rows need the whole-line chunking of this plan and data type");
     const int64_t Gk = compact ? d.Gc : (int64_t)plan->info.G;        // cells of a row as the kernels see it
     if (nfuse > 1) {
@@ -1891,7 +1891,7 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             up(d.ent_den64, ed64); up(d.ent_den32, ed32);
         }
         if (lines_plan) { up(d.part_begin, part_begin); d.n_part = n_part_rows; }
-        if (lines_plan && (kind == 1 || kind == 2)) {
+        if (lines_plan && kind >= 1) {
             // the compact row of the lines-only host path: the distinct quads of this chunking in grid order, side by side
             std::vector<int32_t> uq(ucell);
             std::sort(uq.begin(), uq.end());
@@ -2060,11 +2060,14 @@ static int check_plan_device(const wagg_plan *plan) {
 // The row-block pipeline of a host-resident (time, gridcell) field with a (time, region) result (wagg_host.h), for the plain
 // aggregation and for the fused powers: `launch(xd, rows, ldx_dev, od, st, compact)` queues the device work of one block
 // -- rows x ldx_dev cells in, n_planes planes of rows x ldo out (plane k at od + k * rows * ldo) -- on `st`.
+// `dc`: the whole-line chunking the kernel of this call reads (nullptr: none -- no lines-only form); `X2`: a second field.
 template <typename T, typename LaunchFn>
 static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, T *out, int64_t ldo, int flags,
-                              int n_planes, int64_t opstride, LaunchFn launch) {
+                              int n_planes, int64_t opstride, LaunchFn launch, const SparsePlanDev *dc_ = nullptr, bool dc_given = false,
+                              const T *X2 = nullptr) {
     HostRowsArgs a;
     a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
+    a.X2_host = reinterpret_cast<const char *>(X2);
     a.Tn = Tn;
     a.ldx_bytes = ldx * (int64_t)sizeof(T); a.xrow_bytes = plan->info.G * (int64_t)sizeof(T);
     a.ldo_bytes = ldo * (int64_t)sizeof(T); a.orow_bytes = (int64_t)plan->info.R * (int64_t)sizeof(T);
@@ -2075,8 +2078,8 @@ static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int
     // cross PCIe (c2-real: 64 % of a fp32 row, 47 % of a fp64 row).  Taken when asked for, when the plan has that
     // chunking for T, when the row shrinks to <= 80 % and the field is large enough to be worth a thread team; a team
     // that cannot start (ring in use by a concurrent call, too few usable CPUs) means the plain pipeline below
-    const SparsePlanDev &dc = sizeof(T) == 4 ? plan->dl : plan->dl64;
-    const bool has_c = (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64) && dc.Gc > 0 && !dc.run_len.empty();
+    const SparsePlanDev &dc = dc_given ? (dc_ ? *dc_ : plan->d) : (sizeof(T) == 4 ? plan->dl : plan->dl64);
+    const bool has_c = (dc_given ? dc_ != nullptr : (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64)) && dc.Gc > 0 && !dc.run_len.empty();
     if ((flags & WAGG_HOST_LINES) && has_c && 5 * dc.Gc <= 4 * (int64_t)plan->info.G &&
         Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
         std::vector<int64_t> src(dc.run_src.size());
@@ -2159,6 +2162,43 @@ static int apply_poly_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_
     return check_timeout(plan);
 }
 
+// Snyder degree days of two host-resident fields (wagg_apply_edd_host_*): both fields go through the pipeline together,
+// n_thr result planes per block.  Lines only: the chunking the degree-day kernel reads (128-cell chunks of 16-cell lines for
+// fp32, the 64-cell chunks for fp64), one packed row = tasmin's lines then tasmax's.
+template <typename T>
+static int apply_edd_host(const wagg_plan *plan, const T *tmin, const T *tmax, int64_t Tn, int64_t ldx, double offset,
+                          const double *thr, int n_thr, T *out, int64_t ldo, int64_t out_pstride, int flags) {
+    clear_error();
+    int rc = check_apply_args(plan, tmin, Tn, ldx, WAGG_LAYOUT_TG, out, ldo, WAGG_OUT_TR);
+    if (rc != WAGG_OK) return rc;
+    WAGG_REQUIRE(Tn == 0 || tmax != nullptr, "tasmax is NULL");
+    WAGG_REQUIRE(n_thr >= 1 && n_thr <= 64 && thr != nullptr, "need 1..64 thresholds");
+    WAGG_REQUIRE(n_thr == 1 || out_pstride >= Tn * ldo, "out_pstride %lld overlaps the previous threshold", (long long)out_pstride);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
+    if (Tn == 0) return WAGG_OK;
+    if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
+    constexpr int TB = sizeof(T) == 4 ? 64 : 32;
+    const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
+    const bool edd_lcv = (sizeof(T) == 4 ? plan->has_lines64 : plan->has_lines64e) && !lcv_off;
+    const SparsePlanDev *dc = edd_lcv ? (sizeof(T) == 4 ? &plan->dl64 : &plan->dl64e) : nullptr;
+    const int64_t Gc = dc ? dc->Gc : 0;
+    rc = host_rows_pipeline<T>(plan, tmin, Tn, ldx, out, ldo, flags, n_thr, out_pstride,
+                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                                   // whole rows: tasmax's block behind tasmin's; packed rows: one row = tasmin's lines, then tasmax's
+                                   const T *x2 = compact ? xd + Gc : xd + rows * ldx_dev;
+                                   const int64_t ld = compact ? 2 * Gc : ldx_dev;
+                                   const int64_t ps = rows * ldo;
+                                   int r2 = WAGG_OK;
+                                   for (int i = 0; i < n_thr && r2 == WAGG_OK; i += 4)
+                                       r2 = launch_sparse<T, TB>(plan, xd, rows, ld, WAGG_LAYOUT_TG, od + (int64_t)i * ps, ldo, WAGG_OUT_TR, st,
+                                                                 (T)offset, XF_EDD, 1, ps, x2, thr + i, n_thr - i < 4 ? n_thr - i : 4, compact);
+                                   return r2;
+                               },
+                               dc, true, tmax);
+    if (rc != WAGG_OK) return rc;
+    return check_timeout(plan);
+}
+
 // Multi-device form (SURVEY 8b `n_devices`, 8e "one process driving all devices"): plan replica s lives on device
 // devices[s]; the row blocks of the host field are dealt round-robin to the devices, each device runs its own H2D /
 // kernels / D2H pipeline on its own PCIe link from its own host thread, and every block's result lands directly in
@@ -2221,6 +2261,17 @@ extern "C" int wagg_apply_poly_host_f32(const wagg_plan *plan, const float *X_ho
 extern "C" int wagg_apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
                                         int n_pow, double *out_host, int64_t ldo, int64_t out_pstride, int flags) {
     return wagg::apply_poly_host<double>(plan, X_host, T, ldx, offset, pow_first, n_pow, out_host, ldo, out_pstride, flags);
+}
+
+extern "C" int wagg_apply_edd_host_f32(const wagg_plan *plan, const float *tasmin_host, const float *tasmax_host, int64_t T, int64_t ldx,
+                                       double offset, const double *thresholds, int n_thr, float *out_host, int64_t ldo,
+                                       int64_t out_pstride, int flags) {
+    return wagg::apply_edd_host<float>(plan, tasmin_host, tasmax_host, T, ldx, offset, thresholds, n_thr, out_host, ldo, out_pstride, flags);
+}
+extern "C" int wagg_apply_edd_host_f64(const wagg_plan *plan, const double *tasmin_host, const double *tasmax_host, int64_t T, int64_t ldx,
+                                       double offset, const double *thresholds, int n_thr, double *out_host, int64_t ldo,
+                                       int64_t out_pstride, int flags) {
+    return wagg::apply_edd_host<double>(plan, tasmin_host, tasmax_host, T, ldx, offset, thresholds, n_thr, out_host, ldo, out_pstride, flags);
 }
 
 extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,

@@ -239,6 +239,29 @@ class SparsePlan:
         return out
 
 
+    def apply_edd_host(self, tasmin, tasmax, thresholds, offset=0.0, flags=0):
+        """Snyder degree days of two host-resident (time, gridcell) fields at each threshold, aggregated
+        (``wagg_apply_edd_host_*``): numpy in, a (n_thr, T, R) numpy array out; both fields cross PCIe once
+        (``_lib.HOST_LINES``: only the lines the table references), the formula runs on the device."""
+        tasmin, tasmax = np.ascontiguousarray(tasmin), np.ascontiguousarray(tasmax)
+        if tasmin.dtype not in (np.float32, np.float64) or tasmin.ndim != 2:
+            raise TypeError("fields must be 2-D float32/float64 arrays")
+        if tasmin.shape != tasmax.shape or tasmin.dtype != tasmax.dtype:
+            raise ValueError("tasmin and tasmax must have the same shape and dtype")
+        if tasmin.shape[1] != self.G:
+            raise ValueError("fields have %d grid cells, plan expects %d" % (tasmin.shape[1], self.G))
+        thr = np.ascontiguousarray(np.atleast_1d(thresholds), dtype=np.float64)
+        T = tasmin.shape[0]
+        out = np.empty((len(thr), T, self.R), dtype=tasmin.dtype)
+        L = _lib.load()
+        fn = L.wagg_apply_edd_host_f32 if tasmin.dtype == np.float32 else L.wagg_apply_edd_host_f64
+        with _on_device(self.device):
+            _lib.check(fn(self._h, C.c_void_p(tasmin.ctypes.data), C.c_void_p(tasmax.ctypes.data), T, tasmin.shape[1], float(offset),
+                          _np_ptr(thr, C.c_double), len(thr), C.c_void_p(out.ctypes.data), max(1, self.R), max(1, T * self.R),
+                          int(flags)), "wagg_apply_edd_host")
+        return out
+
+
 class DensePlan:
     """Dense-family plan: W as a (gridcell x region) matrix resident in HBM contracted on the matrix
     cores (full or tile-sparse form; fp32 or fp64 weights), or per-wave entry lists for scattered,

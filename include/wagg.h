@@ -265,6 +265,17 @@ int wagg_apply_edd_f32(const wagg_plan *plan, const float *tasmin_dev, const flo
 int wagg_apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
                        int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
                        double *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream);
+/* The same for two HOST-resident (time, gridcell) fields, (time, region) results in host memory (round 5): tasmin and tasmax go
+ * through the row-block pipeline of wagg_apply_host_ex_* together, every block's degree days are evaluated on the device (four
+ * thresholds per pass over the block) and plane i (threshold i) lands at out_host + i * out_pstride (elements, >= T * ldo).
+ * flags: WAGG_HOST_PIN, WAGG_HOST_LINES (only the lines of both fields the table references cross PCIe).  Blocking.  This is
+ * snyder_edd-then-aggregate (transformations.py:7-93 + aggregations.py:87) on the arrays the reference's callers hold.      */
+int wagg_apply_edd_host_f32(const wagg_plan *plan, const float *tasmin_host, const float *tasmax_host, int64_t T, int64_t ldx,
+                            double offset, const double *thresholds, int n_thr, float *out_host, int64_t ldo,
+                            int64_t out_pstride, int flags);
+int wagg_apply_edd_host_f64(const wagg_plan *plan, const double *tasmin_host, const double *tasmax_host, int64_t T, int64_t ldx,
+                            double offset, const double *thresholds, int n_thr, double *out_host, int64_t ldo,
+                            int64_t out_pstride, int flags);
 
 /* ---- materialised grid-level transforms (device buffers, elementwise) ------------------------ */
 /* What ``.values`` of a lazily transformed variable returns: out[i] = (X[i] + offset)^power

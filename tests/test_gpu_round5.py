@@ -785,3 +785,51 @@ def test_upload_is_the_array_on_the_device(torch_cuda):
     np.testing.assert_array_equal(engine.upload(v).cpu().numpy(), v)
     with pytest.raises(TypeError):
         engine.upload(np.zeros(4, dtype=np.int32))
+
+
+@pytest.mark.parametrize("dtype,T,rtol", [(np.float32, 301, RTOL32), (np.float64, 150, 1e-9)])
+def test_degree_days_of_host_resident_fields(torch_cuda, dtype, T, rtol):
+    """wagg_apply_edd_host_*: snyder_edd-then-aggregate (transformations.py:7-93 + aggregations.py:87) on two HOST arrays --
+    both fields through the row-block pipeline together, with and without WAGG_HOST_LINES, five thresholds (two passes per
+    block) -- bit-equal to the device form of the same kernel (wagg_apply_edd_*), within tolerance of the oracle, and through
+    snyder_edd + the reference-named call on a host-resident Dataset."""
+    from climate_toolbox_amd import _lib, engine, minixr, synth, snyder_edd, weighted_aggregate_grid_to_regions
+    from climate_toolbox_amd import aggregations as A
+    from climate_toolbox_amd.transformations import convert_kelvin_to_celsius
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(nlat=192, nlon=384, R=600, n_iso=20, seed=5, land_frac=0.15, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R = len(lat) * len(lon), len(uniq)
+    plan = engine.SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    rng = np.random.default_rng(12)
+    tmin = (283.15 + 10 * rng.random((T, G))).astype(dtype)
+    tmax = (tmin + 12 * rng.random((T, G))).astype(dtype)
+    thr = [10.0, 15.0, 20.0, 25.0, 30.0]
+    dev = plan.apply_edd(torch.from_numpy(tmin).cuda(), torch.from_numpy(tmax).cuda(), thr, offset=-273.15).cpu().numpy()
+    for flags in (_lib.HOST_PIN, _lib.HOST_PIN | _lib.HOST_LINES, _lib.HOST_LINES, 0):
+        _lib.host_stats(reset=True)
+        got = plan.apply_edd_host(tmin, tmax, thr, offset=-273.15, flags=flags)
+        np.testing.assert_array_equal(got, dev)
+        st = _lib.host_stats()
+        assert (st["lines_h2d_bytes"] > 0) == bool(flags & _lib.HOST_LINES)
+        if flags & _lib.HOST_LINES:
+            assert st["lines_h2d_bytes"] <= 0.8 * (tmin.nbytes + tmax.nbytes) and st["lines_h2d_bytes"] % (2 * T * 16) == 0
+    for k in (0, 2, 4):
+        grid = O.snyder_edd_values(tmin.astype(np.float64) - 273.15, tmax.astype(np.float64) - 273.15, thr[k])
+        _rel_ok(dev[k], O.agg_coded(grid, cell, code, w, R), rtol * 10, scale=1.0)
+    np.testing.assert_array_equal(plan.apply_edd_host(tmin[:40], tmax[:40], thr[1:3], offset=-273.15), dev[1:3, :40])
+    plan.close()
+    A._PLAN_CACHE.clear()
+    time_ = np.datetime64("2001-01-01") + np.arange(T)
+    shape = (T, len(lat), len(lon))
+    ds = minixr.Dataset({"tasmin": (("time", "lat", "lon"), tmin.reshape(shape)), "tasmax": (("time", "lat", "lon"), tmax.reshape(shape))},
+                        coords={"time": time_, "lat": lat, "lon": lon})
+    for v in ("tasmin", "tasmax"):
+        ds[v].attrs["units"] = "K"
+        ds = convert_kelvin_to_celsius(ds, v)                          # lazy offset (utils.py:10-20)
+    _lib.host_stats(reset=True)
+    ds["edd"] = snyder_edd(ds.tasmin, ds.tasmax, 20)
+    out = weighted_aggregate_grid_to_regions(ds, "edd", "areawt", "hierid", df)
+    assert _lib.host_stats()["lines_h2d_bytes"] > 0
+    np.testing.assert_allclose(np.asarray(out["edd"].values), dev[2], rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-6)
