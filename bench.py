@@ -634,6 +634,24 @@ def main():
                                               "x_equivalent_gbs": Xh.nbytes / tl[len(tl) // 2] / 1e9,
                                               "wait_for_copy_engine_ms": st["lines_wait_copy_us"] / 9e3, "wait_for_packing_threads_ms": st["lines_wait_pack_us"] / 9e3,
                                               "packing_threads": min(8, max(1, usable_cpus()[0] // 2))}
+        # the transforms the reference's callers run before they aggregate, on the same host-resident field (round 5): the fused
+        # powers (tas_poly 1..4, transformations.py:188) and one set of Snyder degree days (tasmin = the field, tasmax = field + 9 K;
+        # transformations.py:7-93) through the same pipeline, lines only; results (4 planes / 1 plane) back in host memory
+
+        def med_ms(fn, n=5):
+            fn()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                fn()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return sorted(ts)[len(ts) // 2]
+
+        both = L_.HOST_PIN | L_.HOST_LINES
+        out["host_resident"]["tas_poly_1to4_lines_only_ms"] = med_ms(lambda: plan.apply_poly_host(Xh, -273.15, 4, flags=both))
+        Xh_max = Xh + np.float32(9.0)
+        out["host_resident"]["snyder_edd_lines_only_ms"] = med_ms(lambda: plan.apply_edd_host(Xh, Xh_max, [303.15], flags=both))
+        del Xh_max
 
         def calls(ds, n=30, warm=15):
             # (15 warm-up calls: the first dozen calls after an idle spell run 2-3x slower on this platform whatever they do --

@@ -723,6 +723,20 @@ def test_lines_only_host_path_gives_the_bits_of_the_whole_rows(torch_cuda, dtype
                                equal_nan=True)
     assert _lib.host_stats()["lines_h2d_bytes"] == 0
     quads.close()
+    # a calling thread bound to two CPUs (what an OpenMP runtime with OMP_PROC_BIND leaves behind, or a taskset): too few to
+    # pack faster than PCIe moves whole rows -- the call runs as without the flag, same bits
+    if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) > 2:
+        mask = os.sched_getaffinity(0)
+        try:
+            os.sched_setaffinity(0, set(sorted(mask)[:2]))
+            _lib.host_stats(reset=True)
+            np.testing.assert_array_equal(plan.apply_host(X, flags=_lib.HOST_LINES | _lib.HOST_PIN), ref)
+            assert _lib.host_stats()["lines_h2d_bytes"] == 0
+        finally:
+            os.sched_setaffinity(0, mask)
+        _lib.host_stats(reset=True)
+        np.testing.assert_array_equal(plan.apply_host(X, flags=_lib.HOST_LINES | _lib.HOST_PIN), ref)
+        assert _lib.host_stats()["lines_h2d_bytes"] > 0
     plan.close()
 
 
