@@ -823,6 +823,26 @@ def main():
                             "packed by up to 8 host threads); "
                             "the all-cores CPU restatement reads X from DRAM.  The device-resident step beside them is what a "
                             "pipeline that keeps the field in HBM pays"}
+        if world == 1 and not small and extras and dtype == "float64":
+            # the fp64 field (c3) in host memory: whole rows page-locked in place against lines only (47 % of a fp64 row)
+            from climate_toolbox_amd import _lib as L_
+            try:
+                os.sched_setaffinity(0, AFFINITY_AT_START)           # (see boundary_legs: the OpenMP legs bound this thread)
+            except (AttributeError, OSError, TypeError):
+                pass
+            Xh = Xs.cpu().numpy()
+            hr = {}
+            for name, flags in (("whole_rows_ms", L_.HOST_PIN), ("lines_only_ms", L_.HOST_PIN | L_.HOST_LINES)):
+                ts = []
+                for i in range(8):
+                    t0 = time.perf_counter()
+                    plan.apply_host(Xh, flags=flags)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                ts = sorted(ts[3:])
+                hr[name] = ts[len(ts) // 2]
+            hr["what"] = "wagg_apply_host_ex_f64 on the 3 GB field, result back in host memory (5 calls after 3 warm-up calls, medians)"
+            res["host_resident"] = hr
+            del Xh
         plan.close()
         return res
 
