@@ -12,6 +12,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 
 
+N_LINES = 0
+
+
 def rel_bad(got, ref, rtol, scale):
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     if got.shape != ref.shape:
@@ -84,6 +87,16 @@ def one_case(i, rng):
     got = got if out_layout == "TR" else got.T
     b = rel_bad(got, ref, rtol, 1.0)
     if b: fails.append("apply: " + b)
+    from climate_toolbox_amd import _lib
+    host_forms = layout == "TG" and out_layout == "TR"
+    hflags = int(rng.choice([0, _lib.HOST_PIN, _lib.HOST_LINES, _lib.HOST_PIN | _lib.HOST_LINES]))
+    if host_forms:                                            # the host forms of the same call (row-block pipeline; lines only
+        _lib.host_stats(reset=True)                           #  when the field is large enough -- FUZZ_SCALE >= 6 -- and compact)
+        gh = plan.apply_host(X, flags=hflags)
+        b = rel_bad(gh, ref, rtol, 1.0)
+        if b: fails.append("apply_host(flags %d): %s" % (hflags, b))
+        if pad == 0 and not np.array_equal(gh, got, equal_nan=True): fails.append("apply_host(flags %d) differs from the device apply" % hflags)
+        if _lib.host_stats()["lines_h2d_bytes"]: tag += " [lines]"
     kind = rng.integers(0, 3)
     if kind == 0:                                                                     # fused powers
         K = int(rng.integers(1, 6))
@@ -94,6 +107,12 @@ def one_case(i, rng):
             # (|y| ~ 15 +- 9 here), so |ref| is floored at 10^p
             b = rel_bad(g, O.agg_coded(O.tas_poly_values(X, p), cell, code, w, R), rtol, 10.0 ** p)
             if b: fails.append("poly p=%d: %s" % (p, b))
+        if host_forms:
+            gph = plan.apply_poly_host(X, -273.15, K, flags=hflags)
+            if pad == 0 and not np.array_equal(gph, gp, equal_nan=True): fails.append("apply_poly_host(flags %d) differs from the device form" % hflags)
+            for p in range(1, K + 1):
+                b = rel_bad(gph[p - 1], O.agg_coded(O.tas_poly_values(X, p), cell, code, w, R), rtol, 10.0 ** p)
+                if b: fails.append("poly_host p=%d: %s" % (p, b))
     elif kind == 1:                                                                   # degree days
         half = rng.uniform(0, 8, X.shape).astype(dtype)
         lo, hi = X - half, X + half
@@ -104,6 +123,12 @@ def one_case(i, rng):
             g = ge[k] if out_layout == "TR" else ge[k].T
             b = rel_bad(g, O.agg_coded(O.snyder_edd_values(lo + ft(-273.15), hi + ft(-273.15), e), cell, code, w, R), rtol, 0.05)
             if b: fails.append("edd e=%.2f: %s" % (e, b))
+        if host_forms:
+            geh = plan.apply_edd_host(lo, hi, thr, offset=-273.15, flags=hflags)
+            if pad == 0 and not np.array_equal(geh, ge, equal_nan=True): fails.append("apply_edd_host(flags %d) differs from the device form" % hflags)
+            for k, e in enumerate(thr):
+                b = rel_bad(geh[k], O.agg_coded(O.snyder_edd_values(lo + ft(-273.15), hi + ft(-273.15), e), cell, code, w, R), rtol, 0.05)
+                if b: fails.append("edd_host e=%.2f: %s" % (e, b))
     elif layout == "TG" and not np.isinf(X).any():            # dense family: the library's choice of form, or one pinned
         form = [None, "full", "tiles", "entries"][int(rng.integers(0, 4))]              # (round 5: the choice goes by estimated
         dp = DensePlan.from_segments(cell, code, w, G, R, dtype=dtype, form=form)       #  time, so small tables mostly take entry
@@ -137,7 +162,60 @@ def one_case(i, rng):
     return tag, fails
 
 
+def lines_case(i, rng):
+    """FUZZ_LINES=1: fields large and tables compact enough for the lines-only host path (land masks with coasts, random
+    grids and land fractions): the three host forms with WAGG_HOST_LINES against the device forms of the same kernels, bit
+    for bit, and against the oracle."""
+    from climate_toolbox_amd import _lib, synth
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    rtol = 1e-4 if dtype == np.float32 else 1e-6
+    nlat, nlon = int(rng.integers(64, 200)), 4 * int(rng.integers(40, 160))
+    G = nlat * nlon
+    lat, lon, df = synth.realistic_segments(nlat=nlat, nlon=nlon, R=int(rng.integers(5, 900)), n_iso=5, seed=int(rng.integers(0, 1 << 30)),
+                                            land_frac=float(rng.uniform(0.03, 0.35)), string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "popwt" if rng.random() < 0.5 else "areawt", "hierid")
+    R = len(uniq)
+    T = int(((64 << 20) // (G * np.dtype(dtype).itemsize) + 1) * rng.uniform(1.0, 1.6)) + int(rng.integers(0, 9))
+    X = (288.0 + 9.0 * rng.standard_normal((T, G))).astype(dtype)
+    X[rng.integers(0, T, 50), rng.integers(0, G, 50)] = np.nan
+    if rng.random() < 0.3:
+        X[rng.integers(0, T), cell[rng.integers(0, len(cell))]] = np.inf
+    flags = _lib.HOST_LINES | (_lib.HOST_PIN if rng.random() < 0.7 else 0)
+    tag = "lines case %d: %s T=%d grid=%dx%d R=%d nseg=%d flags=%d" % (i, dtype.__name__, T, nlat, nlon, R, len(cell), flags)
+    plan = SparsePlan(cell, code, w, G, R, row_len=nlon)
+    fails = []
+    Xd = torch.from_numpy(X).cuda()
+    _lib.host_stats(reset=True)
+    gh = plan.apply_host(X, flags=flags)
+    took = _lib.host_stats()["lines_h2d_bytes"] > 0
+    tag += " [lines]" if took else " [whole rows]"
+    if not np.array_equal(gh, plan.apply(Xd).cpu().numpy(), equal_nan=True): fails.append("apply_host differs from the device apply")
+    b = rel_bad(gh, O.agg_coded(X, cell, code, w, R), rtol, 1.0)
+    if b: fails.append("apply_host: " + b)
+    kind = int(rng.integers(0, 2))
+    if kind == 0:
+        K = int(rng.integers(1, 6))
+        gp = plan.apply_poly_host(X, -273.15, K, flags=flags)
+        if not np.array_equal(gp, plan.apply_poly(Xd, -273.15, K).cpu().numpy(), equal_nan=True): fails.append("apply_poly_host differs from the device form")
+        b = rel_bad(gp[K - 1], O.agg_coded(O.tas_poly_values(X, K), cell, code, w, R), rtol, 10.0 ** K)
+        if b: fails.append("poly_host p=%d: %s" % (K, b))
+    else:
+        half = rng.uniform(0, 8, X.shape).astype(dtype)
+        lo, hi = X - half, X + half
+        thr = [float(rng.uniform(5, 35)) for _ in range(int(rng.integers(1, 6)))]
+        ge = plan.apply_edd_host(lo, hi, thr, offset=-273.15, flags=flags)
+        gd = plan.apply_edd(torch.from_numpy(lo).cuda(), torch.from_numpy(hi).cuda(), thr, offset=-273.15).cpu().numpy()
+        if not np.array_equal(ge, gd, equal_nan=True): fails.append("apply_edd_host differs from the device form")
+        b = rel_bad(ge[0], O.agg_coded(O.snyder_edd_values(lo + dtype(-273.15), hi + dtype(-273.15), thr[0]), cell, code, w, R), rtol, 0.05)
+        if b: fails.append("edd_host e=%.2f: %s" % (thr[0], b))
+    plan.close()
+    return tag, fails
+
+
 def main():
+    global one_case
+    if os.environ.get("FUZZ_LINES"):
+        one_case = lines_case
     rng = np.random.default_rng(SEED)
     bad = 0
     for i in range(N):
@@ -145,12 +223,14 @@ def main():
             tag, fails = one_case(i, rng)
         except Exception as e:                                                        # a crash is a failure too
             tag, fails = "case %d" % i, ["exception: %s" % traceback.format_exc().splitlines()[-1]]
+        global N_LINES
+        N_LINES += "[lines]" in tag
         if fails:
             bad += 1
             print(tag, "|", "; ".join(fails), flush=True)
         if i % 25 == 24:
             print("... %d cases, %d failing" % (i + 1, bad), flush=True)
-    print("fuzz: %d cases, %d failing" % (N, bad))
+    print("fuzz: %d cases, %d failing (%d of them took the lines-only host path)" % (N, bad, N_LINES))
     return 1 if bad else 0
 
 
