@@ -633,7 +633,7 @@ def main():
                                               "packed_fraction_of_x": st["lines_h2d_bytes"] / 9 / Xh.nbytes,
                                               "x_equivalent_gbs": Xh.nbytes / tl[len(tl) // 2] / 1e9,
                                               "wait_for_copy_engine_ms": st["lines_wait_copy_us"] / 9e3, "wait_for_packing_threads_ms": st["lines_wait_pack_us"] / 9e3,
-                                              "packing_threads": min(8, max(1, usable_cpus()[0] // 2))}
+                                              "packing_threads": min(12, max(usable_cpus()[0] // 2, usable_cpus()[0] - 4, 1))}
         # the transforms the reference's callers run before they aggregate, on the same host-resident field (round 5): the fused
         # powers (tas_poly 1..4, transformations.py:188) and one set of Snyder degree days (tasmin = the field, tasmax = field + 9 K;
         # transformations.py:7-93) through the same pipeline, lines only; results (4 planes / 1 plane) back in host memory
@@ -820,7 +820,7 @@ def main():
                     "device_resident_step_ms": round(res["median_ms"], 4),
                     "what": "for data that STARTS in host memory the GPU path is bound by PCIe (X crosses it once per call -- with "
                             "WAGG_HOST_LINES, the default of wagg_apply_host_* and the drop-in, only the 128-byte lines the table references, "
-                            "packed by up to 8 host threads); "
+                            "packed by up to 12 host threads); "
                             "the all-cores CPU restatement reads X from DRAM.  The device-resident step beside them is what a "
                             "pipeline that keeps the field in HBM pays"}
         if world == 1 and not small and extras and dtype == "float64":

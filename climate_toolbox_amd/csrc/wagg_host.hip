@@ -305,11 +305,16 @@ struct GatherTeam {
     // false: the team cannot work (no ring, no thread) -- the caller takes the plain path; nothing has been touched
     bool start() {
         try {
-            // half the CPUs this thread may use, eight at most -- and not fewer than it takes to pack faster than the copy
-            // engine would move the WHOLE rows (one thread packs ~10 GB/s, PCIe moves ~56: 6 x the packed fraction of a
-            // row; measured, tools/micro/host_gather.cpp: 4 threads 24-26 ms, 8 threads 18 ms, whole rows 26.3 ms)
-            int want = granted_cpus() / 2;
-            want = want > 8 ? 8 : want;
+            // all but four of the CPUs this thread may use (at least half of them), twelve at most -- and not fewer than it
+            // takes to pack faster than the copy path would move the WHOLE rows (one thread packs ~10 GB/s, PCIe moves ~56:
+            // 6 x the packed fraction of a row; measured, tools/micro/host_gather.cpp: 4 threads 24-26 ms, 8 threads 18 ms,
+            // whole rows 26.3 ms).  Twelve instead of eight of 16 CPUs: nothing for the 455-byte runs of the fp32 lines
+            // (8 threads already hide behind PCIe), but the 189-byte runs of the degree-day chunking and the fp64 lines
+            // stop being a co-bottleneck (degree days: 14-18 ms waiting for the packers -> 1.7 ms, 30.3-34.3 -> 29.9-30.3 ms)
+            const int granted = granted_cpus();
+            int want = granted / 2;
+            if (granted - 4 > want) want = granted - 4;
+            want = want > 12 ? 12 : want;
             const int need = (int)((6 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes);       // (per field: two fields, twice the bytes on both sides)
             if (want < 1 || want < need || (int64_t)want > a.Tn) return false;
             crow_all = a.crow_bytes * (a.X2_host ? 2 : 1);

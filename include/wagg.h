@@ -179,8 +179,8 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
 #define WAGG_HOST_WHOLE 2
 /*   WAGG_HOST_LINES  "lines only" (round 5; segment-table plans, (time, gridcell) data, (time, region) result, one device):
  *                    the table references a fraction of the grid -- the whole 128-byte lines its cells lie in are 64 % of a
- *                    c2-real fp32 row, 47 % of a fp64 row -- so up to eight host threads (half the CPUs the process is
- *                    granted: affinity mask and cgroup quota) pack exactly those runs of every row side by side into a ring of
+ *                    c2-real fp32 row, 47 % of a fp64 row -- so up to twelve host threads (all but four of the CPUs the calling
+ *                    thread is granted -- affinity mask and cgroup quota --, at least half of them) pack exactly those runs of every row side by side into a ring of
  *                    page-locked pieces, only the packed rows cross PCIe, and the kernel reads them through a second cell
  *                    table of the same plan.  X is read by the CPU and never page-locked; the result returns as WAGG_HOST_PIN
  *                    says.  Taken when the packed row is <= 80 % of the row, the field >= 64 MiB and the calling thread's
