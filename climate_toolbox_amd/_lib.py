@@ -48,7 +48,7 @@ EXPORTS = (
 class HostStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("calls", "blocks", "registered", "register_failed", "unregistered", "unregister_failed",
                                          "cleanup_failed", "staged_h2d_bytes", "staged_d2h_bytes", "direct_h2d_bytes",
-                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us", "blocks_retired")]
+                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us", "blocks_retired", "found_page_locked")]
 
 
 def host_stats(reset=False):

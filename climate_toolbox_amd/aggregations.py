@@ -441,12 +441,16 @@ def _pinned_make_room(size):
     return _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP
 
 
-def _to_host(o):
+def _pinned_result(shape, dtype):
+    """An uninitialised host array of ``shape`` / ``dtype`` in a page-locked block of the result pool (returned to the pool
+    when the array and every view of it are gone), or None: the array is small, the pool is at its cap with every block in
+    use, or no page-locked memory can be had."""
     import weakref
     import torch
-    n = o.numel() * o.element_size()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if n < (1 << 20):
-        return o.cpu().numpy()
+        return None
     size = (n + (1 << 20) - 1) >> 20 << 20                          # blocks of whole MiB: results of one shape share them
     block = None
     with _CACHE_LOCK:
@@ -459,18 +463,29 @@ def _to_host(o):
         if block is not None:
             _pinned_touch(size)
     if block is None:
-        return o.cpu().numpy()                                       # the pool is at its cap and every block is in use
+        return None                                                  # the pool is at its cap and every block is in use
     if block is False:
         try:
             block = torch.empty(size, dtype=torch.uint8, pin_memory=True)
-        except RuntimeError:                                         # no page-locked memory to be had: pageable copy
+        except RuntimeError:                                         # no page-locked memory to be had
             with _CACHE_LOCK:
                 _PINNED_POOL["bytes"] -= size
-            return o.cpu().numpy()
-    host = block[:n].view(o.dtype).view(o.shape)
-    host.copy_(o)
-    arr = host.numpy()                            # shares the block; views of `arr` keep `arr` (their base) alive
-    weakref.finalize(arr, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
+            return None
+    arr = block.numpy()[:n].view(dtype).reshape(shape)              # shares the block
+    root = arr
+    while isinstance(root.base, np.ndarray):      # the ndarray every view of this memory keeps alive (numpy collapses chains
+        root = root.base                          # of views onto it): the finalizer goes there, not onto an intermediate view
+    weakref.finalize(root, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
+    return arr
+
+
+def _to_host(o):
+    """Device tensor -> host array, through a page-locked block of the result pool when one can be had."""
+    import torch
+    arr = _pinned_result(tuple(o.shape), str(o.dtype).replace("torch.", "")) if o.numel() else None
+    if arr is None:
+        return o.cpu().numpy()
+    torch.from_numpy(arr).copy_(o)
     return arr
 
 
@@ -1081,7 +1096,9 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             # kernel), 13 % faster than copy-then-compute for a dense 1,369-row shard (tools/host_path_timing.py).
             from ._lib import HOST_LINES, HOST_PIN
             X2c = np.ascontiguousarray(X2)
-            host_out = plan.apply_host(X2c, flags=HOST_PIN | HOST_LINES, replicas=_host_replicas(plan, X2c.shape[0], X2c.strides[0]))
+            # (the result lands in a page-locked block of the result pool: nothing to register, no first-touch page faults)
+            host_out = plan.apply_host(X2c, flags=HOST_PIN | HOST_LINES, replicas=_host_replicas(plan, X2c.shape[0], X2c.strides[0]),
+                                       out=_pinned_result((X2c.shape[0], plan.R), X2c.dtype))
             if isinstance(plan, DensePlan) and plan.saw_inf():       # +-inf: redo in the exact segment-table form (S6)
                 exact = SparsePlan(cell_idx, codes, w_eff, G, len(uniq), row_len=row_len)
                 try:
@@ -1105,7 +1122,8 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             from ._lib import HOST_LINES, HOST_PIN
             X2c = np.ascontiguousarray(X2)
             lo, hi = int(min(powers)), int(max(powers))
-            stack = plan.apply_poly_host(X2c, offset, hi - lo + 1, pow_first=lo, flags=HOST_PIN | HOST_LINES)
+            stack = plan.apply_poly_host(X2c, offset, hi - lo + 1, pow_first=lo, flags=HOST_PIN | HOST_LINES,
+                                         out=_pinned_result((hi - lo + 1, X2c.shape[0], plan.R), X2c.dtype))
             res = [unflatten(stack[int(p) - lo], len(uniq)) for p in powers]
             rdims = _result_dims(dims, agglev)
             coords = {}
@@ -1125,7 +1143,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                     raise ValueError("tasmin and tasmax must have the same shape and dtype")
                 from ._lib import HOST_LINES, HOST_PIN
                 stack = plan.apply_edd_host(np.ascontiguousarray(X2), np.ascontiguousarray(H2), [edd[2][0][1]], offset=edd[1],
-                                            flags=HOST_PIN | HOST_LINES)
+                                            flags=HOST_PIN | HOST_LINES, out=_pinned_result((1, X2.shape[0], plan.R), X2.dtype))
                 rdims = _result_dims(dims, agglev)
                 coords = {}
                 for d in rdims:

@@ -24,7 +24,7 @@ namespace wagg {
 struct HostStats {
     std::atomic<int64_t> calls{0}, registered{0}, register_failed{0}, unregistered{0}, unregister_failed{0},
         cleanup_failed{0}, staged_h2d_bytes{0}, staged_d2h_bytes{0}, direct_h2d_bytes{0}, direct_d2h_bytes{0},
-        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0}, blocks_retired{0};
+        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0}, blocks_retired{0}, found_page_locked{0};
 };
 extern HostStats g_host_stats;
 
@@ -43,16 +43,18 @@ class HostPin {
     HostPin(const HostPin &) = delete;
     HostPin &operator=(const HostPin &) = delete;
     ~HostPin() { (void)release(); }
-    // tries to register; returns whether the array is now page-locked.  A refusal is not an error (the copies are
+    // tries to register; returns whether the array is now page-locked (an array that already is -- hipHostMalloc'ed, registered
+    // by its owner, a framework's pinned block -- is taken as it is, whatever its size).  A refusal is not an error (the copies are
     // staged instead) but it is counted and its reason kept (why()).
     bool acquire(const void *p, size_t bytes, bool portable);
-    bool pinned() const { return ptr_ != nullptr; }
+    bool pinned() const { return ptr_ != nullptr || foreign_; }
     hipError_t why() const { return why_; }
     // explicit release: the unregistration's status (also run by the destructor, which can only count a failure)
     hipError_t release();
 
   private:
     void *ptr_ = nullptr;
+    bool foreign_ = false;          // the array was page-locked already (by its owner): used as it is, nothing to release
     hipError_t why_ = hipSuccess;
 };
 

@@ -46,8 +46,23 @@ void host_block_plan(int64_t Tn, int64_t row_bytes, int64_t quantum, int n_devic
 }
 
 // ---- page-lock of a caller array ---------------------------------------------------------------------------------
+// the whole range [p, p + bytes) lies in memory the runtime already knows as page-locked host memory (hipHostMalloc, an
+// earlier hipHostRegister, a framework's pinned allocator): the copy paths can use it as it is
+static bool already_page_locked(const void *p, size_t bytes) {
+    if (!p || !bytes) return false;
+    const char *ends[2] = {static_cast<const char *>(p), static_cast<const char *>(p) + bytes - 1};
+    for (const char *q : ends) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
 bool HostPin::acquire(const void *p, size_t bytes, bool portable) {
-    if (ptr_ || p == nullptr || bytes < PIN_MIN) return pinned();
+    if (ptr_ || foreign_ || p == nullptr) return pinned();
+    if (already_page_locked(p, bytes)) { foreign_ = true; g_host_stats.found_page_locked++; return true; }     // (any size: nothing to lock)
+    if (bytes < PIN_MIN) return pinned();
     const hipError_t e = hipHostRegister(const_cast<void *>(p), bytes, portable ? hipHostRegisterPortable : hipHostRegisterDefault);
     if (e == hipSuccess) {
         ptr_ = const_cast<void *>(p);
@@ -61,6 +76,7 @@ bool HostPin::acquire(const void *p, size_t bytes, bool portable) {
 }
 
 hipError_t HostPin::release() {
+    foreign_ = false;
     if (!ptr_) return hipSuccess;
     const hipError_t e = hipHostUnregister(ptr_);
     ptr_ = nullptr;
@@ -648,12 +664,12 @@ extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
     out->cleanup_failed = s.cleanup_failed;
     out->staged_h2d_bytes = s.staged_h2d_bytes; out->staged_d2h_bytes = s.staged_d2h_bytes;
     out->direct_h2d_bytes = s.direct_h2d_bytes; out->direct_d2h_bytes = s.direct_d2h_bytes;
-    out->blocks_retired = s.blocks_retired;
+    out->blocks_retired = s.blocks_retired; out->found_page_locked = s.found_page_locked;
     out->lines_h2d_bytes = s.lines_h2d_bytes; out->lines_wait_pack_us = s.lines_wait_pack_us; out->lines_wait_copy_us = s.lines_wait_copy_us;
     if (reset) {
         s.calls = 0; s.blocks = 0; s.registered = 0; s.register_failed = 0; s.unregistered = 0; s.unregister_failed = 0;
         s.cleanup_failed = 0; s.staged_h2d_bytes = 0; s.staged_d2h_bytes = 0; s.direct_h2d_bytes = 0; s.direct_d2h_bytes = 0;
-        s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0; s.blocks_retired = 0;
+        s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0; s.blocks_retired = 0; s.found_page_locked = 0;
     }
     return WAGG_OK;
 }

@@ -64,6 +64,17 @@ def _np_ptr(a, ct):
     return a.ctypes.data_as(C.POINTER(ct))
 
 
+def _host_out(out, shape, dtype):
+    """The result array of a host form: the caller's (C-contiguous, right shape and dtype -- e.g. a page-locked block,
+    which the library then uses as it is) or a fresh one."""
+    if out is None:
+        return np.empty(shape, dtype=dtype)
+    if not (isinstance(out, np.ndarray) and tuple(out.shape) == tuple(shape) and out.dtype == np.dtype(dtype) and out.flags.c_contiguous
+            and out.flags.writeable):
+        raise ValueError("out must be a writeable C-contiguous %s array of shape %s" % (np.dtype(dtype), tuple(shape)))
+    return out
+
+
 def _check_X(X, layout):
     import torch
     if not (isinstance(X, torch.Tensor) and X.is_cuda and X.dim() == 2):
@@ -188,7 +199,7 @@ class SparsePlan:
         """The same table as a plan on another device (multi-device host streaming)."""
         return SparsePlan(*self._args, device=device)
 
-    def apply_host(self, X, layout="TG", out_layout="TR", flags=0, replicas=()):
+    def apply_host(self, X, layout="TG", out_layout="TR", flags=0, replicas=(), out=None):
         """Blocking host-buffer form (wagg_apply_host_ex_*): numpy in, numpy out.  (time, gridcell) data
         is streamed through the device in row blocks (H2D of block i+1, the kernels of block i and the
         return of block i-1 at once); ``flags``: ``_lib.HOST_PIN`` page-locks the arrays for the call,
@@ -201,7 +212,7 @@ class SparsePlan:
             raise TypeError("X must be a 2-D float32/float64 array")
         T = X.shape[0] if layout == "TG" else X.shape[1]
         shape = (T, self.R) if out_layout == "TR" else (self.R, T)
-        out = np.empty(shape, dtype=X.dtype)
+        out = _host_out(out, shape, X.dtype)
         L = _lib.load()
         if replicas:
             if layout != "TG" or out_layout != "TR":
@@ -220,7 +231,7 @@ class SparsePlan:
         return out
 
 
-    def apply_poly_host(self, X, offset, n_pow, pow_first=1, flags=0):
+    def apply_poly_host(self, X, offset, n_pow, pow_first=1, flags=0, out=None):
         """The fused powers of a host-resident (time, gridcell) field (``wagg_apply_poly_host_*``): numpy in, a
         (n_pow, T, R) numpy array out; the field crosses PCIe once (``_lib.HOST_LINES``: only the lines the table
         references), every row block is raised to its powers on the device."""
@@ -230,7 +241,7 @@ class SparsePlan:
         if X.shape[1] != self.G:
             raise ValueError("X has %d grid cells, plan expects %d" % (X.shape[1], self.G))
         T = X.shape[0]
-        out = np.empty((int(n_pow), T, self.R), dtype=X.dtype)
+        out = _host_out(out, (int(n_pow), T, self.R), X.dtype)
         L = _lib.load()
         fn = L.wagg_apply_poly_host_f32 if X.dtype == np.float32 else L.wagg_apply_poly_host_f64
         with _on_device(self.device):
@@ -239,7 +250,7 @@ class SparsePlan:
         return out
 
 
-    def apply_edd_host(self, tasmin, tasmax, thresholds, offset=0.0, flags=0):
+    def apply_edd_host(self, tasmin, tasmax, thresholds, offset=0.0, flags=0, out=None):
         """Snyder degree days of two host-resident (time, gridcell) fields at each threshold, aggregated
         (``wagg_apply_edd_host_*``): numpy in, a (n_thr, T, R) numpy array out; both fields cross PCIe once
         (``_lib.HOST_LINES``: only the lines the table references), the formula runs on the device."""
@@ -252,7 +263,7 @@ class SparsePlan:
             raise ValueError("fields have %d grid cells, plan expects %d" % (tasmin.shape[1], self.G))
         thr = np.ascontiguousarray(np.atleast_1d(thresholds), dtype=np.float64)
         T = tasmin.shape[0]
-        out = np.empty((len(thr), T, self.R), dtype=tasmin.dtype)
+        out = _host_out(out, (len(thr), T, self.R), tasmin.dtype)
         L = _lib.load()
         fn = L.wagg_apply_edd_host_f32 if tasmin.dtype == np.float32 else L.wagg_apply_edd_host_f64
         with _on_device(self.device):
@@ -442,7 +453,7 @@ class DensePlan:
             "wagg_dense_apply_edd")
         return out
 
-    def apply_host(self, X, flags=0, replicas=()):
+    def apply_host(self, X, flags=0, replicas=(), out=None):
         """Host-resident (time, gridcell) array through the plan in row blocks (``wagg_dense_apply_host_*``):
         numpy in, numpy out; flags and ``replicas`` as for :meth:`SparsePlan.apply_host` (``_lib.HOST_LINES`` means nothing
         to a dense-family plan -- every cell of a row is an operand -- and is dropped)."""
@@ -451,7 +462,7 @@ class DensePlan:
         X = np.ascontiguousarray(X)
         if X.dtype != want or X.ndim != 2 or X.shape[1] != self.G:
             raise TypeError("X must be a (T, %d) %s array" % (self.G, self.dtype))
-        out = np.empty((X.shape[0], self.R), dtype=want)
+        out = _host_out(out, (X.shape[0], self.R), want)
         if replicas:
             plans = (self,) + tuple(replicas)
             hs = (C.c_void_p * len(plans))(*[p._h for p in plans])

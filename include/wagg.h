@@ -162,6 +162,8 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *   WAGG_HOST_PIN    page-lock the caller's arrays in place for the call (hipHostRegister / hipHostUnregister,
  *                    both statuses checked) so that the copy engines read and write them directly
  *   WAGG_HOST_WHOLE  one copy of the whole field, one apply, one copy back (the other layouts always do)
+ * A caller array that is page-locked already (hipHostMalloc, the caller's own hipHostRegister, a framework's pinned
+ * allocator) is used as it is, whatever its size -- the drop-in hands in result arrays from its pool of such blocks.
  * What is not page-locked -- arrays below 32 MiB (registration locks whole pages, which a small heap array
  * shares with unrelated objects), arrays whose registration the runtime refuses, and everything without
  * WAGG_HOST_PIN -- passes through the library's own page-locked staging pieces by CPU copy.  A pageable caller
@@ -223,6 +225,7 @@ typedef struct wagg_host_stats {
     int64_t lines_wait_pack_us;   /* ... time its pipeline thread waited for the packing threads (they are the bottleneck) */
     int64_t lines_wait_copy_us;   /* ... and for the copy engine to hand a ring piece back (PCIe is the bottleneck)        */
     int64_t blocks_retired;       /* calls whose copies ran < 70 % of the best rate seen: their device blocks left the pool  */
+    int64_t found_page_locked;    /* caller arrays that were page-locked already (used as they are, no registration)          */
 } wagg_host_stats;
 int wagg_host_stats_read(wagg_host_stats *out, int reset);
 

@@ -34,3 +34,4 @@ def ref_fixture(golden_dir):
     for k in ("seg_lat", "seg_lon", "areawt", "popwt", "hierid", "ISO"):
         np.testing.assert_array_equal(fx[k], gold[k])
     return fx, gold
+

@@ -1107,7 +1107,8 @@ def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
     X = (280 + 10 * np.random.default_rng(0).standard_normal((T, len(lat), len(lon)))).astype(np.float32)
     ds = minixr.Dataset({"tas": (("time", "lat", "lon"), torch.from_numpy(X).cuda())}, coords={"lat": lat, "lon": lon})
     gc.collect()
-    pool = A._PINNED_POOL
+    A.clear_caches()                                            # (free blocks of other shapes left by earlier tests go: the
+    pool = A._PINNED_POOL                                       #  accounting below is about this test's blocks only)
     n_free = lambda: sum(len(v) for v in pool["free"].values())
     base, free0 = pool["bytes"], n_free()
     a = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)

@@ -847,3 +847,40 @@ def test_degree_days_of_host_resident_fields(torch_cuda, dtype, T, rtol):
     out = weighted_aggregate_grid_to_regions(ds, "edd", "areawt", "hierid", df)
     assert _lib.host_stats()["lines_h2d_bytes"] > 0
     np.testing.assert_allclose(np.asarray(out["edd"].values), dev[2], rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-6)
+
+
+def test_host_results_land_in_page_locked_pool_blocks(torch_cuda):
+    """The drop-in's host-resident calls hand the library a result array from their pool of page-locked blocks: the library
+    finds it page-locked (wagg_host_stats.found_page_locked) and uses it as it is -- nothing is registered, the field is read
+    by the packing threads --, the numbers are those of a plain call, and the block returns to the pool when the result goes.
+    engine.apply_host(out=...) refuses arrays of the wrong shape / dtype / layout."""
+    import gc
+    from climate_toolbox_amd import _lib, engine, minixr, synth, weighted_aggregate_grid_to_regions
+    from climate_toolbox_amd import aggregations as A
+    lat, lon, df = synth.realistic_segments(nlat=192, nlon=384, R=600, n_iso=20, seed=5, land_frac=0.15, string_labels=False)
+    T = 500                                                       # (a result of 1.2 MB: the pool serves results >= 1 MiB)
+    rng = np.random.default_rng(2)
+    tas = (280 + 10 * rng.standard_normal((T, len(lat), len(lon)))).astype(np.float32)
+    ds = minixr.Dataset({"tas": (("time", "lat", "lon"), tas)}, coords={"time": np.arange(T), "lat": lat, "lon": lon})
+    A.clear_caches()
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    plan = engine.SparsePlan(cell, code, w, tas[0].size, len(uniq), row_len=len(lon))
+    ref = plan.apply_host(tas.reshape(T, -1), flags=_lib.HOST_PIN)
+    _lib.host_stats(reset=True)
+    out = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
+    st = _lib.host_stats()
+    np.testing.assert_array_equal(np.asarray(out.tas.values), ref)
+    assert st["found_page_locked"] == 1 and st["registered"] == 0 and st["lines_h2d_bytes"] > 0 and st["staged_d2h_bytes"] == 0
+    with A._CACHE_LOCK:
+        in_pool = sum(len(v) for v in A._PINNED_POOL["free"].values())
+    del out
+    gc.collect()
+    with A._CACHE_LOCK:
+        assert sum(len(v) for v in A._PINNED_POOL["free"].values()) == in_pool + 1           # the block came back
+    for bad in (np.empty((T, len(uniq) + 1), np.float32), np.empty((T, len(uniq)), np.float64), np.empty((len(uniq), T), np.float32).T):
+        with pytest.raises(ValueError):
+            plan.apply_host(tas.reshape(T, -1), out=bad)
+    mine = np.empty((T, len(uniq)), np.float32)
+    assert plan.apply_host(tas.reshape(T, -1), flags=_lib.HOST_LINES, out=mine) is mine
+    np.testing.assert_array_equal(mine, ref)
+    plan.close()
