@@ -79,7 +79,7 @@ typedef struct wagg_plan_info {
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */
-int wagg_version(void);                 /* 10000*major + 100*minor + patch */
+int wagg_version(void);                 /* 10000*major + 100*minor + patch; 0.3.0: wagg_host_stats has 16 fields */
 int wagg_device_count(void);            /* number of visible HIP devices (0 if none), never <0  */
 /* Time-axis sharding rule of the multi-GPU form (one process per GPU; climate_toolbox_amd/timeshard.py):
  * rank `rank` of `world` owns rows [*start, *stop) of T; the first T mod world ranks hold one row more. */
