@@ -318,7 +318,8 @@ struct GatherTeam {
     explicit GatherTeam(const HostRowsArgs &args) : a(args) {}
     GatherTeam(const GatherTeam &) = delete;
     GatherTeam &operator=(const GatherTeam &) = delete;
-    // false: the team cannot work (no ring, no thread) -- the caller takes the plain path; nothing has been touched
+    // false: the team cannot work (too few usable CPUs, the ring is busy, threads cannot be had) -- the caller takes the plain
+    // path; no copy has been queued (threads that did start are joined by the destructor)
     bool start() {
         try {
             // all but four of the CPUs this thread may use (at least half of them), twelve at most -- and not fewer than it
