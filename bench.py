@@ -633,6 +633,7 @@ def main():
                                               "packed_fraction_of_x": st["lines_h2d_bytes"] / 9 / Xh.nbytes,
                                               "x_equivalent_gbs": Xh.nbytes / tl[len(tl) // 2] / 1e9,
                                               "wait_for_copy_engine_ms": st["lines_wait_copy_us"] / 9e3, "wait_for_packing_threads_ms": st["lines_wait_pack_us"] / 9e3,
+                                              "blocks_retired_by_the_rate_watch": st["blocks_retired"],
                                               "packing_threads": min(12, max(usable_cpus()[0] // 2, usable_cpus()[0] - 4, 1))}
         # the transforms the reference's callers run before they aggregate, on the same host-resident field (round 5): the fused
         # powers (tas_poly 1..4, transformations.py:188) and one set of Snyder degree days (tasmin = the field, tasmax = field + 9 K;
