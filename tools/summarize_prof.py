@@ -75,8 +75,9 @@ if os.path.exists(tr):
                      ("c2-real", "sparse_lcv_kernel<float, true, 1, false, false>#big"), ("c3-real", "sparse_lcv_kernel<double, true, 1, false, false>#big"),
                      ("c1", "sparse_lcv_kernel<double, true, 1, false, false>#small"), ("c5-block: 6 full row blocks", "dense_pieces_kernel<float, 21"), ("c5-block: the remainder (266 rows)", "dense_pieces_kernel<float, 18"),
                      ("c5-block-f64", "dense_pieces_kernel<double"), ("c5-uniform", "spmm_kernel<float>"),
-                     ("c5-uniform-f64", "spmm_kernel<double>"), ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>"),
-                     ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>"),
+                     ("c5-uniform-f64", "spmm_kernel<double>"), # (round 5, third part: the host forms of the fused transforms launch the same instantiations on 64-row blocks: "#big")
+                     ("c2-real fused tas_poly 1..4", "sparse_lcv_kernel<float, true, 4, false, false>#big"),
+                     ("c2-real fused snyder_edd, one threshold", "sparse_lcv_kernel<float, true, 1, true, false>#big"),
                      ("c2-real fused snyder_edd, three thresholds", "sparse_lcv_kernel<float, true, 3, true, false>"),
                      ("c2-real combine + transpose, one plane", "combine_parts_kernel<float, true>#band:0.02:0.04"),
                      ("c2-real combine + transpose, 3-4 planes (fused transforms)", "combine_parts_kernel<float, true>#big"),
