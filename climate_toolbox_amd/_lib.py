@@ -21,6 +21,7 @@ OUT_TR, OUT_RT = 0, 1
 # every symbol include/wagg.h declares (tests check that the .so exports all of them)
 EXPORTS = (
     "wagg_version", "wagg_device_count", "wagg_shard_rows", "wagg_last_error", "wagg_profile_enable", "wagg_profile_read",
+    "wagg_profile_event_overhead",
     "wagg_resolve_cells", "wagg_backup_fill", "wagg_relabel", "wagg_factorize_i64", "wagg_factorize_bytes",
     "wagg_plan_create", "wagg_plan_destroy", "wagg_plan_get_info", "wagg_plan_get_den", "wagg_plan_status",
     "wagg_apply_f32", "wagg_apply_f64", "wagg_apply_host_f32", "wagg_apply_host_f64",
@@ -110,6 +111,7 @@ def load():
     L.wagg_last_error.restype = C.c_char_p
     L.wagg_profile_enable.argtypes = [C.c_int]
     L.wagg_profile_read.argtypes = [f32p, C.c_int, C.POINTER(C.c_int)]
+    L.wagg_profile_event_overhead.argtypes = [vp, C.c_int, f32p, f32p]
     u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
     L.wagg_resolve_cells.argtypes = [f64p, C.c_int64, f64p, C.c_int64, f64p, f64p, C.c_int64, C.c_int, i32p, i64p]
     L.wagg_backup_fill.argtypes = [f64p, f64p, C.c_int64, f64p]
@@ -201,7 +203,7 @@ def load():
         getattr(L, name).argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64p, C.c_int64, vp, C.c_int64, C.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("wagg_last_error",):
+        if name not in ("wagg_last_error", "wagg_scratch_bytes"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -171,6 +171,29 @@ extern "C" int wagg_shard_group_info(const wagg_shard_group *g, int *n_shards, i
 
 namespace wagg {
 
+// Leaves apply_sharded in a defined state on EVERY exit: an RCCL group that was opened is closed -- a thread that
+// returns between ncclGroupStart and ncclGroupEnd would have every later RCCL call it makes (torch.distributed's included)
+// silently batched into the open group -- and after a failure every shard stream is drained before the caller gets the status:
+// the function is documented as blocking, so the caller may free the result, the fields or the plans as soon as it returns, and
+// work queued by the shards that did not fail must not still be using them.  (Declared AFTER the DeviceGuard: it runs first, the
+// guard then restores the caller's device.  Statuses are ignored here: the error that is being reported stays the message.)
+struct ShardExit {
+    wagg_shard_group *g;
+    const RcclApi *api = nullptr;
+    bool group_open = false;
+    bool ok = false;
+    explicit ShardExit(wagg_shard_group *g_) : g(g_) {}
+    ~ShardExit() {
+        if (group_open && api) (void)api->GroupEnd();
+        if (ok) return;
+        for (int i = 0; i < g->n; ++i) {
+            if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess) continue;
+            (void)hipStreamSynchronize(g->streams[(size_t)i]);
+        }
+        (void)hipGetLastError();
+    }
+};
+
 // apply(i, X_i, rows_i, out_i, ld_i, stream_i) enqueues shard i's kernels on ITS device (current when called)
 template <typename T, typename Apply>
 static int apply_sharded(wagg_shard_group *g, const int *plan_devices, int32_t R, const T *const *X_dev, const int64_t *rows, T *out_root,
@@ -196,6 +219,7 @@ static int apply_sharded(wagg_shard_group *g, const int *plan_devices, int32_t R
     const bool rccl = g->transport == WAGG_GATHER_RCCL;
     WAGG_REQUIRE(!rccl || ldo == R || n == 1, "the RCCL transport moves whole blocks: out_root must have contiguous rows (ldo == R)");
     DeviceGuard guard;
+    ShardExit leave(g);
     // 1. every shard computes on its own device and stream: the root's block straight into its rows of the result, the others
     //    into a block of their own
     for (int i = 0; i < n; ++i) {
@@ -224,6 +248,8 @@ static int apply_sharded(wagg_shard_group *g, const int *plan_devices, int32_t R
         const RcclApi &api = rccl_api();
         const ncclDataType_t dt = sizeof(T) == 8 ? ncclFloat64 : ncclFloat32;
         WAGG_NCCL(api, api.GroupStart());
+        leave.api = &api;
+        leave.group_open = true;
         for (int i = 0; i < n; ++i) {
             if (i == root || rows[i] == 0) continue;
             const size_t count = (size_t)rows[i] * (size_t)R;
@@ -232,6 +258,7 @@ static int apply_sharded(wagg_shard_group *g, const int *plan_devices, int32_t R
             WAGG_NCCL(api, api.Send(g->local[(size_t)i], count, dt, root, g->comms[(size_t)i], g->streams[(size_t)i]));
             WAGG_NCCL(api, api.Recv(out_root + off[(size_t)i] * ldo, count, dt, i, g->comms[(size_t)root], g->streams[(size_t)root]));
         }
+        leave.group_open = false;
         WAGG_NCCL(api, api.GroupEnd());
     } else {
         for (int i = 0; i < n; ++i) {
@@ -251,6 +278,7 @@ static int apply_sharded(wagg_shard_group *g, const int *plan_devices, int32_t R
         WAGG_HIP(hipSetDevice(g->devices[(size_t)i]));
         WAGG_HIP(hipStreamSynchronize(g->streams[(size_t)i]));
     }
+    leave.ok = true;
     return WAGG_OK;
 }
 

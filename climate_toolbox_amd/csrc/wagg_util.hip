@@ -434,6 +434,40 @@ extern "C" int wagg_profile_enable(int on) {
     return WAGG_OK;
 }
 
+namespace wagg { __global__ void empty_kernel() {} }
+
+// What an event pair handed to hipExtLaunchKernel reads for a kernel that does nothing: the floor every wagg_profile_read
+// figure sits on (dispatch + end-of-kernel signal between the two stamps).  rocprofv3's dispatch durations do not carry
+// it, which is why sub-millisecond kernels read a few percent longer on this clock than in profiles/.
+extern "C" int wagg_profile_event_overhead(void *stream, int n, float *median_ms, float *min_ms) {
+    using namespace wagg;
+    WAGG_REQUIRE(n >= 1 && n <= 256 && median_ms != nullptr, "n must be 1..256 and median_ms non-NULL");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n, nullptr);
+    int rc = WAGG_OK;
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { rc = WAGG_EHIP; break; }
+    std::vector<float> ms;
+    if (rc == WAGG_OK) {
+        for (int i = 0; i < n + 8; ++i) {          // the first eight launches (untimed) wake the queue up
+            if (i < 8) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, st);
+            else hipExtLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0u, st, ev[2 * (i - 8)], ev[2 * (i - 8) + 1], 0u);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) rc = WAGG_EHIP;
+        for (int i = 0; rc == WAGG_OK && i < n; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = WAGG_EHIP;
+            ms.push_back(t);
+        }
+    }
+    for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    if (rc != WAGG_OK) { set_error("wagg_profile_event_overhead: a HIP call failed"); return rc; }
+    std::sort(ms.begin(), ms.end());
+    *median_ms = ms[ms.size() / 2];
+    if (min_ms) *min_ms = ms[0];
+    return WAGG_OK;
+}
+
 extern "C" int wagg_profile_read(float *ms_out, int max_out, int *n_out) {
     using namespace wagg;
     WAGG_REQUIRE(n_out != nullptr && (ms_out != nullptr || max_out == 0), "NULL argument");

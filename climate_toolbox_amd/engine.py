@@ -780,3 +780,12 @@ def profile_read():
     n = C.c_int(0)
     _lib.check(_lib.load().wagg_profile_read(buf, PROFILE_SLOTS, C.byref(n)), "wagg_profile_read")
     return [float(buf[i]) for i in range(n.value)]
+
+
+def profile_event_overhead(n=64, stream=None):
+    """(median, minimum) milliseconds that an event pair handed to the launch of an EMPTY kernel reads
+    (``wagg_profile_event_overhead``): the floor under every ``profile_read`` figure."""
+    med, mn = C.c_float(0.0), C.c_float(0.0)
+    _lib.check(_lib.load().wagg_profile_event_overhead(_stream_handle(stream), int(n), C.byref(med), C.byref(mn)),
+               "wagg_profile_event_overhead")
+    return float(med.value), float(mn.value)

@@ -96,6 +96,10 @@ const char *wagg_last_error(void);      /* thread-local, never NULL             
 #define WAGG_PROFILE_SLOTS 1024
 int wagg_profile_enable(int on);        /* also resets the ring */
 int wagg_profile_read(float *ms_out, int max_out, int *n_out);
+/* The floor of that clock: median (and minimum) of what `n` (1..256) event pairs read for a kernel that does nothing,
+ * launched on `stream` the same way.  rocprofv3's dispatch durations (profiles/) do not contain it; sub-millisecond
+ * kernels therefore read a few percent longer through wagg_profile_read than there.  Blocks until the launches finished. */
+int wagg_profile_event_overhead(void *stream, int n, float *median_ms, float *min_ms /* may be NULL */);
 
 /* ---- label work ahead of the plan (host only) ------------------------------------- */
 /* Exact-equality join of the segment table's lat/lon labels to the grid's (Dataset.sel without

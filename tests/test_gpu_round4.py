@@ -328,9 +328,9 @@ def test_bench_over_rccl_with_one_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2-real", "--steps", "3", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    from tests.bench_io import split_bench_output
+    line, rec = split_bench_output(p)              # one stdout line under 6 KB; `rec` = the detail from stderr
+    assert line["roofline"]["frac"] > 0 and line["rccl_ranks"] == 1 and line["gather_ok"] is True and line["value"] == rec["value"]
     assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["scaling_measured"] is False
     assert rec["roofline"]["bound"] == "hbm" and rec["value"] > 0 and rec["min_ms"] <= rec["median_ms"] <= rec["max_ms"]
     # the N > 1 fields, here over RCCL itself (one rank): the all-reduce proof, one blocking gather timed, per-rank medians
@@ -508,9 +508,13 @@ def test_bench_multi_rank_control_flow_rehearsal():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--nlat", "180", "--nlon", "360", "--R", "600",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    rec = json.loads(lines[0])
+    from tests.bench_io import split_bench_output
+    line, rec = split_bench_output(p)              # one stdout line under 6 KB; `rec` = the detail from stderr
+    # the compact line is what the driver's scaling run parses: headline + roofline + the N > 1 proof + one row per workload
+    assert line["n_gpus"] == 3 and line["roofline"]["frac"] > 0 and line["rccl_ranks"] == 3 and len(line["per_rank_ms"]) == 3
+    assert line["gather_ms"] > 0 and line["gather_ok"] is True and "cpu_baseline" in line
+    assert [r["wl"] for r in line["summary"]["rows"]] == ["c2-dense", "c4", "c5-uniform"]
+    assert all(r["gather_ok"] is True and r["gather_ms"] > 0 for r in line["summary"]["rows"])
     assert rec["n_gpus"] == 3 and rec["scaling"] == "weak" and rec["scaling_measured"] is False and "rehearsal" in rec
     assert rec["gather_ok"] is True and rec["config"]["T_job"] == 3 * 365
     # what the driver needs to check an N > 1 line: the all-reduce-of-ones proof that the collective
@@ -530,7 +534,8 @@ def test_bench_multi_rank_control_flow_rehearsal():
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--budget-s", "0"], capture_output=True, text=True, env=env,
                        timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")][0])
+    line, rec = split_bench_output(p)
+    assert [(r["wl"], r.get("skipped")) for r in line["summary"]["rows"][1:]] == [("c4", "budget"), ("c5-uniform", "budget")]
     assert [(s_["workload"], s_["skipped"]) for s_ in rec["secondary"]] == [("c4", "budget"), ("c5-uniform", "budget")]
 
 

@@ -115,55 +115,45 @@ def _blocklocal_csr(G, R, share, fill_in, rng):
 FORM_POINTS = [("uniform", 0.01), ("uniform", 0.06), ("uniform", 0.20), ("blocklocal", 0.05), ("blocklocal", 0.30), ("blocklocal", 0.75)]
 
 
-@pytest.mark.parametrize("kind,param", FORM_POINTS)
-def test_default_form_is_within_10_percent_of_the_fastest_forced_form(torch_cuda, kind, param):
-    """The caller never names a form (the reference has one weights type, aggregations.py:64-73).  At six points either
-    side of the measured crossovers (tools/form_crossover.py, DESIGN.md (b)) the same CSR table is built in every form by
-    force and by the library's own choice: the choice must run within 10 % of the fastest forced form, and every form must
-    give the oracle's numbers."""
-    import scipy.sparse as sp
+def form_point_table(kind, param):
+    """(rowptr, col, val, G, R, T) of one point of FORM_POINTS (also used by tests/test_gpu_zz_perf_guards.py)"""
     from climate_toolbox_amd import engine
-    from climate_toolbox_amd.engine import DensePlan
-    torch = torch_cuda
     G, R, T = 360 * 360, 6000, 1141
     rng = np.random.default_rng(int(param * 1000) + len(kind))
     if kind == "uniform":
         rowptr, col, val = engine.synth_table_csr(G, R, 3, param, blocklocal=False)
     else:
         rowptr, col, val = _blocklocal_csr(G, R, param, 0.30, rng)
+    return rowptr, col, val, G, R, T
+
+
+@pytest.mark.parametrize("kind,param", FORM_POINTS)
+def test_every_form_of_a_table_gives_the_oracles_numbers(torch_cuda, kind, param):
+    """The caller never names a form (the reference has one weights type, aggregations.py:64-73).  At six points either
+    side of the measured crossovers (tools/form_crossover.py, DESIGN.md (b)) the same CSR table is built in every form by
+    force and by the library's own choice: every form must give the oracle's numbers, and the choice must have been made
+    from positive cost estimates.  (How FAST the chosen form runs against the forced ones is a perf guard, not parity: it
+    lives in tests/test_gpu_zz_perf_guards.py, which collects last, so a noisy box cannot stop the `-x` parity run here.)"""
+    import scipy.sparse as sp
+    from climate_toolbox_amd import engine
+    from climate_toolbox_amd.engine import DensePlan
+    torch = torch_cuda
+    rowptr, col, val, G, R, T = form_point_table(kind, param)
     X = engine.synth_field(T, G, seed=31, base=280.0, amp=60.0, dtype="float32")
-    Xs = X[:6].cpu().numpy().astype(np.float64)
+    rows = [0, 1, 2, 367, 368, T - 1]               # both sides of a 368-row block border and the ragged tail
+    Xs = X[rows].cpu().numpy().astype(np.float64)
     W = sp.csr_matrix((val, col, rowptr), shape=(G, R))
     ref = (W.T @ Xs.T).T / np.asarray(W.sum(axis=0)).ravel()[None, :]          # the oracle's CSR restatement (ref_numpy.agg_csr) on the coded table
-
-    def timed(plan):
-        out = torch.empty((T, R), dtype=torch.float32, device="cuda")
-        for _ in range(3):
-            plan.apply(X, out=out)
-        torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
-        for a, b in ev:
-            a.record(); plan.apply(X, out=out); b.record()
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        return ms[len(ms) // 2], out[:6].cpu().numpy()
-
-    times = {}
     for form in (None, "full", "tiles", "entries"):
         plan = DensePlan.from_csr(rowptr, col, val, G, R, form=form)
-        ms, got = timed(plan)
-        _rel_ok(got, ref, RTOL32)
-        times[form or "auto"] = ms
+        out = plan.apply(X)
+        _rel_ok(out[rows].cpu().numpy(), ref, RTOL32)
         if form is None:
-            picked = {0: "full", 1: "tiles", 2: "entries"}[plan.info["form"]]
-            est = (plan.info["est_full_s"], plan.info["est_tiles_s"], plan.info["est_entries_s"])
-            assert min(est) > 0
+            assert plan.info["form"] in (0, 1, 2)
+            assert min(plan.info["est_full_s"], plan.info["est_tiles_s"], plan.info["est_entries_s"]) > 0
+        else:
+            assert plan.info["form"] == {"full": 0, "tiles": 1, "entries": 2}[form]
         plan.close()
-    forced = {k: v for k, v in times.items() if k != "auto"}
-    best = min(forced, key=forced.get)
-    print("%s %g: picked %s %.3f ms | full %.3f tiles %.3f entries %.3f | fastest %s" % (
-        kind, param, picked, times["auto"], forced["full"], forced["tiles"], forced["entries"], best))
-    assert times["auto"] <= 1.10 * forced[best], (kind, param, picked, times)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -109,9 +109,8 @@ def test_bench_launches_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1
-    rec = json.loads(lines[0])
+    from tests.bench_io import split_bench_output
+    rec, _ = split_bench_output(p)                # exactly one stdout line, under 6 KB, the contract's keys present
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["gather_ok"] is True and rec["config"]["T_job"] == 730
     assert rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"       # the all-reduce-of-ones proof an N > 1 line carries
     if torch.cuda.device_count() < 2:
