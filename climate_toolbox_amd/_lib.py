@@ -43,19 +43,27 @@ EXPORTS = (
     "wagg_dense_create_from_csr", "wagg_dense_create_from_csr_f64", "wagg_synth_table_csr", "wagg_relayout_to_f64", "wagg_upload",
     "wagg_shard_group_create", "wagg_shard_group_destroy", "wagg_shard_group_info",
     "wagg_apply_sharded_f32", "wagg_apply_sharded_f64", "wagg_dense_apply_sharded_f32", "wagg_dense_apply_sharded_f64",
+    "wagg_apply", "wagg_struct_size", "wagg_struct_ordinals", "wagg_plan_get_info_sized", "wagg_dense_get_info_sized",
+    "wagg_host_stats_read_sized",
 )
+STRUCT_PLAN_INFO, STRUCT_DENSE_INFO, STRUCT_HOST_STATS, STRUCT_APPLY_DESC = 0, 1, 2, 3
+PLAN_SEGMENT, PLAN_DENSE = 0, 1
+SRC_DEVICE, SRC_HOST, SRC_HOST_MULTI, SRC_SHARDED = 0, 1, 2, 3
+XF_NONE, XF_POLY, XF_EDD = 0, 1, 2
+T_F32, T_F64 = 7, 8
 
 
 class HostStats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("calls", "blocks", "registered", "register_failed", "unregistered", "unregister_failed",
                                          "cleanup_failed", "staged_h2d_bytes", "staged_d2h_bytes", "direct_h2d_bytes",
-                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us", "blocks_retired", "found_page_locked")]
+                                         "direct_d2h_bytes", "lines_h2d_bytes", "lines_wait_pack_us", "lines_wait_copy_us", "blocks_retired", "found_page_locked",
+                                         "watched_calls", "last_rate_permille")]
 
 
 def host_stats(reset=False):
     """What the host-buffer paths did since the last reset (``wagg_host_stats_read``): a dict of counters."""
     st = HostStats()
-    check(load().wagg_host_stats_read(C.byref(st), 1 if reset else 0), "wagg_host_stats_read")
+    check(load().wagg_host_stats_read_sized(C.byref(st), C.sizeof(st), 1 if reset else 0), "wagg_host_stats_read_sized")
     return {k: int(getattr(st, k)) for k, _ in HostStats._fields_}
 
 
@@ -88,6 +96,44 @@ class PlanInfo(C.Structure):
                 ("lines_chunks", C.c_int64), ("lines_ucells", C.c_int64), ("lines_lines128", C.c_int64),
                 ("n_partial_rows64", C.c_int64), ("lines64_chunks", C.c_int64), ("lines64_ucells", C.c_int64)]
 
+
+class ApplyDesc(C.Structure):
+    """wagg_apply_desc (include/wagg.h): the one descriptor every apply goes through."""
+    _fields_ = [("struct_size", C.c_uint64), ("plan_kind", C.c_int32), ("elem", C.c_int32), ("source", C.c_int32), ("transform", C.c_int32),
+                ("plan", C.c_void_p), ("x", C.c_void_p), ("x2", C.c_void_p), ("out", C.c_void_p),
+                ("T", C.c_int64), ("ldx", C.c_int64), ("ldo", C.c_int64), ("out_pstride", C.c_int64),
+                ("layout", C.c_int32), ("out_layout", C.c_int32), ("offset", C.c_double), ("pow_first", C.c_int32), ("n_pow", C.c_int32),
+                ("thresholds", C.c_void_p), ("n_thr", C.c_int32), ("flags", C.c_int32), ("ksplit", C.c_int32), ("n_plans", C.c_int32),
+                ("devices", C.c_void_p), ("rows", C.c_void_p), ("group", C.c_void_p), ("root", C.c_int32), ("reserved0", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+STRUCTS = {STRUCT_PLAN_INFO: PlanInfo, STRUCT_DENSE_INFO: DenseInfo, STRUCT_HOST_STATS: HostStats, STRUCT_APPLY_DESC: ApplyDesc}
+
+
+def _ptr(v):
+    """an address for a c_void_p field: ints, c_void_p, ctypes arrays / pointers, None"""
+    if v is None:
+        return None
+    if isinstance(v, int):
+        return v
+    if isinstance(v, C.c_void_p):
+        return v.value
+    return C.cast(v, C.c_void_p).value
+
+
+def run(what, **fields):
+    """Fill a wagg_apply_desc and call wagg_apply(): the ONE way this package applies a plan.  Pointer-valued fields take
+    addresses, c_void_p or ctypes arrays; the caller keeps the objects behind them alive for the call."""
+    d = ApplyDesc()
+    d.struct_size = C.sizeof(ApplyDesc)
+    d.pow_first = d.n_pow = 1
+    for k, v in fields.items():
+        setattr(d, k, _ptr(v) if k in _DESC_POINTERS else v)
+    check(load().wagg_apply(C.byref(d)), what)
+
+
+_DESC_POINTERS = frozenset(k for k, t in ApplyDesc._fields_ if t is C.c_void_p)
 
 _lib = None
 
@@ -122,6 +168,12 @@ def load():
                                    C.c_int, C.POINTER(vp)]
     L.wagg_plan_destroy.argtypes = [vp]
     L.wagg_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.wagg_plan_get_info_sized.argtypes = [vp, vp, C.c_uint64]
+    L.wagg_dense_get_info_sized.argtypes = [vp, vp, C.c_uint64]
+    L.wagg_host_stats_read_sized.argtypes = [vp, C.c_uint64, C.c_int]
+    L.wagg_struct_size.argtypes = [C.c_int]
+    L.wagg_struct_ordinals.argtypes = [C.c_int, vp, C.c_uint64]
+    L.wagg_apply.argtypes = [C.POINTER(ApplyDesc)]
     L.wagg_plan_get_den.argtypes = [vp, f64p]
     L.wagg_plan_status.argtypes = [vp, vp]
     for name in ("wagg_apply_f32", "wagg_apply_f64"):

@@ -141,6 +141,10 @@ template <typename V, typename T> __device__ __forceinline__ V xform4(V v, T off
     return r;
 }
 
+// a struct that crosses the C boundary by layout, into a caller's buffer of `dst_size` bytes: min(dst_size, src_size) bytes are
+// written, what the caller has beyond the library's size is zeroed (wagg_desc.hip; include/wagg.h "structs that cross ...")
+void copy_sized(void *dst, uint64_t dst_size, const void *src, size_t src_size);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of once per apply
 hipError_t allow_dynamic_lds(const void *kern, size_t bytes);
 

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "wagg_dense_int.h"
+#include "wagg_entry.h"
 
 namespace wagg {
 
@@ -1108,9 +1109,12 @@ extern "C" int wagg_dense_create_from_csr_f64(const int64_t *rowptr, const int32
     return create_from_table<double>(nullptr, rowptr, col, val, 0, G, R, flags, out);
 }
 
-extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
+extern "C" int wagg_dense_get_info_sized(const wagg_dense *d, void *info_buf, uint64_t size) {
     using namespace wagg;
-    WAGG_REQUIRE(d && info, "NULL argument");
+    WAGG_REQUIRE(d && info_buf, "NULL argument");
+    wagg_dense_info st;
+    std::memset(&st, 0, sizeof(st));
+    wagg_dense_info *info = &st;
     info->G = d->G; info->R = d->R; info->n_kt = d->n_kt; info->n_nt = d->n_nt;
     info->n_tiles = d->n_tiles; info->tiled = d->tiled ? 1 : 0;
     info->w_bytes = d->spmm ? (int64_t)d->sp.n_groups * 4 * (d->f64 ? wagg::SpT<double>::GW : wagg::SpT<float>::GW) : d->w_slots() * 16;
@@ -1123,7 +1127,11 @@ extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
     info->walked_entries = d->walked_entries;
     info->one_pass_sort = d->one_pass_sort ? 1 : 0;
     info->reserved0 = 0;
+    copy_sized(info_buf, size, &st, sizeof(st));
     return WAGG_OK;
+}
+extern "C" int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info) {
+    return wagg_dense_get_info_sized(d, info, sizeof(wagg_dense_info));
 }
 
 namespace wagg {
@@ -1200,28 +1208,28 @@ extern "C" int wagg_dense_get_den(const wagg_dense *d, double *den_host) {
     return WAGG_OK;
 }
 
-extern "C" int wagg_dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
+int wagg::entry::dense_apply_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx,
                                     float *out_dev, int64_t ldo, int ksplit, void *stream) {
     return wagg::dense_apply<float>(d, X_dev, T, ldx, wagg::PackXfT<float>{}, out_dev, ldo, ksplit, stream);
 }
-extern "C" int wagg_dense_apply_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx,
+int wagg::entry::dense_apply_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx,
                                     double *out_dev, int64_t ldo, int ksplit, void *stream) {
     return wagg::dense_apply<double>(d, X_dev, T, ldx, wagg::PackXfT<double>{}, out_dev, ldo, ksplit, stream);
 }
-extern "C" int wagg_dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, double offset,
+int wagg::entry::dense_apply_poly_f32(wagg_dense *d, const float *X_dev, int64_t T, int64_t ldx, double offset,
                                          int power, float *out_dev, int64_t ldo, int ksplit, void *stream) {
     return wagg::apply_poly<float>(d, X_dev, T, ldx, offset, power, out_dev, ldo, ksplit, stream);
 }
-extern "C" int wagg_dense_apply_poly_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx, double offset,
+int wagg::entry::dense_apply_poly_f64(wagg_dense *d, const double *X_dev, int64_t T, int64_t ldx, double offset,
                                          int power, double *out_dev, int64_t ldo, int ksplit, void *stream) {
     return wagg::apply_poly<double>(d, X_dev, T, ldx, offset, power, out_dev, ldo, ksplit, stream);
 }
-extern "C" int wagg_dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+int wagg::entry::dense_apply_edd_f32(wagg_dense *d, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
                                         int64_t ldx, double offset, double threshold, float *out_dev, int64_t ldo,
                                         int ksplit, void *stream) {
     return wagg::apply_edd<float>(d, tasmin_dev, tasmax_dev, T, ldx, offset, threshold, out_dev, ldo, ksplit, stream);
 }
-extern "C" int wagg_dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+int wagg::entry::dense_apply_edd_f64(wagg_dense *d, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
                                         int64_t ldx, double offset, double threshold, double *out_dev, int64_t ldo,
                                         int ksplit, void *stream) {
     return wagg::apply_edd<double>(d, tasmin_dev, tasmax_dev, T, ldx, offset, threshold, out_dev, ldo, ksplit, stream);
@@ -1298,19 +1306,19 @@ static int dense_apply_host_multi(wagg_dense *const *plans, const int *devices, 
 }
 }  // namespace wagg
 
-extern "C" int wagg_dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int64_t ldx,
+int wagg::entry::dense_apply_host_f32(wagg_dense *d, const float *X_host, int64_t T, int64_t ldx,
                                          float *out_host, int64_t ldo, int flags) {
     return wagg::dense_apply_host<float>(d, X_host, T, ldx, out_host, ldo, flags);
 }
-extern "C" int wagg_dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
+int wagg::entry::dense_apply_host_f64(wagg_dense *d, const double *X_host, int64_t T, int64_t ldx,
                                          double *out_host, int64_t ldo, int flags) {
     return wagg::dense_apply_host<double>(d, X_host, T, ldx, out_host, ldo, flags);
 }
-extern "C" int wagg_dense_apply_host_multi_f32(wagg_dense *const *plans, const int *devices, int n_devices, const float *X_host,
+int wagg::entry::dense_apply_host_multi_f32(wagg_dense *const *plans, const int *devices, int n_devices, const float *X_host,
                                                int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags) {
     return wagg::dense_apply_host_multi<float>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags);
 }
-extern "C" int wagg_dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices, int n_devices, const double *X_host,
+int wagg::entry::dense_apply_host_multi_f64(wagg_dense *const *plans, const int *devices, int n_devices, const double *X_host,
                                                int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags) {
     return wagg::dense_apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags);
 }

@@ -24,7 +24,8 @@ namespace wagg {
 struct HostStats {
     std::atomic<int64_t> calls{0}, registered{0}, register_failed{0}, unregistered{0}, unregister_failed{0},
         cleanup_failed{0}, staged_h2d_bytes{0}, staged_d2h_bytes{0}, direct_h2d_bytes{0}, direct_d2h_bytes{0},
-        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0}, blocks_retired{0}, found_page_locked{0};
+        blocks{0}, lines_h2d_bytes{0}, lines_wait_pack_us{0}, lines_wait_copy_us{0}, blocks_retired{0}, found_page_locked{0},
+        watched_calls{0}, last_rate_permille{0};
 };
 extern HostStats g_host_stats;
 

@@ -454,7 +454,6 @@ DevicePipe::~DevicePipe() {
     scratch_stream_done(sc, 1);
     scratch_stream_done(sk, 0);
     scratch_stream_done(sd, 2);
-    if (retire) release_scratch(1);              // (and what idles in the pool: fresh blocks for the next call)
 }
 
 // ---- the pipeline of one device: blocks slot, slot + n_dev, ... ---------------------------------------------------------
@@ -559,22 +558,45 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     // Copy-rate watch.  The pipeline can get into a state in which the copies into its pooled device blocks run at half the
     // rate (seen on MI355X / ROCm 7.2 in one call sequence -- plain lines-only calls after wagg_apply_poly_host_* calls with
     // page-locked whole rows, tools/host_poly_timing.py: 21.3 -> 47 ms per call, wait for the copy engine 16.6 -> 31 ms; it
-    // stays until the pool's device blocks go back to the driver -- fresh streams or a fresh ring do not help -- and a
-    // different call order does not show it; cause inside the runtime not established).  A call that moved >= 256 MiB at
-    // < 70 % of the best rate this process has seen on the device for the same kind of call therefore hands its device
-    // blocks, and the idle ones of the pool, back to the driver: the next call allocates its own (~1 ms).
+    // stays until the device blocks go back to the driver -- fresh streams or a fresh ring do not help -- and a different call
+    // order does not show it; DESIGN.md "host-resident fields" has what is known of the cause).  What the watch compares, per
+    // device and per SHAPE of call (lines only or whole rows, one or two fields, the number of result planes, the packed
+    // fraction of a row, where the result goes -- a call with four result planes or two fields is legitimately slower than a
+    // plain one and never shares a record with it):
+    //   * lines only: the packed bytes over the time this thread waited for their copies, and only for calls in which that wait
+    //     was at least half of the wall time -- a call held up by the packing threads (a busy host) says nothing about the
+    //     copies and neither sets nor fails the record;
+    //   * whole rows page-locked in place: the bytes over the call's wall time (PCIe-bound by construction).
+    // A call that moved >= 256 MiB at < 70 % of the best rate seen for its shape hands ITS OWN four device blocks back to the
+    // driver (the next call allocates fresh ones, ~1 ms); what idles in the pool -- the build arena among it -- is left alone.
+    // The verdict is visible: wagg_host_stats.watched_calls / .last_rate_permille / .blocks_retired.
     {
         const int64_t moved = gather ? team->sent_bytes : moved_plain;
-        const int64_t us = now_us() - t_begin_us;         // (the whole pipeline: a PCIe-bound call's wall time is its copy time)
-        if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x)) {
+        const int64_t wall_us = now_us() - t_begin_us;
+        const int64_t us = gather ? team->copy_wait_us : wall_us;
+        const bool copy_bound = !gather || 2 * team->copy_wait_us >= wall_us;
+        if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x) && copy_bound) {
+            struct Best { uint64_t key; double rate; };
             static std::mutex mu;
-            static double best[MAX_DEV][2] = {};
+            static std::vector<Best> best;
+            const uint64_t frac16 = gather ? (uint64_t)((16 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes) : 16u;
+            const uint64_t key = ((uint64_t)(P.device & 0xff) << 32) | ((uint64_t)(gather ? 1 : 0) << 31) | ((uint64_t)(a.X2_host ? 1 : 0) << 30) |
+                                 ((uint64_t)(pin_o ? 1 : 0) << 29) | ((uint64_t)(a.n_planes & 0xff) << 8) | frac16;
             const double rate = (double)moved / (double)us;
-            const int di = P.device >= 0 && P.device < MAX_DEV ? P.device : 0;
-            std::lock_guard<std::mutex> lock(mu);
-            double &b = best[di][gather ? 1 : 0];
-            if (rate > b) b = rate;
-            else if (rate < 0.7 * b) { P.retire = true; g_host_stats.blocks_retired++; }
+            try {
+                std::lock_guard<std::mutex> lock(mu);
+                Best *b = nullptr;
+                for (Best &k : best) if (k.key == key) { b = &k; break; }
+                if (!b) { best.push_back(Best{key, 0.0}); b = &best.back(); }
+                g_host_stats.watched_calls++;
+                if (rate >= b->rate) { b->rate = rate; g_host_stats.last_rate_permille = 1000; }
+                else {
+                    g_host_stats.last_rate_permille = (int64_t)(1000.0 * rate / b->rate);
+                    if (rate < 0.7 * b->rate) { P.retire = true; g_host_stats.blocks_retired++; }
+                }
+            } catch (const std::bad_alloc &) {}           // (no record: nothing watched)
+        } else {
+            g_host_stats.last_rate_permille = 0;          // the last call was not one the watch judges
         }
     }
     return WAGG_OK;
@@ -655,10 +677,13 @@ extern "C" int wagg_host_block_plan(int64_t T, int64_t row_bytes, int64_t quantu
     return WAGG_OK;
 }
 
-extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
+extern "C" int wagg_host_stats_read_sized(void *out_buf, uint64_t size, int reset) {
     using namespace wagg;
-    WAGG_REQUIRE(out != nullptr, "NULL argument");
+    WAGG_REQUIRE(out_buf != nullptr, "NULL argument");
     HostStats &s = g_host_stats;
+    wagg_host_stats st;
+    std::memset(&st, 0, sizeof(st));
+    wagg_host_stats *out = &st;
     out->calls = s.calls; out->blocks = s.blocks;
     out->registered = s.registered; out->register_failed = s.register_failed;
     out->unregistered = s.unregistered; out->unregister_failed = s.unregister_failed;
@@ -667,10 +692,16 @@ extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
     out->direct_h2d_bytes = s.direct_h2d_bytes; out->direct_d2h_bytes = s.direct_d2h_bytes;
     out->blocks_retired = s.blocks_retired; out->found_page_locked = s.found_page_locked;
     out->lines_h2d_bytes = s.lines_h2d_bytes; out->lines_wait_pack_us = s.lines_wait_pack_us; out->lines_wait_copy_us = s.lines_wait_copy_us;
+    out->watched_calls = s.watched_calls; out->last_rate_permille = s.last_rate_permille;
     if (reset) {
+        s.watched_calls = 0;                       // (last_rate_permille is a state, not a counter: it stays)
         s.calls = 0; s.blocks = 0; s.registered = 0; s.register_failed = 0; s.unregistered = 0; s.unregister_failed = 0;
         s.cleanup_failed = 0; s.staged_h2d_bytes = 0; s.staged_d2h_bytes = 0; s.direct_h2d_bytes = 0; s.direct_d2h_bytes = 0;
         s.lines_h2d_bytes = 0; s.lines_wait_pack_us = 0; s.lines_wait_copy_us = 0; s.blocks_retired = 0; s.found_page_locked = 0;
     }
+    copy_sized(out_buf, size, &st, sizeof(st));
     return WAGG_OK;
+}
+extern "C" int wagg_host_stats_read(wagg_host_stats *out, int reset) {
+    return wagg_host_stats_read_sized(out, sizeof(wagg_host_stats), reset);
 }

@@ -18,6 +18,7 @@
 
 #include "wagg_dense_int.h"
 #include "wagg_sparse_int.h"
+#include "wagg_entry.h"
 
 namespace wagg {
 
@@ -295,8 +296,8 @@ static int sparse_sharded(wagg_shard_group *g, const wagg_plan *const *plans, co
     WAGG_REQUIRE(ldx >= plans[0]->info.G, "ldx too small");
     return apply_sharded<T>(g, devs.data(), plans[0]->info.R, X_dev, rows, out_root, ldo, root,
                             [&](int i, const T *x, int64_t r, T *o, int64_t ld, hipStream_t st) {
-                                if constexpr (sizeof(T) == 4) return wagg_apply_f32(plans[i], x, r, ldx, WAGG_LAYOUT_TG, o, ld, WAGG_OUT_TR, st);
-                                else return wagg_apply_f64(plans[i], x, r, ldx, WAGG_LAYOUT_TG, o, ld, WAGG_OUT_TR, st);
+                                if constexpr (sizeof(T) == 4) return entry::apply_f32(plans[i], x, r, ldx, WAGG_LAYOUT_TG, o, ld, WAGG_OUT_TR, st);
+                                else return entry::apply_f64(plans[i], x, r, ldx, WAGG_LAYOUT_TG, o, ld, WAGG_OUT_TR, st);
                             });
 }
 
@@ -314,26 +315,26 @@ static int dense_sharded(wagg_shard_group *g, wagg_dense *const *plans, const T 
     WAGG_REQUIRE(ldx >= plans[0]->G, "ldx too small");
     return apply_sharded<T>(g, devs.data(), plans[0]->R, X_dev, rows, out_root, ldo, root,
                             [&](int i, const T *x, int64_t r, T *o, int64_t ld, hipStream_t st) {
-                                if constexpr (sizeof(T) == 4) return wagg_dense_apply_f32(plans[i], x, r, ldx, o, ld, 0, st);
-                                else return wagg_dense_apply_f64(plans[i], x, r, ldx, o, ld, 0, st);
+                                if constexpr (sizeof(T) == 4) return entry::dense_apply_f32(plans[i], x, r, ldx, o, ld, 0, st);
+                                else return entry::dense_apply_f64(plans[i], x, r, ldx, o, ld, 0, st);
                             });
 }
 
 }  // namespace wagg
 
-extern "C" int wagg_apply_sharded_f32(wagg_shard_group *g, const wagg_plan *const *plans, const float *const *X_dev, const int64_t *rows,
+int wagg::entry::apply_sharded_f32(wagg_shard_group *g, const wagg_plan *const *plans, const float *const *X_dev, const int64_t *rows,
                                       int64_t ldx, float *out_root, int64_t ldo, int root) {
     return wagg::sparse_sharded<float>(g, plans, X_dev, rows, ldx, out_root, ldo, root);
 }
-extern "C" int wagg_apply_sharded_f64(wagg_shard_group *g, const wagg_plan *const *plans, const double *const *X_dev, const int64_t *rows,
+int wagg::entry::apply_sharded_f64(wagg_shard_group *g, const wagg_plan *const *plans, const double *const *X_dev, const int64_t *rows,
                                       int64_t ldx, double *out_root, int64_t ldo, int root) {
     return wagg::sparse_sharded<double>(g, plans, X_dev, rows, ldx, out_root, ldo, root);
 }
-extern "C" int wagg_dense_apply_sharded_f32(wagg_shard_group *g, wagg_dense *const *plans, const float *const *X_dev, const int64_t *rows,
+int wagg::entry::dense_apply_sharded_f32(wagg_shard_group *g, wagg_dense *const *plans, const float *const *X_dev, const int64_t *rows,
                                             int64_t ldx, float *out_root, int64_t ldo, int root) {
     return wagg::dense_sharded<float>(g, plans, X_dev, rows, ldx, out_root, ldo, root);
 }
-extern "C" int wagg_dense_apply_sharded_f64(wagg_shard_group *g, wagg_dense *const *plans, const double *const *X_dev, const int64_t *rows,
+int wagg::entry::dense_apply_sharded_f64(wagg_shard_group *g, wagg_dense *const *plans, const double *const *X_dev, const int64_t *rows,
                                             int64_t ldx, double *out_root, int64_t ldo, int root) {
     return wagg::dense_sharded<double>(g, plans, X_dev, rows, ldx, out_root, ldo, root);
 }

@@ -33,6 +33,7 @@
 #include <utility>
 
 #include "wagg_sparse_int.h"
+#include "wagg_entry.h"
 
 namespace wagg {
 
@@ -1993,10 +1994,13 @@ extern "C" int wagg_plan_destroy(wagg_plan *plan) {
     return WAGG_OK;
 }
 
-extern "C" int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info) {
+extern "C" int wagg_plan_get_info_sized(const wagg_plan *plan, void *info, uint64_t size) {
     WAGG_REQUIRE(plan && info, "NULL argument");
-    *info = plan->info;
+    wagg::copy_sized(info, size, &plan->info, sizeof(plan->info));
     return WAGG_OK;
+}
+extern "C" int wagg_plan_get_info(const wagg_plan *plan, wagg_plan_info *info) {
+    return wagg_plan_get_info_sized(plan, info, sizeof(wagg_plan_info));
 }
 
 extern "C" int wagg_plan_status(const wagg_plan *plan, void *stream) {
@@ -2011,7 +2015,7 @@ extern "C" int wagg_plan_get_den(const wagg_plan *plan, double *den_host) {
     return WAGG_OK;
 }
 
-extern "C" int wagg_apply_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx,
+int wagg::entry::apply_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx,
                               int layout, float *out_dev, int64_t ldo, int out_layout, void *stream) {
     int rc = wagg::check_apply_args(plan, X_dev, T, ldx, layout, out_dev, ldo, out_layout);
     if (rc != WAGG_OK) return rc;
@@ -2019,7 +2023,7 @@ extern "C" int wagg_apply_f32(const wagg_plan *plan, const float *X_dev, int64_t
                                           (hipStream_t)stream);
 }
 
-extern "C" int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx,
+int wagg::entry::apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx,
                               int layout, double *out_dev, int64_t ldo, int out_layout, void *stream) {
     int rc = wagg::check_apply_args(plan, X_dev, T, ldx, layout, out_dev, ldo, out_layout);
     if (rc != WAGG_OK) return rc;
@@ -2229,58 +2233,58 @@ static int apply_host_multi(const wagg_plan *const *plans, const int *devices, i
 }
 }  // namespace wagg
 
-extern "C" int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                                    int layout, float *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, wagg_apply_f32);
+    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, entry::apply_f32);
 }
-extern "C" int wagg_apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_host_ex_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                                       int layout, float *out_host, int64_t ldo, int out_layout, int flags) {
-    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, wagg_apply_f32);
+    return wagg::apply_host<float>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, entry::apply_f32);
 }
-extern "C" int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                    int layout, double *out_host, int64_t ldo, int out_layout) {
-    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, wagg_apply_f64);
+    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, WAGG_HOST_PIN | WAGG_HOST_LINES, entry::apply_f64);
 }
-extern "C" int wagg_apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_host_ex_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,
                                       int layout, double *out_host, int64_t ldo, int out_layout, int flags) {
-    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, wagg_apply_f64);
+    return wagg::apply_host<double>(plan, X_host, T, ldx, layout, out_host, ldo, out_layout, flags, entry::apply_f64);
 }
-extern "C" int wagg_apply_host_multi_f32(const wagg_plan *const *plans, const int *devices, int n_devices, const float *X_host,
+int wagg::entry::apply_host_multi_f32(const wagg_plan *const *plans, const int *devices, int n_devices, const float *X_host,
                                          int64_t T, int64_t ldx, float *out_host, int64_t ldo, int flags) {
-    return wagg::apply_host_multi<float>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, wagg_apply_f32);
+    return wagg::apply_host_multi<float>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, entry::apply_f32);
 }
-extern "C" int wagg_apply_host_multi_f64(const wagg_plan *const *plans, const int *devices, int n_devices, const double *X_host,
+int wagg::entry::apply_host_multi_f64(const wagg_plan *const *plans, const int *devices, int n_devices, const double *X_host,
                                          int64_t T, int64_t ldx, double *out_host, int64_t ldo, int flags) {
-    return wagg::apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, wagg_apply_f64);
+    return wagg::apply_host_multi<double>(plans, devices, n_devices, X_host, T, ldx, out_host, ldo, flags, entry::apply_f64);
 }
 
-extern "C" int wagg_apply_poly_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+int wagg::entry::apply_poly_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
                                         int n_pow, float *out_host, int64_t ldo, int64_t out_pstride, int flags) {
     return wagg::apply_poly_host<float>(plan, X_host, T, ldx, offset, pow_first, n_pow, out_host, ldo, out_pstride, flags);
 }
-extern "C" int wagg_apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
+int wagg::entry::apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
                                         int n_pow, double *out_host, int64_t ldo, int64_t out_pstride, int flags) {
     return wagg::apply_poly_host<double>(plan, X_host, T, ldx, offset, pow_first, n_pow, out_host, ldo, out_pstride, flags);
 }
 
-extern "C" int wagg_apply_edd_host_f32(const wagg_plan *plan, const float *tasmin_host, const float *tasmax_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_edd_host_f32(const wagg_plan *plan, const float *tasmin_host, const float *tasmax_host, int64_t T, int64_t ldx,
                                        double offset, const double *thresholds, int n_thr, float *out_host, int64_t ldo,
                                        int64_t out_pstride, int flags) {
     return wagg::apply_edd_host<float>(plan, tasmin_host, tasmax_host, T, ldx, offset, thresholds, n_thr, out_host, ldo, out_pstride, flags);
 }
-extern "C" int wagg_apply_edd_host_f64(const wagg_plan *plan, const double *tasmin_host, const double *tasmax_host, int64_t T, int64_t ldx,
+int wagg::entry::apply_edd_host_f64(const wagg_plan *plan, const double *tasmin_host, const double *tasmax_host, int64_t T, int64_t ldx,
                                        double offset, const double *thresholds, int n_thr, double *out_host, int64_t ldo,
                                        int64_t out_pstride, int flags) {
     return wagg::apply_edd_host<double>(plan, tasmin_host, tasmax_host, T, ldx, offset, thresholds, n_thr, out_host, ldo, out_pstride, flags);
 }
 
-extern "C" int wagg_apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
+int wagg::entry::apply_poly_f32(const wagg_plan *plan, const float *X_dev, int64_t T, int64_t ldx, int layout,
                                    double offset, int pow_first, int n_pow, float *out_dev, int64_t ldo,
                                    int64_t out_pstride, int out_layout, void *stream) {
     return wagg::apply_poly<float, 64>(plan, X_dev, T, ldx, layout, offset, pow_first, n_pow, out_dev, ldo, out_pstride,
                                        out_layout, (hipStream_t)stream);
 }
-extern "C" int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
+int wagg::entry::apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_t ldx, int layout,
                                    double offset, int pow_first, int n_pow, double *out_dev, int64_t ldo,
                                    int64_t out_pstride, int out_layout, void *stream) {
     return wagg::apply_poly<double, 32>(plan, X_dev, T, ldx, layout, offset, pow_first, n_pow, out_dev, ldo, out_pstride,
@@ -2308,13 +2312,13 @@ static int apply_edd(const wagg_plan *plan, const T *tmin, const T *tmax, int64_
 }
 }  // namespace wagg
 
-extern "C" int wagg_apply_edd_f32(const wagg_plan *plan, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
+int wagg::entry::apply_edd_f32(const wagg_plan *plan, const float *tasmin_dev, const float *tasmax_dev, int64_t T,
                                   int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
                                   float *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream) {
     return wagg::apply_edd<float, 64>(plan, tasmin_dev, tasmax_dev, T, ldx, layout, offset, thresholds, n_thr, out_dev,
                                       ldo, out_pstride, out_layout, (hipStream_t)stream);
 }
-extern "C" int wagg_apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
+int wagg::entry::apply_edd_f64(const wagg_plan *plan, const double *tasmin_dev, const double *tasmax_dev, int64_t T,
                                   int64_t ldx, int layout, double offset, const double *thresholds, int n_thr,
                                   double *out_dev, int64_t ldo, int64_t out_pstride, int out_layout, void *stream) {
     return wagg::apply_edd<double, 32>(plan, tasmin_dev, tasmax_dev, T, ldx, layout, offset, thresholds, n_thr, out_dev,

@@ -378,7 +378,7 @@ extern "C" int wagg_any_less_f64(const double *a, const double *b, int64_t n, in
 }
 
 // 0.3.0: wagg_host_stats grew (lines_*, blocks_retired, found_page_locked); host forms of the fused transforms; wagg_upload
-extern "C" int wagg_version(void) { return 10000 * 0 + 100 * 3 + 0; }
+extern "C" int wagg_version(void) { return 10000 * 0 + 100 * 4 + 0; }
 
 extern "C" int wagg_device_count(void) {
     int n = 0;

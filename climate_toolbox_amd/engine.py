@@ -54,6 +54,11 @@ def _stream_handle(stream):
     return C.c_void_p(s.cuda_stream)
 
 
+def _elem(dtype):
+    """WAGG_T_F32 / WAGG_T_F64 of a torch or numpy dtype"""
+    return _lib.T_F64 if str(dtype).endswith("float64") else _lib.T_F32
+
+
 def _ld(t):
     """Leading dimension of a 2-D row-contiguous tensor: the row pitch; a single row carries an
     arbitrary stride(0), so its own length stands in."""
@@ -109,7 +114,7 @@ class SparsePlan:
                                           _np_ptr(we, C.c_double), len(ci), self.G, self.R,
                                           int(row_len), int(flags), C.byref(self._h)), "wagg_plan_create")
         info = _lib.PlanInfo()
-        _lib.check(L.wagg_plan_get_info(self._h, C.byref(info)), "wagg_plan_get_info")
+        _lib.check(L.wagg_plan_get_info_sized(self._h, C.byref(info), C.sizeof(info)), "wagg_plan_get_info_sized")
         self.info = {k: getattr(info, k) for k, _ in _lib.PlanInfo._fields_}
         den = np.empty(self.R, dtype=np.float64)
         _lib.check(L.wagg_plan_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_plan_get_den")
@@ -142,11 +147,9 @@ class SparsePlan:
             out = torch.empty(shape, dtype=X.dtype, device=X.device)
         elif tuple(out.shape) != shape or out.dtype != X.dtype or (shape[1] > 1 and out.stride(1) != 1):
             raise ValueError("out must be a %s %s tensor with contiguous rows" % (shape, X.dtype))
-        L = _lib.load()
-        fn = L.wagg_apply_f32 if X.dtype == torch.float32 else L.wagg_apply_f64
-        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout],
-                      C.c_void_p(out.data_ptr()), _ld(out), _OUTS[out_layout], _stream_handle(stream)),
-                   "wagg_apply")
+        _lib.run("wagg_apply", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(X.dtype), source=_lib.SRC_DEVICE,
+                 x=X.data_ptr(), T=T, ldx=_ld(X), layout=_LAYOUTS[layout], out=out.data_ptr(), ldo=_ld(out),
+                 out_layout=_OUTS[out_layout], stream=_stream_handle(stream))
         return out
 
     def apply_poly(self, X, offset, n_pow, layout="TG", out=None, out_layout="TR", stream=None, pow_first=1):
@@ -163,11 +166,10 @@ class SparsePlan:
             out = torch.empty(shape, dtype=X.dtype, device=X.device)
         elif tuple(out.shape) != shape or out.dtype != X.dtype or not out.is_contiguous():
             raise ValueError("out must be a contiguous %s %s tensor" % (shape, X.dtype))
-        L = _lib.load()
-        fn = L.wagg_apply_poly_f32 if X.dtype == torch.float32 else L.wagg_apply_poly_f64
-        _lib.check(fn(self._h, C.c_void_p(X.data_ptr()), T, _ld(X), _LAYOUTS[layout], float(offset), int(pow_first),
-                      int(n_pow), C.c_void_p(out.data_ptr()), max(1, shape[2]), shape[1] * shape[2], _OUTS[out_layout],
-                      _stream_handle(stream)), "wagg_apply_poly")
+        _lib.run("wagg_apply (poly)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(X.dtype), source=_lib.SRC_DEVICE,
+                 transform=_lib.XF_POLY, offset=float(offset), pow_first=int(pow_first), n_pow=int(n_pow),
+                 x=X.data_ptr(), T=T, ldx=_ld(X), layout=_LAYOUTS[layout], out=out.data_ptr(), ldo=max(1, shape[2]),
+                 out_pstride=shape[1] * shape[2], out_layout=_OUTS[out_layout], stream=_stream_handle(stream))
         return out
 
     def apply_edd(self, tasmin, tasmax, thresholds, offset=0.0, layout="TG", out=None, out_layout="TR", stream=None):
@@ -187,12 +189,10 @@ class SparsePlan:
             out = torch.empty(shape, dtype=tasmin.dtype, device=tasmin.device)
         elif tuple(out.shape) != shape or out.dtype != tasmin.dtype or not out.is_contiguous():
             raise ValueError("out must be a contiguous %s %s tensor" % (shape, tasmin.dtype))
-        L = _lib.load()
-        fn = L.wagg_apply_edd_f32 if tasmin.dtype == torch.float32 else L.wagg_apply_edd_f64
-        _lib.check(fn(self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin),
-                      _LAYOUTS[layout], float(offset), _np_ptr(thr, C.c_double), len(thr), C.c_void_p(out.data_ptr()),
-                      max(1, shape[2]), shape[1] * shape[2], _OUTS[out_layout], _stream_handle(stream)),
-                   "wagg_apply_edd")
+        _lib.run("wagg_apply (edd)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(tasmin.dtype), source=_lib.SRC_DEVICE,
+                 transform=_lib.XF_EDD, offset=float(offset), thresholds=thr.ctypes.data, n_thr=len(thr),
+                 x=tasmin.data_ptr(), x2=tasmax.data_ptr(), T=T, ldx=_ld(tasmin), layout=_LAYOUTS[layout], out=out.data_ptr(),
+                 ldo=max(1, shape[2]), out_pstride=shape[1] * shape[2], out_layout=_OUTS[out_layout], stream=_stream_handle(stream))
         return out
 
     def replica(self, device):
@@ -213,21 +213,20 @@ class SparsePlan:
         T = X.shape[0] if layout == "TG" else X.shape[1]
         shape = (T, self.R) if out_layout == "TR" else (self.R, T)
         out = _host_out(out, shape, X.dtype)
-        L = _lib.load()
         if replicas:
             if layout != "TG" or out_layout != "TR":
                 raise ValueError("the multi-device form takes (time, gridcell) data only")
             plans = (self,) + tuple(replicas)
             hs = (C.c_void_p * len(plans))(*[p._h for p in plans])
             devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
-            fn = L.wagg_apply_host_multi_f32 if X.dtype == np.float32 else L.wagg_apply_host_multi_f64
-            _lib.check(fn(hs, devs, len(plans), C.c_void_p(X.ctypes.data), T, X.shape[1], C.c_void_p(out.ctypes.data),
-                          max(1, self.R), int(flags) & ~_lib.HOST_LINES), "wagg_apply_host_multi")
+            _lib.run("wagg_apply (host, multi-device)", plan_kind=_lib.PLAN_SEGMENT, plan=hs, n_plans=len(plans), devices=devs,
+                     elem=_elem(X.dtype), source=_lib.SRC_HOST_MULTI, x=X.ctypes.data, T=T, ldx=X.shape[1], out=out.ctypes.data,
+                     ldo=max(1, self.R), flags=int(flags) & ~_lib.HOST_LINES)
             return out
-        fn = L.wagg_apply_host_ex_f32 if X.dtype == np.float32 else L.wagg_apply_host_ex_f64
         with _on_device(self.device):
-            _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], _LAYOUTS[layout],
-                          C.c_void_p(out.ctypes.data), max(1, shape[1]), _OUTS[out_layout], int(flags)), "wagg_apply_host")
+            _lib.run("wagg_apply (host)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(X.dtype), source=_lib.SRC_HOST,
+                     x=X.ctypes.data, T=T, ldx=X.shape[1], layout=_LAYOUTS[layout], out=out.ctypes.data, ldo=max(1, shape[1]),
+                     out_layout=_OUTS[out_layout], flags=int(flags))
         return out
 
 
@@ -242,11 +241,10 @@ class SparsePlan:
             raise ValueError("X has %d grid cells, plan expects %d" % (X.shape[1], self.G))
         T = X.shape[0]
         out = _host_out(out, (int(n_pow), T, self.R), X.dtype)
-        L = _lib.load()
-        fn = L.wagg_apply_poly_host_f32 if X.dtype == np.float32 else L.wagg_apply_poly_host_f64
         with _on_device(self.device):
-            _lib.check(fn(self._h, C.c_void_p(X.ctypes.data), T, X.shape[1], float(offset), int(pow_first), int(n_pow),
-                          C.c_void_p(out.ctypes.data), max(1, self.R), max(1, T * self.R), int(flags)), "wagg_apply_poly_host")
+            _lib.run("wagg_apply (host, poly)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(X.dtype), source=_lib.SRC_HOST,
+                     transform=_lib.XF_POLY, offset=float(offset), pow_first=int(pow_first), n_pow=int(n_pow), x=X.ctypes.data, T=T,
+                     ldx=X.shape[1], out=out.ctypes.data, ldo=max(1, self.R), out_pstride=max(1, T * self.R), flags=int(flags))
         return out
 
 
@@ -264,12 +262,11 @@ class SparsePlan:
         thr = np.ascontiguousarray(np.atleast_1d(thresholds), dtype=np.float64)
         T = tasmin.shape[0]
         out = _host_out(out, (len(thr), T, self.R), tasmin.dtype)
-        L = _lib.load()
-        fn = L.wagg_apply_edd_host_f32 if tasmin.dtype == np.float32 else L.wagg_apply_edd_host_f64
         with _on_device(self.device):
-            _lib.check(fn(self._h, C.c_void_p(tasmin.ctypes.data), C.c_void_p(tasmax.ctypes.data), T, tasmin.shape[1], float(offset),
-                          _np_ptr(thr, C.c_double), len(thr), C.c_void_p(out.ctypes.data), max(1, self.R), max(1, T * self.R),
-                          int(flags)), "wagg_apply_edd_host")
+            _lib.run("wagg_apply (host, edd)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(tasmin.dtype), source=_lib.SRC_HOST,
+                     transform=_lib.XF_EDD, offset=float(offset), thresholds=thr.ctypes.data, n_thr=len(thr), x=tasmin.ctypes.data,
+                     x2=tasmax.ctypes.data, T=T, ldx=tasmin.shape[1], out=out.ctypes.data, ldo=max(1, self.R),
+                     out_pstride=max(1, T * self.R), flags=int(flags))
         return out
 
 
@@ -288,7 +285,7 @@ class DensePlan:
         _lib.check(_lib.load().wagg_dense_get_den(self._h, _np_ptr(den, C.c_double)), "wagg_dense_get_den")
         self.den = den
         inf = _lib.DenseInfo()
-        _lib.check(_lib.load().wagg_dense_get_info(self._h, C.byref(inf)), "wagg_dense_get_info")
+        _lib.check(_lib.load().wagg_dense_get_info_sized(self._h, C.byref(inf), C.sizeof(inf)), "wagg_dense_get_info_sized")
         self.info = {k: (float if ct is C.c_double else int)(getattr(inf, k)) for k, ct in _lib.DenseInfo._fields_}
         self.dtype = "float64" if self.info["elem_bytes"] == 8 else "float32"
 
@@ -421,23 +418,22 @@ class DensePlan:
             raise ValueError("out must be a (%d, %d) %s tensor with contiguous rows" % (T, self.R, self.dtype))
         return X, T, out
 
-    def _fn(self, stem):
-        return getattr(_lib.load(), stem + ("_f64" if self.dtype == "float64" else "_f32"))
+    def _run(self, what, **fields):
+        _lib.run(what, plan_kind=_lib.PLAN_DENSE, elem=_elem(self.dtype), **fields)
 
     def apply(self, X, out=None, ksplit=0, stream=None):
         X, T, out = self._prep(X, out)
-        _lib.check(self._fn("wagg_dense_apply")(
-            self._h, C.c_void_p(X.data_ptr()), T, _ld(X), C.c_void_p(out.data_ptr()),
-            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply")
+        self._run("wagg_apply (dense)", plan=self._h, source=_lib.SRC_DEVICE, x=X.data_ptr(), T=T, ldx=_ld(X), out=out.data_ptr(),
+                  ldo=_ld(out), ksplit=int(ksplit), stream=_stream_handle(stream))
         return out
 
     def apply_poly(self, X, offset, power, out=None, ksplit=0, stream=None):
         """Aggregate of (X + offset) ** power (``wagg_dense_apply_poly_*``): the transform of
         tas_poly (transformations.py:188) is evaluated while X is packed."""
         X, T, out = self._prep(X, out)
-        _lib.check(self._fn("wagg_dense_apply_poly")(
-            self._h, C.c_void_p(X.data_ptr()), T, _ld(X), float(offset), int(power), C.c_void_p(out.data_ptr()),
-            _ld(out), int(ksplit), _stream_handle(stream)), "wagg_dense_apply_poly")
+        self._run("wagg_apply (dense, poly)", plan=self._h, source=_lib.SRC_DEVICE, transform=_lib.XF_POLY, offset=float(offset),
+                  pow_first=int(power), n_pow=1, x=X.data_ptr(), T=T, ldx=_ld(X), out=out.data_ptr(), ldo=_ld(out), ksplit=int(ksplit),
+                  stream=_stream_handle(stream))
         return out
 
     def apply_edd(self, tasmin, tasmax, threshold, offset=0.0, out=None, ksplit=0, stream=None):
@@ -447,10 +443,10 @@ class DensePlan:
         tasmax = _check_X(tasmax, "TG")
         if tasmax.shape != tasmin.shape or tasmax.dtype != tasmin.dtype or _ld(tasmax) != _ld(tasmin):
             raise ValueError("tasmin and tasmax must have the same shape, dtype and row stride")
-        _lib.check(self._fn("wagg_dense_apply_edd")(
-            self._h, C.c_void_p(tasmin.data_ptr()), C.c_void_p(tasmax.data_ptr()), T, _ld(tasmin), float(offset),
-            float(threshold), C.c_void_p(out.data_ptr()), _ld(out), int(ksplit), _stream_handle(stream)),
-            "wagg_dense_apply_edd")
+        thr = (C.c_double * 1)(float(threshold))
+        self._run("wagg_apply (dense, edd)", plan=self._h, source=_lib.SRC_DEVICE, transform=_lib.XF_EDD, offset=float(offset),
+                  thresholds=thr, n_thr=1, x=tasmin.data_ptr(), x2=tasmax.data_ptr(), T=T, ldx=_ld(tasmin), out=out.data_ptr(),
+                  ldo=_ld(out), ksplit=int(ksplit), stream=_stream_handle(stream))
         return out
 
     def apply_host(self, X, flags=0, replicas=(), out=None):
@@ -467,14 +463,12 @@ class DensePlan:
             plans = (self,) + tuple(replicas)
             hs = (C.c_void_p * len(plans))(*[p._h for p in plans])
             devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
-            _lib.check(self._fn("wagg_dense_apply_host_multi")(hs, devs, len(plans), C.c_void_p(X.ctypes.data), X.shape[0],
-                                                               X.shape[1], C.c_void_p(out.ctypes.data), max(1, self.R),
-                                                               int(flags)), "wagg_dense_apply_host_multi")
+            self._run("wagg_apply (dense, host, multi-device)", plan=hs, n_plans=len(plans), devices=devs, source=_lib.SRC_HOST_MULTI,
+                      x=X.ctypes.data, T=X.shape[0], ldx=X.shape[1], out=out.ctypes.data, ldo=max(1, self.R), flags=int(flags))
             return out
         with _on_device(self.device):
-            _lib.check(self._fn("wagg_dense_apply_host")(self._h, C.c_void_p(X.ctypes.data), X.shape[0], X.shape[1],
-                                                         C.c_void_p(out.ctypes.data), max(1, self.R), int(flags)),
-                       "wagg_dense_apply_host")
+            self._run("wagg_apply (dense, host)", plan=self._h, source=_lib.SRC_HOST, x=X.ctypes.data, T=X.shape[0], ldx=X.shape[1],
+                      out=out.ctypes.data, ldo=max(1, self.R), flags=int(flags))
         return out
 
     def saw_inf(self, stream=None):
@@ -541,15 +535,13 @@ class ShardGroup:
             out = torch.empty((total, R), dtype=dtype, device="cuda:%d" % self.devices[root])
         elif tuple(out.shape) != (total, R) or out.dtype != dtype or out.device.index != self.devices[root] or (R > 1 and out.stride(1) != 1):
             raise ValueError("out must be a (%d, %d) %s tensor on device %d" % (total, R, dtype, self.devices[root]))
-        L = _lib.load()
-        stem = "wagg_dense_apply_sharded" if dense else "wagg_apply_sharded"
-        fn = getattr(L, stem + ("_f32" if dtype == torch.float32 else "_f64"))
         hp = (C.c_void_p * n)(*[p._h for p in plans])
         xp = (C.c_void_p * n)(*[C.c_void_p(x.data_ptr()) for x in shards])
         rw = (C.c_int64 * n)(*rows)
         for d in set(self.devices):                      # the shards' producers ran on torch's streams: the group uses its own
             torch.cuda.synchronize(d)
-        _lib.check(fn(self._h, hp, xp, rw, ldx, C.c_void_p(out.data_ptr()), _ld(out), int(root)), stem)
+        _lib.run("wagg_apply (sharded)", plan_kind=_lib.PLAN_DENSE if dense else _lib.PLAN_SEGMENT, plan=hp, n_plans=n, elem=_elem(dtype),
+                 source=_lib.SRC_SHARDED, group=self._h, x=xp, rows=rw, ldx=ldx, out=out.data_ptr(), ldo=_ld(out), root=int(root))
         return out
 
 

@@ -79,7 +79,8 @@ typedef struct wagg_plan_info {
 } wagg_plan_info;
 
 /* ---- process / device ------------------------------------------------------------------- */
-int wagg_version(void);                 /* 10000*major + 100*minor + patch; 0.3.0: wagg_host_stats has 16 fields */
+int wagg_version(void);                 /* 10000*major + 100*minor + patch; 0.4.0: sized struct getters, wagg_apply_desc,
+                                           wagg_host_stats has 18 fields */
 int wagg_device_count(void);            /* number of visible HIP devices (0 if none), never <0  */
 /* Time-axis sharding rule of the multi-GPU form (one process per GPU; climate_toolbox_amd/timeshard.py):
  * rank `rank` of `world` owns rows [*start, *stop) of T; the first T mod world ranks hold one row more. */
@@ -228,10 +229,32 @@ typedef struct wagg_host_stats {
     int64_t lines_h2d_bytes;      /* packed rows of the lines-only path (WAGG_HOST_LINES) ...                              */
     int64_t lines_wait_pack_us;   /* ... time its pipeline thread waited for the packing threads (they are the bottleneck) */
     int64_t lines_wait_copy_us;   /* ... and for the copy engine to hand a ring piece back (PCIe is the bottleneck)        */
-    int64_t blocks_retired;       /* calls whose copies ran < 70 % of the best rate seen: their device blocks left the pool  */
+    int64_t blocks_retired;       /* calls whose copies ran < 70 % of the best rate seen for calls of their shape: their own
+                                     device blocks went back to the driver instead of the pool                                */
     int64_t found_page_locked;    /* caller arrays that were page-locked already (used as they are, no registration)          */
+    int64_t watched_calls;        /* calls the copy-rate watch judged (>= 256 MiB moved, bound by the copies)                  */
+    int64_t last_rate_permille;   /* the LAST call's copy rate over the best seen for its shape, x 1000 (1000 = it set or met the
+                                     record; below 700 the call retired its blocks); 0 = the last call was not judged.  A state,
+                                     not a counter: `reset` leaves it                                                          */
 } wagg_host_stats;
-int wagg_host_stats_read(wagg_host_stats *out, int reset);
+int wagg_host_stats_read(wagg_host_stats *out, int reset);     /* = the _sized form with sizeof(wagg_host_stats) of THIS header */
+
+/* ---- structs that cross the boundary by layout --------------------------------------------------------------------- */
+/* wagg_plan_info, wagg_dense_info, wagg_host_stats and wagg_apply_desc only ever GROW AT THE END.  A binding that mirrors
+ * them by hand (ctypes, cffi, cgo) asks the library for its sizes and hands its OWN size to the *_sized getters: the library
+ * fills min(size, its own size) bytes and zeroes what the caller has beyond that, so a binding built against an older or a
+ * newer header is memory-safe without a version check (fields it does not know are not written; fields the library does
+ * not know read 0).  wagg_struct_ordinals writes, into every scalar field in declaration order, its 1-based ordinal (array
+ * elements count one each): a binding's self-test that its field ORDER and TYPES are the library's
+ * (tests/test_abi.py does exactly that for climate_toolbox_amd/_lib.py).                                                 */
+#define WAGG_STRUCT_PLAN_INFO 0
+#define WAGG_STRUCT_DENSE_INFO 1
+#define WAGG_STRUCT_HOST_STATS 2
+#define WAGG_STRUCT_APPLY_DESC 3
+int wagg_struct_size(int which);                                   /* sizeof in this library; WAGG_EINVAL for an unknown id */
+int wagg_struct_ordinals(int which, void *out, uint64_t size);     /* fills min(size, sizeof) bytes as described above      */
+int wagg_plan_get_info_sized(const wagg_plan *plan, void *info, uint64_t size);
+int wagg_host_stats_read_sized(void *out, uint64_t size, int reset);
 
 /* ---- fused grid-level transform ---------------------------------------------- */
 /* Replaces  tas_poly  (climate_toolbox/transformations/transformations.py:160-208, the arithmetic
@@ -426,6 +449,7 @@ typedef struct wagg_dense_info {
                                       columns, nothing dropped), 0 = by the general radix sort */
 } wagg_dense_info;
 int wagg_dense_get_info(const wagg_dense *d, wagg_dense_info *info);
+int wagg_dense_get_info_sized(const wagg_dense *d, void *info, uint64_t size);   /* see "structs that cross the boundary by layout" */
 /* Device blocks and streams the library needs for the length of one call -- the arena of a table -> plan build (11 GB for
  * a 2.5e8-row table), the block buffers and streams of a host-resident apply, a plan's per-stream staging -- come from a
  * per-device pool and return to it (csrc/wagg_scratch.hip: giving 11 GB back to the driver and asking again costs a wait
@@ -532,6 +556,60 @@ int wagg_dense_apply_sharded_f32(wagg_shard_group *g, wagg_dense *const *plans, 
                                  int64_t ldx, float *out_root, int64_t ldo, int root);
 int wagg_dense_apply_sharded_f64(wagg_shard_group *g, wagg_dense *const *plans, const double *const *X_dev, const int64_t *rows,
                                  int64_t ldx, double *out_root, int64_t ldo, int root);
+
+/* ---- one entry point for every apply (round 6) ------------------------------------------------------------------- */
+/* Every wagg_*apply* function above is a three-line wrapper that fills this descriptor and calls wagg_apply(): a new
+ * transform or a new kind of source is a new VALUE of a field here, not eight new symbols.  New bindings should call
+ * wagg_apply() only (INTEGRATION.md section 2 shows both forms; climate_toolbox_amd/engine.py uses nothing else).
+ *
+ *   struct_size  sizeof(wagg_apply_desc) of the header the caller was built against (the struct only grows at the end;
+ *                fields beyond the caller's size read 0 = "not given")
+ *   plan_kind    WAGG_PLAN_SEGMENT: `plan` is a wagg_plan*;  WAGG_PLAN_DENSE: a wagg_dense*
+ *   elem         WAGG_T_F32 / WAGG_T_F64: element type of x, x2 and out (a dense-family plan must have been built for it)
+ *   source       where the field lies and who moves it:
+ *                  WAGG_SRC_DEVICE      device pointers, asynchronous on `stream`             (wagg_apply_f32 ...)
+ *                  WAGG_SRC_HOST        host arrays through the row-block pipeline, blocking; `flags` = WAGG_HOST_*
+ *                  WAGG_SRC_HOST_MULTI  the same over `n_plans` plan replicas on `devices[]`; `plan` is an ARRAY of handles
+ *                  WAGG_SRC_SHARDED     `plan` = array of n_plans handles, `x` = array of n_plans device pointers (shard i on
+ *                                       the device of plan i), rows[i] rows each; results gathered into `out` on shard `root`
+ *                                       of `group` (a wagg_shard_group*); blocking
+ *   transform    WAGG_XF_NONE; WAGG_XF_POLY: (x + offset)^p for p = pow_first .. pow_first + n_pow - 1, plane i at
+ *                out + i * out_pstride; WAGG_XF_EDD: Snyder degree days of (x = tasmin, x2 = tasmax) + offset at
+ *                thresholds[0 .. n_thr), plane i at out + i * out_pstride.  (Dense-family plans: one power / one threshold
+ *                per call.)
+ *   T, ldx, layout / out, ldo, out_layout   as in wagg_apply_f32 (dense-family plans: WAGG_LAYOUT_TG / WAGG_OUT_TR only)
+ *   ksplit       dense-family plans: k-slice count, 0 = the library's choice
+ * A combination the library has no kernel path for returns WAGG_EUNSUPPORTED with a message that names it; nothing is
+ * emulated.                                                                                                            */
+#define WAGG_PLAN_SEGMENT 0
+#define WAGG_PLAN_DENSE 1
+#define WAGG_SRC_DEVICE 0
+#define WAGG_SRC_HOST 1
+#define WAGG_SRC_HOST_MULTI 2
+#define WAGG_SRC_SHARDED 3
+#define WAGG_XF_NONE 0
+#define WAGG_XF_POLY 1
+#define WAGG_XF_EDD 2
+typedef struct wagg_apply_desc {
+    uint64_t struct_size;
+    int32_t plan_kind, elem, source, transform;
+    const void *plan;
+    const void *x, *x2;
+    void *out;
+    int64_t T, ldx, ldo, out_pstride;
+    int32_t layout, out_layout;
+    double offset;
+    int32_t pow_first, n_pow;
+    const double *thresholds;
+    int32_t n_thr, flags;
+    int32_t ksplit, n_plans;
+    const int32_t *devices;
+    const int64_t *rows;
+    void *group;
+    int32_t root, reserved0;
+    void *stream;
+} wagg_apply_desc;
+int wagg_apply(const wagg_apply_desc *desc);
 
 #ifdef __cplusplus
 }
