@@ -12,481 +12,59 @@ What stays on the host (before the C-ABI), exactly as SURVEY.md section 8b lays 
 label matching (S1), the per-row backup fill (S4), sorted-unique label factorisation (S3).  What
 the GPU does: the gather of :27 fused into the weighted group sums of :78-79 and the division.
 There is no CPU compute path: without the HIP library or a GPU these functions raise.
+
+This module holds the four reference names, the shared aggregation body and the two switches of the drop-in
+(``HOST_DEVICES``, ``results_on_device``).  What they stand on lives beside it (round 6) and is re-exported here, so
+``aggregations.X`` resolves as before:
+  _memo.py       table fingerprints, the per-table memo, the caches' lock
+  _labels.py     exact label join, backup fill, label factorisation (native, memoised)
+  _layout.py     (..., lat, lon, ...) <-> (time x gridcell) bookkeeping
+  _reindexed.py  the lazy ReindexedDataset and the Dataset accessors
+  _pinned.py     the page-locked result pool
+  _plans.py      family choice, the leased plan cache, replicas
+  _prepared.py   PreparedWeights / prepare_weights
 """
 from __future__ import annotations
 
 import functools
-import hashlib
-import os
 import threading
-from collections import OrderedDict
 
 import numpy as np
 import pandas as pd
 
-from . import _lib as _libmod, engine as _engine, minixr
-from ._lib import FORM_ENTRIES, WaggError
-from .engine import DensePlan, SparsePlan, gather as _device_gather, require_gpu
-
-try:  # optional: return real xarray objects when the caller hands us xarray objects
-    import xarray as _xr
-except Exception:  # pragma: no cover - xarray is absent from this image
-    _xr = None
+from . import _labels, _lib as _libmod, _pinned, _plans, engine as _engine, minixr
+from ._labels import (_backup_fill, _exact_index, _factorize_labels, _factorize_labels_impl, _is_null_label, _native,  # noqa: F401
+                      _resolve_cells, _resolve_cells_impl)
+from ._layout import _flatten_for_device, _is_device_tensor, _result_dims, _spatial_layout, _to_device  # noqa: F401
+from ._lib import FORM_ENTRIES, WaggError  # noqa: F401
+from ._memo import (_CACHE_LOCK, _POINTER_TABLES, _TABLE_MEMO, _TABLE_MEMO_MAX, _Unhashable, _f64, _fingerprint, _frozen,  # noqa: F401
+                    _clear_memos, _memo, _raw_view)
+from ._pinned import _PINNED_POOL, _pinned_result, _to_host  # noqa: F401
+from ._plans import (DENSE_SWITCH, _PLAN_CACHE, _dense_bytes, _drop_plan, _evict_plans, _host_quantum, _plan_bytes, _plan_for,  # noqa: F401
+                     _prefer_dense, _wants_dense)
+from ._prepared import PreparedWeights, prepare_weights
+from ._reindexed import ReindexedDataset, _edds, _extract, _is_xarray, _lon_perms, _ReindexedArray, _xforms, _xr  # noqa: F401
+from .engine import DensePlan, SparsePlan, require_gpu
 
 __all__ = ["weighted_aggregate_grid_to_regions", "prepare_spatial_weights_data", "prepare_weights", "PreparedWeights", "clear_caches",
            "_reindex_spatial_data_to_regions", "_aggregate_reindexed_data_to_regions"]
 
-try:  # optional: a 10 GB/s hash for the table fingerprints below (blake2b, ~1 GB/s, otherwise)
-    import xxhash as _xxhash
-except Exception:  # pragma: no cover
-    _xxhash = None
 
-_PLAN_CACHE: "OrderedDict[str, SparsePlan]" = OrderedDict()
-_PLAN_CACHE_MAX = 8                 # plans
-_PLAN_CACHE_MAX_FRAC = 0.5          # ... and at most this share of the device's memory (dense plans are GBs)
-# One lock for every look-up / insert / evict of the module-level caches below (_PLAN_CACHE, _TABLE_MEMO,
-# _PINNED_POOL): the drop-in may be called from several Python threads (ctypes releases the GIL inside the
-# library).  A plan handed out by _plan_for is LEASED: its own lock is held until the caller is done with it, and
-# eviction skips leased plans, so no thread can close a plan another one is applying.
-_CACHE_LOCK = threading.RLock()
+# Host-resident fields stream through the CURRENT device only by default.  Several row-block pipelines from one process
+# (one per device, each on its own PCIe link; SURVEY 8b `n_devices`, 8e "one process driving all devices") are an explicit
+# opt-in: HOST_DEVICES = "all" (every visible device -- never inside a one-process-per-GPU job, where every rank sees all
+# devices: such processes, recognised by WORLD_SIZE > 1 in the environment, stay on their own device) or a list of device
+# ordinals (a device may be listed twice: two pipelines on one GPU).  The multi-device form has only ever run with several
+# pipelines on ONE physical device (gpurun exposes one GPU), hence the conservative default.
+HOST_DEVICES = None
 
 
-# ----------------------------------------------------------------------------------------------
-# small helpers
-# ----------------------------------------------------------------------------------------------
-def _is_xarray(obj):
-    return _xr is not None and isinstance(obj, (_xr.Dataset, _xr.DataArray))
+def _host_devices():
+    return _plans._host_devices(HOST_DEVICES)
 
 
-def _native():
-    from . import _lib
-    return _lib, _lib.load()
-
-
-def _f64(a):
-    return np.ascontiguousarray(a, dtype=np.float64)
-
-
-# ----------------------------------------------------------------------------------------------
-# Per-table memo (SURVEY 8f-1: "removes the last O(nseg) Python step").  A pipeline aggregates many
-# variables and files with ONE weights table: the label join, the label factorisation and the plan key
-# are functions of that table alone, so they are kept per table CONTENT.  The fingerprint is a hash of
-# the columns' memory -- for object columns (string labels) of the pointer table, with the hashed array
-# kept alive by the memo entry: equal pointers to live immutable objects mean equal labels, and an entry
-# can never be confused with a later table whose objects reuse freed addresses.  Any in-place edit of
-# the table changes the fingerprint and the work is redone.
-# ----------------------------------------------------------------------------------------------
-_TABLE_MEMO: "OrderedDict[tuple, tuple]" = OrderedDict()
-_TABLE_MEMO_MAX = 32
-
-
-class _Unhashable(Exception):
-    """A column whose memory does not identify its content (see _raw_view): the work is done unmemoised."""
-
-
-_POINTER_SAFE = ("string", "bytes", "empty")
-_POINTER_TABLES: "OrderedDict[tuple, np.ndarray]" = OrderedDict()     # pointer tables already found to hold immutable labels only
-
-
-def _raw_view(a):
-    """(array kept alive, its memory as a bytes-like object); object arrays: the pointer table.
-
-    The pointer table identifies the labels only while equal pointers mean equal VALUES, i.e. for immutable
-    objects: ``str`` / ``bytes`` labels and nulls (None / NaN).  Any other object column (lists, mutable
-    user objects, mixed types) raises :class:`_Unhashable` and is never memoised."""
-    import ctypes as C
-    a = np.asarray(a)
-    if not a.flags.c_contiguous:
-        a = np.ascontiguousarray(a)
-    if a.dtype.kind == "O":
-        raw = C.string_at(a.ctypes.data, a.nbytes) if a.nbytes else b""
-        # whether the pointer table identifies the labels (str / bytes / None only) is a property of the very objects it points
-        # to: it is decided once per pointer table (pandas' C loop over 400k pointers costs 2 ms -- per call and column, before
-        # round 4) and remembered under the table's own hash, with a copy of the array that keeps those objects alive
-        tag = (_xxhash.xxh3_128_digest(raw) if _xxhash is not None else hashlib.blake2b(raw, digest_size=16).digest(), a.shape)
-        with _CACHE_LOCK:
-            known = tag in _POINTER_TABLES
-            if known:
-                _POINTER_TABLES.move_to_end(tag)
-        if not known:
-            if pd.api.types.infer_dtype(a, skipna=True) not in _POINTER_SAFE:     # C loop over the pointers
-                raise _Unhashable("object column with labels other than str / bytes / None")
-            with _CACHE_LOCK:
-                _POINTER_TABLES[tag] = np.array(a, dtype=object, copy=True)
-                while len(_POINTER_TABLES) > _TABLE_MEMO_MAX:
-                    _POINTER_TABLES.popitem(last=False)
-        return a, raw
-    if a.dtype.kind in "Mm":               # datetime64 / timedelta64 refuse the buffer protocol
-        return a, memoryview(a.reshape(-1).view(np.int64)).cast("B")
-    try:
-        return a, memoryview(a.reshape(-1)).cast("B")
-    except (ValueError, TypeError):        # any other dtype without a buffer format: its bytes
-        try:
-            return a, memoryview(a.reshape(-1).view(np.uint8))
-        except (ValueError, TypeError) as e:
-            raise _Unhashable(str(e))
-
-
-def _fingerprint(*arrays, extra=""):
-    h = _xxhash.xxh3_128() if _xxhash is not None else hashlib.blake2b(digest_size=16)
-    keep = []
-    for a in arrays:
-        a, raw = _raw_view(a)
-        keep.append(a)
-        h.update(repr((a.dtype.str, a.shape)).encode())
-        h.update(raw)
-    h.update(extra.encode())
-    return h.hexdigest(), keep
-
-
-def _memo(tag, arrays, compute, extra=""):
-    try:
-        key, _ = _fingerprint(*arrays, extra=extra)
-    except _Unhashable:
-        return compute()
-    with _CACHE_LOCK:
-        hit = _TABLE_MEMO.get((tag, key))
-        if hit is not None:
-            _TABLE_MEMO.move_to_end((tag, key))
-            return hit[1]
-    val = compute()                          # outside the lock: two threads may both compute, the values are equal
-    # the entry owns COPIES of the object columns' pointer tables: they hold references to the very objects that
-    # were hashed, so none of them can be freed -- and its address handed to a different label -- while the entry
-    # lives, even if the caller's own array is edited in place later
-    keep = [np.array(a, dtype=object, copy=True) for a in arrays if np.asarray(a).dtype.kind == "O"]
-    with _CACHE_LOCK:
-        _TABLE_MEMO[(tag, key)] = (keep, val)
-        while len(_TABLE_MEMO) > _TABLE_MEMO_MAX:
-            _TABLE_MEMO.popitem(last=False)
-    return val
-
-
-def _frozen(a):
-    a = np.asarray(a)
-    a.flags.writeable = False
-    return a
-
-
-def _resolve_cells(lat, lon, seg_lat, seg_lon, lon_major=False):
-    """Exact-equality join of the segment labels to the grid labels in native code
-    (``wagg_resolve_cells``; ``Dataset.sel`` without ``method=``, aggregations.py:27; S1).
-    A missing label raises KeyError, like the reference.  Memoised per (grid labels, table columns)."""
-    lat, lon, sa, so = _f64(lat), _f64(lon), _f64(seg_lat), _f64(seg_lon)
-    return _memo("cells", (lat, lon, sa, so), lambda: _frozen(_resolve_cells_impl(lat, lon, sa, so, lon_major)),
-                 extra=str(bool(lon_major)))
-
-
-def _resolve_cells_impl(lat, lon, sa, so, lon_major):
-    import ctypes as C
-    _lib, L = _native()
-    if sa.shape != so.shape or sa.ndim != 1:
-        raise ValueError("segment lat/lon columns must be 1-D and of equal length")
-    cell = np.empty(len(sa), dtype=np.int32)
-    bad = C.c_int64(-1)
-    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    rc = L.wagg_resolve_cells(p(lat, C.c_double), len(lat), p(lon, C.c_double), len(lon), p(sa, C.c_double),
-                              p(so, C.c_double), len(sa), 1 if lon_major else 0, p(cell, C.c_int32), C.byref(bad))
-    if rc == _lib.EKEY:
-        raise KeyError("not all values found in index: row %d (lat %r, lon %r)"
-                       % (bad.value, float(sa[bad.value]), float(so[bad.value])))
-    _lib.check(rc, "wagg_resolve_cells")
-    return cell
-
-
-def _exact_index(coord_values, wanted, name):
-    """1-D form of the exact label lookup (kept for callers that need the two axes separately)."""
-    idx = pd.Index(np.asarray(coord_values))
-    pos = idx.get_indexer(np.asarray(wanted))
-    if (pos < 0).any():
-        bad = np.asarray(wanted)[pos < 0][:5]
-        raise KeyError("not all values found in index %r: %r" % (name, bad.tolist()))
-    return pos.astype(np.int64)
-
-
-def _backup_fill(w, backup):
-    """aggregations.py:73 per-row fill (``wagg_backup_fill``): w if w > 0 else backup (S4)."""
-    import ctypes as C
-    _lib, L = _native()
-    w, backup = _f64(w), _f64(backup)
-    out = np.empty_like(w)
-    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    _lib.check(L.wagg_backup_fill(p(w), p(backup), len(w), p(out)), "wagg_backup_fill")
-    return out
-
-
-def _is_null_label(v):
-    if v is None:
-        return True
-    try:
-        return bool(v != v)
-    except Exception:
-        return False
-
-
-def _factorize_labels(labels):
-    """Sorted unique labels and per-row codes, -1 for null labels (xarray groupby, :78; S3), in
-    native code for integer and string labels (``wagg_factorize_i64`` / ``_bytes``); other label
-    types go through ``pandas.factorize(sort=True)``, which has the same contract.  Memoised per label
-    column content (see _TABLE_MEMO); the codes come back read-only, the unique labels as a fresh copy."""
-    labels = np.asarray(labels)
-
-    def compute():
-        uniq, codes = _factorize_labels_impl(labels)
-        return np.array(uniq, copy=True), _frozen(codes)
-
-    uniq, codes = _memo("factorize", (labels,), compute)
-    return uniq.copy(), codes
-
-
-def _factorize_labels_impl(labels):
-    import ctypes as C
-    n = len(labels)
-    kind = labels.dtype.kind
-    if kind in "iu" and labels.dtype.itemsize <= 8 and not (kind == "u" and labels.dtype.itemsize == 8):
-        _lib, L = _native()
-        lab = np.ascontiguousarray(labels, dtype=np.int64)
-        codes = np.empty(n, dtype=np.int32)
-        uniq = np.empty(n, dtype=np.int64)
-        nu = C.c_int64(0)
-        _lib.check(L.wagg_factorize_i64(lab.ctypes.data_as(C.POINTER(C.c_int64)), None, n,
-                                        codes.ctypes.data_as(C.POINTER(C.c_int32)),
-                                        uniq.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)), "wagg_factorize_i64")
-        return uniq[:nu.value].astype(labels.dtype), codes
-    if kind in "OUS" and n:
-        null = None
-        is_str = kind != "O"
-        if kind == "O":
-            what = pd.api.types.infer_dtype(labels, skipna=False)           # C loop, no Python objects made
-            if what != "string" and pd.api.types.infer_dtype(labels, skipna=True) == "string":
-                null, what = pd.isna(labels), "string"
-            is_str = what == "string"
-        if is_str:
-            _lib, L = _native()
-            filled = labels if null is None else np.where(null, "", labels)
-            if kind == "S":
-                enc = filled
-            else:
-                try:
-                    enc = filled.astype("S")                                 # ASCII labels: one C pass
-                except UnicodeEncodeError:
-                    enc = np.char.encode(filled.astype(str), "utf-8")        # UTF-8 keeps code point order
-            enc = np.ascontiguousarray(enc)
-            width = enc.dtype.itemsize
-            if width == 0:
-                return np.array([], dtype=object), np.full(n, -1, dtype=np.int32)
-            codes = np.empty(n, dtype=np.int32)
-            rows = np.empty(n, dtype=np.int64)
-            nu = C.c_int64(0)
-            nm = None if null is None else np.ascontiguousarray(null, dtype=np.uint8)
-            _lib.check(L.wagg_factorize_bytes(enc.ctypes.data_as(C.c_char_p), width,
-                                              None if nm is None else nm.ctypes.data_as(C.POINTER(C.c_uint8)), n,
-                                              codes.ctypes.data_as(C.POINTER(C.c_int32)),
-                                              rows.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(nu)),
-                       "wagg_factorize_bytes")
-            return labels[rows[:nu.value]], codes
-    codes, uniq = pd.factorize(labels, sort=True)
-    return np.asarray(uniq), np.asarray(codes, dtype=np.int32)
-
-
-def _spatial_layout(dims):
-    """Where lat/lon sit among the dims -> how the array flattens to (T x G) or (G x T)."""
-    dims = tuple(dims)
-    if "lat" not in dims or "lon" not in dims:
-        raise KeyError("dataset must have dimensions named 'lat' and 'lon' (aggregations.py:27), "
-                       "got %r" % (dims,))
-    ia, io = dims.index("lat"), dims.index("lon")
-    first, second = (ia, io) if ia < io else (io, ia)
-    others = [i for i in range(len(dims)) if i not in (ia, io)]
-    return ia, io, first, second, others
-
-
-def _result_dims(dims, group_dim):
-    """S10: the group dim takes the slot of the first indexed dim; the second one disappears."""
-    _, _, first, second, _ = _spatial_layout(dims)
-    return tuple(group_dim if i == first else d for i, d in enumerate(dims) if i != second)
-
-
-class _ReindexedArray:
-    """Lazy stand-in for one gathered data variable of aggregations.py:27."""
-
-    def __init__(self, owner, name):
-        self._owner, self.name = owner, name
-
-    @property
-    def dims(self):
-        return _result_dims(self._owner._src_dims[self.name], "reshape_index")
-
-    @property
-    def shape(self):
-        src_dims = self._owner._src_dims[self.name]
-        src_shape = dict(zip(src_dims, self._owner._src_values[self.name].shape))
-        return tuple(self._owner._nseg if d == "reshape_index" else src_shape[d] for d in self.dims)
-
-    @property
-    def dtype(self):
-        return self._owner._src_values[self.name].dtype
-
-    @property
-    def values(self):
-        return self._owner._materialise(self.name)
-
-    def isnull(self):
-        return minixr.DataArray(self.values, self.dims).isnull()
-
-    def __array__(self, dtype=None, copy=None):
-        v = self.values
-        return v.astype(dtype) if dtype is not None else v
-
-
-class ReindexedDataset(minixr.Dataset):
-    """What ``_reindex_spatial_data_to_regions`` returns here: the source arrays plus the cell
-    index of every segment row.  Nothing is copied until ``.values`` of a variable is asked for
-    (then a device gather kernel runs); ``_aggregate_reindexed_data_to_regions`` never
-    materialises it -- the gather is fused into the aggregation kernel."""
-
-    def __init__(self, src_values, src_dims, coords, ilat, ilon, seg_lat, seg_lon, was_xarray,
-                 lon_perms=None, xforms=None, edds=None):
-        super().__init__()
-        self._src_values, self._src_dims = src_values, src_dims
-        self._ilat, self._ilon = ilat, ilon
-        self._lon_perms = dict(lon_perms or {})     # variable -> file column of each sorted lon label
-        self._xforms = dict(xforms or {})           # variable -> (offset, power), evaluated on the GPU
-        self._edds = dict(edds or {})               # variable -> (tasmax buffer, offset, [(coef, threshold)])
-        self._nseg = len(ilat)
-        self._was_xarray = was_xarray
-        for k, v in coords.items():
-            if k not in ("lat", "lon"):
-                self.coords[k] = v
-        self.coords["lat"] = minixr.DataArray(np.asarray(seg_lat), ("reshape_index",))
-        self.coords["lon"] = minixr.DataArray(np.asarray(seg_lon), ("reshape_index",))
-        for name in src_values:
-            self.data_vars[name] = _ReindexedArray(self, name)
-
-    @property
-    def dims(self):
-        out = {}
-        for name in self._src_values:
-            arr = self.data_vars[name]
-            if isinstance(arr, _ReindexedArray):
-                out.update(zip(arr.dims, arr.shape))
-        for c in self.coords.values():
-            for d, n in zip(c.dims, c.shape):
-                out.setdefault(d, n)
-        return out
-
-    def _cell_index(self, name):
-        dims = self._src_dims[name]
-        shape = dict(zip(dims, self._src_values[name].shape))
-        ia, io, *_ = _spatial_layout(dims)
-        perm = self._lon_perms.get(name)
-        ready = getattr(self, "_row_major_cell", None)
-        if ready is not None and perm is None and ia < io and (shape["lat"], shape["lon"]) == ready[1:]:
-            return ready[0], shape["lat"] * shape["lon"]                          # a PreparedWeights' own (frozen) index
-        ilon = self._ilon if perm is None else np.asarray(perm)[self._ilon]     # SURVEY 8f-2
-        if ia < io:
-            return (self._ilat * shape["lon"] + ilon).astype(np.int32), shape["lat"] * shape["lon"]
-        return (ilon * shape["lat"] + self._ilat).astype(np.int32), shape["lat"] * shape["lon"]
-
-    def _materialise(self, name):
-        torch = require_gpu()
-        X2, layout, others_shape, unflatten = _flatten_for_device(self._src_values[name], self._src_dims[name])
-        cell, _ = self._cell_index(name)
-        Xd = _to_device(X2)
-        ci = torch.from_numpy(np.ascontiguousarray(cell)).cuda()
-        out = _device_gather(Xd, ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
-        if name in self._xforms:                     # wagg_transform_poly_*: the kernels' own device function
-            off, pw = self._xforms[name]
-            out = _engine.transform_poly(out, off, pw)
-        if name in self._edds:
-            hi, off, terms = self._edds[name]
-            H2 = _flatten_for_device(hi, self._src_dims[name])[0]
-            hig = _device_gather(_to_device(H2), ci, layout=layout, out_layout="TR" if layout == "TG" else "RT")
-            out = _engine.transform_edd(out, hig, off, terms)
-        return unflatten(out.cpu().numpy(), self._nseg)
-
-
-# Results go back to the host through page-locked memory (one DMA at PCIe speed instead of the runtime's staged
-# pageable copy: 36 MB in 0.8 instead of 3.6 ms).  The blocks come from a small pool of the module's own (round 4): a block
-# returns to the pool when the caller drops the result and is handed out again as it is -- page-locking 36 MB anew costs
-# 3-4 ms, and whether torch's caching host allocator had a recycled block ready decided between a 3 ms and an 8 ms call.
-# The amount of pooled memory is capped; beyond it (and for small results) the pageable copy is used.
-_PINNED_POOL = {"bytes": 0, "free": {}, "lru": []}  # free: rounded size -> [uint8 pinned tensors]; lru: sizes, least recently used first
-_PINNED_OUT_CAP = 512 << 20
-
-
-def _pinned_return(block):
-    with _CACHE_LOCK:
-        _PINNED_POOL["free"].setdefault(block.numel(), []).append(block)
-
-
-def _pinned_touch(size):
-    lru = _PINNED_POOL["lru"]
-    if size in lru:
-        lru.remove(size)
-    lru.append(size)
-
-
-def _pinned_make_room(size):
-    """Pool at its cap: give back FREE blocks of other sizes, least recently used size first, until ``size`` more bytes fit
-    (a workload whose result shapes change would otherwise fill the pool with blocks nobody asks for again and send every
-    new shape down the pageable copy for good).  Caller holds _CACHE_LOCK; returns True when the bytes fit now."""
-    free = _PINNED_POOL["free"]
-    for other in [z for z in _PINNED_POOL["lru"] if z != size] + [z for z in list(free) if z != size and z not in _PINNED_POOL["lru"]]:
-        blocks = free.get(other)
-        while blocks and _PINNED_POOL["bytes"] + size > _PINNED_OUT_CAP:
-            blocks.pop()                                             # (the tensor's storage is unpinned and freed with it)
-            _PINNED_POOL["bytes"] -= other
-        if _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP:
-            break
-    return _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP
-
-
-def _pinned_result(shape, dtype):
-    """An uninitialised host array of ``shape`` / ``dtype`` in a page-locked block of the result pool (returned to the pool
-    when the array and every view of it are gone), or None: the array is small, the pool is at its cap with every block in
-    use, or no page-locked memory can be had."""
-    import weakref
-    import torch
-    dtype = np.dtype(dtype)
-    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-    if n < (1 << 20):
-        return None
-    size = (n + (1 << 20) - 1) >> 20 << 20                          # blocks of whole MiB: results of one shape share them
-    block = None
-    with _CACHE_LOCK:
-        free = _PINNED_POOL["free"].get(size)
-        if free:
-            block = free.pop()
-        elif _PINNED_POOL["bytes"] + size <= _PINNED_OUT_CAP or (size <= _PINNED_OUT_CAP and _pinned_make_room(size)):
-            _PINNED_POOL["bytes"] += size
-            block = False                                            # allocate below, outside the lock
-        if block is not None:
-            _pinned_touch(size)
-    if block is None:
-        return None                                                  # the pool is at its cap and every block is in use
-    if block is False:
-        try:
-            block = torch.empty(size, dtype=torch.uint8, pin_memory=True)
-        except RuntimeError:                                         # no page-locked memory to be had
-            with _CACHE_LOCK:
-                _PINNED_POOL["bytes"] -= size
-            return None
-    arr = block.numpy()[:n].view(dtype).reshape(shape)              # shares the block
-    root = arr
-    while isinstance(root.base, np.ndarray):      # the ndarray every view of this memory keeps alive (numpy collapses chains
-        root = root.base                          # of views onto it): the finalizer goes there, not onto an intermediate view
-    weakref.finalize(root, _pinned_return, block)  # the finalizer holds the block: it outlives every view of the result
-    return arr
-
-
-def _to_host(o):
-    """Device tensor -> host array, through a page-locked block of the result pool when one can be had."""
-    import torch
-    arr = _pinned_result(tuple(o.shape), str(o.dtype).replace("torch.", "")) if o.numel() else None
-    if arr is None:
-        return o.cpu().numpy()
-    torch.from_numpy(arr).copy_(o)
-    return arr
+def _host_replicas(plan, n_rows, row_bytes):
+    return _plans._host_replicas(plan, n_rows, row_bytes, HOST_DEVICES)
 
 
 _TLS = threading.local()
@@ -498,18 +76,38 @@ class results_on_device:
     the current stream; the call does not wait for it).  A loop over variables that feeds further GPU work then pays the
     kernels only; everything else about the call -- names, dims, the ``agglev`` coordinate, the numbers -- is unchanged
     (bit-equal to the host route).  Per thread; nests; host-resident variables and xarray Datasets still return host arrays.
-    The reference has no such switch (it computes on the host, aggregations.py:75-82): this is an extension."""
+    The reference has no such switch (it computes on the host, aggregations.py:75-82): this is an extension.
+
+    Failures stay visible: a call inside the block does not wait for its kernels, so it cannot report a device-side failure
+    of its segment-table plan itself; the plans such calls used are remembered and checked (``wagg_plan_status``: one stream
+    synchronisation per plan) when the OUTERMOST block ends, and a failed one raises there -- before the caller's code
+    behind the block consumes the tensors -- and is dropped from the cache.  (No kernel of libwagg.so can fail that way;
+    the diagnostic build's bounded-spin kernel can.)"""
 
     def __init__(self, on=True):
         self._on = bool(on)
 
     def __enter__(self):
         self._prev = getattr(_TLS, "device_results", False)
+        self._outermost = not hasattr(_TLS, "unchecked_plans")
+        if self._outermost:
+            _TLS.unchecked_plans = []
         _TLS.device_results = self._on
         return self
 
     def __exit__(self, *exc):
         _TLS.device_results = self._prev
+        if self._outermost:
+            plans = _TLS.unchecked_plans
+            del _TLS.unchecked_plans
+            if exc[0] is None:
+                for plan in plans:
+                    if getattr(plan, "_h", None) is not None and plan._h.value:       # (a plan evicted meanwhile has been drained by close)
+                        try:
+                            plan.status()
+                        except WaggError:
+                            _drop_plan(plan)
+                            raise
         return False
 
 
@@ -518,465 +116,17 @@ def _device_results_wanted():
 
 
 def clear_caches():
-    """Give back what the module keeps between calls: cached plans that no call is using (device memory), the table memos,
+    """Give back what the package keeps between calls: cached plans that no call is using (device memory), the table memos,
     the coded tables of the CSV route, the FREE blocks of the page-locked result pool (blocks behind results the caller
     still holds return to the pool when those are dropped, and go with the next call of this function) and the device
     scratch the library keeps from one plan build to the next (``wagg_release_scratch``)."""
+    _plans._clear_plans()
+    _clear_memos()
     with _CACHE_LOCK:
-        for key in list(_PLAN_CACHE):
-            plan = _PLAN_CACHE[key]
-            if plan._lease.acquire(blocking=False):
-                try:
-                    del _PLAN_CACHE[key]
-                    plan.close()
-                finally:
-                    plan._lease.release()
-        _TABLE_MEMO.clear()
-        _POINTER_TABLES.clear()
         _PREPARED_BY_PATH.clear()
-        # (a snapshot: a result dropped while we are here returns its block through _pinned_return -- same thread, the lock is
-        #  re-entrant -- and may add a size to the dict)
-        for size, blocks in list(_PINNED_POOL["free"].items()):
-            _PINNED_POOL["bytes"] -= size * len(blocks)
-            blocks.clear()
-        _PINNED_POOL["lru"].clear()
+    _pinned._clear_free_blocks()
     if _libmod._lib is not None:
         _libmod._lib.wagg_release_scratch()
-
-
-def _is_device_tensor(values):
-    """A torch CUDA tensor handed in as a variable's buffer: the field is already in HBM."""
-    return type(values).__module__.startswith("torch") and getattr(values, "is_cuda", False)
-
-
-def _to_device(X2):
-    """2-D host array -> device tensor (``wagg_upload``: one DMA from the array page-locked in place for the call -- no
-    pageable pointer goes to a runtime copy, no pin is left behind); device tensors pass through."""
-    if _is_device_tensor(X2):
-        return X2
-    return _engine.upload(X2)
-
-
-def _flatten_for_device(values, dims):
-    """(values, dims) -> (2-D C-contiguous array, layout, others_shape, unflatten(result2d, R)).
-    ``values`` is a NumPy array or a torch CUDA tensor (then the re-layout, if any, runs on the
-    device and nothing crosses PCIe)."""
-    on_dev = _is_device_tensor(values)
-    if on_dev:
-        import torch
-        if values.dtype not in (torch.float32, torch.float64):
-            values = _engine.to_float64(values)      # the reference's promotion (S8), in the library's own kernel
-        # the re-layout of a device field runs in the library's own kernel (wagg_relayout_*), not in a torch one
-        contig = lambda a: a if a.is_contiguous() else _engine.relayout(a)
-        transpose = lambda a, order: _engine.relayout(a, order)
-    else:
-        values = np.asarray(values)
-        if values.dtype not in (np.float32, np.float64):
-            values = values.astype(np.float64)
-        contig, transpose = np.ascontiguousarray, np.transpose
-    ia, io, first, second, others = _spatial_layout(dims)
-    shape = tuple(values.shape)
-    G = shape[ia] * shape[io]
-    adjacent = second == first + 1
-    if adjacent and all(i < first for i in others):          # (..., lat, lon): gridcell axis contiguous
-        T = int(np.prod([shape[i] for i in others])) if others else 1
-        X2 = contig(values).reshape(T, G)
-        layout = "TG"
-    elif adjacent and all(i > second for i in others):       # (lat, lon, ...): the test fixture
-        T = int(np.prod([shape[i] for i in others])) if others else 1
-        X2 = contig(values).reshape(G, T)
-        layout = "GT"
-    else:                                                    # anything else: one transpose
-        order = others + [first, second]
-        X2 = contig(transpose(values, order)).reshape(-1, G)
-        layout = "TG"
-    others_shape = tuple(shape[i] for i in others)
-    n_before = sum(1 for i in others if i < first)
-
-    def unflatten(res2d, R):
-        # (NumPy arrays, or -- under results_on_device() -- torch CUDA tensors: views only, nothing moves)
-        moveaxis = np.moveaxis if isinstance(res2d, np.ndarray) else (lambda t, src, dst: t.movedim(src, dst))
-        if layout == "TG":
-            arr = res2d.reshape(others_shape + (R,))
-        else:
-            arr = moveaxis(res2d.reshape((R,) + others_shape), 0, -1)
-        return moveaxis(arr, -1, n_before)
-
-    return X2, layout, others_shape, unflatten
-
-
-# Host-resident fields stream through the CURRENT device only by default.  Several row-block pipelines from one process
-# (one per device, each on its own PCIe link; SURVEY 8b `n_devices`, 8e "one process driving all devices") are an explicit
-# opt-in: HOST_DEVICES = "all" (every visible device -- never inside a one-process-per-GPU job, where every rank sees all
-# devices: such processes, recognised by WORLD_SIZE > 1 in the environment, stay on their own device) or a list of device
-# ordinals (a device may be listed twice: two pipelines on one GPU).  The multi-device form has only ever run with several
-# pipelines on ONE physical device (gpurun exposes one GPU), hence the conservative default.
-HOST_DEVICES = None
-_REPLICA_MAX_BYTES = 8 << 30          # plans above this (the 101 GB dense operand) are not replicated
-
-
-def _host_devices():
-    import torch
-    if HOST_DEVICES is None:
-        return []
-    if isinstance(HOST_DEVICES, str):
-        if HOST_DEVICES != "all":
-            raise ValueError('HOST_DEVICES must be None, "all" or a list of device ordinals')
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            return []                  # one process per GPU: the other devices belong to the other ranks
-        return list(range(torch.cuda.device_count()))
-    return [int(d) for d in HOST_DEVICES]
-
-
-def _host_quantum(plan):
-    """Rows one launch of the plan's kernel handles well (what wagg_host_block_plan sizes the row blocks by)."""
-    if isinstance(plan, DensePlan):
-        f64 = plan.dtype == "float64"
-        if plan.info["form"] == FORM_ENTRIES:
-            return 64 if f64 else 128
-        return 176 if f64 else 368
-    return 64
-
-
-def _host_replicas(plan, n_rows, row_bytes):
-    """Replicas of a leased plan for the other pipelines of HOST_DEVICES, built once and kept with the plan; () when one
-    device serves the call (the default, a field of few blocks, a plan too large to copy around).  The plan itself
-    serves the first pipeline on its own device (the first pipeline at all when its device is not listed, in place of
-    that entry): len(devices) pipelines in every case."""
-    devs = _host_devices()
-    if len(devs) < 2 or _plan_bytes(plan) > _REPLICA_MAX_BYTES:
-        return ()
-    from ._lib import host_block_plan
-    if host_block_plan(n_rows, row_bytes, _host_quantum(plan), len(devs))[1] < 2 * len(devs):
-        return ()                      # not enough blocks for every device to overlap its copies with its kernels
-    own = devs.index(plan.device) if plan.device in devs else 0
-    cache = plan.__dict__.setdefault("_replicas", {})
-    out = []
-    for slot, d in enumerate(devs):
-        if slot == own:
-            continue                   # the plan itself
-        key = (slot, d)
-        if key not in cache:
-            cache[key] = plan.replica(d)
-        out.append(cache[key])
-    return tuple(out)
-
-
-# Which FAMILY serves a table -- the segment-table gather or the dense family -- by estimated time per row of X, each at its
-# measured rate (tools/form_crossover.py, profiles/r05_form_crossover.txt, DESIGN.md (b)):
-#   segment table   n_ucells cell slots gathered per row at _SPARSE_CELLS_PER_S (2.7e11 / s in fp32: 0.13 ms for 0.46 G
-#                   compact cells x 365 rows, 0.64 ms for 1.8 G scattered ones; fp64 moves twice the bytes per cell)
-#   dense family    at best its entry lists: never faster than the X stream that each block of 688 regions pulls through the
-#                   LDS-DMA path (b G n_rb bytes per row at 10.1e12 B/s), nor than 2 x 1.3 nseg flop at the entry-loop rate
-# The dense family takes over when the gather would cost _DENSE_MARGIN times as much (the estimate of the dense side is its
-# floor; building it costs more and holds more memory).  Round 4's rule -- n_ucells > 16 G whatever the region count -- sat
-# on the wrong side for small region counts (R = 600: the dense family wins from n_ucells ~ 0.2 G).
-DENSE_SWITCH = 16.0   # the old rule, kept for callers that do not know R (then: n_ucells > DENSE_SWITCH * G)
-_SPARSE_CELLS_PER_S = {True: 2.7e11, False: 1.8e11}      # is_f32 -> gathered cell slots per second
-_DENSE_MARGIN = 1.5
-_DENSE_BUILD_BYTES_PER_ROW = 64      # device scratch of wagg_dense_create_from_segments while it builds (48 + 16 per row)
-_ENOMEM = -3                         # wagg.h WAGG_ENOMEM
-
-
-def _dense_floor_s(G, R, nseg, is_f32):
-    """Seconds per row of X the dense family cannot beat for this table (its entry-list form)."""
-    b = 4 if is_f32 else 8
-    n_rb = -(-int(R) // (16 * 43))
-    loop = 2.0 * 1.3 * float(nseg) / (30e12 if is_f32 else 13e12)
-    pack = 2.0 * b * float(G) / 5.3e12                  # X is packed once per apply (read + write at the HBM rate)
-    return max(b * float(G) * n_rb / 10.1e12, loop) + pack
-
-
-def _wants_dense(n_ucells, G, layout, R=None, nseg=None, is_f32=True):
-    """Device-family choice for one weights table.  The gather form fetches ``n_ucells`` cell slots
-    per timestep; when regions are scattered all over the grid (e.g. <=1 % non-zeros at random
-    columns: every region is a multi-chunk "giant") that is many times the grid itself and the
-    dense-family forms (MFMA contraction of the stored tiles in fp32 or fp64, entry lists for very
-    sparse tables), whose cost does not depend on where a region's cells lie, are faster -- for a
-    (time, gridcell) problem."""
-    if layout != "TG":
-        return False
-    if R is None or nseg is None:
-        return n_ucells > DENSE_SWITCH * G
-    return n_ucells / _SPARSE_CELLS_PER_S[bool(is_f32)] > _DENSE_MARGIN * _dense_floor_s(G, R, nseg, is_f32)
-
-
-def _dense_bytes(G, R, is_f32=True, nseg=None):
-    """Upper bound of what a dense-family plan of this table holds in HBM: the full matrix, or -- knowing the number of rows --
-    what the library's form choice can store for that many pairs: entry lists (8 B per pair in fp32, 16 B in fp64), or the
-    tile-sparse form, which it only takes while the stored tiles' flops beat the entry loop, i.e. up to ~1.1e-3 (fp32) /
-    2.5e-3 (fp64) tiles of 32 KB per walked entry (csrc/wagg_dense.hip: table_form_cost) -- 64 / 160 bytes per row."""
-    eb = 4 if is_f32 else 8
-    full = eb * ((int(G) + 31) // 32 * 32) * ((int(R) + 255) // 256 * 256)
-    if nseg is not None:
-        return min(full, (64 if is_f32 else 160) * int(nseg))
-    return full
-
-
-def _prefer_dense(n_ucells, G, R, is_f32, layout, free_bytes, nseg=None):
-    """The family choice as one predicate (tests, tools): the gather would cost more AND the dense-family plan fits."""
-    return (_wants_dense(n_ucells, G, layout, R=R, nseg=nseg if nseg is not None else n_ucells, is_f32=is_f32)
-            and _dense_bytes(G, R, is_f32, nseg=nseg) < 0.6 * free_bytes)
-
-
-def _plan_bytes(plan):
-    return int(plan.info.get("w_bytes", 0)) if isinstance(plan, DensePlan) else 16 * int(plan.info.get("nnz", 0))
-
-
-def _evict_plans(byte_budget, keep):
-    """Close cached plans, oldest first, until at most ``keep`` remain and they hold no more than
-    ``byte_budget`` bytes of device memory; returns the bytes released.  Plans leased to a running call
-    (their lock is held) are passed over.  Caller holds _CACHE_LOCK."""
-    freed = 0
-    held = sum(_plan_bytes(p) for p in _PLAN_CACHE.values())
-    for key in list(_PLAN_CACHE):
-        if not (len(_PLAN_CACHE) > keep or held > max(byte_budget, 0)):
-            break
-        old = _PLAN_CACHE[key]
-        if not old._lease.acquire(blocking=False):
-            continue                                   # in use by another thread: not ours to close
-        try:
-            del _PLAN_CACHE[key]
-            b = _plan_bytes(old)
-            old.close()
-        finally:
-            old._lease.release()
-        held -= b
-        freed += b
-    return freed
-
-
-def _drop_plan(plan):
-    """Forget a plan that failed on the device (a poisoned plan keeps failing: its timeout word is sticky)."""
-    with _CACHE_LOCK:
-        for key, p in list(_PLAN_CACHE.items()):
-            if p is plan:
-                del _PLAN_CACHE[key]
-    plan.close()
-
-
-_BUILDING = {}        # plan key -> threading.Event of the thread that is building that plan right now (under _CACHE_LOCK)
-
-
-def _plan_for(cell_idx, codes, w_eff, G, R, row_len, is_f32=False, layout="TG", prepared=None):
-    """The cached plan of this table, LEASED: ``plan._lease`` is held on return and the caller releases
-    it when its device work is done (see _CACHE_LOCK).  A table that is not cached is built by ONE thread, outside the
-    cache lock (a dense-family plan can be GBs: other tables must not wait for it); threads that want the same table
-    meanwhile wait for that build instead of starting their own."""
-    if prepared is not None:
-        key = prepared.plan_key(cell_idx, G, R, row_len, is_f32, layout)       # hashed once per (table, grid)
-    else:
-        key, _ = _fingerprint(cell_idx, codes, w_eff, extra=repr((int(G), int(R), int(row_len), bool(is_f32), layout)))
-    while True:
-        with _CACHE_LOCK:
-            plan = _PLAN_CACHE.get(key)
-            pending = None
-            if plan is not None:
-                _PLAN_CACHE.move_to_end(key)
-            else:
-                pending = _BUILDING.get(key)
-                if pending is None:
-                    _BUILDING[key] = threading.Event()
-        if plan is not None:
-            plan._lease.acquire()                  # waits for a thread that is applying the same table
-            if plan._h.value:
-                return plan
-            plan._lease.release()                  # closed in the meantime (failed on the device): forget it, build anew
-            with _CACHE_LOCK:
-                if _PLAN_CACHE.get(key) is plan:
-                    del _PLAN_CACHE[key]
-            continue
-        if pending is not None:
-            pending.wait()                         # another thread builds this very table: take its plan from the cache
-            continue
-        break
-    import torch
-    plan = None
-    try:
-        with _CACHE_LOCK:
-            free_bytes, total_bytes = torch.cuda.mem_get_info()
-            # keep the cache under its plan count and byte budget (what a sparse plan adds is a few MB)
-            free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes, keep=_PLAN_CACHE_MAX - 1)
-        # the finished plan plus what the device-side build holds while it runs (csrc/wagg_build.h: 48 bytes of arena per
-        # table row -- the sort's key / value pairs and the uploaded table -- and 16 per distinct pair)
-        need = _dense_bytes(G, R, is_f32, nseg=len(cell_idx)) + _DENSE_BUILD_BYTES_PER_ROW * len(cell_idx)
-
-        def dense_fits():
-            # only now is the dense byte budget charged: cached plans can be given back (oldest first) before
-            # the dense form is declined for lack of memory
-            nonlocal free_bytes
-            if need >= 0.6 * free_bytes:
-                with _CACHE_LOCK:
-                    free_bytes += _evict_plans(_PLAN_CACHE_MAX_FRAC * total_bytes - need, keep=_PLAN_CACHE_MAX - 1)
-            return need < 0.6 * free_bytes
-
-        dt = "float32" if is_f32 else "float64"
-        # a table with far more rows than grid cells (c5: ~244 per cell) cannot win in the gather
-        # form: go to the dense-family form directly instead of building the sparse plan first just to
-        # read its statistics
-
-        def dense_plan():
-            # a build that runs out of device memory after all (another process took it meanwhile; the estimate was short)
-            # is not the caller's problem: cached plans go and it is tried once more, then the segment-table form serves
-            if len(cell_idx) >= 2 ** 31:           # wagg_dense_create_from_segments: at most 2^31 - 1 rows
-                return None
-            for attempt in (0, 1):
-                try:
-                    return DensePlan.from_segments(cell_idx, codes, w_eff, G, R, dtype=dt)
-                except WaggError as e:
-                    if getattr(e, "code", None) != _ENOMEM:
-                        raise
-                    if attempt == 0:
-                        with _CACHE_LOCK:
-                            _evict_plans(0, keep=0)
-            return None
-
-        # (n_ucells >= the table's distinct cells: a table with that many rows per cell needs no sparse plan to know)
-        sure = len(cell_idx) > 4 * DENSE_SWITCH * G and _wants_dense(len(cell_idx) / 4.0, G, layout, R=R, nseg=len(cell_idx), is_f32=is_f32)
-        if sure and dense_fits():
-            plan = dense_plan()
-        if plan is None:
-            plan = SparsePlan(cell_idx, codes, w_eff, G, R, row_len=row_len)
-            if not sure and _wants_dense(plan.info["n_ucells"], G, layout, R=R, nseg=len(cell_idx), is_f32=is_f32) and dense_fits():
-                dense = dense_plan()
-                if dense is not None:
-                    plan.close()
-                    plan = dense
-        plan._lease.acquire()
-    finally:
-        with _CACHE_LOCK:
-            if plan is not None and plan._h.value:
-                _PLAN_CACHE[key] = plan
-            _BUILDING.pop(key).set()               # (a failed build wakes the waiters too: the first of them tries again)
-    return plan
-
-
-def _extract(ds):
-    """Pull (values, dims) of every data variable and the 1-D coords out of an xarray or minixr
-    Dataset."""
-    if _is_xarray(ds):
-        src_values = {k: v.values for k, v in ds.data_vars.items()}
-        src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
-        coords = {k: minixr.DataArray(v.values, tuple(v.dims)) for k, v in ds.coords.items()}
-        return src_values, src_dims, coords, True
-    # a lazily lon-sorted variable (standardize.py) hands over its file-order buffer; the column
-    # permutation is folded into the cell index by _reindex_spatial_data_to_regions
-    src_values = {k: (v._values if isinstance(v, minixr.LazyArray) or _is_device_tensor(v._values) else v.values)
-                  for k, v in ds.data_vars.items()}
-    src_dims = {k: tuple(v.dims) for k, v in ds.data_vars.items()}
-    return src_values, src_dims, dict(ds.coords), False
-
-
-def _lon_perms(ds):
-    if _is_xarray(ds):
-        return {}
-    return {k: v._lon_perm for k, v in ds.data_vars.items() if getattr(v, "_lon_perm", None) is not None}
-
-
-def _edds(ds):
-    """variable -> (tasmax buffer, offset, [(coef, threshold)]) of a lazy degree-day variable."""
-    if _is_xarray(ds):
-        return {}
-    return {k: v._edd for k, v in ds.data_vars.items() if getattr(v, "_edd", None) is not None}
-
-
-def _xforms(ds):
-    """variable -> (offset, power) of a lazily transformed variable (transformations.tas_poly)."""
-    if _is_xarray(ds):
-        return {}
-    return {k: v._xform for k, v in ds.data_vars.items() if getattr(v, "_xform", None) is not None}
-
-
-# ----------------------------------------------------------------------------------------------
-# A weights table coded ONCE (VERDICT r3 item 8): a pipeline that loops over variables, files or years with one table pays
-# the label join, the backup fill, the factorisation and the fingerprints a single time instead of re-hashing ~16 MB of
-# table columns on every call to find out that nothing changed.
-# ----------------------------------------------------------------------------------------------
-class PreparedWeights:
-    """A SNAPSHOT of one segment-weights table, coded for one ``(aggwt, agglev, backup_aggwt)``: backup-filled weights
-    (aggregations.py:73), sorted unique region labels and per-row codes (:78), and -- per grid it has met -- the resolved
-    cell of every row (:27) and the key of its plan.  Pass it as ``weights`` to :func:`weighted_aggregate_grid_to_regions`
-    (or the two helpers) wherever the DataFrame went; ``aggwt`` / ``agglev`` of the call must be the ones it was prepared
-    for.  It copies what it needs: later edits of the DataFrame do not reach it (a bare DataFrame is still fingerprinted by
-    content on every call, so edits of THAT are always seen)."""
-
-    def __init__(self, df, aggwt, agglev, backup_aggwt="areawt"):
-        self.aggwt, self.agglev, self.backup_aggwt = aggwt, agglev, backup_aggwt
-        self.seg_lat = _frozen(np.array(df["lat"].values, dtype=np.float64, copy=True))
-        self.seg_lon = _frozen(np.array(df["lon"].values, dtype=np.float64, copy=True))
-        self.w_eff = _frozen(_backup_fill(df[aggwt].values, df[backup_aggwt].values))
-        self.labels = _frozen(np.array(df[agglev].values, copy=True))
-        uniq, codes = _factorize_labels(self.labels)
-        self.uniq, self.codes = uniq, codes                       # (codes is read-only; uniq is handed out as a copy)
-        self.nseg = len(self.w_eff)
-        self._grids = {}        # (nlat, nlon, lat[0], lon[0]) -> [(lat, lon, cell, ilat, ilon)]
-        self._plan_keys = {}    # (id of a cell array this object owns, G, R, row_len, is_f32, layout) -> plan key
-        self._lock = threading.Lock()
-
-    # DataFrame-like access for code that reads the columns the reference reads (weights[aggwt].values ...)
-    def __getitem__(self, col):
-        if col == "lat":
-            return pd.Series(self.seg_lat)
-        if col == "lon":
-            return pd.Series(self.seg_lon)
-        if col == self.agglev:
-            return pd.Series(self.labels)
-        if col == self.aggwt:
-            return pd.Series(self.w_eff)
-        raise KeyError("%r: this PreparedWeights holds lat, lon, %r (backup-filled) and %r" % (col, self.aggwt, self.agglev))
-
-    def __len__(self):
-        return self.nseg
-
-    def check(self, aggwt, agglev, backup_aggwt="areawt"):
-        if (aggwt, agglev, backup_aggwt) != (self.aggwt, self.agglev, self.backup_aggwt):
-            raise ValueError("weights were prepared for aggwt=%r, agglev=%r, backup_aggwt=%r; the call asks for %r, %r, %r"
-                             % (self.aggwt, self.agglev, self.backup_aggwt, aggwt, agglev, backup_aggwt))
-
-    def cells_for(self, lat, lon):
-        """(cell, ilat, ilon) of every row on this grid (exact label match, KeyError on a miss: S1), resolved once per grid."""
-        lat, lon = np.asarray(lat), np.asarray(lon)
-        gk = (len(lat), len(lon), float(lat[0]) if len(lat) else 0.0, float(lon[0]) if len(lon) else 0.0)
-        with self._lock:
-            for glat, glon, cell, ilat, ilon in self._grids.get(gk, ()):
-                if np.array_equal(glat, lat) and np.array_equal(glon, lon):
-                    return cell, ilat, ilon
-        cell = _resolve_cells(lat, lon, self.seg_lat, self.seg_lon)
-        ilat, ilon = _frozen((cell // len(lon)).astype(np.int64)), _frozen((cell % len(lon)).astype(np.int64))
-        with self._lock:
-            self._grids.setdefault(gk, []).append((_f64(lat).copy(), _f64(lon).copy(), cell, ilat, ilon))
-        return cell, ilat, ilon
-
-    def plan_key(self, cell_idx, G, R, row_len, is_f32, layout):
-        """Key of the plan of (this table, this cell index): hashed once per cell array this object owns, else per call."""
-        extra = repr((int(G), int(R), int(row_len), bool(is_f32), layout))
-        with self._lock:
-            owned = any(cell_idx is c for entries in self._grids.values() for _, _, c, _, _ in entries)
-        if not owned:                                  # e.g. a lon-permuted or lon-major index: a fresh array every call
-            return _fingerprint(cell_idx, self.codes, self.w_eff, extra=extra)[0]
-        k = (id(cell_idx), extra)
-        with self._lock:
-            key = self._plan_keys.get(k)
-        if key is None:                                # the key a bare DataFrame of the same content gets: one plan serves both
-            key = _fingerprint(cell_idx, self.codes, self.w_eff, extra=extra)[0]
-            with self._lock:
-                self._plan_keys[k] = key
-        return key
-
-
-def prepare_weights(weights, aggwt, agglev, backup_aggwt="areawt", lat=None, lon=None):
-    """Code a segment-weights table (DataFrame, or the path of its CSV) once for ``(aggwt, agglev)``; with the grid's
-    ``lat`` / ``lon`` labels the cells are resolved now (KeyError on a label that is not on the grid), else at first use."""
-    if isinstance(weights, PreparedWeights):
-        weights.check(aggwt, agglev, backup_aggwt)
-        prep = weights
-    else:
-        if isinstance(weights, str):
-            weights = prepare_spatial_weights_data(weights)
-        prep = PreparedWeights(weights, aggwt, agglev, backup_aggwt)
-    if lat is not None and lon is not None:
-        prep.cells_for(lat, lon)
-    return prep
 
 
 _PREPARED_BY_PATH = {}      # (path, aggwt, agglev) -> PreparedWeights: the CSV route is memoised on the path like the reference (:127)
@@ -1086,6 +236,13 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
     X2, layout, _, unflatten = _flatten_for_device(values, dims)
     is_f32 = str(X2.dtype).endswith("float32")
 
+    def result_coords():
+        """dims of the result (S10) and its coordinates: the carried 1-D coords plus the sorted unique labels (S3)"""
+        rdims = _result_dims(dims, agglev)
+        coords = {d: np.asarray(carried[d].values) for d in rdims if d != agglev and d in carried and tuple(carried[d].dims) == (d,)}
+        coords[agglev] = uniq
+        return rdims, coords
+
     def _aggregate_on_plan(plan):
         out_layout = "TR" if layout == "TG" else "RT"
         if (not _is_device_tensor(X2)) and layout == "TG" and powers is None and edd is None:
@@ -1106,12 +263,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                 finally:
                     exact.close()
             res0 = unflatten(host_out, len(uniq))
-            rdims = _result_dims(dims, agglev)
-            coords = {}
-            for d in rdims:
-                if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-                    coords[d] = np.asarray(carried[d].values)
-            coords[agglev] = uniq
+            rdims, coords = result_coords()
             return res0, rdims, coords, was_xr
         if ((not _is_device_tensor(X2)) and layout == "TG" and powers is not None and edd is None and isinstance(plan, SparsePlan)
                 and max(powers) <= 16 and min(powers) >= 1 and len(_host_devices()) < 2):
@@ -1125,12 +277,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
             stack = plan.apply_poly_host(X2c, offset, hi - lo + 1, pow_first=lo, flags=HOST_PIN | HOST_LINES,
                                          out=_pinned_result((hi - lo + 1, X2c.shape[0], plan.R), X2c.dtype))
             res = [unflatten(stack[int(p) - lo], len(uniq)) for p in powers]
-            rdims = _result_dims(dims, agglev)
-            coords = {}
-            for d in rdims:
-                if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-                    coords[d] = np.asarray(carried[d].values)
-            coords[agglev] = uniq
+            rdims, coords = result_coords()
             return (res[0] if single else res), rdims, coords, was_xr
         if ((not _is_device_tensor(X2)) and layout == "TG" and edd is not None and isinstance(plan, SparsePlan)
                 and len(edd[2]) == 1 and edd[2][0][0] == 1.0 and len(_host_devices()) < 2):
@@ -1144,12 +291,7 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
                 from ._lib import HOST_LINES, HOST_PIN
                 stack = plan.apply_edd_host(np.ascontiguousarray(X2), np.ascontiguousarray(H2), [edd[2][0][1]], offset=edd[1],
                                             flags=HOST_PIN | HOST_LINES, out=_pinned_result((1, X2.shape[0], plan.R), X2.dtype))
-                rdims = _result_dims(dims, agglev)
-                coords = {}
-                for d in rdims:
-                    if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-                        coords[d] = np.asarray(carried[d].values)
-                coords[agglev] = uniq
+                rdims, coords = result_coords()
                 return unflatten(stack[0], len(uniq)), rdims, coords, was_xr
         # everything else: one pageable H2D copy of the field (fields already on the device pass through), the
         # kernels, one D2H copy of the result
@@ -1198,15 +340,14 @@ def _aggregate_core(ds, variable, aggwt, agglev, weights, backup_aggwt, powers=N
         # device buffers on the input side.  (xarray cannot carry one: xarray callers always get host arrays.)
         keep_dev = _device_results_wanted() and _is_device_tensor(X2) and not was_xr
         res = [unflatten(o if keep_dev else _to_host(o), len(uniq)) for o in outs]
-        if isinstance(plan, SparsePlan) and not keep_dev:
-            plan.status()                                        # a device-side failure must not pass silently
-        rdims = _result_dims(dims, agglev)
-
-        coords = {}
-        for d in rdims:
-            if d != agglev and d in carried and tuple(carried[d].dims) == (d,):
-                coords[d] = np.asarray(carried[d].values)
-        coords[agglev] = uniq
+        if isinstance(plan, SparsePlan):
+            if not keep_dev:
+                plan.status()                                    # a device-side failure must not pass silently
+            else:                                                # (no wait inside results_on_device(): checked when the block ends)
+                pending = getattr(_TLS, "unchecked_plans", None)
+                if pending is not None and not any(p is plan for p in pending):
+                    pending.append(plan)
+        rdims, coords = result_coords()
         return (res[0] if single or edd is not None else res), rdims, coords, was_xr
 
     plan = _plan_for(cell_idx, codes, w_eff, G, len(uniq), row_len, is_f32=is_f32, layout=layout, prepared=prepared)

@@ -804,7 +804,7 @@ def test_dropin_from_two_threads_shares_the_caches_safely(torch_cuda):
 
     A._PLAN_CACHE.clear()
     expect = [run(j) for j in jobs]
-    saved = A._PLAN_CACHE_MAX
+    saved = A._plans._PLAN_CACHE_MAX
     errs, got = [], {}
 
     def worker(k):
@@ -816,13 +816,13 @@ def test_dropin_from_two_threads_shares_the_caches_safely(torch_cuda):
             errs.append(repr(e))
 
     try:
-        A._PLAN_CACHE_MAX = 1
+        A._plans._PLAN_CACHE_MAX = 1
         A._PLAN_CACHE.clear()
         ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
         [t.start() for t in ts]
         [t.join() for t in ts]
     finally:
-        A._PLAN_CACHE_MAX = saved
+        A._plans._PLAN_CACHE_MAX = saved
     assert not errs, errs
     assert len(got) == 2 * 6 * len(jobs)
     for (k, rep, i), v in got.items():
@@ -1128,16 +1128,16 @@ def test_results_come_back_through_recycled_page_locked_memory(torch_cuda):
     assert pool["bytes"] == in_use_bytes and n_free() == free1 - 1          # a pooled block was reused: nothing new page-locked
     assert c.tas.values.ctypes.data != pa
     np.testing.assert_array_equal(c.tas.values[3:5], keep)
-    old_cap = A._PINNED_OUT_CAP
+    old_cap = A._pinned._PINNED_OUT_CAP
     try:
-        A._PINNED_OUT_CAP = 0                                   # at the cap with every block in use: pageable copy, same numbers
+        A._pinned._PINNED_OUT_CAP = 0                                   # at the cap with every block in use: pageable copy, same numbers
         for blocks in pool["free"].values():
             blocks.clear()
         d = weighted_aggregate_grid_to_regions(ds, "tas", "areawt", "hierid", df)
         np.testing.assert_array_equal(d.tas.values[3:5], keep)
         assert pool["bytes"] == in_use_bytes and n_free() == 0
     finally:
-        A._PINNED_OUT_CAP = old_cap
+        A._pinned._PINNED_OUT_CAP = old_cap
     del keep, c, d
     gc.collect()
     assert n_free() >= 2                                        # both blocks (a's via its view, c's) came back

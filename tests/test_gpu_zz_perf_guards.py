@@ -12,6 +12,13 @@ from tests.test_gpu_round5 import FORM_POINTS, form_point_table
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return torch
+
+
 WARM_S = 0.3        # seconds of the same apply before any sample (bench.py's WARM_S)
 SAMPLES = 15
 

@@ -368,7 +368,7 @@ def test_table_memo_follows_the_table_content(monkeypatch):
         calls["n"] += 1
         return real(lab)
 
-    monkeypatch.setattr(A, "_factorize_labels_impl", counting)
+    monkeypatch.setattr(A._labels, "_factorize_labels_impl", counting)
 
     def check():
         uniq, codes = A._factorize_labels(labels)
@@ -433,7 +433,7 @@ def test_table_memo_label_types_without_a_buffer_or_a_safe_identity(monkeypatch)
         calls["n"] += 1
         return real(lab)
 
-    monkeypatch.setattr(A, "_factorize_labels_impl", counting)
+    monkeypatch.setattr(A._labels, "_factorize_labels_impl", counting)
     n = len(A._TABLE_MEMO)
     for lab in (np.array([3, "a", 2.5, "a"], dtype=object), np.array([(1, 2), (0, 1), (1, 2)] + [None], dtype=object)[:3]):
         with pytest.raises(A._Unhashable):

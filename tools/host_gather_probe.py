@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Writes the referenced line runs of the c2-real table (32-cell lines for fp32, 16-cell lines for fp64, optionally with
-gaps of <= `gap` lines merged) to runs_<elem>_<gap>.bin for tools/micro/host_gather.cpp.  usage: host_gather_probe.py outdir"""
+gaps of <= `gap` lines merged) to runs_<elem>_<gap>.bin for tools/micro/host_gather.cpp, and (round 6, VERDICT r5 Next #8) the
+runs at finer granules -- runs_<elem>_g<granule bytes>.bin for 16 / 32 / 64 / 128-byte granules.  usage: host_gather_probe.py outdir"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,4 +19,14 @@ for elem, LINE in ((4, 32), (8, 16)):
         last = np.concatenate([lines[brk], [lines[-1]]])
         runs = np.stack([first * LINE, (last - first + 1) * LINE], axis=1).astype(np.int64)
         with open(os.path.join(out, "runs_%d_%d.bin" % (elem, gap)), "wb") as f:
+            f.write(np.int64(len(runs)).tobytes()); f.write(runs.tobytes())
+
+    for gb in (16, 32, 64, 128):
+        LINE = gb // elem
+        lines = np.unique(cell // LINE)
+        brk = np.flatnonzero(np.diff(lines) > 1)
+        first = np.concatenate([[lines[0]], lines[brk + 1]])
+        last = np.concatenate([lines[brk], [lines[-1]]])
+        runs = np.stack([first * LINE, (last - first + 1) * LINE], axis=1).astype(np.int64)
+        with open(os.path.join(out, "runs_%d_g%d.bin" % (elem, gb)), "wb") as f:
             f.write(np.int64(len(runs)).tobytes()); f.write(runs.tobytes())
