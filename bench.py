@@ -779,6 +779,17 @@ def main():
                                               "wait_for_copy_engine_ms": st["lines_wait_copy_us"] / 9e3, "wait_for_packing_threads_ms": st["lines_wait_pack_us"] / 9e3,
                                               "blocks_retired_by_the_rate_watch": st["blocks_retired"],
                                               "packing_threads": min(12, max(usable_cpus()[0] // 2, usable_cpus()[0] - 4, 1))}
+        # (round 6: the default packs only the quads that hold a referenced cell; the round-5 form -- whole 128-byte lines -- beside it)
+        tw = []
+        L_.host_stats(reset=True)
+        for _ in range(7):
+            t0 = time.perf_counter()
+            plan.apply_host(Xh, flags=L_.HOST_PIN | L_.HOST_LINES | L_.HOST_LINES_WHOLE)
+            tw.append(time.perf_counter() - t0)
+        stw = L_.host_stats()
+        tw = sorted(tw[2:])
+        out["host_resident"]["lines_only"]["whole_128B_lines"] = {"ms_per_step": tw[len(tw) // 2] * 1e3, "min_ms": tw[0] * 1e3,
+                                                                  "packed_fraction_of_x": stw["lines_h2d_bytes"] / 7 / Xh.nbytes}
         # the transforms the reference's callers run before they aggregate, on the same host-resident field (round 5): the fused
         # powers (tas_poly 1..4, transformations.py:188) and one set of Snyder degree days (tasmin = the field, tasmax = field + 9 K;
         # transformations.py:7-93) through the same pipeline, lines only; results (4 planes / 1 plane) back in host memory

@@ -12,7 +12,7 @@ EKEY, EINTERNAL = -6, -7
 PLAN_NO_LC, PLAN_NO_STREAM, PLAN_NO_LINES, PLAN_LC_MFMA, PLAN_SERIAL_BUILD = 1, 2, 4, 8, 16
 FORM_FULL, FORM_TILES, FORM_ENTRIES = 0, 1, 2
 FORCE_FORM = {None: 0, "auto": 0, "full": 1, "tiles": 2, "entries": 3}      # WAGG_DENSE_FORCE_*
-HOST_PIN, HOST_WHOLE, HOST_LINES = 1, 2, 4
+HOST_PIN, HOST_WHOLE, HOST_LINES, HOST_LINES_WHOLE = 1, 2, 4, 8
 DENSE_GENERAL_SORT = 16        # WAGG_DENSE_GENERAL_SORT
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER = 0, 1, 2
 LAYOUT_TG, LAYOUT_GT = 0, 1

@@ -125,6 +125,8 @@ int stream_host_rows(const T *X_host, int64_t Tn, int64_t ldx, int64_t G, T *out
 
 // CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one
 int granted_cpus();
+// host threads the lines-only gather would start for a call made from this thread right now
+int gather_team_threads();
 // the page-locked ring of the gather (process lifetime, one call at a time; a second concurrent call does without and
 // takes the plain path): nullptr when it is in use or cannot be had.  release_host_ring(): free it (wagg_release_scratch)
 char *acquire_host_ring(size_t bytes);

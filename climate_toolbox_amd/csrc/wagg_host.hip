@@ -247,6 +247,14 @@ int granted_cpus() {
     return cpus;
 }
 
+int gather_team_threads() {
+    // all but four of the CPUs this thread may use (at least half of them), twelve at most
+    const int granted = granted_cpus();
+    int want = granted / 2;
+    if (granted - 4 > want) want = granted - 4;
+    return want > 12 ? 12 : want;
+}
+
 namespace {
 struct HostRing { std::mutex mu; char *p = nullptr; size_t cap = 0; bool busy = false; } g_ring;
 }  // namespace
@@ -328,10 +336,7 @@ struct GatherTeam {
             // whole rows 26.3 ms).  Twelve instead of eight of 16 CPUs: nothing for the 455-byte runs of the fp32 lines
             // (8 threads already hide behind PCIe), but the 189-byte runs of the degree-day chunking and the fp64 lines
             // stop being a co-bottleneck (degree days: 14-18 ms waiting for the packers -> 1.7 ms, 30.3-34.3 -> 29.9-30.3 ms)
-            const int granted = granted_cpus();
-            int want = granted / 2;
-            if (granted - 4 > want) want = granted - 4;
-            want = want > 12 ? 12 : want;
+            const int want = gather_team_threads();
             const int need = (int)((6 * a.crow_bytes + a.xrow_bytes - 1) / a.xrow_bytes);       // (per field: two fields, twice the bytes on both sides)
             if (want < 1 || want < need || (int64_t)want > a.Tn) return false;
             crow_all = a.crow_bytes * (a.X2_host ? 2 : 1);

@@ -1180,9 +1180,10 @@ template <typename T, int TB>
 static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_t ldx, int layout,
                          T *out, int64_t ldo, int out_layout, hipStream_t stream, T xoff = T(0), int xpow = 0,
                          int nfuse = 1, int64_t pstride = 0, const T *X2 = nullptr, const double *thr = nullptr,
-                         int n_thr = 0, bool compact = false) {
-    // compact: X holds COMPACT rows (ldx >= Gc cells: the distinct quads of the whole-line chunking side by side, the
-    // lines-only host path) -- the plain aggregation of (time, gridcell) data on that chunking, read through ucell_c
+                         int n_thr = 0, int compact = COMPACT_NONE) {
+    // compact: X holds COMPACT rows of the lines-only host path -- COMPACT_LINES: ldx >= Gc cells, the distinct quads of the
+    // whole-line chunking side by side, read through ucell_c; COMPACT_QUADS: ldx >= Gq cells, only the quads a segment reads,
+    // through ucell_q -- (time, gridcell) data on that chunking
     // nfuse > 1: powers xpow .. xpow + nfuse - 1 of (x + xoff) in one pass over X (fused tas_poly); the i-th goes to
     // out + i * pstride.  sparse_lcv_kernel fuses up to four planes (powers or degree-day thresholds) in both element types and
     // both layouts on the chunkings of the table above; everything it does not serve (giant groups, plans whose flags or
@@ -1201,9 +1202,10 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const auto &d = edd_lcv ? d_edd
                             : (gt_lcv ? (sizeof(T) == 4 ? plan->d : plan->dl64) : (use_lines ? (sizeof(T) == 4 ? plan->dl : plan->dl64) : plan->d));
     if (int rc = check_timeout(plan)) return rc;
-    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse <= 4 && (xpow != XF_EDD || edd_lcv) && d.Gc > 0 && ldx >= d.Gc),
+    const int64_t Gcomp = compact == COMPACT_QUADS ? d.Gq : d.Gc;
+    WAGG_REQUIRE(!compact || (use_lines && !lcv_off && nfuse <= 4 && (xpow != XF_EDD || edd_lcv) && Gcomp > 0 && ldx >= Gcomp),
                  "compact rows need the whole-line chunking of this plan and data type");
-    const int64_t Gk = compact ? d.Gc : (int64_t)plan->info.G;        // cells of a row as the kernels see it
+    const int64_t Gk = compact ? Gcomp : (int64_t)plan->info.G;        // cells of a row as the kernels see it
     if (nfuse > 1) {
         // fused: fp32 in either loader/consumer kernel; fp64 in sparse_lcv_kernel on its whole-line chunking
         const bool lc_ok = ((layout == WAGG_LAYOUT_TG && (sizeof(T) == 4 || (use_lines && !lcv_off))) || gt_lcv) &&
@@ -1225,7 +1227,7 @@ static int launch_sparse(const wagg_plan *plan, const T *X, int64_t Ttot, int64_
     const int nplanes = xpow == XF_EDD ? pv.n_thr : nfuse;
     pv.grp_chunk_begin = d.grp_chunk_begin.p; pv.grp_giant = d.grp_giant.p;
     pv.chunk_u_begin = d.chunk_u_begin.p; pv.chunk_e_begin = d.chunk_e_begin.p;
-    pv.ucell = compact ? d.ucell_c.p : d.ucell.p; pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
+    pv.ucell = compact == COMPACT_QUADS ? d.ucell_q.p : (compact ? d.ucell_c.p : d.ucell.p); pv.ent_region = d.ent_region.p; pv.ent_seg_begin = d.ent_seg_begin.p;
     pv.seg_u = d.seg_u.p;
     if constexpr (sizeof(T) == 4) { pv.seg_w = d.seg_w32.p; pv.den = d.den32.p; pv.ent_den = d.ent_den32.p; }
     else { pv.seg_w = d.seg_w64.p; pv.den = d.den64.p; pv.ent_den = d.ent_den64.p; }
@@ -1907,6 +1909,26 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
             up(d.ucell_c, ucell_c);
             d.Gc = 4 * (int64_t)uq.size();
+            // ... and the quads that a segment of their chunk really reads (wagg_sparse_int.h: ucell_q)
+            std::vector<char> used(ucell.size(), 0);
+            for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c)
+                for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1]; ++e)
+                    for (int32_t sg = ent_seg_begin[(size_t)e]; sg < ent_seg_begin[(size_t)e + 1]; ++sg)
+                        used[(size_t)chunk_u_begin[c] + (size_t)(seg_u[(size_t)sg] >> 2)] = 1;
+            std::vector<int32_t> uqq;
+            for (size_t i = 0; i < ucell.size(); ++i) if (used[i]) uqq.push_back(ucell[i]);
+            std::sort(uqq.begin(), uqq.end());
+            uqq.erase(std::unique(uqq.begin(), uqq.end()), uqq.end());
+            std::vector<int32_t> ucell_q(ucell.size(), 0);
+            for (size_t i = 0; i < ucell.size(); ++i)
+                if (used[i]) ucell_q[i] = (int32_t)(4 * (std::lower_bound(uqq.begin(), uqq.end(), ucell[i]) - uqq.begin()));
+            d.run_src_q.clear(); d.run_len_q.clear();
+            for (size_t i = 0; i < uqq.size(); ++i) {
+                if (i > 0 && uqq[i] == uqq[i - 1] + 4) d.run_len_q.back() += 4;
+                else { d.run_src_q.push_back((int64_t)uqq[i]); d.run_len_q.push_back(4); }
+            }
+            up(d.ucell_q, ucell_q);
+            d.Gq = 4 * (int64_t)uqq.size();
         }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         d.n_groups = (int64_t)grp_giant.size(); d.n_empty = (int64_t)empty.size();
@@ -2084,23 +2106,31 @@ static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int
     // that cannot start (ring in use by a concurrent call, too few usable CPUs) means the plain pipeline below
     const SparsePlanDev &dc = dc_given ? (dc_ ? *dc_ : plan->d) : (sizeof(T) == 4 ? plan->dl : plan->dl64);
     const bool has_c = (dc_given ? dc_ != nullptr : (sizeof(T) == 4 ? plan->has_lines : plan->has_lines64)) && dc.Gc > 0 && !dc.run_len.empty();
-    if ((flags & WAGG_HOST_LINES) && has_c && 5 * dc.Gc <= 4 * (int64_t)plan->info.G &&
+    // ... and of those lines only the QUADS (16 bytes) that hold a referenced cell ("quads only", round 6; c2-real: 33.5 % of a
+    // fp32 row instead of 63.6 %, 10.2 instead of 18.1 ms for packing + copy in tools/host_granule_gonogo.sh) when the packing
+    // team is large enough for the shorter runs (116 instead of 455 bytes on average: twelve threads stay ahead of PCIe,
+    // eight do not -- profiles/r06_host_granule.txt) and the caller has not asked for whole lines (WAGG_HOST_LINES_WHOLE)
+    const bool quads = has_c && dc.Gq > 0 && !dc.run_len_q.empty() && !(flags & WAGG_HOST_LINES_WHOLE) && gather_team_threads() >= 10;
+    const int64_t Gc = quads ? dc.Gq : dc.Gc;
+    if ((flags & WAGG_HOST_LINES) && has_c && 5 * Gc <= 4 * (int64_t)plan->info.G &&
         Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
-        std::vector<int64_t> src(dc.run_src.size());
-        std::vector<int32_t> len(dc.run_len.size());
-        for (size_t k = 0; k < src.size(); ++k) { src[k] = dc.run_src[k] * (int64_t)sizeof(T); len[k] = dc.run_len[k] * (int32_t)sizeof(T); }
+        const std::vector<int64_t> &rs = quads ? dc.run_src_q : dc.run_src;
+        const std::vector<int32_t> &rl = quads ? dc.run_len_q : dc.run_len;
+        std::vector<int64_t> src(rs.size());
+        std::vector<int32_t> len(rl.size());
+        for (size_t k = 0; k < src.size(); ++k) { src[k] = rs[k] * (int64_t)sizeof(T); len[k] = rl[k] * (int32_t)sizeof(T); }
         HostRowsArgs c = a;
-        c.run_src = src.data(); c.run_len = len.data(); c.n_runs = (int64_t)src.size(); c.crow_bytes = dc.Gc * (int64_t)sizeof(T);
-        const int64_t Gc = dc.Gc;
+        c.run_src = src.data(); c.run_len = len.data(); c.n_runs = (int64_t)src.size(); c.crow_bytes = Gc * (int64_t)sizeof(T);
+        const int mode = quads ? COMPACT_QUADS : COMPACT_LINES;
         c.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
-            return launch(static_cast<const T *>(xd), rows, Gc, static_cast<T *>(od), st, true);
+            return launch(static_cast<const T *>(xd), rows, Gc, static_cast<T *>(od), st, mode);
         };
         const int rc = stream_host_rows_any(c);
         if (rc != WAGG_EUNSUPPORTED) return rc;
         clear_error();
     }
     a.apply = [&](int, const void *xd, int64_t rows, void *od, hipStream_t st) {
-        return launch(static_cast<const T *>(xd), rows, ldx, static_cast<T *>(od), st, false);
+        return launch(static_cast<const T *>(xd), rows, ldx, static_cast<T *>(od), st, COMPACT_NONE);
     };
     return stream_host_rows_any(a);
 }
@@ -2111,14 +2141,14 @@ static int apply_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx
     clear_error();
     int rc = check_apply_args(plan, X, Tn, ldx, layout, out, ldo, out_layout);
     if (rc != WAGG_OK || Tn == 0) return rc;
-    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_WHOLE | WAGG_HOST_LINES | WAGG_HOST_LINES_WHOLE)) == 0, "unknown host flags 0x%x", flags);
     if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     if (layout == WAGG_LAYOUT_TG && out_layout == WAGG_OUT_TR && !(flags & WAGG_HOST_WHOLE)) {
         rc = host_rows_pipeline<T>(plan, X, Tn, ldx, out, ldo, flags, 1, 0,
-                                   [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                                   [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, int compact) {
                                        if (!compact) return fn(plan, xd, rows, ldx_dev, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, (void *)st);
                                        return launch_sparse<T, (sizeof(T) == 4 ? 64 : 32)>(plan, xd, rows, ldx_dev, WAGG_LAYOUT_TG, od, ldo, WAGG_OUT_TR, st,
-                                                                                           T(0), 0, 1, 0, nullptr, nullptr, 0, true);
+                                                                                           T(0), 0, 1, 0, nullptr, nullptr, 0, compact);
                                    });
         if (rc != WAGG_OK) return rc;
         return check_timeout(plan);
@@ -2149,12 +2179,12 @@ static int apply_poly_host(const wagg_plan *plan, const T *X, int64_t Tn, int64_
     WAGG_REQUIRE(pow_first >= 1 && n_pow >= 1 && pow_first + n_pow - 1 <= 16, "powers must lie in [1, 16], got %d..%d", pow_first,
                  pow_first + n_pow - 1);
     WAGG_REQUIRE(n_pow == 1 || out_pstride >= Tn * ldo, "out_pstride %lld overlaps the previous power", (long long)out_pstride);
-    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES | WAGG_HOST_LINES_WHOLE)) == 0, "unknown host flags 0x%x", flags);
     if (Tn == 0) return WAGG_OK;
     if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     constexpr int TB = sizeof(T) == 4 ? 64 : 32;
     rc = host_rows_pipeline<T>(plan, X, Tn, ldx, out, ldo, flags, n_pow, out_pstride,
-                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, int compact) {
                                    int r2 = WAGG_OK;
                                    const int64_t ps = rows * ldo;                 // planes of one block lie side by side
                                    for (int i = 0; i < n_pow && r2 == WAGG_OK; i += 4)      // one pass over the block per four powers
@@ -2178,19 +2208,19 @@ static int apply_edd_host(const wagg_plan *plan, const T *tmin, const T *tmax, i
     WAGG_REQUIRE(Tn == 0 || tmax != nullptr, "tasmax is NULL");
     WAGG_REQUIRE(n_thr >= 1 && n_thr <= 64 && thr != nullptr, "need 1..64 thresholds");
     WAGG_REQUIRE(n_thr == 1 || out_pstride >= Tn * ldo, "out_pstride %lld overlaps the previous threshold", (long long)out_pstride);
-    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES)) == 0, "unknown host flags 0x%x", flags);
+    WAGG_REQUIRE((flags & ~(WAGG_HOST_PIN | WAGG_HOST_LINES | WAGG_HOST_LINES_WHOLE)) == 0, "unknown host flags 0x%x", flags);
     if (Tn == 0) return WAGG_OK;
     if ((rc = check_plan_device(plan)) != WAGG_OK) return rc;
     constexpr int TB = sizeof(T) == 4 ? 64 : 32;
     const bool lcv_off = (plan->flags & (WAGG_PLAN_NO_LC | WAGG_PLAN_NO_STREAM | WAGG_PLAN_LC_MFMA)) != 0;
     const bool edd_lcv = (sizeof(T) == 4 ? plan->has_lines64 : plan->has_lines64e) && !lcv_off;
     const SparsePlanDev *dc = edd_lcv ? (sizeof(T) == 4 ? &plan->dl64 : &plan->dl64e) : nullptr;
-    const int64_t Gc = dc ? dc->Gc : 0;
     rc = host_rows_pipeline<T>(plan, tmin, Tn, ldx, out, ldo, flags, n_thr, out_pstride,
-                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, bool compact) {
+                               [&](const T *xd, int64_t rows, int64_t ldx_dev, T *od, hipStream_t st, int compact) {
                                    // whole rows: tasmax's block behind tasmin's; packed rows: one row = tasmin's lines, then tasmax's
-                                   const T *x2 = compact ? xd + Gc : xd + rows * ldx_dev;
-                                   const int64_t ld = compact ? 2 * Gc : ldx_dev;
+                                   // (packed rows: ldx_dev = the cells of ONE field's compact row)
+                                   const T *x2 = compact ? xd + ldx_dev : xd + rows * ldx_dev;
+                                   const int64_t ld = compact ? 2 * ldx_dev : ldx_dev;
                                    const int64_t ps = rows * ldo;
                                    int r2 = WAGG_OK;
                                    for (int i = 0; i < n_thr && r2 == WAGG_OK; i += 4)

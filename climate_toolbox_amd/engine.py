@@ -221,7 +221,7 @@ class SparsePlan:
             devs = (C.c_int32 * len(plans))(*[p.device for p in plans])
             _lib.run("wagg_apply (host, multi-device)", plan_kind=_lib.PLAN_SEGMENT, plan=hs, n_plans=len(plans), devices=devs,
                      elem=_elem(X.dtype), source=_lib.SRC_HOST_MULTI, x=X.ctypes.data, T=T, ldx=X.shape[1], out=out.ctypes.data,
-                     ldo=max(1, self.R), flags=int(flags) & ~_lib.HOST_LINES)
+                     ldo=max(1, self.R), flags=int(flags) & ~(_lib.HOST_LINES | _lib.HOST_LINES_WHOLE))
             return out
         with _on_device(self.device):
             _lib.run("wagg_apply (host)", plan_kind=_lib.PLAN_SEGMENT, plan=self._h, elem=_elem(X.dtype), source=_lib.SRC_HOST,
@@ -453,7 +453,7 @@ class DensePlan:
         """Host-resident (time, gridcell) array through the plan in row blocks (``wagg_dense_apply_host_*``):
         numpy in, numpy out; flags and ``replicas`` as for :meth:`SparsePlan.apply_host` (``_lib.HOST_LINES`` means nothing
         to a dense-family plan -- every cell of a row is an operand -- and is dropped)."""
-        flags = int(flags) & ~_lib.HOST_LINES
+        flags = int(flags) & ~(_lib.HOST_LINES | _lib.HOST_LINES_WHOLE)
         want = np.float64 if self.dtype == "float64" else np.float32
         X = np.ascontiguousarray(X)
         if X.dtype != want or X.ndim != 2 or X.shape[1] != self.G:

@@ -199,6 +199,14 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *                    Measured (tools/host_path_timing.py, c2-real T = 365): fp32 29.8 -> 21.3 ms per call (the C call alone
  *                    18.5 ms, of which 16.7 ms are the copy engine's), fp64 59.2 -> 33.5 ms; DESIGN.md (f).              */
 #define WAGG_HOST_LINES 4
+/*   WAGG_HOST_LINES_WHOLE  with WAGG_HOST_LINES: pack the whole 128-byte lines as in round 5.  Without it (round 6, "quads
+ *                    only") the packed row holds only the 16-byte QUADS that contain a referenced cell -- a whole-line chunk
+ *                    fetches every quad of its lines, but the kernel reads only those; the others are pointed at a valid
+ *                    dummy position -- whenever at least ten packing threads can be had (the runs are shorter: 116 instead of
+ *                    455 bytes on c2-real; twelve threads stay ahead of PCIe, eight do not): 33.5 % of a c2-real fp32 row
+ *                    instead of 63.6 %, c2-real T = 365 packing + copy 18.1 -> 10.2 ms (tools/host_granule_gonogo.sh,
+ *                    profiles/r06_host_granule.txt).  Same kernel, same cells in the same order: the same bits.        */
+#define WAGG_HOST_LINES_WHOLE 8
 int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                         int layout, float *out_host, int64_t ldo, int out_layout);
 int wagg_apply_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx,

@@ -89,7 +89,7 @@ def one_case(i, rng):
     if b: fails.append("apply: " + b)
     from climate_toolbox_amd import _lib
     host_forms = layout == "TG" and out_layout == "TR"
-    hflags = int(rng.choice([0, _lib.HOST_PIN, _lib.HOST_LINES, _lib.HOST_PIN | _lib.HOST_LINES]))
+    hflags = int(rng.choice([0, _lib.HOST_PIN, _lib.HOST_LINES, _lib.HOST_PIN | _lib.HOST_LINES, _lib.HOST_PIN | _lib.HOST_LINES | _lib.HOST_LINES_WHOLE]))
     if host_forms:                                            # the host forms of the same call (row-block pipeline; lines only
         _lib.host_stats(reset=True)                           #  when the field is large enough -- FUZZ_SCALE >= 6 -- and compact)
         gh = plan.apply_host(X, flags=hflags)
@@ -180,7 +180,7 @@ def lines_case(i, rng):
     X[rng.integers(0, T, 50), rng.integers(0, G, 50)] = np.nan
     if rng.random() < 0.3:
         X[rng.integers(0, T), cell[rng.integers(0, len(cell))]] = np.inf
-    flags = _lib.HOST_LINES | (_lib.HOST_PIN if rng.random() < 0.7 else 0)
+    flags = _lib.HOST_LINES | (_lib.HOST_PIN if rng.random() < 0.7 else 0) | (_lib.HOST_LINES_WHOLE if rng.random() < 0.4 else 0)    # quads only / whole lines
     tag = "lines case %d: %s T=%d grid=%dx%d R=%d nseg=%d flags=%d" % (i, dtype.__name__, T, nlat, nlon, R, len(cell), flags)
     plan = SparsePlan(cell, code, w, G, R, row_len=nlon)
     fails = []

@@ -691,6 +691,20 @@ def test_lines_only_host_path_gives_the_bits_of_the_whole_rows(torch_cuda, dtype
     np.testing.assert_array_equal(got, ref)
     assert 0 < st["lines_h2d_bytes"] <= 0.8 * X.nbytes and st["lines_h2d_bytes"] % (T * 16) == 0
     assert st["direct_h2d_bytes"] == 0 and st["staged_h2d_bytes"] == 0 and st["registered"] <= 1      # X: read by the CPU only
+    # round 6: by default only the QUADS that hold a referenced cell are packed (when >= 10 packing threads can be had);
+    # WAGG_HOST_LINES_WHOLE packs the whole 128-byte lines as round 5 did.  Same kernel, same cells: the same bits, fewer bytes.
+    _lib.host_stats(reset=True)
+    np.testing.assert_array_equal(plan.apply_host(X, flags=_lib.HOST_LINES | _lib.HOST_PIN | _lib.HOST_LINES_WHOLE), ref)
+    whole_lines = _lib.host_stats()["lines_h2d_bytes"]
+    assert 0 < st["lines_h2d_bytes"] <= whole_lines <= 0.8 * X.nbytes and whole_lines % (T * 16) == 0
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpus = min(len(os.sched_getaffinity(0)), int(quota[0]) // int(quota[1]) if quota[0] != "max" else 1 << 20)
+    except (OSError, ValueError, IndexError):
+        cpus = len(os.sched_getaffinity(0))
+    print("packed bytes per row: quads %d, whole lines %d, row %d (%d usable CPUs)" % (st["lines_h2d_bytes"] // T, whole_lines // T, X.nbytes // T, cpus))
+    if cpus >= 14:                                        # >= 10 packing threads: the quads-only row is the one taken
+        assert st["lines_h2d_bytes"] < 0.7 * whole_lines
     np.testing.assert_array_equal(plan.apply_host(X, flags=_lib.HOST_LINES), ref)                       # result staged
     # pitched arrays through the C-ABI
     ldx, ldo = G + 40, R + 12
