@@ -69,7 +69,7 @@ def _host_replicas(plan, n_rows, row_bytes, setting=None):
 
 
 # Which FAMILY serves a table -- the segment-table gather or the dense family -- by estimated time per row of X, each at its
-# measured rate (tools/form_crossover.py, profiles/r05_form_crossover.txt):
+# measured rate (tools/form_crossover.py, profiles/r05_form_crossover.txt, docs/HISTORY.md (b)):
 #   segment table   n_ucells cell slots gathered per row at _SPARSE_CELLS_PER_S (2.7e11 / s in fp32: 0.13 ms for 0.46 G
 #                   compact cells x 365 rows, 0.64 ms for 1.8 G scattered ones; fp64 moves twice the bytes per cell)
 #   dense family    at best its entry lists: never faster than the X stream that each block of 688 regions pulls through the

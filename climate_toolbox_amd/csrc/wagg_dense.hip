@@ -506,7 +506,7 @@ constexpr double SPMM_MAX_FILL = 0.10;
 // ---- which form a caller's table takes (wagg_dense_create_from_csr* / _from_segments*) ---------------------------------
 // The reference knows one weights type (aggregations.py:64-73) and so does the caller here: the form is the library's
 // business.  It is chosen by the estimated time per row of X of the three forms, each priced at the rate its kernel was
-// MEASURED at on the c5 grid (tools/form_crossover.py -> profiles/r05_form_crossover.txt; DESIGN.md (b) has the table):
+// MEASURED at on the c5 grid (tools/form_crossover.py -> profiles/r05_form_crossover.txt; docs/HISTORY.md (b) has the table):
 //   full matrix     2 x (all tiles x BK x 256) flop     at the full-form MFMA rate (padding of G and R to whole tiles included)
 //   tile-sparse     2 x (stored tiles x BK x 256) flop  at the tile-sparse MFMA rate (a little lower: the tile list is walked)
 //   entry lists     2 x walked entries flop at the entry-loop rate of their mean list length, but never faster than the X
@@ -792,7 +792,7 @@ static int create_from_table(const int32_t *cell_idx, const int64_t *rowptr, con
         for (int64_t i = 0; i < n_words; ++i)
             for (uint32_t m = hbits[(size_t)i]; m; m &= m - 1) tiles.push_back(i * 32 + __builtin_ctz(m));
     } catch (const std::bad_alloc &) { set_error("host allocation failed"); return WAGG_ENOMEM; }
-    // the form: measured crossovers (tools/form_crossover.py); a WAGG_DENSE_FORCE_* flag overrides the choice
+    // the form: measured crossovers (tools/form_crossover.py, docs/HISTORY.md (b)); a WAGG_DENSE_FORCE_* flag overrides the choice
     const double fill_all = (double)se.n_u / ((double)G * (double)R);
     int64_t walked = 0;
     if (se.n_u > 0) { if (int rc = spmm_list_cost(ctx, se, &walked)) return rc; }

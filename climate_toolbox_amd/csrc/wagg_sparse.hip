@@ -20,7 +20,7 @@
 // (The round-1/2 kernel with MFMA consumers, sparse_lc_kernel, is in wagg_sparse_diag.hip: diagnostic build only.)
 // Common to all: a t-major LDS image of the item (swizzled or padded rows), NaN products count 0
 // (S6), the division by den[r] (aggregations.py:79-80) is fused, results are stored once, no
-// atomics anywhere: bitwise reproducible.  DESIGN.md section (d) has the measurements behind the
+// atomics anywhere: bitwise reproducible.  docs/HISTORY.md section (d) has the measurements behind the
 // shapes chosen here.
 #include <algorithm>
 #include <cmath>
@@ -1148,7 +1148,7 @@ static int check_timeout(const wagg_plan *plan) {
     return WAGG_OK;
 }
 
-// ---- which kernel runs what (one table instead of an if-ladder; DESIGN.md (d) carries the same table) -----------------
+// ---- which kernel runs what (one table instead of an if-ladder; docs/HISTORY.md (d) carries the same table) -----------------
 // Single-chunk ("normal") groups of a plan, by (element type, data layout, transform):
 //   transform            (time, gridcell) data                          (gridcell, time) data
 //   none / one power     sparse_lcv_kernel<T,VEC,1>      [L32 | L64]    sparse_lcv_kernel<T,VEC,1,false,GT>    [R | L64]
@@ -1910,11 +1910,18 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             up(d.ucell_c, ucell_c);
             d.Gc = 4 * (int64_t)uq.size();
             // ... and the quads that a segment of their chunk really reads (wagg_sparse_int.h: ucell_q)
+            // (a segment's local cell index is the low byte of seg_u -- bit 15 and bits 16..23 carry flags by now, see above)
             std::vector<char> used(ucell.size(), 0);
-            for (size_t c = 0; c + 1 < chunk_u_begin.size(); ++c)
-                for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1]; ++e)
-                    for (int32_t sg = ent_seg_begin[(size_t)e]; sg < ent_seg_begin[(size_t)e + 1]; ++sg)
-                        used[(size_t)chunk_u_begin[c] + (size_t)(seg_u[(size_t)sg] >> 2)] = 1;
+            bool map_ok = true;
+            for (size_t c = 0; c + 1 < chunk_u_begin.size() && map_ok; ++c) {
+                const int32_t nq = chunk_u_begin[c + 1] - chunk_u_begin[c];
+                for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1] && map_ok; ++e)
+                    for (int32_t sg = ent_seg_begin[(size_t)e]; sg < ent_seg_begin[(size_t)e + 1]; ++sg) {
+                        const int32_t q = (seg_u[(size_t)sg] & 0xff) >> 2;
+                        if (q >= nq) { map_ok = false; break; }                  // (cannot happen; then: no quad map, whole lines serve)
+                        used[(size_t)chunk_u_begin[c] + (size_t)q] = 1;
+                    }
+            }
             std::vector<int32_t> uqq;
             for (size_t i = 0; i < ucell.size(); ++i) if (used[i]) uqq.push_back(ucell[i]);
             std::sort(uqq.begin(), uqq.end());
@@ -1927,8 +1934,10 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                 if (i > 0 && uqq[i] == uqq[i - 1] + 4) d.run_len_q.back() += 4;
                 else { d.run_src_q.push_back((int64_t)uqq[i]); d.run_len_q.push_back(4); }
             }
-            up(d.ucell_q, ucell_q);
-            d.Gq = 4 * (int64_t)uqq.size();
+            if (map_ok) {
+                up(d.ucell_q, ucell_q);
+                d.Gq = 4 * (int64_t)uqq.size();
+            }
         }
         d.g0_normal = g0_normal; d.c0_normal = c0_normal;
         d.n_groups = (int64_t)grp_giant.size(); d.n_empty = (int64_t)empty.size();

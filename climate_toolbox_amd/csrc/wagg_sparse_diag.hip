@@ -2,9 +2,9 @@
 // with MFMA consumers -- the one kernel of this code base whose waves wait on each other through a bounded spin with a
 // sticky, host-mapped timeout word.  It serves no default plan since round 3 (sparse_lcv_kernel took the plain
 // aggregation, the fused powers and the degree days) and is kept as the reference point of the consumer comparison in
-// DESIGN.md (d) and for the forced-timeout test (plans created with WAGG_PLAN_LC_MFMA; the production library refuses
+// docs/HISTORY.md (d) and for the forced-timeout test (plans created with WAGG_PLAN_LC_MFMA; the production library refuses
 // that flag with WAGG_EUNSUPPORTED).  The LDS-DMA loader experiment of round 4 (sparse_lcd_kernel) was deleted in round
-// 5: its numbers live in profiles/r04_lds_dma_loader.txt and DESIGN.md (d).
+// 5: its numbers live in profiles/r04_lds_dma_loader.txt and docs/HISTORY.md (d).
 #ifndef WAGG_DIAG
 #error "wagg_sparse_diag.hip belongs to the diagnostic build (make diag)"
 #endif

@@ -30,7 +30,7 @@
 //     per lane, the same 512-byte cell rows.  The loop is generated (tools/gen_spmm_asm.py ->
 //     wagg_spmm_asm.inc); tools/check_spmm_codegen.py verifies in the Makefile that the compiler's glue code
 //     between the inline-asm statements leaves the live list registers v[3:35] alone.
-//   * bound (profiles/r04_pmc.csv): 2.85 vector + 1.42 LDS instructions per entry; three
+//   * bound (docs/HISTORY.md (d), profiles/r04_pmc.csv): 2.85 vector + 1.42 LDS instructions per entry; three
 //     resources of a CU are each within 1.6x of the kernel's time -- the LDS array (the 512-byte cell row per
 //     entry plus the DMA writes), the LDS-DMA ingest of the X stream (36 region blocks re-stream X) and vector
 //     issue; the formulation tops out near 25 % of the fp32 vector peak, measured 15.8 % (fp64 13.9 %).  This is

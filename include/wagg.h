@@ -173,7 +173,7 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  * shares with unrelated objects), arrays whose registration the runtime refuses, and everything without
  * WAGG_HOST_PIN -- passes through the library's own page-locked staging pieces by CPU copy.  A pageable caller
  * pointer is never handed to a runtime copy: the runtime would page-lock the range on the fly and keep that
- * pin, keyed by address, beyond the call.  Every HIP status on this path is checked; failures
+ * pin, keyed by address, beyond the call (docs/HISTORY.md (f)).  Every HIP status on this path is checked; failures
  * while resources are released are counted (wagg_host_stats) and fail the call.
  * Pitched arrays (ldx > G, ldo > R) are honoured: nothing behind the used cells of the last row is read and the
  * padding between result rows is not written.  The plan must live on the current device.
@@ -197,7 +197,7 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *                    the flag permits, it never fails a call.  Same bits as every other form (the kernel sees the same cells
  *                    in the same order).  wagg_host_stats.lines_h2d_bytes counts the packed bytes sent.
  *                    Measured (tools/host_path_timing.py, c2-real T = 365): fp32 29.8 -> 21.3 ms per call (the C call alone
- *                    18.5 ms, of which 16.7 ms are the copy engine's), fp64 59.2 -> 33.5 ms; DESIGN.md (f).              */
+ *                    18.5 ms, of which 16.7 ms are the copy engine's), fp64 59.2 -> 33.5 ms; docs/HISTORY.md (f).              */
 #define WAGG_HOST_LINES 4
 /*   WAGG_HOST_LINES_WHOLE  with WAGG_HOST_LINES: pack the whole 128-byte lines as in round 5.  Without it (round 6, "quads
  *                    only") the packed row holds only the 16-byte QUADS that contain a referenced cell -- a whole-line chunk
@@ -285,7 +285,7 @@ int wagg_apply_poly_f64(const wagg_plan *plan, const double *X_dev, int64_t T, i
  * per pass -- and plane i of the result (power pow_first + i) lands at out_host + i * out_pstride (elements, >= T * ldo)
  * with leading dimension ldo.  flags: WAGG_HOST_PIN, WAGG_HOST_LINES (as there; WAGG_HOST_LINES sends only the 128-byte
  * lines the table references).  This is the reference's tas_poly-then-aggregate on the arrays its callers hold
- * (transformations.py:188 + aggregations.py:87): c2-real, four powers, 1.5 GB field: DESIGN.md (f).  Blocking. */
+ * (transformations.py:188 + aggregations.py:87): c2-real, four powers, 1.5 GB field: docs/HISTORY.md (f).  Blocking. */
 int wagg_apply_poly_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
                              int n_pow, float *out_host, int64_t ldo, int64_t out_pstride, int flags);
 int wagg_apply_poly_host_f64(const wagg_plan *plan, const double *X_host, int64_t T, int64_t ldx, double offset, int pow_first,
@@ -390,7 +390,7 @@ int wagg_dense_create_host(const float *W_host, int64_t G, int32_t R, wagg_dense
 /* from a sparse plan's coded table (weights whose regions are scattered over the grid).  The caller brings ONE kind of
  * table, like the reference (aggregations.py:64-73); which of the three device forms it takes is the library's choice,
  * made from the structure it finds (a census of the occupied (32-cell x 256-region) tiles and the number of distinct
- * pairs) by the estimated time per row of X of each form at its measured rate (tools/form_crossover.py):
+ * pairs) by the estimated time per row of X of each form at its measured rate (tools/form_crossover.py, docs/HISTORY.md (b)):
  * only the non-empty tiles on the MFMA kernel (WAGG_FORM_TILES: c5's block-local weights), entry lists on the vector ALU
  * (WAGG_FORM_ENTRIES: c5's uniformly random 1 %), or the full matrix (WAGG_FORM_FULL).
  * flags: WAGG_DENSE_FORM_AUTO (0), or WAGG_DENSE_FORCE_* to pin the form -- for measurements and tests; results agree

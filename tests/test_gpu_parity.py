@@ -857,6 +857,40 @@ def test_integration_md_binding_runs_as_written(torch_cuda):
     _rel_ok(out, ref, RTOL64)
 
 
+def test_integration_md_descriptor_binding_runs_as_written(torch_cuda):
+    """The descriptor form INTEGRATION.md shows beside the stub (wagg_apply + a hand-written mirror of wagg_apply_desc) is
+    executed as written, in the stub's namespace: a plain host apply and a fused-powers one, against the oracle."""
+    import ctypes as C
+    import re
+    from climate_toolbox_amd import _lib, synth
+    from climate_toolbox_amd.engine import SparsePlan
+    from oracle import ref_numpy as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    base = re.search(r"```python\n(# climate_toolbox/aggregations/_wagg.py.*?)```", text, re.S).group(1)
+    base = base.replace('C.CDLL("libwagg.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    block = re.search(r"```python\n(class ApplyDesc\(C.Structure\):.*?)```", text, re.S).group(1)
+    _lib.load()
+    ns = {}
+    exec(compile(base, "INTEGRATION.md", "exec"), ns)
+    exec(compile(block, "INTEGRATION.md#descriptor", "exec"), ns)
+    assert [f for f, _ in ns["ApplyDesc"]._fields_] == [f for f, _ in _lib.ApplyDesc._fields_]
+    lat, lon, df = synth.realistic_segments(nlat=96, nlon=192, R=150, n_iso=10, seed=3, land_frac=0.2, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R, T = len(lat) * len(lon), len(uniq), 37
+    plan = SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    rng = np.random.default_rng(4)
+    for dtype, rtol in ((np.float32, RTOL32), (np.float64, RTOL64)):
+        X = (273.15 + 25 * rng.random((T, G))).astype(dtype)
+        out = ns["apply_host_desc"](plan._h, X, R)
+        _rel_ok(out, O.agg_coded(X.astype(np.float64), cell, code, w, R), rtol)
+        stack = ns["apply_host_desc"](plan._h, X, R, powers=(2, 3), offset=-273.15)
+        assert stack.shape == (3, T, R)
+        for i, pw in enumerate((2, 3, 4)):
+            _rel_ok(stack[i], O.agg_coded(O.tas_poly_values(X.astype(np.float64), pw), cell, code, w, R), rtol * 4, scale=1.0)
+    plan.close()
+
+
 def test_c_abi_argument_errors_are_reported_not_crashed(torch_cuda):
     """Every entry point returns a negative status with a message for bad arguments (no throw, no
     exit, no launch): shapes, strides, ranges."""

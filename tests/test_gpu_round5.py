@@ -130,7 +130,7 @@ def form_point_table(kind, param):
 @pytest.mark.parametrize("kind,param", FORM_POINTS)
 def test_every_form_of_a_table_gives_the_oracles_numbers(torch_cuda, kind, param):
     """The caller never names a form (the reference has one weights type, aggregations.py:64-73).  At six points either
-    side of the measured crossovers (tools/form_crossover.py) the same CSR table is built in every form by
+    side of the measured crossovers (tools/form_crossover.py, docs/HISTORY.md (b)) the same CSR table is built in every form by
     force and by the library's own choice: every form must give the oracle's numbers, and the choice must have been made
     from positive cost estimates.  (How FAST the chosen form runs against the forced ones is a perf guard, not parity: it
     lives in tests/test_gpu_zz_perf_guards.py, which collects last, so a noisy box cannot stop the `-x` parity run here.)"""

@@ -30,7 +30,7 @@ def copy_then_kernel():
     return out
 
 
-VARIANTS = "variants" in sys.argv          # (with these calls in between the slow state of DESIGN.md (f) did not show)
+VARIANTS = "variants" in sys.argv          # (with these calls in between the slow state of docs/HISTORY.md (f) did not show)
 OUT_KEEP = np.empty((T, R), dtype=np.float32)
 
 
