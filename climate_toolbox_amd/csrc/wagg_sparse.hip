@@ -2099,7 +2099,7 @@ static int check_plan_device(const wagg_plan *plan) {
 template <typename T, typename LaunchFn>
 static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, T *out, int64_t ldo, int flags,
                               int n_planes, int64_t opstride, LaunchFn launch, const SparsePlanDev *dc_ = nullptr, bool dc_given = false,
-                              const T *X2 = nullptr) {
+                              const T *X2 = nullptr, bool allow_quads = true) {
     HostRowsArgs a;
     a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
     a.X2_host = reinterpret_cast<const char *>(X2);
@@ -2119,7 +2119,12 @@ static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int
     // fp32 row instead of 63.6 %, 10.2 instead of 18.1 ms for packing + copy in tools/host_granule_gonogo.sh) when the packing
     // team is large enough for the shorter runs (116 instead of 455 bytes on average: twelve threads stay ahead of PCIe,
     // eight do not -- profiles/r06_host_granule.txt) and the caller has not asked for whole lines (WAGG_HOST_LINES_WHOLE)
-    const bool quads = has_c && dc.Gq > 0 && !dc.run_len_q.empty() && !(flags & WAGG_HOST_LINES_WHOLE) && gather_team_threads() >= 10;
+    // `allow_quads`: not for the degree days -- their kernel picks the formula of an item (the general one, or the one for finite
+    // fields) from EVERY value the item loads, so a NaN in an unreferenced cell of a fetched line (a masked ocean cell) selects
+    // the general form in the device apply; with dummy quads in its place the finite form would run: the same number to within
+    // the last bits, but no longer the device form's bits.  (The plain and power forms only change path on +-inf: there the two
+    // rows differ in the last bit when an UNREFERENCED cell of a fetched line holds +-inf -- include/wagg.h says so.)
+    const bool quads = allow_quads && has_c && dc.Gq > 0 && !dc.run_len_q.empty() && !(flags & WAGG_HOST_LINES_WHOLE) && gather_team_threads() >= 10;
     const int64_t Gc = quads ? dc.Gq : dc.Gc;
     if ((flags & WAGG_HOST_LINES) && has_c && 5 * Gc <= 4 * (int64_t)plan->info.G &&
         Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
@@ -2237,7 +2242,7 @@ static int apply_edd_host(const wagg_plan *plan, const T *tmin, const T *tmax, i
                                                                  (T)offset, XF_EDD, 1, ps, x2, thr + i, n_thr - i < 4 ? n_thr - i : 4, compact);
                                    return r2;
                                },
-                               dc, true, tmax);
+                               dc, true, tmax, false);
     if (rc != WAGG_OK) return rc;
     return check_timeout(plan);
 }

@@ -85,3 +85,24 @@ def test_non_finite_numbers_do_not_reach_the_line():
     assert "NaN" not in text and "Infinity" not in text
     c = json.loads(text)
     assert c["roofline"]["traffic"] is None and c["max_ms"] is None
+
+
+def test_reference_shaped_cpu_leg_times_the_literal_restatements():
+    """bench.cpu_reference_shaped (VERDICT r5 Next #2): the NumPy scatter-add and the pandas groupby restatements of
+    aggregations.py:24-27,73,78-80 on the workload's own operands -- full size when it fits the budget, else a window of
+    leading rows with the per-call fixed cost (label lookup, factorisation) kept out of the scaling."""
+    import numpy as np
+    from climate_toolbox_amd import synth
+    lat, lon, tas, df = synth.c1_workload(T=40)
+    X = np.ascontiguousarray(tas.reshape(40, -1))
+    full = bench.cpu_reference_shaped(X, lat, lon, df, "areawt", "hierid", budget_s=30.0)
+    for leg in ("numpy_scatter", "pandas_groupby"):
+        r = full[leg]
+        assert r["rows_timed"] == r["rows"] == 40 and r["scaled"] is False and r["wall_s"] == r["timed_wall_s"] > 0
+        assert 0 <= r["fixed_s"] <= r["wall_s"] * 1.5 and r["value"] > 0
+    assert full["threads"] == 1
+    tight = bench.cpu_reference_shaped(X, lat, lon, df, "areawt", "hierid", budget_s=1e-4)      # nothing fits: the 8-row probe window
+    for leg in ("numpy_scatter", "pandas_groupby"):
+        r = tight[leg]
+        assert r["rows_timed"] == 8 and r["scaled"] is True and r["wall_s"] >= r["fixed_s"]
+        assert r["wall_s"] == pytest.approx(r["fixed_s"] + (r["timed_wall_s"] - r["fixed_s"]) * 40 / 8, rel=1e-2, abs=1e-3)          # (the fields are rounded to 1e-4 s)
