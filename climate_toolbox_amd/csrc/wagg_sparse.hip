@@ -121,7 +121,7 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
         const int tw0 = wave * TPW;
         if constexpr (LAYOUT == WAGG_LAYOUT_TG) {
             if (lane < nu) {
-                const int64_t cell0 = pv.ucell[u0 + lane];
+                const int64_t cell0 = pv.ucell[u0 + lane] & ~UCELL_UNREF;          // (whole-line chunkings flag unreferenced quads)
                 const int64_t lim = G - 1 - cell0;                   // >= 0
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(UC, 2) void sparse_gather_kernel(PlanView<T> pv, co
                 }
             } else {
                 for (int u = wave; u < 4 * nu; u += NWAVE) {
-                    int64_t cell = (int64_t)pv.ucell[u0 + (u >> 2)] + (u & 3);
+                    int64_t cell = (int64_t)(pv.ucell[u0 + (u >> 2)] & ~UCELL_UNREF) + (u & 3);
                     cell = cell < G ? cell : G - 1;
                     if (lane < TB) {
                         T xv = lane_live ? X[cell * ldx + t0 + lane] : T(0);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(STHREADS, 4) void sparse_stream_kernel(PlanView<T> 
         d.split = (unsigned long long)(unsigned)y[2] | ((unsigned long long)(unsigned)y[3] << 32);
     };
     auto load_cell = [&](const StreamDesc &d) {
-        return pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
+        return pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)] & ~UCELL_UNREF;     // (whole-line chunkings flag unreferenced quads)
     };
     vec4 v[TPW];
     auto issue_x = [&](int cell0, int tb) {
@@ -659,9 +659,21 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
         };
         const T *const Xl = EDD && lane >= 32 ? pv.X2 : X;        // this lane's field
         [[maybe_unused]] int dma_buf = 0;        // (diagnostic build, knob 0x4000: image buffer the NEXT item's rows are sent to by LDS-DMA)
-        struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; };
+        // `unref`: this lane's quad holds no referenced cell (bit 0 of its ucell entry, set by the plan builder for the whole-line
+        // chunkings) -- what it loads is parked like everything else but does NOT count when the item decides between the
+        // finite-data forms and the general ones below: that choice then depends on referenced data only, and is the same whether
+        // the unreferenced quads of a line hold the field's values (device apply, whole lines from the host) or a dummy (the
+        // quads-only rows of the host path).  (GT: one bit per load of the wave -- a load's cells belong to one quad.)
+        struct Regs { vecE v[TPW]; int mu; T mw; int er, es; T ed; int unref; };
         static_assert(LC_SEGS <= LV_LW * 64, "one metadata element per loader thread");
         auto issue = [&](Regs &R, const StreamDesc &d, int cell0, int tb) {
+            if constexpr (GT) {
+                R.unref = 0;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) R.unref |= (__builtin_amdgcn_readlane(cell0, (i * CPL) / 4) & UCELL_UNREF) << i;
+            } else
+                R.unref = cell0 & UCELL_UNREF;
+            cell0 &= ~UCELL_UNREF;
             // small metadata loads first, the rows last (vmcnt retires in order)
             {
                 const int k = tid < d.ns ? tid : d.ns - 1;
@@ -756,13 +768,18 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
                     for (int c = 0; c < E; ++c) R.v[i][c] = xform1<T>(R.v[i][c], pv.xoff, pv.xpow);
             }
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW; ++i) {
+                bool o = false;
 #pragma unroll
                 for (int c = 0; c < E; ++c) {
-                    if (NPOW > 1 && !EDD) odd |= !(__builtin_fabs(R.v[i][c]) < ylim);     // NaN, +-inf, or a power overflows
-                    else if constexpr (sizeof(T) == 4) odd |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN | qNaN | -inf | +inf
-                    else odd |= __builtin_amdgcn_class(R.v[i][c], 0x207);
+                    if (NPOW > 1 && !EDD) o |= !(__builtin_fabs(R.v[i][c]) < ylim);     // NaN, +-inf, or a power overflows
+                    else if constexpr (sizeof(T) == 4) o |= __builtin_amdgcn_classf(R.v[i][c], 0x207);   // sNaN | qNaN | -inf | +inf
+                    else o |= __builtin_amdgcn_class(R.v[i][c], 0x207);
                 }
+                if constexpr (GT) odd |= o && !((R.unref >> i) & 1);
+                else odd |= o;
+            }
+            if constexpr (!GT) odd = odd && !R.unref;              // (see Regs::unref)
             bool inf_any = false;
             if (EDD) {
                 // a NaN in either field must reach the formula (NaN tasmin -> NaN, skipped; NaN tasmax below the threshold -> 0:
@@ -1876,6 +1893,29 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
                     lines_plan ? line_cells : 0, band_rows, (long long)chunk_u_begin.size() - 1, (long long)grp_giant.size(), (long long)n_giant,
                     (long long)ucell.size() * 4, (long long)l128s, (long long)s64s, (long long)nnz, (long long)n_part_rows);
 #endif
+        // Whole-line chunkings: which quads of a chunk does a segment really read?  A chunk fetches every quad of its lines; the
+        // others are parked in the image and never read -- except quad 0, whose first cell the padding lanes of the consumers
+        // read with weight 0 (so it counts as referenced: its data must be sane for 0 * x = 0).  Unreferenced quads get bit 0 of
+        // their ucell entry set (UCELL_UNREF; quads are 4-cell aligned, the low bits are free): the kernels mask it off the address,
+        // and sparse_lcv_kernel leaves what such a quad loads out of its finite / general decision (Regs::unref).
+        // (a segment's local cell index is the low byte of seg_u -- bit 15 and bits 16..23 carry flags by now, see above)
+        std::vector<char> used;
+        bool map_ok = lines_plan && kind >= 1;
+        if (map_ok) {
+            used.assign(ucell.size(), 0);
+            for (size_t c = 0; c + 1 < chunk_u_begin.size() && map_ok; ++c) {
+                const int32_t nq = chunk_u_begin[c + 1] - chunk_u_begin[c];
+                if (nq > 0) used[(size_t)chunk_u_begin[c]] = 1;
+                for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1] && map_ok; ++e)
+                    for (int32_t sg = ent_seg_begin[(size_t)e]; sg < ent_seg_begin[(size_t)e + 1]; ++sg) {
+                        const int32_t q = (seg_u[(size_t)sg] & 0xff) >> 2;
+                        if (q >= nq) { map_ok = false; break; }                  // (cannot happen; then: no flags, no quad map)
+                        used[(size_t)chunk_u_begin[c] + (size_t)q] = 1;
+                    }
+            }
+            if (map_ok)
+                for (size_t i = 0; i < ucell.size(); ++i) if (!used[i]) ucell[i] |= UCELL_UNREF;
+        }
         std::vector<float> seg_w32(seg_w.size());
         for (size_t i = 0; i < seg_w.size(); ++i) seg_w32[i] = (float)seg_w[i];
         auto up = [&](auto &buf, const auto &h) { if (he == hipSuccess) he = buf.upload(h); };
@@ -1896,12 +1936,14 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
         if (lines_plan) { up(d.part_begin, part_begin); d.n_part = n_part_rows; }
         if (lines_plan && kind >= 1) {
             // the compact row of the lines-only host path: the distinct quads of this chunking in grid order, side by side
-            std::vector<int32_t> uq(ucell);
+            // (ucell entries carry UCELL_UNREF in bit 0: compared without it, handed on with it)
+            std::vector<int32_t> uq(ucell.size());
+            for (size_t i = 0; i < ucell.size(); ++i) uq[i] = ucell[i] & ~UCELL_UNREF;
             std::sort(uq.begin(), uq.end());
             uq.erase(std::unique(uq.begin(), uq.end()), uq.end());
             std::vector<int32_t> ucell_c(ucell.size());
             for (size_t i = 0; i < ucell.size(); ++i)
-                ucell_c[i] = (int32_t)(4 * (std::lower_bound(uq.begin(), uq.end(), ucell[i]) - uq.begin()));
+                ucell_c[i] = (int32_t)(4 * (std::lower_bound(uq.begin(), uq.end(), ucell[i] & ~UCELL_UNREF) - uq.begin())) | (ucell[i] & UCELL_UNREF);
             d.run_src.clear(); d.run_len.clear();
             for (size_t i = 0; i < uq.size(); ++i) {
                 if (i > 0 && uq[i] == uq[i - 1] + 4) d.run_len.back() += 4;
@@ -1909,32 +1951,21 @@ extern "C" int wagg_plan_create(const int32_t *cell_idx, const int32_t *region_c
             }
             up(d.ucell_c, ucell_c);
             d.Gc = 4 * (int64_t)uq.size();
-            // ... and the quads that a segment of their chunk really reads (wagg_sparse_int.h: ucell_q)
-            // (a segment's local cell index is the low byte of seg_u -- bit 15 and bits 16..23 carry flags by now, see above)
-            std::vector<char> used(ucell.size(), 0);
-            bool map_ok = true;
-            for (size_t c = 0; c + 1 < chunk_u_begin.size() && map_ok; ++c) {
-                const int32_t nq = chunk_u_begin[c + 1] - chunk_u_begin[c];
-                for (int32_t e = chunk_e_begin[c]; e < chunk_e_begin[c + 1] && map_ok; ++e)
-                    for (int32_t sg = ent_seg_begin[(size_t)e]; sg < ent_seg_begin[(size_t)e + 1]; ++sg) {
-                        const int32_t q = (seg_u[(size_t)sg] & 0xff) >> 2;
-                        if (q >= nq) { map_ok = false; break; }                  // (cannot happen; then: no quad map, whole lines serve)
-                        used[(size_t)chunk_u_begin[c] + (size_t)q] = 1;
-                    }
-            }
-            std::vector<int32_t> uqq;
-            for (size_t i = 0; i < ucell.size(); ++i) if (used[i]) uqq.push_back(ucell[i]);
-            std::sort(uqq.begin(), uqq.end());
-            uqq.erase(std::unique(uqq.begin(), uqq.end()), uqq.end());
-            std::vector<int32_t> ucell_q(ucell.size(), 0);
-            for (size_t i = 0; i < ucell.size(); ++i)
-                if (used[i]) ucell_q[i] = (int32_t)(4 * (std::lower_bound(uqq.begin(), uqq.end(), ucell[i]) - uqq.begin()));
-            d.run_src_q.clear(); d.run_len_q.clear();
-            for (size_t i = 0; i < uqq.size(); ++i) {
-                if (i > 0 && uqq[i] == uqq[i - 1] + 4) d.run_len_q.back() += 4;
-                else { d.run_src_q.push_back((int64_t)uqq[i]); d.run_len_q.push_back(4); }
-            }
+            // ... and the quads that count as referenced only (wagg_sparse_int.h: ucell_q); the others point at position 0 of
+            // the row (any valid address: what they load is neither read nor counted)
             if (map_ok) {
+                std::vector<int32_t> uqq;
+                for (size_t i = 0; i < ucell.size(); ++i) if (used[i]) uqq.push_back(ucell[i]);
+                std::sort(uqq.begin(), uqq.end());
+                uqq.erase(std::unique(uqq.begin(), uqq.end()), uqq.end());
+                std::vector<int32_t> ucell_q(ucell.size(), UCELL_UNREF);
+                for (size_t i = 0; i < ucell.size(); ++i)
+                    if (used[i]) ucell_q[i] = (int32_t)(4 * (std::lower_bound(uqq.begin(), uqq.end(), ucell[i]) - uqq.begin()));
+                d.run_src_q.clear(); d.run_len_q.clear();
+                for (size_t i = 0; i < uqq.size(); ++i) {
+                    if (i > 0 && uqq[i] == uqq[i - 1] + 4) d.run_len_q.back() += 4;
+                    else { d.run_src_q.push_back((int64_t)uqq[i]); d.run_len_q.push_back(4); }
+                }
                 up(d.ucell_q, ucell_q);
                 d.Gq = 4 * (int64_t)uqq.size();
             }
@@ -2099,7 +2130,7 @@ static int check_plan_device(const wagg_plan *plan) {
 template <typename T, typename LaunchFn>
 static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int64_t ldx, T *out, int64_t ldo, int flags,
                               int n_planes, int64_t opstride, LaunchFn launch, const SparsePlanDev *dc_ = nullptr, bool dc_given = false,
-                              const T *X2 = nullptr, bool allow_quads = true) {
+                              const T *X2 = nullptr) {
     HostRowsArgs a;
     a.X_host = reinterpret_cast<const char *>(X); a.out_host = reinterpret_cast<char *>(out);
     a.X2_host = reinterpret_cast<const char *>(X2);
@@ -2119,12 +2150,7 @@ static int host_rows_pipeline(const wagg_plan *plan, const T *X, int64_t Tn, int
     // fp32 row instead of 63.6 %, 10.2 instead of 18.1 ms for packing + copy in tools/host_granule_gonogo.sh) when the packing
     // team is large enough for the shorter runs (116 instead of 455 bytes on average: twelve threads stay ahead of PCIe,
     // eight do not -- profiles/r06_host_granule.txt) and the caller has not asked for whole lines (WAGG_HOST_LINES_WHOLE)
-    // `allow_quads`: not for the degree days -- their kernel picks the formula of an item (the general one, or the one for finite
-    // fields) from EVERY value the item loads, so a NaN in an unreferenced cell of a fetched line (a masked ocean cell) selects
-    // the general form in the device apply; with dummy quads in its place the finite form would run: the same number to within
-    // the last bits, but no longer the device form's bits.  (The plain and power forms only change path on +-inf: there the two
-    // rows differ in the last bit when an UNREFERENCED cell of a fetched line holds +-inf -- include/wagg.h says so.)
-    const bool quads = allow_quads && has_c && dc.Gq > 0 && !dc.run_len_q.empty() && !(flags & WAGG_HOST_LINES_WHOLE) && gather_team_threads() >= 10;
+    const bool quads = has_c && dc.Gq > 0 && !dc.run_len_q.empty() && !(flags & WAGG_HOST_LINES_WHOLE) && gather_team_threads() >= 10;
     const int64_t Gc = quads ? dc.Gq : dc.Gc;
     if ((flags & WAGG_HOST_LINES) && has_c && 5 * Gc <= 4 * (int64_t)plan->info.G &&
         Tn * (int64_t)plan->info.G * (int64_t)sizeof(T) >= ((int64_t)64 << 20)) {
@@ -2242,7 +2268,7 @@ static int apply_edd_host(const wagg_plan *plan, const T *tmin, const T *tmax, i
                                                                  (T)offset, XF_EDD, 1, ps, x2, thr + i, n_thr - i < 4 ? n_thr - i : 4, compact);
                                    return r2;
                                },
-                               dc, true, tmax, false);
+                               dc, true, tmax);
     if (rc != WAGG_OK) return rc;
     return check_timeout(plan);
 }

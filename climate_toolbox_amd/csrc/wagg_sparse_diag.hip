@@ -129,7 +129,7 @@ __global__ __launch_bounds__(LC_THREADS, 3) void sparse_lc_kernel(PlanView<float
             d.u0 = x[0]; d.nq = x[1]; d.e0 = x[2]; d.ne = x[3]; d.sb = y[0]; d.ns = y[1]; d.split = 0;
         };
         auto load_cell = [&](const StreamDesc &d) {
-            const int c = pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)];
+            const int c = pv.ucell[d.u0 + (lane < d.nq ? lane : d.nq - 1)] & ~UCELL_UNREF;
 #ifdef WAGG_DIAG      // timing-only address patterns on the 720 x 1440 grid (results are wrong)
             if (knob & 16) {                    // aligned 8 x 128-B patch instead of the chunk's quads
                 const int rowlen = 1440, pc = (d.u0 >> 6) % 45, pr = ((d.u0 >> 6) / 45) % 90;

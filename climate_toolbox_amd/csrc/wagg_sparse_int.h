@@ -27,6 +27,7 @@ constexpr int UQ = UC / 4;   // aligned 4-cell quads per chunk (one per lane of 
 template <typename T> constexpr int urow() { return sizeof(T) == 8 ? UC + 2 : UC + 4; }
 constexpr int RG_MAX = 127;  // regions per group
 constexpr int SEG_MAX = 512; // segments per chunk staged in LDS
+constexpr int UCELL_UNREF = 1;     // bit 0 of a ucell entry of a WHOLE-LINE chunking: the quad holds no referenced cell (wagg_sparse.hip)
 constexpr int SEG_LAST = 0x8000;   // flag bit in a segment's local cell index: last segment of its entry
 constexpr int SEG_UMASK = 0x7fff;
 constexpr int NWAVE = 4;      // waves of the chunk-walking kernel (256 threads)
@@ -63,9 +64,10 @@ struct SparsePlanDev {
     int64_t Gc = 0;
     // the same at QUAD granularity (round 6, "quads only"): a whole-line chunk fetches every quad of its lines, but only the
     // quads that hold a referenced cell matter -- the others are loaded into the LDS image and never read.  ucell_q[i] = position
-    // in the quad-compact row of quad ucell[i] if a segment of its chunk reads it, else 0 (any valid address: the value is never
-    // used); run_src_q / run_len_q / Gq as above for the referenced quads only.  c2-real: 33.5 % of a fp32 row where the whole
-    // lines are 63.6 %.  Same kernel, same cells in the same order: the same bits.
+    // in the quad-compact row of quad ucell[i] if a segment of its chunk reads it (or it is the chunk's quad 0, which the
+    // consumers' padding lanes read with weight 0), else position 0 with UCELL_UNREF set (any valid address: the value is neither
+    // read nor counted); run_src_q / run_len_q / Gq as above for those quads only.  c2-real: ~35 % of a fp32 row where the whole
+    // lines are 63.6 %.  Same kernel, same cells in the same order, the same finite / general decisions: the same bits.
     DevBuf<int32_t> ucell_q;
     std::vector<int64_t> run_src_q;
     std::vector<int32_t> run_len_q;

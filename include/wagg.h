@@ -205,13 +205,9 @@ int wagg_apply_f64(const wagg_plan *plan, const double *X_dev, int64_t T, int64_
  *                    dummy position -- whenever at least ten packing threads can be had (the runs are shorter: 116 instead of
  *                    455 bytes on c2-real; twelve threads stay ahead of PCIe, eight do not): 33.5 % of a c2-real fp32 row
  *                    instead of 63.6 %, c2-real T = 365 packing + copy 18.1 -> 10.2 ms (tools/host_granule_gonogo.sh,
- *                    profiles/r06_host_granule.txt).  Same kernel, same cells in the same order: the same bits -- with one
- *                    exception: an item whose lines hold +-inf (or a power that overflows) takes the kernel's general
- *                    accumulation form (product, NaN test, add) instead of the fused multiply-add; when that +-inf sits in an
- *                    UNREFERENCED cell of a fetched line, the quads-only row does not carry it and the item keeps the fused
- *                    form: the last bit of that item's sums can differ from the device apply (both within tolerance).  The
- *                    degree-day form (wagg_apply_edd_host_*) chooses its formula from every loaded value, NaN included, and
- *                    therefore always packs whole lines.                                                              */
+ *                    profiles/r06_host_granule.txt).  Same kernel, same cells in the same order, and the kernel's choice between
+ *                    its finite-data and general accumulation forms looks at REFERENCED quads only: the same bits as the device
+ *                    apply for the plain, power and degree-day forms alike.                                              */
 #define WAGG_HOST_LINES_WHOLE 8
 int wagg_apply_host_f32(const wagg_plan *plan, const float *X_host, int64_t T, int64_t ldx,
                         int layout, float *out_host, int64_t ldo, int out_layout);
