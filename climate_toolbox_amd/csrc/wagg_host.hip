@@ -561,26 +561,23 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
     if (int rc2 = drain_prev()) return rc2;
     WAGG_HIP(P.drain());
     // Copy-rate watch.  The pipeline can get into a state in which the copies into its pooled device blocks run at half the
-    // rate (seen on MI355X / ROCm 7.2 in one call sequence -- plain lines-only calls after wagg_apply_poly_host_* calls with
-    // page-locked whole rows, tools/host_poly_timing.py: 21.3 -> 47 ms per call, wait for the copy engine 16.6 -> 31 ms; it
-    // stays until the device blocks go back to the driver -- fresh streams or a fresh ring do not help -- and a different call
-    // order does not show it; DESIGN.md "host-resident fields" has what is known of the cause).  What the watch compares, per
-    // device and per SHAPE of call (lines only or whole rows, one or two fields, the number of result planes, the packed
-    // fraction of a row, where the result goes -- a call with four result planes or two fields is legitimately slower than a
-    // plain one and never shares a record with it):
-    //   * lines only: the packed bytes over the time this thread waited for their copies, and only for calls in which that wait
-    //     was at least half of the wall time -- a call held up by the packing threads (a busy host) says nothing about the
-    //     copies and neither sets nor fails the record;
-    //   * whole rows page-locked in place: the bytes over the call's wall time (PCIe-bound by construction).
-    // A call that moved >= 256 MiB at < 70 % of the best rate seen for its shape hands ITS OWN four device blocks back to the
-    // driver (the next call allocates fresh ones, ~1 ms); what idles in the pool -- the build arena among it -- is left alone.
-    // The verdict is visible: wagg_host_stats.watched_calls / .last_rate_permille / .blocks_retired.
+    // rate (seen on MI355X / ROCm 7.2 in one call sequence of round 5 -- plain lines-only calls after wagg_apply_poly_host_* calls
+    // with page-locked whole rows: 21.3 -> 47 ms per call, wait for the copy engine 16.6 -> 31 ms; it stayed until the device
+    // blocks went back to the driver -- fresh streams or a fresh ring did not help; not reproduced in five fresh processes in
+    // round 6, with the SDMA engines on or off: DESIGN.md section 6).  What the watch compares, per device and per SHAPE of call
+    // (lines only or whole rows, one or two fields, the number of result planes, the packed fraction of a row, where the result
+    // goes -- a call with four result planes or two fields is legitimately slower than a plain one and never shares a record
+    // with it): the bytes that crossed PCIe over the call's wall time.  (Round 6 first judged lines-only calls on the time spent
+    // waiting for their copies; with the quads-only rows the packing threads and the copies take turns as the bottleneck, a call
+    // that waited little for its copies set a record the next one could not meet, and the watch misfired four times in nine
+    // calls.)  A call that moved >= 256 MiB at < 60 % of the best rate seen for its shape hands ITS OWN four device blocks back
+    // to the driver (the next call allocates fresh ones, ~1 ms); what idles in the pool -- the build arena among it -- is left
+    // alone.  A merely busy host or PCIe link can trip it too: the cost is that one millisecond.  The verdict is visible:
+    // wagg_host_stats.watched_calls / .last_rate_permille / .blocks_retired.
     {
         const int64_t moved = gather ? team->sent_bytes : moved_plain;
-        const int64_t wall_us = now_us() - t_begin_us;
-        const int64_t us = gather ? team->copy_wait_us : wall_us;
-        const bool copy_bound = !gather || 2 * team->copy_wait_us >= wall_us;
-        if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x) && copy_bound) {
+        const int64_t us = now_us() - t_begin_us;
+        if (moved >= ((int64_t)256 << 20) && us > 0 && (gather || pin_x)) {
             struct Best { uint64_t key; double rate; };
             static std::mutex mu;
             static std::vector<Best> best;
@@ -597,7 +594,7 @@ static int run_device_(const HostRowsArgs &a, int slot, bool set_device, int64_t
                 if (rate >= b->rate) { b->rate = rate; g_host_stats.last_rate_permille = 1000; }
                 else {
                     g_host_stats.last_rate_permille = (int64_t)(1000.0 * rate / b->rate);
-                    if (rate < 0.7 * b->rate) { P.retire = true; g_host_stats.blocks_retired++; }
+                    if (rate < 0.6 * b->rate) { P.retire = true; g_host_stats.blocks_retired++; }
                 }
             } catch (const std::bad_alloc &) {}           // (no record: nothing watched)
         } else {

@@ -239,12 +239,12 @@ typedef struct wagg_host_stats {
     int64_t lines_h2d_bytes;      /* packed rows of the lines-only path (WAGG_HOST_LINES) ...                              */
     int64_t lines_wait_pack_us;   /* ... time its pipeline thread waited for the packing threads (they are the bottleneck) */
     int64_t lines_wait_copy_us;   /* ... and for the copy engine to hand a ring piece back (PCIe is the bottleneck)        */
-    int64_t blocks_retired;       /* calls whose copies ran < 70 % of the best rate seen for calls of their shape: their own
-                                     device blocks went back to the driver instead of the pool                                */
+    int64_t blocks_retired;       /* calls that ran < 60 % of the best rate (bytes over PCIe / wall time) seen for calls of their
+                                     shape: their own device blocks went back to the driver instead of the pool               */
     int64_t found_page_locked;    /* caller arrays that were page-locked already (used as they are, no registration)          */
-    int64_t watched_calls;        /* calls the copy-rate watch judged (>= 256 MiB moved, bound by the copies)                  */
+    int64_t watched_calls;        /* calls the copy-rate watch judged (>= 256 MiB moved from page-locked memory)               */
     int64_t last_rate_permille;   /* the LAST call's copy rate over the best seen for its shape, x 1000 (1000 = it set or met the
-                                     record; below 700 the call retired its blocks); 0 = the last call was not judged.  A state,
+                                     record; below 600 the call retired its blocks); 0 = the last call was not judged.  A state,
                                      not a counter: `reset` leaves it                                                          */
 } wagg_host_stats;
 int wagg_host_stats_read(wagg_host_stats *out, int reset);     /* = the _sized form with sizeof(wagg_host_stats) of THIS header */

@@ -745,6 +745,60 @@ def test_lines_only_host_path_gives_the_bits_of_the_whole_rows(torch_cuda, dtype
 
 
 @pytest.mark.parametrize("dtype,T,rtol", [(np.float32, 301, RTOL32), (np.float64, 150, RTOL64)])
+def test_garbage_in_unreferenced_cells_changes_nothing(torch_cuda, dtype, T, rtol):
+    """Round 6: a whole-line chunk fetches every quad of its lines, but only quads that hold a referenced cell may influence the
+    result -- including the kernel's choice between its finite-data and its general (NaN-testing) accumulation forms, which
+    used to look at every loaded value.  Here EVERY cell the table does not reference is NaN (a masked ocean), with +-inf
+    sprinkled in: the results are finite, match the oracle, and are the same BITS from the device apply, the host pipeline with
+    whole rows, with whole 128-byte lines and with quads only -- for the plain aggregation, the fused powers and the degree
+    days (whose finite / general formulas differ in the last bits: the forms agree only because the decision is the same)."""
+    from climate_toolbox_amd import _lib, engine, synth
+    from oracle import ref_numpy as O
+    torch = torch_cuda
+    lat, lon, df = synth.realistic_segments(nlat=192, nlon=384, R=600, n_iso=20, seed=5, land_frac=0.15, string_labels=False)
+    cell, code, w, uniq = synth.code_segments(df, lat, lon, "areawt", "hierid")
+    G, R = len(lat) * len(lon), len(uniq)
+    plan = engine.SparsePlan(cell, code, w, G, R, row_len=len(lon))
+    rng = np.random.default_rng(17)
+    ref_cells = np.zeros(G, dtype=bool)
+    ref_cells[cell] = True
+    X = (283.15 + 12 * rng.random((T, G))).astype(dtype)
+    Xh = (X + (2 + 6 * rng.random((T, G))).astype(dtype)).astype(dtype)                        # tasmax >= tasmin
+    junk = ~ref_cells
+    X[:, junk] = np.nan
+    Xh[:, junk] = np.nan
+    some = np.flatnonzero(junk)[rng.integers(0, junk.sum(), 400)]
+    X[rng.integers(0, T, 400), some] = np.inf
+    Xh[rng.integers(0, T, 400), some] = -np.inf
+    clean, clean_h = np.where(ref_cells[None, :], X, 0).astype(np.float64), np.where(ref_cells[None, :], Xh, 0).astype(np.float64)
+    Xd, Xhd = torch.from_numpy(X).cuda(), torch.from_numpy(Xh).cuda()
+    both, whole_lines = _lib.HOST_PIN | _lib.HOST_LINES, _lib.HOST_PIN | _lib.HOST_LINES | _lib.HOST_LINES_WHOLE
+    # plain
+    dev = plan.apply(Xd).cpu().numpy()
+    assert np.isfinite(dev).all()
+    _rel_ok(dev, O.agg_coded(clean, cell, code, w, R), rtol)
+    for flags in (_lib.HOST_PIN, whole_lines, both):
+        np.testing.assert_array_equal(plan.apply_host(X, flags=flags), dev)
+    # fused powers
+    devp = plan.apply_poly(Xd, -273.15, 3).cpu().numpy()
+    assert np.isfinite(devp).all()
+    _rel_ok(devp[2], O.agg_coded(O.tas_poly_values(clean, 3), cell, code, w, R), rtol * 4, scale=1.0)
+    for flags in (_lib.HOST_PIN, whole_lines, both):
+        np.testing.assert_array_equal(plan.apply_poly_host(X, -273.15, 3, flags=flags), devp)
+    # degree days
+    thr = [289.0, 295.0]
+    deve = plan.apply_edd(Xd, Xhd, thr).cpu().numpy()
+    assert np.isfinite(deve).all()
+    for k, e in enumerate(thr):
+        keep = ref_cells[None, :]
+        edd = np.where(keep, O.snyder_edd_values(np.where(keep, clean, 280.0), np.where(keep, clean_h, 281.0), e), 0.0)
+        _rel_ok(deve[k], O.agg_coded(edd, cell, code, w, R), rtol * 10, scale=1.0)
+    for flags in (_lib.HOST_PIN, whole_lines, both):
+        np.testing.assert_array_equal(plan.apply_edd_host(X, Xh, thr, flags=flags), deve)
+    plan.close()
+
+
+@pytest.mark.parametrize("dtype,T,rtol", [(np.float32, 301, RTOL32), (np.float64, 150, RTOL64)])
 def test_fused_powers_of_a_host_resident_field(torch_cuda, dtype, T, rtol):
     """wagg_apply_poly_host_*: tas_poly-then-aggregate (transformations.py:188 + aggregations.py:87) on a HOST array -- the
     row-block pipeline with n_pow result planes per block, with and without WAGG_HOST_LINES -- bit-equal to the device form
