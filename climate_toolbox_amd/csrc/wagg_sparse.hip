@@ -788,14 +788,19 @@ __global__ __launch_bounds__(LV_THREADS) void sparse_lcv_kernel(PlanView<T> pv, 
             } else if (__builtin_amdgcn_readfirstlane(__ballot(odd) != 0ull)) {
                 bool inf_seen = false;
 #pragma unroll
-                for (int i = 0; i < TPW; ++i)
+                for (int i = 0; i < TPW; ++i) {
+                    bool s_i = false;
 #pragma unroll
                     for (int c = 0; c < E; ++c) {
                         const T x = R.v[i][c];
-                        if (NPOW > 1 && !EDD) inf_seen |= __builtin_fabs(x) >= ylim;   // the consumers then take the general form
-                        else inf_seen |= __builtin_isinf(x);
+                        if (NPOW > 1 && !EDD) s_i |= __builtin_fabs(x) >= ylim;   // the consumers then take the general form
+                        else s_i |= __builtin_isinf(x);
                         R.v[i][c] = (x == x) ? x : T(0);                           // NaN data counts 0 (S6)
                     }
+                    if constexpr (GT) inf_seen |= s_i && !((R.unref >> i) & 1);
+                    else inf_seen |= s_i;
+                }
+                if constexpr (!GT) inf_seen = inf_seen && !R.unref;               // (unreferenced quads do not count: Regs::unref)
                 inf_any = __builtin_amdgcn_readfirstlane(__ballot(inf_seen) != 0ull);
             }
             if (lane == 0) hdr[buf * 16 + 8 + wave] = inf_any ? 1 : 0;            // every wave, every item: no reset needed
