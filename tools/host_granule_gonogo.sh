@@ -5,7 +5,7 @@
 set -e
 D=$(mktemp -d)
 python3 tools/host_gather_probe.py $D
-/opt/rocm/bin/hipcc -O2 -pthread --offload-arch=gfx950 -o $D/host_gather tools/micro/host_gather.cpp
+/opt/rocm/bin/hipcc -O2 -mavx2 -pthread --offload-arch=gfx950 -o $D/host_gather tools/micro/host_gather.cpp
 for th in 12 8; do
   for g in 128 64 32 16; do
     echo "== fp32 granule $g B, threads $th, streaming stores, ring of 4"

@@ -1,8 +1,8 @@
 // Go / no-go for a "lines only" host path: how fast can N host threads compact the referenced runs of every
 // row of a pageable (T, G) field into page-locked staging, and does the DMA of the compact rows keep the PCIe rate?
 //   runs.bin: int64 n_runs, then n_runs x (int64 first_cell, int64 n_cells) -- written by tools/host_gather_probe.py
-// build: hipcc -O2 -pthread --offload-arch=gfx950 -o /tmp/host_gather tools/micro/host_gather.cpp
-// usage: host_gather runs.bin T G elem_bytes threads [nt: 1 = non-temporal stores] [slots: ring pieces in (c), 0 = whole field]
+// build: hipcc -O2 -mavx2 -pthread --offload-arch=gfx950 -o /tmp/host_gather tools/micro/host_gather.cpp
+// usage: host_gather runs.bin T G elem_bytes threads [nt: 0 = memcpy, 1 = 16-byte loads + streaming stores, 2 = 32-byte AVX2 loads + streaming stores] [slots: ring pieces in (c), 0 = whole field]
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
 #include <atomic>
@@ -45,9 +45,19 @@ int main(int argc, char **argv) {
     auto copy_nt = [](char *d, const char *s, size_t n) {       // d 16-byte aligned, n a multiple of 16
         for (size_t i = 0; i < n; i += 16) _mm_stream_si128((__m128i *)(d + i), _mm_loadu_si128((const __m128i *)(s + i)));
     };
+    auto copy_nt2 = [](char *d, const char *s, size_t n) {      // 32-byte loads, two 16-byte streaming stores (nt = 2)
+        size_t i = 0;
+        for (; i + 32 <= n; i += 32) {
+            const __m256i v = _mm256_loadu_si256((const __m256i *)(s + i));
+            _mm_stream_si128((__m128i *)(d + i), _mm256_castsi256_si128(v));
+            _mm_stream_si128((__m128i *)(d + i + 16), _mm256_extracti128_si256(v, 1));
+        }
+        if (i < n) _mm_stream_si128((__m128i *)(d + i), _mm_loadu_si128((const __m128i *)(s + i)));
+    };
     auto gather_to = [&](char *d, long long r) {
         const char *s = X + (size_t)(r * G * eb);
-        if (nt) { for (long long k = 0; k < n_runs; ++k) copy_nt(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
+        if (nt == 2) { for (long long k = 0; k < n_runs; ++k) copy_nt2(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
+        else if (nt) { for (long long k = 0; k < n_runs; ++k) copy_nt(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
         else for (long long k = 0; k < n_runs; ++k) memcpy(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]);
     };
     auto gather_rows = [&](long long r0, long long r1) {
