@@ -33,7 +33,9 @@ The default N=1 run carries every BASELINE config in its line: c2-dense is the h
 c2-real, c3-real, one rank's share of c4 (1,369 rows on the c2-dense operand) and of c5 in both structures
 (2,282 rows; block-local fp32, uniform fp32 and fp64), each with its own roofline and cpu_baseline.
 
-Prints ONE JSON line on rank 0.
+Output (rank 0): ONE JSON line on stdout, below 6 KB -- the contract's keys, `roofline`, `cpu_baseline` and one short row per
+workload of the run (compact_line()) -- and the full record (every secondary in full, boundary legs, CPU legs) as one
+`BENCH_DETAIL {...}` line on stderr and in gpurun_out/bench_line_n<N>.json.
 """
 import argparse
 import json
