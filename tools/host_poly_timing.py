@@ -50,7 +50,7 @@ def plain(tag):
     st = _lib.host_stats()
     res["plain_aggregation_lines_only_" + tag] = {"ms": ms, "wait_pack_ms": round(st["lines_wait_pack_us"] / 7e3, 2),
                                                   "wait_copy_ms": round(st["lines_wait_copy_us"] / 7e3, 2),
-                                                  "lines_calls_of_7": round(st["lines_h2d_bytes"] / (0.636 * X.nbytes), 2),
+                                                  "packed_fraction_of_x": round(st["lines_h2d_bytes"] / 7 / X.nbytes, 3),
                                                   "blocks_retired": st["blocks_retired"]}
 
 
