@@ -2,7 +2,7 @@
 // row of a pageable (T, G) field into page-locked staging, and does the DMA of the compact rows keep the PCIe rate?
 //   runs.bin: int64 n_runs, then n_runs x (int64 first_cell, int64 n_cells) -- written by tools/host_gather_probe.py
 // build: hipcc -O2 -mavx2 -pthread --offload-arch=gfx950 -o /tmp/host_gather tools/micro/host_gather.cpp
-// usage: host_gather runs.bin T G elem_bytes threads [nt: 0 = memcpy, 1 = 16-byte loads + streaming stores, 2 = 32-byte AVX2 loads + streaming stores] [slots: ring pieces in (c), 0 = whole field]
+// usage: host_gather runs.bin T G elem_bytes threads [nt: 0 = memcpy, 1 = 16-byte loads + streaming stores, 2 = 32-byte AVX2 loads + streaming stores, 3 / 4 = 1 / 2 with software prefetch of the source six runs ahead] [slots: ring pieces in (c), 0 = whole field]
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
 #include <atomic>
@@ -56,7 +56,15 @@ int main(int argc, char **argv) {
     };
     auto gather_to = [&](char *d, long long r) {
         const char *s = X + (size_t)(r * G * eb);
-        if (nt == 2) { for (long long k = 0; k < n_runs; ++k) copy_nt2(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
+        if (nt == 3 || nt == 4) {                   // nt 1 / nt 2 with the source of the run PF runs ahead prefetched (two cache lines)
+            constexpr long long PF = 6;
+            for (long long k = 0; k < n_runs; ++k) {
+                if (k + PF < n_runs) { _mm_prefetch(s + soff[(size_t)(k + PF)], _MM_HINT_NTA); _mm_prefetch(s + soff[(size_t)(k + PF)] + 64, _MM_HINT_NTA); }
+                if (nt == 3) copy_nt(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]);
+                else copy_nt2(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]);
+            }
+            _mm_sfence();
+        } else if (nt == 2) { for (long long k = 0; k < n_runs; ++k) copy_nt2(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
         else if (nt) { for (long long k = 0; k < n_runs; ++k) copy_nt(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]); _mm_sfence(); }
         else for (long long k = 0; k < n_runs; ++k) memcpy(d + doff[(size_t)k], s + soff[(size_t)k], (size_t)len[(size_t)k]);
     };
