@@ -192,9 +192,8 @@ def compact_line(line, limit=COMPACT_LIMIT):
     c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "wall_s", "sample")) if cb else None
     c.update(_pick(line, ("gather_ok", "rccl_ranks", "backend", "gather_ms", "gather_bytes", "per_rank_ms", "warmup_done",
                           "step_outlier", "elapsed_s", "plan_build_s")))
-    for k in ("cpu_reference_shaped_s", "cpu_port_s"):
-        if k in line:
-            c[k] = line[k]
+    if "cpu_reference_shaped_s" in line:
+        c["cpu_reference_shaped_s"] = line["cpu_reference_shaped_s"]
     if line.get("summary"):
         c["summary"] = line["summary"]
     c["detail"] = "stderr line `BENCH_DETAIL {...}`; gpurun_out/bench_line_n%s.json" % line.get("n_gpus", 1)
@@ -1232,8 +1231,8 @@ def main():
         # the reference-shaped CPU legs run on the segment-table workloads: the headline line names the c2-real pair at top level
         for r in rows:
             if r.get("wl") == "c2-real" and "cpu_reference_shaped_s" in r:
-                line["cpu_reference_shaped_s"] = r["cpu_reference_shaped_s"]
-                line["cpu_port_s"] = r["cpu_port_s"]
+                line["cpu_reference_shaped_s"] = dict(r["cpu_reference_shaped_s"], workload="c2-real", c_port_s=r["cpu_port_s"],
+                                                      gpu_step_s=round(r["step_ms"][0] * 1e-3, 7))
         emit(line, world)
     if use_dist:
         dist.barrier()
