@@ -15,7 +15,9 @@
  * device-side entry points is the coded segment table (cell_idx, region_code, w_eff) and plain
  * device/host pointers.  The helpers either side of the path that have been folded in
  * (tas_poly, snyder_edd: transformations.py) are evaluated while the data is loaded
- * (wagg_apply_poly_*, wagg_apply_edd_*).
+ * (wagg_apply_poly_*, wagg_apply_edd_*).  Since round 6 every apply is ONE entry point, wagg_apply(const
+ * wagg_apply_desc *) at the end of this header; the per-combination wagg_*apply* functions below are wrappers
+ * around it and stay for existing bindings.
  *
  * Conventions: every function returns 0 (WAGG_OK) or a negative wagg_status; nothing throws,
  * nothing calls exit(); wagg_last_error() gives the thread-local message of the last failure.
