@@ -25,5 +25,11 @@ torch.cuda.synchronize()
 ms = sorted(engine.profile_read())
 engine.profile_enable(False)
 med = ms[len(ms) // 2]
+import subprocess
+try:
+    smi = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showtemp", "--showmemuse"], capture_output=True, text=True, timeout=30).stdout
+    print("\n".join(l for l in smi.splitlines() if any(k in l for k in ("mclk", "sclk", "fclk", "Temperature", "memory use", "Memory Activity"))))
+except Exception as e:
+    print("rocm-smi:", e)
 print("c2-real kernel median %.4f ms (min %.4f) -- threshold %.4f" % (med, ms[0], thr))
 sys.exit(0 if med < thr else 1)
