@@ -51,11 +51,17 @@ def test_default_form_is_within_10_percent_of_the_fastest_forced_form(torch_cuda
     rowptr, col, val, G, R, T = form_point_table(kind, param)
     X = engine.synth_field(T, G, seed=31, base=280.0, amp=60.0, dtype="float32")
     times, picked = {}, None
+    plans = {}
     for form in (None, "full", "tiles", "entries"):
-        plan = DensePlan.from_csr(rowptr, col, val, G, R, form=form)
-        times[form or "auto"] = _median_ms(torch, plan, X, T, R)
-        if form is None:
-            picked = {0: "full", 1: "tiles", 2: "entries"}[plan.info["form"]]
+        plans[form or "auto"] = DensePlan.from_csr(rowptr, col, val, G, R, form=form)
+    picked = {0: "full", 1: "tiles", 2: "entries"}[plans["auto"].info["form"]]
+    # two interleaved rounds, the lower median of each form: a disturbance that lasts for one measurement (another tenant of the
+    # host, a clock step) cannot make one form look slow
+    for _ in range(2):
+        for name, plan in plans.items():
+            ms = _median_ms(torch, plan, X, T, R)
+            times[name] = min(times.get(name, ms), ms)
+    for plan in plans.values():
         plan.close()
     forced = {k: v for k, v in times.items() if k != "auto"}
     best = min(forced, key=forced.get)
